@@ -1,0 +1,259 @@
+#!/usr/bin/env python
+"""Benchmark: CogVideoX-5B + TTT-MLP training step (forward + backward + AdamW), BASELINE.json metric
+"DiT+TTT fwd/bwd video-tokens/sec".
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (config.workload): BASELINE.json configs[1] - the ("5B", "3sec") preset (42 layers, D=3072,
+48 heads, TTT-MLP with CS=64, 13 latent frames of 30x45 tokens + 498 text tokens = 18 048 tokens),
+adapter "sft" (every parameter trains), bf16 compute with fp32 master weights via FSDP2 (same wrapping
+as the reference's apply_fsdp), local batch 1 per GPU (weak scaling), layer-group re-materialisation
+as in the reference, synthetic latents/text embeddings, random-init weights.  One step = zero_grad,
+loss = CogVideoX(vid, text).mean(), backward, clip_grad_norm, fused AdamW step.
+
+Rank 0 prints ONE JSON line.  Besides the driver contract it carries
+  roofline     - the dominant hand-written kernel (TTT-MLP scan), algorithmic FLOPs / measured launch time
+  cpu_baseline - the CPU port (torch-CPU DiT layer + oracle scan) timed on the host cores, N=1 only
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "ttt-video-dit_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ.setdefault("TORCHDYNAMO_DISABLE", "1")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
+TOKENS_PER_FRAME = 30 * 45
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--video-length", default="3sec", choices=["3sec", "9sec", "18sec", "30sec", "63sec"])
+    ap.add_argument("--ssm-layer", default="ttt_mlp", choices=["ttt_mlp", "ttt_linear"])
+    ap.add_argument("--impl", default="auto", choices=["auto", "generic", "mfma"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true")
+    # debugging knobs: anything that shrinks the workload marks the result invalid
+    ap.add_argument("--layers", type=int, default=None, help="DEBUG: fewer layers (result flagged invalid)")
+    return ap.parse_args()
+
+
+TEXT_LEN = {"3sec": 498, "9sec": 502, "18sec": 500, "30sec": 497, "63sec": 458}   # configs/eval/ttt-mlp/*.toml:16 (L % 64 == 0)
+
+
+class KernelTimer:
+    """HIP-event timing of every TTT scan launch, recorded on the stream the kernel is enqueued on
+    (torch's current stream - the extension launches there)."""
+
+    def __init__(self, ext):
+        self.ext, self.active, self.events = ext, False, {"fwd": [], "bwd": []}
+        self._orig = {}
+
+    def install(self):
+        for name, key in (("ttt_forward", "fwd"), ("ttt_backward", "bwd"), ("ttt_linear_forward", "fwd"), ("ttt_linear_backward", "bwd")):
+            orig = getattr(self.ext, name)
+            self._orig[name] = orig
+
+            def wrapped(*a, _o=orig, _k=key):
+                if not self.active:
+                    return _o(*a)
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                _o(*a)
+                e.record()
+                self.events[_k].append((s, e, tuple(a[0].shape)))
+            setattr(self.ext, name, wrapped)
+
+    def summary(self):
+        out = {}
+        for k, ev in self.events.items():
+            if ev:
+                ms = [s.elapsed_time(e) for s, e, _ in ev]
+                out[k] = {"launches": len(ms), "avg_ms": sum(ms) / len(ms), "total_ms": sum(ms), "shape": ev[0][2]}
+        return out
+
+
+def cpu_baseline(ssm_layer):
+    """CPU port of the same workload on the host cores: ONE 5B-geometry TransformerLayer (torch CPU fp32,
+    TTT scan by the oracle through oracle/cpu_ext.py), fwd+bwd, at a bounded sequence (1 latent frame +
+    58 text tokens = 1408 tokens); scaled to whole-model video-tokens/s by the 42 layers."""
+    from oracle import cpu_ext
+    from ttt_amd.models.cogvideo.dit import TransformerLayer
+    from ttt_amd.models.cogvideo.utils import SequenceMetadata
+    from ttt_amd.models.configs import ModelConfig
+
+    real = sys.modules.pop("test_time_training", None)
+    cpu_ext.install()
+    try:
+        torch.manual_seed(0)
+        cfg = ModelConfig.get_preset("5B", "3sec", ssm_layer=ssm_layer, adapter_method="sft", compressed_num_frames=1)
+        layer = TransformerLayer(cfg)
+        n_text, n_vid = 58, TOKENS_PER_FRAME
+        meta = SequenceMetadata(text_length=n_text, seq_text_length=n_text, num_frames=1, num_chunks=1,
+                                tokens_per_frame=n_vid, latent_height=60, latent_width=90, t_emb=torch.randn(1, cfg.time_embed_dim))
+        vid = torch.randn(1, n_vid, cfg.model_dim, requires_grad=True)
+        txt = torch.randn(1, n_text, cfg.model_dim, requires_grad=True)
+        threads = torch.get_num_threads()
+
+        def step():
+            # TkMLP requires bf16 activations: autocast like the GPU run; GEMMs then run in bf16 on the CPU too
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                v, t = layer(vid, txt, meta)
+            (v.float().square().mean() + t.float().square().mean()).backward()
+
+        step()                       # warm-up
+        t0 = time.perf_counter()
+        n = 2
+        for _ in range(n):
+            step()
+        dt = (time.perf_counter() - t0) / n
+    finally:
+        cpu_ext.uninstall()
+        if real is not None:
+            sys.modules["test_time_training"] = real
+    tok_s = n_vid / (dt * 42)
+    return {"value": tok_s, "unit": "video-tokens/s", "cores": threads, "kind": "port",
+            "sample": f"1 of 42 TransformerLayers (5B geometry, {ssm_layer}) fwd+bwd at 1 latent frame + 58 text tokens "
+                      f"(L=1408), {dt:.2f} s/layer-step on {threads} threads; scaled by 42 layers"}
+
+
+def main():
+    args = parse()
+    if args.cpu_baseline_only:
+        print(json.dumps({"cpu_baseline": cpu_baseline(args.ssm_layer)}))
+        return
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import test_time_training as ext
+    from ttt_amd.infra.parallelisms import apply_fsdp, get_dp_mesh, init_distributed, init_model_parameters
+    from ttt_amd.models.cogvideo.model import CogVideoX
+    from ttt_amd.models.configs import ModelConfig
+
+    ext.load_library()
+    ext.set_impl(args.impl)
+    init_distributed("nccl")
+
+    over = {}
+    if args.layers is not None:
+        over["num_layers"] = args.layers
+    cfg = ModelConfig.get_preset("5B", args.video_length, ssm_layer=args.ssm_layer, adapter_method="sft", **over)
+    frames, text_len = cfg.compressed_num_frames, TEXT_LEN[args.video_length]
+    scenes = max((frames - 1) // 12, 1)
+    L = frames * TOKENS_PER_FRAME + scenes * text_len
+    assert L % cfg.mini_batch_size == 0
+
+    with torch.device("meta"):
+        model = CogVideoX(cfg, effective_rank=rank, effective_world_size=world)
+    apply_fsdp(model, get_dp_mesh())                       # reference parallelisms.py:155-175
+    model.to_empty(device=dev)
+    torch.manual_seed(1234)                                # same init on every rank, then sharded
+    with torch.no_grad():
+        init_model_parameters(model)
+        model.init_ssm_weights()
+    model.setup_generator(seed=rank, device=dev)
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-5, weight_decay=1e-4, fused=True)
+
+    g = torch.Generator(device=dev).manual_seed(100 + rank)
+    vid = torch.randn(1, frames, 16, 60, 90, device=dev, generator=g)
+    text = torch.randn(1, scenes, text_len, cfg.text_dim, device=dev, generator=g)
+
+    timer = KernelTimer(ext)
+    timer.install()
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = model(vid, text).mean()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    dist.barrier(device_ids=[local_rank])
+    torch.cuda.synchronize()
+    timer.active = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dist.barrier(device_ids=[local_rank])
+    dt = time.perf_counter() - t0
+    timer.active = False
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+    loss_val = float(loss)
+    peak_mem = torch.cuda.max_memory_allocated() / 2 ** 30
+
+    if rank == 0:
+        ms_per_step = 1e3 * dt / args.steps
+        video_tokens = world * 1 * frames * TOKENS_PER_FRAME
+        value = video_tokens / (dt / args.steps)
+        ks = timer.summary()
+        # ---- roofline of the dominant hand-written kernel ---------------------------------
+        B, NH, NC, CS, F = 1, cfg.num_heads, L // cfg.mini_batch_size, cfg.mini_batch_size, cfg.head_dim
+        if args.ssm_layer == "ttt_mlp":
+            gemm = 2.0 * CS * F * 4 * F
+            flops = {"fwd": 7 * gemm, "bwd": 14 * gemm}         # algorithmic; the in-kernel recompute (7g) is excluded
+        else:
+            gemm = 2.0 * CS * F * F
+            flops = {"fwd": 3 * gemm, "bwd": 6 * gemm}
+        dom = max(ks, key=lambda k: ks[k]["total_ms"]) if ks else None
+        roof = None
+        if dom:
+            per_launch = B * NH * NC * flops[dom]
+            ach = per_launch / (ks[dom]["avg_ms"] * 1e-3) / 1e12
+            impl = ext.resolved_impl(B, NH, NC, CS, F, min(cfg.scan_checkpoint_group_size, NC), torch.bfloat16,
+                                     mlp=args.ssm_layer == "ttt_mlp", backward=dom == "bwd")
+            roof = {"bound": "mfma", "kernel": f"{args.ssm_layer}_{dom}_scan[{impl}]", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                    "flops_per_launch": per_launch, "avg_launch_ms": ks[dom]["avg_ms"], "launches_timed": ks[dom]["launches"],
+                    "occupied_cu_frac": ach / (MFMA_BF16_PEAK_TFLOPS * min(B * NH, 256) / 256.0),
+                    "other": {k: {"avg_ms": v["avg_ms"], "launches": v["launches"],
+                                  "achieved_tflops": B * NH * NC * flops[k] / (v["avg_ms"] * 1e-3) / 1e12} for k, v in ks.items() if k != dom},
+                    "scan_share_of_step": sum(v["total_ms"] for v in ks.values()) / (1e3 * dt)}
+        line = {"metric": "DiT+TTT fwd/bwd video-tokens/sec", "value": value, "unit": "video-tokens/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                "config": {"workload": f"CogVideoX-5B+{args.ssm_layer} {args.video_length} training step (fwd+bwd+AdamW), "
+                                       f"{cfg.num_layers} layers, L={L} tokens/sample, adapter=sft",
+                           "global_batch": world, "seq_len": L, "parallelism": f"fsdp{world}", "ttt_impl": args.impl,
+                           "valid": args.layers is None},
+                "roofline": roof, "loss": loss_val, "peak_mem_gib": peak_mem, "total_tokens_per_s": world * L / (dt / args.steps)}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(args.ssm_layer)
+            except Exception as ex:  # never lose the GPU measurement because the CPU leg failed
+                line["cpu_baseline"] = {"error": repr(ex)}
+        print(json.dumps(line), flush=True)
+    dist.barrier(device_ids=[local_rank])
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,152 @@
+/*
+ * ttt_hip.h - C ABI of the MI355X (gfx950) TTT scan kernels: the drop-in boundary.
+ *
+ * This library replaces, for the reference test-time-training/ttt-video-dit:
+ *   - the un-vendored CUDA extension `test_time_training` (ttt-tk):
+ *       ttt_forward  called at ttt/models/ssm/mlp_tk.py:116-133   -> ttt_hip_mlp_forward
+ *       ttt_backward called at ttt/models/ssm/mlp_tk.py:227-275   -> ttt_hip_mlp_backward
+ *   - the Triton TTT-Linear kernels:
+ *       ttt_linear_scan_forward  (ttt/models/ssm/kernels/linear_forward.py:5-148,
+ *                                 launched at ttt/models/ssm/linear_triton.py:98-129)   -> ttt_hip_linear_forward
+ *       ttt_linear_scan_backward (ttt/models/ssm/kernels/linear_backward.py:200-520,
+ *                                 launched at ttt/models/ssm/linear_triton.py:203-246)  -> ttt_hip_linear_backward
+ *
+ * Conventions (identical to the reference call sites):
+ *   - every buffer is allocated by the caller and is contiguous; the library allocates nothing
+ *     and owns nothing; results are written through the given pointers;
+ *   - all pointers are DEVICE pointers on the current device;
+ *   - kernels are enqueued on `stream` (a hipStream_t, NULL = default stream) and the call
+ *     returns without synchronising;
+ *   - return value 0 = enqueued; negative = argument/launch error, message via ttt_hip_last_error().
+ *
+ * Tensor shapes use the reference's names: B batch, NH heads, NC mini-batches, CS mini-batch
+ * size, F head dim, H = 4F (TTT-MLP hidden), G checkpoint_group_size, K = ceil(NC/G).
+ * "act" tensors (XQ/XK/XV/eta/XQW and their gradients) are bf16 or fp32 according to
+ * ttt_dims.act_dtype; state, checkpoints and LayerNorm parameters are always fp32
+ * (mlp_tk.py:95-98,107-113).
+ */
+#ifndef TTT_HIP_H
+#define TTT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TTT_HIP_ABI_VERSION 1
+
+enum { TTT_DTYPE_BF16 = 0, TTT_DTYPE_F32 = 1 };
+/* implementation selector: AUTO picks the MFMA kernels when the geometry is supported
+ * (bf16, CS=64, F=64) and the generic fp32-arithmetic kernels otherwise. */
+enum { TTT_IMPL_AUTO = 0, TTT_IMPL_GENERIC = 1, TTT_IMPL_MFMA = 2 };
+
+typedef struct ttt_dims {
+    int32_t B, NH, NC, CS, F, G;
+    int32_t act_dtype;   /* TTT_DTYPE_* of XQ/XK/XV/last_eta/XQW and their gradients          */
+    int32_t impl;        /* TTT_IMPL_*                                                          */
+    float   eps;         /* LayerNorm epsilon; 1e-8 = reference ops path (ops/utils.py:4,21)    */
+} ttt_dims;
+
+/* ---- TTT-MLP forward: the 15 tensors of mlp_tk.py:116-133, same order ------------------- */
+typedef struct ttt_mlp_fwd_args {
+    const void*  XQ;             /* [B,NH,NC,CS,F] act                                          */
+    const void*  XK;
+    const void*  XV;
+    const void*  last_eta;       /* [B,NH,NC,CS,1] act  (last row of the eta tile, mlp_tk.py:105)*/
+    const float* ttt_norm_weight;/* [1,NH,1,F] */
+    const float* ttt_norm_bias;  /* [1,NH,1,F] */
+    const float* W1_init;        /* [B,NH,F,H] */
+    const float* b1_init;        /* [B,NH,1,H] */
+    const float* W2_init;        /* [B,NH,H,F] */
+    const float* b2_init;        /* [B,NH,1,F] */
+    float* W1_checkpoints;       /* [B,NH,K,F,H]  out: state entering steps 0,G,2G,...          */
+    float* b1_checkpoints;       /* [B,NH,K,1,H] */
+    float* W2_checkpoints;       /* [B,NH,K,H,F] */
+    float* b2_checkpoints;       /* [B,NH,K,1,F] */
+    void*  XQW;                  /* [B,NH,NC,CS,F] act, out                                     */
+} ttt_mlp_fwd_args;
+
+/* ---- TTT-MLP backward: the 42 tensors of mlp_tk.py:227-275, same order ------------------ */
+typedef struct ttt_mlp_bwd_args {
+    const void*  XQ; const void* XK; const void* XV; const void* last_eta;
+    const float* ttt_norm_weight; const float* ttt_norm_bias;
+    const float* W1_checkpoints; const float* b1_checkpoints;
+    const float* W2_checkpoints; const float* b2_checkpoints;
+    const void*  XQW;            /* forward output (unused by the arithmetic; kept for ABI parity) */
+    /* caller-allocated re-materialisation scratch, [B,NH,G,...] (mlp_tk.py:192-210) */
+    float* W1_init_group; float* b1_init_group; float* W2_init_group; float* b2_init_group;
+    void*  x_hat_ln_group;          /* bf16 [B,NH,G,CS,F]  */
+    float* std_ln_group;            /* f32  [B,NH,G,CS,1]  */
+    void*  X2_group;                /* bf16 [B,NH,G,CS,H]  */
+    void*  Z1_group;                /* bf16 [B,NH,G,CS,H]  */
+    void*  Z1_bar_group;            /* bf16 [B,NH,G,CS,H]  */
+    void*  X2_bar_group;            /* bf16 [B,NH,G,CS,H]  */
+    void*  grad_l_wrt_Z2_group;     /* bf16 [B,NH,G,CS,F]  */
+    void*  grad_l_wrt_Z1_group;     /* bf16 [B,NH,G,CS,H]  */
+    void*  x_hat_fused_group;       /* bf16 [B,NH,G,CS,F]  */
+    void*  grad_x_hat_fused_group;  /* bf16 [B,NH,G,CS,F]  */
+    void*  grad_output_fused_group; /* bf16 [B,NH,G,CS,F]  */
+    float* std_fused_group;         /* f32  [B,NH,G,CS,1]  */
+    /* upstream gradients */
+    const float* grad_L_W1_last; const float* grad_L_b1_last;   /* [B,NH,F,H] / [B,NH,1,H] (zeros) */
+    const float* grad_L_W2_last; const float* grad_L_b2_last;
+    const void*  grad_L_XQW;        /* [B,NH,NC,CS,F] act */
+    /* outputs */
+    float* grad_L_ttt_norm_weight;  /* [B,NH,1,F] per batch element (caller sums, mlp_tk.py:277) */
+    float* grad_L_ttt_norm_bias;
+    float* grad_L_W1_init; float* grad_L_b1_init; float* grad_L_W2_init; float* grad_L_b2_init;
+    void*  grad_L_last_eta;         /* [B,NH,NC,CS,1] act */
+    void*  grad_L_XQ; void* grad_L_XK; void* grad_L_XV;          /* [B,NH,NC,CS,F] act */
+} ttt_mlp_bwd_args;
+
+/* ---- TTT-Linear: tensor contract of linear_triton.py:98-129 / 203-246, except that eta is
+ * passed as its last row [B,NH,NC,CS,1] (the Triton kernels index the last row of the full tile
+ * themselves, kernels/linear_forward.py:90-101; the binding slices it) ----------------------- */
+typedef struct ttt_linear_fwd_args {
+    const void*  XQ; const void* XK; const void* XV; const void* last_eta;
+    const float* ttt_norm_weight; const float* ttt_norm_bias;   /* [NH,F] */
+    const float* W1_init;        /* [B,NH,F,F] */
+    const float* b1_init;        /* [B,NH,1,F] */
+    float* W1_checkpoints;       /* [B,NH,K,F,F] */
+    float* b1_checkpoints;       /* [B,NH,K,1,F] */
+    void*  XQW;                  /* [B,NH,NC,CS,F] act */
+} ttt_linear_fwd_args;
+
+typedef struct ttt_linear_bwd_args {
+    const void*  XQ; const void* XK; const void* XV; const void* last_eta;
+    const float* ttt_norm_weight; const float* ttt_norm_bias;
+    const float* W1_checkpoints; const float* b1_checkpoints;
+    const float* grad_L_W1_last; const float* grad_L_b1_last;
+    const void*  grad_L_XQW;
+    float* W1_init_group;        /* [B,NH,G,F,F] scratch (linear_triton.py:172) */
+    float* b1_init_group;        /* [B,NH,G,1,F] scratch                          */
+    float* grad_L_ttt_norm_weight; float* grad_L_ttt_norm_bias;  /* [B,NH,1,F] */
+    float* grad_L_W1_init; float* grad_L_b1_init;
+    void*  grad_L_last_eta;      /* [B,NH,NC,CS,1] act */
+    void*  grad_L_XQ; void* grad_L_XK; void* grad_L_XV;
+} ttt_linear_bwd_args;
+
+/* Bytes of extra device workspace the chosen implementation needs for this call (0 = none).
+ * The binding allocates it (the reference allocates all scratch on the Python side too). */
+size_t ttt_hip_mlp_forward_workspace(const ttt_dims* d);
+size_t ttt_hip_mlp_backward_workspace(const ttt_dims* d);
+size_t ttt_hip_linear_forward_workspace(const ttt_dims* d);
+size_t ttt_hip_linear_backward_workspace(const ttt_dims* d);
+
+int ttt_hip_mlp_forward(const ttt_dims* d, const ttt_mlp_fwd_args* a, void* workspace, size_t workspace_bytes, void* stream);
+int ttt_hip_mlp_backward(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* workspace, size_t workspace_bytes, void* stream);
+int ttt_hip_linear_forward(const ttt_dims* d, const ttt_linear_fwd_args* a, void* workspace, size_t workspace_bytes, void* stream);
+int ttt_hip_linear_backward(const ttt_dims* d, const ttt_linear_bwd_args* a, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Which implementation TTT_IMPL_AUTO resolves to for these dims (returns TTT_IMPL_GENERIC/MFMA). */
+int ttt_hip_resolve_impl(const ttt_dims* d, int is_mlp, int is_backward);
+
+int         ttt_hip_abi_version(void);
+const char* ttt_hip_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TTT_HIP_H */

@@ -78,14 +78,16 @@ def module_case(ssm_layer, multiscene, seed, dtype=torch.float32):
                     latent_height=4, latent_width=8)
         L = 256
     else:
-        # 3 scenes, 7 frames of 4x4 latent (16 tok/frame), text 16 per scene: L = 48 + 112 = 160, CS=16
+        # 2 scenes, 5 frames of 4x4 latent (16 tok/frame), text 8 per scene: L = 16 + 80 = 96, CS=16.
+        # Scene offsets (56, 40) are NOT multiples of CS, so interleave mixes mini-batches: eta rows of a
+        # tile differ (SURVEY.md hazard C2), as in the real 9 s config (text 502, 1350 tokens/frame, CS 64).
         cfg = ModelConfig(model_dim=128, num_heads=2, num_layers=1, mini_batch_size=16, latent_height=4,
-                          latent_width=4, compressed_num_frames=7, ssm_layer=ssm_layer,
+                          latent_width=4, compressed_num_frames=5, ssm_layer=ssm_layer,
                           scan_checkpoint_group_size=4)
-        meta = dict(text_length=16, seq_text_length=48, num_frames=7, num_chunks=3, tokens_per_frame=16,
+        meta = dict(text_length=8, seq_text_length=16, num_frames=5, num_chunks=2, tokens_per_frame=16,
                     latent_height=4, latent_width=4)
-        L = 160
-    m = TTTWrapper(cfg).to(dtype)
+        L = 96
+    m = TTTWrapper(cfg)  # NOT .to(dtype): that would cast the complex RoPE table to real
     m.ttt.init_weights()
     with torch.no_grad():  # make LN params / biases non-trivial so their gradients are exercised
         m.ttt.ttt_norm_weight.add_(0.1 * torch.randn_like(m.ttt.ttt_norm_weight))
@@ -116,7 +118,7 @@ def dit_case(ssm_layer, scenes, seed, dtype=torch.float32):
                       latent_width=8, compressed_num_frames=frames, ssm_layer=ssm_layer, text_dim=32,
                       time_embed_dim=64, attn_length=2, prefix_temporal_length=1, adapter_method="sft",
                       scan_checkpoint_group_size=2, remat_transformer_layer_group_size=1)
-    m = DiffusionTransformer(cfg).to(dtype)
+    m = DiffusionTransformer(cfg)  # fp32 default; never .to() (complex RoPE buffer)
     for mod in m.modules():
         if hasattr(mod, "use_kernel"):
             mod.use_kernel = False

@@ -23,12 +23,12 @@ def op_inputs(g):
 
 
 def rel_l2(a, b):
-    a = a.double(); b = b.double()
+    a = a.detach().double().cpu(); b = b.detach().double().cpu()
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
 
 
 def max_abs(a, b):
-    return float((a.double() - b.double()).abs().max())
+    return float((a.detach().double().cpu() - b.detach().double().cpu()).abs().max())
 
 
 def tile_states(d, B):

@@ -1,0 +1,97 @@
+#!/usr/bin/env python
+"""Op-level micro-benchmark of the TTT scan kernels at a CogVideoX-5B geometry (default: 3 s,
+B=1, NH=48, NC=282, CS=64, F=64, G=16).  Prints one JSON line per kernel family with the average
+launch time and the achieved algorithmic TFLOP/s (fwd 7g, bwd 14g, g = 2*CS*F*4F).
+
+    python tools/op_bench.py [--impl auto|generic|mfma] [--kind mlp|linear] [--nc 282] [--iters 10]
+"""
+import argparse
+import json
+import math
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "ttt-video-dit_amd")):
+    sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--impl", default="auto")
+    ap.add_argument("--kind", default="mlp")
+    ap.add_argument("--b", type=int, default=1)
+    ap.add_argument("--nh", type=int, default=48)
+    ap.add_argument("--nc", type=int, default=282)
+    ap.add_argument("--cs", type=int, default=64)
+    ap.add_argument("--g", type=int, default=16)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--fwd-only", action="store_true")
+    a = ap.parse_args()
+    import test_time_training as ext
+    from ttt_amd.models.ssm.linear_hip import HipLinear
+    from ttt_amd.models.ssm.mlp_tk import TkMLP
+    ext.load_library()
+    ext.set_impl(a.impl)
+    dev = torch.device("cuda:0")
+    B, NH, NC, CS, F, G = a.b, a.nh, a.nc, a.cs, 64, a.g
+    H = 4 * F if a.kind == "mlp" else F
+    gen = torch.Generator(device=dev).manual_seed(0)
+    rn = lambda *s: torch.randn(*s, device=dev, generator=gen)
+    XQ = torch.nn.functional.normalize(rn(B, NH, NC, CS, F), dim=-1).bfloat16().requires_grad_(True)
+    XK = torch.nn.functional.normalize(rn(B, NH, NC, CS, F), dim=-1).bfloat16().requires_grad_(True)
+    XV = rn(B, NH, NC, CS, F).bfloat16().requires_grad_(True)
+    base_lr = 0.1 if a.kind == "mlp" else 1.0
+    eta = (base_lr * torch.sigmoid(rn(B, NH, NC, 1, CS)) / (F * CS)).bfloat16().requires_grad_(True)
+    ln_w = torch.ones(NH, F, device=dev, requires_grad=True)
+    ln_b = torch.zeros(NH, F, device=dev, requires_grad=True)
+    W1 = (0.02 * rn(NH, F, H)).requires_grad_(True)
+    b1 = torch.zeros(NH, 1, H, device=dev, requires_grad=True)
+    W2 = (0.02 * rn(NH, H, F)).requires_grad_(True)
+    b2 = torch.zeros(NH, 1, F, device=dev, requires_grad=True)
+    dOut = rn(B, NH, NC, CS, F).bfloat16()
+    ex = lambda p: p.unsqueeze(0).expand(B, *p.shape)
+
+    def fwd():
+        if a.kind == "mlp":
+            return TkMLP.apply(ln_w, ln_b, ex(W1), ex(b1), ex(W2), ex(b2), XQ, XV, XK, eta, G)
+        return HipLinear.apply(ln_w, ln_b, ex(W1), ex(b1), XQ, XV, XK, eta, G)
+
+    # time the raw kernel launches with events around the extension calls
+    times = {"fwd": [], "bwd": []}
+    for name, key in (("ttt_forward", "fwd"), ("ttt_backward", "bwd"), ("ttt_linear_forward", "fwd"), ("ttt_linear_backward", "bwd")):
+        orig = getattr(ext, name)
+
+        def wrapped(*args, _o=orig, _k=key):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record(); _o(*args); e.record()
+            times[_k].append((s, e))
+        setattr(ext, name, wrapped)
+
+    for it in range(a.iters + 2):
+        if it == 2:
+            torch.cuda.synchronize()
+            times = {"fwd": [], "bwd": []}
+        out = fwd()
+        if not a.fwd_only:
+            out.backward(dOut)
+    torch.cuda.synchronize()
+    g = 2.0 * CS * F * H
+    nfl = {"fwd": (7 if a.kind == "mlp" else 3) * g, "bwd": (14 if a.kind == "mlp" else 6) * g}
+    res = {"kind": a.kind, "impl_requested": a.impl, "shape": [B, NH, NC, CS, F], "G": G}
+    for k, ev in times.items():
+        if not ev:
+            continue
+        ms = sorted(s.elapsed_time(e) for s, e in ev)
+        avg = sum(ms) / len(ms)
+        fl = B * NH * NC * nfl[k]
+        res[k] = {"impl": ext.resolved_impl(B, NH, NC, CS, F, G, torch.bfloat16, a.kind == "mlp", k == "bwd"),
+                  "avg_ms": avg, "min_ms": ms[0], "us_per_step": 1e3 * avg / NC, "tflops": fl / (avg * 1e-3) / 1e12,
+                  "frac_mfma_peak": fl / (avg * 1e-3) / 2.5e15, "frac_occupied_cu_peak": fl / (avg * 1e-3) / (2.5e15 * min(B * NH, 256) / 256)}
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,15 @@
+// Host-side entry points of the MFMA (bf16 matrix-core) kernels: CS=64, F=64, bf16 activations.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/ttt_hip.h"
+
+namespace ttt {
+namespace mfma {
+bool   supports(const ttt_dims* d, bool mlp, bool backward);
+size_t workspace_bytes(const ttt_dims* d, bool mlp, bool backward);
+void mlp_forward(const ttt_dims* d, const ttt_mlp_fwd_args* a, void* ws, hipStream_t s);
+void mlp_backward(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hipStream_t s);
+void linear_forward(const ttt_dims* d, const ttt_linear_fwd_args* a, void* ws, hipStream_t s);
+void linear_backward(const ttt_dims* d, const ttt_linear_bwd_args* a, void* ws, hipStream_t s);
+}  // namespace mfma
+}  // namespace ttt

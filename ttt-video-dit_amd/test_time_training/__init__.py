@@ -1,0 +1,279 @@
+"""Drop-in replacement for the reference's un-vendored ``test_time_training`` CUDA extension
+(ttt-tk), backed by hand-written HIP kernels for MI355X / gfx950 behind the C ABI of
+``include/ttt_hip.h``.
+
+``ttt_forward`` / ``ttt_backward`` take exactly the positional tensors the reference passes at
+``ttt/models/ssm/mlp_tk.py:116-133`` and ``:227-275``: every buffer (outputs, checkpoints,
+re-materialisation scratch) is allocated by the caller, results are written in place, nothing
+is returned, kernels are enqueued on the current torch stream without synchronising.
+
+``ttt_linear_forward`` / ``ttt_linear_backward`` expose the TTT-Linear kernels with the tensor
+contract of the reference's Triton launch sites (``ttt/models/ssm/linear_triton.py:98-129``,
+``:203-246``).
+
+There is no CPU path and no fallback: if ``lib/libttt_hip.so`` is missing or a tensor is not on
+a HIP device the call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libttt_hip.so")
+
+IMPL_AUTO, IMPL_GENERIC, IMPL_MFMA = 0, 1, 2
+_IMPL_NAMES = {"auto": IMPL_AUTO, "generic": IMPL_GENERIC, "mfma": IMPL_MFMA}
+
+# LayerNorm epsilon of the reference's ops path (ops/utils.py:4,21); the Triton kernels use 1e-6
+# (kernels/linear_forward.py:111) - SURVEY.md hazard C1.  Adjustable for experiments.
+_state = {"impl": IMPL_AUTO, "eps": 1e-8}
+
+
+class _Dims(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("B", "NH", "NC", "CS", "F", "G", "act_dtype", "impl")] + [("eps", ctypes.c_float)]
+
+
+def _ptr_struct(name, fields):
+    return type(name, (ctypes.Structure,), {"_fields_": [(f, ctypes.c_void_p) for f in fields]})
+
+
+MLP_FWD_FIELDS = ("XQ", "XK", "XV", "last_eta", "ttt_norm_weight", "ttt_norm_bias", "W1_init", "b1_init", "W2_init",
+                  "b2_init", "W1_checkpoints", "b1_checkpoints", "W2_checkpoints", "b2_checkpoints", "XQW")
+MLP_BWD_FIELDS = ("XQ", "XK", "XV", "last_eta", "ttt_norm_weight", "ttt_norm_bias", "W1_checkpoints", "b1_checkpoints",
+                  "W2_checkpoints", "b2_checkpoints", "XQW", "W1_init_group", "b1_init_group", "W2_init_group",
+                  "b2_init_group", "x_hat_ln_group", "std_ln_group", "X2_group", "Z1_group", "Z1_bar_group", "X2_bar_group",
+                  "grad_l_wrt_Z2_group", "grad_l_wrt_Z1_group", "x_hat_fused_group", "grad_x_hat_fused_group",
+                  "grad_output_fused_group", "std_fused_group", "grad_L_W1_last", "grad_L_b1_last", "grad_L_W2_last",
+                  "grad_L_b2_last", "grad_L_XQW", "grad_L_ttt_norm_weight", "grad_L_ttt_norm_bias", "grad_L_W1_init",
+                  "grad_L_b1_init", "grad_L_W2_init", "grad_L_b2_init", "grad_L_last_eta", "grad_L_XQ", "grad_L_XK", "grad_L_XV")
+LIN_FWD_FIELDS = ("XQ", "XK", "XV", "last_eta", "ttt_norm_weight", "ttt_norm_bias", "W1_init", "b1_init",
+                  "W1_checkpoints", "b1_checkpoints", "XQW")
+LIN_BWD_FIELDS = ("XQ", "XK", "XV", "last_eta", "ttt_norm_weight", "ttt_norm_bias", "W1_checkpoints", "b1_checkpoints",
+                  "grad_L_W1_last", "grad_L_b1_last", "grad_L_XQW", "W1_init_group", "b1_init_group",
+                  "grad_L_ttt_norm_weight", "grad_L_ttt_norm_bias", "grad_L_W1_init", "grad_L_b1_init", "grad_L_last_eta",
+                  "grad_L_XQ", "grad_L_XK", "grad_L_XV")
+
+_MlpFwd = _ptr_struct("_MlpFwd", MLP_FWD_FIELDS)
+_MlpBwd = _ptr_struct("_MlpBwd", MLP_BWD_FIELDS)
+_LinFwd = _ptr_struct("_LinFwd", LIN_FWD_FIELDS)
+_LinBwd = _ptr_struct("_LinBwd", LIN_BWD_FIELDS)
+
+# every extern "C" symbol declared in include/ttt_hip.h
+EXPORTED_SYMBOLS = (
+    "ttt_hip_mlp_forward_workspace", "ttt_hip_mlp_backward_workspace", "ttt_hip_linear_forward_workspace",
+    "ttt_hip_linear_backward_workspace", "ttt_hip_mlp_forward", "ttt_hip_mlp_backward", "ttt_hip_linear_forward",
+    "ttt_hip_linear_backward", "ttt_hip_resolve_impl", "ttt_hip_abi_version", "ttt_hip_last_error",
+)
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+def library_path() -> str:
+    return _LIB_PATH
+
+
+def load_library() -> ctypes.CDLL:
+    """dlopen libttt_hip.so (built by ``__graft_entry__.build()`` / ``csrc/build.sh``).  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise RuntimeError(
+            f"test_time_training: HIP library not found at {_LIB_PATH}; build it with "
+            f"`python -c 'import __graft_entry__ as g; g.build()'` (there is no CPU fallback)")
+    lib = ctypes.CDLL(_LIB_PATH)
+    for n in ("mlp_forward", "mlp_backward", "linear_forward", "linear_backward"):
+        getattr(lib, f"ttt_hip_{n}_workspace").restype = ctypes.c_size_t
+        getattr(lib, f"ttt_hip_{n}_workspace").argtypes = [ctypes.c_void_p]
+        getattr(lib, f"ttt_hip_{n}").restype = ctypes.c_int
+        getattr(lib, f"ttt_hip_{n}").argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    lib.ttt_hip_resolve_impl.restype = ctypes.c_int
+    lib.ttt_hip_resolve_impl.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    lib.ttt_hip_abi_version.restype = ctypes.c_int
+    lib.ttt_hip_last_error.restype = ctypes.c_char_p
+    if lib.ttt_hip_abi_version() != 1:
+        raise RuntimeError("test_time_training: libttt_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def set_impl(name: str) -> None:
+    """Select the kernel family: 'auto' (MFMA when the geometry allows), 'generic', 'mfma'."""
+    _state["impl"] = _IMPL_NAMES[name]
+
+
+def get_impl() -> str:
+    return {v: k for k, v in _IMPL_NAMES.items()}[_state["impl"]]
+
+
+def set_ln_eps(eps: float) -> None:
+    _state["eps"] = float(eps)
+
+
+def get_ln_eps() -> float:
+    return _state["eps"]
+
+
+# ------------------------------------------------------------------------------------------------
+def _check(t: torch.Tensor, name: str, shape, dtype) -> None:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: tensor must live on a HIP device (got {t.device}); there is no CPU path")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if tuple(t.shape) != tuple(shape):
+        raise RuntimeError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name}: tensor must be contiguous")
+
+
+def _dims(B, NH, NC, CS, F, G, act_dtype) -> _Dims:
+    if act_dtype == torch.bfloat16:
+        code = 0
+    elif act_dtype == torch.float32:
+        code = 1
+    else:
+        raise RuntimeError(f"activations must be bfloat16 or float32, got {act_dtype}")
+    if G < 1:
+        raise RuntimeError("checkpoint_group_size must be >= 1")
+    return _Dims(B, NH, NC, CS, F, G, code, _state["impl"], _state["eps"])
+
+
+def _launch(fn_name: str, dims: _Dims, args, device) -> None:
+    lib = load_library()
+    ws_bytes = getattr(lib, fn_name + "_workspace")(ctypes.byref(dims))
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=device) if ws_bytes else None
+    stream = torch.cuda.current_stream(device).cuda_stream
+    with torch.cuda.device(device):
+        rc = getattr(lib, fn_name)(ctypes.byref(dims), ctypes.byref(args), ws.data_ptr() if ws is not None else None,
+                                   ws_bytes, ctypes.c_void_p(stream))
+    if rc != 0:
+        raise RuntimeError(lib.ttt_hip_last_error().decode())
+
+
+def resolved_impl(B, NH, NC, CS, F, G, act_dtype=torch.bfloat16, mlp=True, backward=False) -> str:
+    """Name of the kernel family a call with these dims would run ('generic' / 'mfma')."""
+    lib = load_library()
+    d = _dims(B, NH, NC, CS, F, G, act_dtype)
+    r = lib.ttt_hip_resolve_impl(ctypes.byref(d), int(mlp), int(backward))
+    return {1: "generic", 2: "mfma"}.get(r, "unsupported")
+
+
+# ------------------------------------------------------------------------------------------------
+def ttt_forward(XQ, XK, XV, last_eta, ttt_norm_weight, ttt_norm_bias, W1_init, b1_init, W2_init, b2_init,
+                W1_checkpoints, b1_checkpoints, W2_checkpoints, b2_checkpoints, XQW_batch, checkpoint_group_size):
+    """TTT-MLP forward scan; argument list of the reference call site mlp_tk.py:116-133."""
+    B, NH, NC, CS, F = XQ.shape
+    G = int(checkpoint_group_size)
+    K = -(-NC // G)
+    H = 4 * F
+    act, f32 = XQ.dtype, torch.float32
+    t = dict(XQ=XQ, XK=XK, XV=XV, last_eta=last_eta, ttt_norm_weight=ttt_norm_weight, ttt_norm_bias=ttt_norm_bias,
+             W1_init=W1_init, b1_init=b1_init, W2_init=W2_init, b2_init=b2_init, W1_checkpoints=W1_checkpoints,
+             b1_checkpoints=b1_checkpoints, W2_checkpoints=W2_checkpoints, b2_checkpoints=b2_checkpoints, XQW=XQW_batch)
+    spec = dict(XQ=((B, NH, NC, CS, F), act), XK=((B, NH, NC, CS, F), act), XV=((B, NH, NC, CS, F), act),
+                last_eta=((B, NH, NC, CS, 1), act), ttt_norm_weight=((1, NH, 1, F), f32), ttt_norm_bias=((1, NH, 1, F), f32),
+                W1_init=((B, NH, F, H), f32), b1_init=((B, NH, 1, H), f32), W2_init=((B, NH, H, F), f32),
+                b2_init=((B, NH, 1, F), f32), W1_checkpoints=((B, NH, K, F, H), f32), b1_checkpoints=((B, NH, K, 1, H), f32),
+                W2_checkpoints=((B, NH, K, H, F), f32), b2_checkpoints=((B, NH, K, 1, F), f32), XQW=((B, NH, NC, CS, F), act))
+    for k, (shape, dt) in spec.items():
+        _check(t[k], k, shape, dt)
+    args = _MlpFwd(*[t[k].data_ptr() for k in MLP_FWD_FIELDS])
+    _launch("ttt_hip_mlp_forward", _dims(B, NH, NC, CS, F, G, act), args, XQ.device)
+
+
+def ttt_backward(XQ, XK, XV, last_eta, ttt_norm_weight, ttt_norm_bias, W1_checkpoints, b1_checkpoints, W2_checkpoints,
+                 b2_checkpoints, XQW_batch, W1_init_group, b1_init_group, W2_init_group, b2_init_group, x_hat_ln_group,
+                 std_ln_group, X2_group, Z1_group, Z1_bar_group, X2_bar_group, grad_l_wrt_Z2_group, grad_l_wrt_Z1_group,
+                 x_hat_fused_group, grad_x_hat_fused_group, grad_output_fused_group, std_fused_group, grad_L_W1_last,
+                 grad_L_b1_last, grad_L_W2_last, grad_L_b2_last, grad_L_XQW_batch, grad_L_ttt_norm_weight,
+                 grad_L_ttt_norm_bias, grad_L_W1_init, grad_L_b1_init, grad_L_W2_init, grad_L_b2_init, grad_L_last_eta,
+                 grad_L_XQ, grad_L_XK, grad_L_XV, checkpoint_group_size):
+    """TTT-MLP backward; the 42 tensors + 1 int of the reference call site mlp_tk.py:227-275."""
+    B, NH, NC, CS, F = XQ.shape
+    G = int(checkpoint_group_size)
+    K = -(-NC // G)
+    H = 4 * F
+    act, f32, bf = XQ.dtype, torch.float32, torch.bfloat16
+    vals = (XQ, XK, XV, last_eta, ttt_norm_weight, ttt_norm_bias, W1_checkpoints, b1_checkpoints, W2_checkpoints,
+            b2_checkpoints, XQW_batch, W1_init_group, b1_init_group, W2_init_group, b2_init_group, x_hat_ln_group,
+            std_ln_group, X2_group, Z1_group, Z1_bar_group, X2_bar_group, grad_l_wrt_Z2_group, grad_l_wrt_Z1_group,
+            x_hat_fused_group, grad_x_hat_fused_group, grad_output_fused_group, std_fused_group, grad_L_W1_last,
+            grad_L_b1_last, grad_L_W2_last, grad_L_b2_last, grad_L_XQW_batch, grad_L_ttt_norm_weight,
+            grad_L_ttt_norm_bias, grad_L_W1_init, grad_L_b1_init, grad_L_W2_init, grad_L_b2_init, grad_L_last_eta,
+            grad_L_XQ, grad_L_XK, grad_L_XV)
+    t = dict(zip(MLP_BWD_FIELDS, vals))
+    A = ((B, NH, NC, CS, F), act)
+    spec = dict(XQ=A, XK=A, XV=A, last_eta=((B, NH, NC, CS, 1), act),
+                ttt_norm_weight=((1, NH, 1, F), f32), ttt_norm_bias=((1, NH, 1, F), f32),
+                W1_checkpoints=((B, NH, K, F, H), f32), b1_checkpoints=((B, NH, K, 1, H), f32),
+                W2_checkpoints=((B, NH, K, H, F), f32), b2_checkpoints=((B, NH, K, 1, F), f32), XQW=A,
+                W1_init_group=((B, NH, G, F, H), f32), b1_init_group=((B, NH, G, 1, H), f32),
+                W2_init_group=((B, NH, G, H, F), f32), b2_init_group=((B, NH, G, 1, F), f32),
+                x_hat_ln_group=((B, NH, G, CS, F), bf), std_ln_group=((B, NH, G, CS, 1), f32),
+                X2_group=((B, NH, G, CS, H), bf), Z1_group=((B, NH, G, CS, H), bf), Z1_bar_group=((B, NH, G, CS, H), bf),
+                X2_bar_group=((B, NH, G, CS, H), bf), grad_l_wrt_Z2_group=((B, NH, G, CS, F), bf),
+                grad_l_wrt_Z1_group=((B, NH, G, CS, H), bf), x_hat_fused_group=((B, NH, G, CS, F), bf),
+                grad_x_hat_fused_group=((B, NH, G, CS, F), bf), grad_output_fused_group=((B, NH, G, CS, F), bf),
+                std_fused_group=((B, NH, G, CS, 1), f32),
+                grad_L_W1_last=((B, NH, F, H), f32), grad_L_b1_last=((B, NH, 1, H), f32),
+                grad_L_W2_last=((B, NH, H, F), f32), grad_L_b2_last=((B, NH, 1, F), f32), grad_L_XQW=A,
+                grad_L_ttt_norm_weight=((B, NH, 1, F), f32), grad_L_ttt_norm_bias=((B, NH, 1, F), f32),
+                grad_L_W1_init=((B, NH, F, H), f32), grad_L_b1_init=((B, NH, 1, H), f32),
+                grad_L_W2_init=((B, NH, H, F), f32), grad_L_b2_init=((B, NH, 1, F), f32),
+                grad_L_last_eta=((B, NH, NC, CS, 1), act), grad_L_XQ=A, grad_L_XK=A, grad_L_XV=A)
+    for k, (shape, dt) in spec.items():
+        _check(t[k], k, shape, dt)
+    args = _MlpBwd(*[t[k].data_ptr() for k in MLP_BWD_FIELDS])
+    _launch("ttt_hip_mlp_backward", _dims(B, NH, NC, CS, F, G, act), args, XQ.device)
+
+
+def ttt_linear_forward(XQ, XK, XV, last_eta, ttt_norm_weight, ttt_norm_bias, W1_init, b1_init, W1_checkpoints,
+                       b1_checkpoints, XQW_batch, checkpoint_group_size):
+    """TTT-Linear forward scan (replaces ttt_linear_scan_forward, linear_triton.py:98-129)."""
+    B, NH, NC, CS, F = XQ.shape
+    G = int(checkpoint_group_size)
+    K = -(-NC // G)
+    act, f32 = XQ.dtype, torch.float32
+    vals = (XQ, XK, XV, last_eta, ttt_norm_weight, ttt_norm_bias, W1_init, b1_init, W1_checkpoints, b1_checkpoints, XQW_batch)
+    t = dict(zip(LIN_FWD_FIELDS, vals))
+    A = ((B, NH, NC, CS, F), act)
+    spec = dict(XQ=A, XK=A, XV=A, last_eta=((B, NH, NC, CS, 1), act), ttt_norm_weight=((NH, F), f32),
+                ttt_norm_bias=((NH, F), f32), W1_init=((B, NH, F, F), f32), b1_init=((B, NH, 1, F), f32),
+                W1_checkpoints=((B, NH, K, F, F), f32), b1_checkpoints=((B, NH, K, 1, F), f32), XQW=A)
+    for k, (shape, dt) in spec.items():
+        _check(t[k], k, shape, dt)
+    args = _LinFwd(*[t[k].data_ptr() for k in LIN_FWD_FIELDS])
+    _launch("ttt_hip_linear_forward", _dims(B, NH, NC, CS, F, G, act), args, XQ.device)
+
+
+def ttt_linear_backward(XQ, XK, XV, last_eta, ttt_norm_weight, ttt_norm_bias, W1_checkpoints, b1_checkpoints,
+                        grad_L_W1_last, grad_L_b1_last, grad_L_XQW_batch, W1_init_group, b1_init_group,
+                        grad_L_ttt_norm_weight, grad_L_ttt_norm_bias, grad_L_W1_init, grad_L_b1_init, grad_L_last_eta,
+                        grad_L_XQ, grad_L_XK, grad_L_XV, checkpoint_group_size):
+    """TTT-Linear backward (replaces ttt_linear_scan_backward, linear_triton.py:203-246)."""
+    B, NH, NC, CS, F = XQ.shape
+    G = int(checkpoint_group_size)
+    K = -(-NC // G)
+    act, f32 = XQ.dtype, torch.float32
+    vals = (XQ, XK, XV, last_eta, ttt_norm_weight, ttt_norm_bias, W1_checkpoints, b1_checkpoints, grad_L_W1_last,
+            grad_L_b1_last, grad_L_XQW_batch, W1_init_group, b1_init_group, grad_L_ttt_norm_weight, grad_L_ttt_norm_bias,
+            grad_L_W1_init, grad_L_b1_init, grad_L_last_eta, grad_L_XQ, grad_L_XK, grad_L_XV)
+    t = dict(zip(LIN_BWD_FIELDS, vals))
+    A = ((B, NH, NC, CS, F), act)
+    spec = dict(XQ=A, XK=A, XV=A, last_eta=((B, NH, NC, CS, 1), act), ttt_norm_weight=((NH, F), f32),
+                ttt_norm_bias=((NH, F), f32), W1_checkpoints=((B, NH, K, F, F), f32), b1_checkpoints=((B, NH, K, 1, F), f32),
+                grad_L_W1_last=((B, NH, F, F), f32), grad_L_b1_last=((B, NH, 1, F), f32), grad_L_XQW=A,
+                W1_init_group=((B, NH, G, F, F), f32), b1_init_group=((B, NH, G, 1, F), f32),
+                grad_L_ttt_norm_weight=((B, NH, 1, F), f32), grad_L_ttt_norm_bias=((B, NH, 1, F), f32),
+                grad_L_W1_init=((B, NH, F, F), f32), grad_L_b1_init=((B, NH, 1, F), f32),
+                grad_L_last_eta=((B, NH, NC, CS, 1), act), grad_L_XQ=A, grad_L_XK=A, grad_L_XV=A)
+    for k, (shape, dt) in spec.items():
+        _check(t[k], k, shape, dt)
+    args = _LinBwd(*[t[k].data_ptr() for k in LIN_BWD_FIELDS])
+    _launch("ttt_hip_linear_backward", _dims(B, NH, NC, CS, F, G, act), args, XQ.device)

@@ -1,0 +1,76 @@
+"""Process-group set-up and FSDP wrapping for one 8xMI355X node.
+
+``apply_fsdp`` is the behavioural mirror of the reference's ``ttt/infra/parallelisms.py:155-175``:
+FSDP2 ``fully_shard`` on every ``TransformerLayer`` and on the DiT root, ``reshard_after_forward``,
+bf16 parameters / fp32 gradient reduction.  Backend string ``"nccl"`` is RCCL on ROCm; on one node
+the collectives run over xGMI.  Tensor parallelism (reference :106-152) is a next-row item.
+"""
+from __future__ import annotations
+
+import os
+from datetime import timedelta
+
+import torch
+import torch.distributed as dist
+from torch.distributed.device_mesh import init_device_mesh
+from torch.distributed.fsdp import MixedPrecisionPolicy, fully_shard
+
+
+def init_distributed(backend: str | None = None, timeout_s: int = 600):
+    """One process per GPU (torchrun env: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)."""
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
+        os.environ.setdefault("TORCH_NCCL_AVOID_RECORD_STREAMS", "1")   # reference parallelisms.py:36
+    if not dist.is_initialized():
+        dist.init_process_group(backend, timeout=timedelta(seconds=timeout_s))
+    return dist.get_rank(), dist.get_world_size()
+
+
+def end_distributed():
+    if dist.is_initialized():
+        if torch.cuda.is_available():
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+            torch.cuda.synchronize()
+        else:
+            dist.barrier()
+        dist.destroy_process_group()
+
+
+def get_dp_mesh(dp_shard: int | None = None, dp_replicate: int = 1):
+    world = dist.get_world_size()
+    dp_shard = dp_shard or world // dp_replicate
+    assert dp_shard * dp_replicate == world, "world size must equal dp_replicate * dp_shard"
+    dev = "cuda" if torch.cuda.is_available() else "cpu"
+    if dp_replicate > 1:   # HSDP (reference :160-162)
+        return init_device_mesh(dev, (dp_replicate, dp_shard), mesh_dim_names=("dp_replicate", "dp_shard"))
+    return init_device_mesh(dev, (dp_shard,), mesh_dim_names=("dp_shard",))
+
+
+def apply_fsdp(model, dp_mesh, param_dtype=torch.bfloat16, reduce_dtype=torch.float32):
+    """Shard every transformer layer, then the DiT root; nothing outside the DiT (reference :164-175)."""
+    mp = MixedPrecisionPolicy(param_dtype=param_dtype, reduce_dtype=reduce_dtype)
+    dit = model.dit if hasattr(model, "dit") else model
+    for layer in dit.layers:
+        fully_shard(layer, mesh=dp_mesh, mp_policy=mp, reshard_after_forward=True)
+    fully_shard(dit, mesh=dp_mesh, mp_policy=mp, reshard_after_forward=True)
+    return model
+
+
+def init_model_parameters(model, initializer_range: float = 0.02):
+    """N(0, 0.02) weights / zero biases everywhere except TTT modules, which initialise themselves
+    (reference :178-196)."""
+    from ttt_amd.models.ssm.ttt_layer import TTTBase
+
+    for module in model.modules():
+        if isinstance(module, TTTBase):
+            module.init_weights()
+            continue
+        for name, p in module.named_parameters(recurse=False):
+            if p is None:
+                continue
+            if "bias" in name:
+                torch.nn.init.zeros_(p)
+            else:
+                torch.nn.init.normal_(p, mean=0.0, std=initializer_range)

@@ -1,0 +1,272 @@
+"""CogVideoX DiT with TTT layers: host-side (PyTorch-ROCm) assembly of the block that surrounds the
+TTT scan.  Class names, constructor signatures, parameter names (state-dict keys) and numerical
+behaviour follow the reference's ``ttt/models/cogvideo/dit.py`` (PatchEmbedding :17-40, MLP
+:43-87, SSMGating :90-103, SeqModelingBlock :106-278, TransformerLayer :281-382, FinalLayer
+:385-418, DiffusionTransformer :421-505).
+
+Dense projections / MLP GEMMs go to hipBLASLt through PyTorch; the TTT scan goes to the
+hand-written gfx950 kernels (``ttt_amd.models.ssm``); local attention goes through
+``segment_attention`` below.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+from torch.utils.checkpoint import checkpoint
+
+from ttt_amd.models.cogvideo.utils import (Rotary3DPositionEmbedding, SequenceMetadata, modulate,
+                                           timestep_embedding, unpatchify)
+from ttt_amd.models.configs import ModelConfig
+from ttt_amd.models.ssm.ttt_layer import TTTWrapper
+
+
+def _ckpt(fn, enabled: bool):
+    if not enabled:
+        return fn
+    return lambda *a: checkpoint(fn, *a, use_reentrant=False)
+
+
+def segment_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+    """Non-causal self-attention over one 3-second segment, [B, NH, S, D] (reference dit.py:196-198)."""
+    return F.scaled_dot_product_attention(q, k, v, attn_mask=None, dropout_p=0.0, is_causal=False)
+
+
+class PatchEmbedding(nn.Module):
+    """2x2 patch conv for video latents + Linear for text (reference :17-40)."""
+
+    def __init__(self, config: ModelConfig):
+        super().__init__()
+        train = config.adapter_method == "sft"
+        self.vid_proj = nn.Conv2d(config.in_channels, config.model_dim, config.patch_size, config.patch_size, bias=True).requires_grad_(train)
+        self.text_proj = nn.Linear(config.text_dim, config.model_dim, bias=True).requires_grad_(train)
+
+    def forward(self, video, text_encoding):
+        b, t = video.shape[:2]
+        x = self.vid_proj(video.flatten(0, 1))                       # [(b t), D, h, w]
+        x = x.flatten(2).transpose(1, 2).reshape(b, -1, x.shape[1])  # [b, t*h*w, D]
+        return self.text_proj(text_encoding).contiguous(), x.contiguous()
+
+
+class MLP(nn.Module):
+    """3072 -> 12288 -> 3072 with tanh-GELU (reference :43-87)."""
+
+    def __init__(self, config: ModelConfig):
+        super().__init__()
+        train = config.adapter_method == "sft"
+        self.do_remat = config.remat_mlp
+        self.requires_grad = train
+        self.layer1 = nn.Linear(config.model_dim, 4 * config.model_dim, bias=True).requires_grad_(train)
+        self.layer2 = nn.Linear(4 * config.model_dim, config.model_dim, bias=True).requires_grad_(train)
+        self.tp_mesh = None
+
+    def _run(self, x):
+        return self.layer2(F.gelu(self.layer1(x), approximate="tanh"))
+
+    def forward(self, x):
+        return _ckpt(self._run, self.do_remat)(x)
+
+
+class SSMGating(nn.Module):
+    """``tanh(alpha) * x`` with a learned per-channel alpha (reference :90-103)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.gating_alpha = nn.Parameter(torch.ones(config.model_dim) * config.gating_alpha_init)
+
+    def forward(self, x):
+        return torch.tanh(self.gating_alpha) * x
+
+
+class SeqModelingBlock(nn.Module):
+    """Local (per 3 s segment) attention followed by a bidirectional, weight-shared TTT pass
+    (reference :106-278)."""
+
+    def __init__(self, config: ModelConfig):
+        super().__init__()
+        train = config.adapter_method in ("sft", "qkvo")
+        assert config.adapter_method in ("sft", "qkvo", "none"), f"Invalid adapter method: {config.adapter_method}"
+        self.do_attn_remat = config.remat_attention
+        self.do_forward_ssm_remat = config.remat_forward_ssm
+        self.do_reverse_ssm_remat = config.remat_reverse_ssm
+        self.num_heads = config.num_heads
+        self.head_dim = config.model_dim // config.num_heads
+        self.prefix_temporal_length = config.prefix_temporal_length
+        self.attn_length = config.attn_length
+
+        self.q_norm = nn.LayerNorm(self.head_dim, eps=config.layer_norm_eps).requires_grad_(train)
+        self.k_norm = nn.LayerNorm(self.head_dim, eps=config.layer_norm_eps).requires_grad_(train)
+        self.rotary = Rotary3DPositionEmbedding(config.latent_height, config.latent_width, config.compressed_num_frames,
+                                                self.head_dim, config.theta)
+        D = config.model_dim
+        self.q = nn.Linear(D, D, bias=True)
+        self.k = nn.Linear(D, D, bias=True)
+        self.v = nn.Linear(D, D, bias=True)
+        self.o = nn.Linear(D, D, bias=True)
+        self.ssm = TTTWrapper(config)
+        self.forward_ssm_gating_video = SSMGating(config)
+        self.forward_ssm_gating_text = SSMGating(config)
+        self.backward_ssm_gating_video = SSMGating(config)
+        self.backward_ssm_gating_text = SSMGating(config)
+
+    # -- local attention ------------------------------------------------------------------------
+    def _segment(self, emb, n_text):
+        """q/k/v projections, per-head LayerNorm on q,k, 3-D RoPE on the video tokens, SDPA, o."""
+        b, s, _ = emb.shape
+        heads = lambda t: t.view(b, s, self.num_heads, self.head_dim).transpose(1, 2)   # [b, h, s, d]
+        q, k, v = heads(self.q(emb)), heads(self.k(emb)), heads(self.v(emb))
+        q, k = self.q_norm(q), self.k_norm(k)
+        q = torch.cat((q[:, :, :n_text], self.rotary(q[:, :, n_text:])), dim=2)
+        k = torch.cat((k[:, :, :n_text], self.rotary(k[:, :, n_text:])), dim=2)
+        a = segment_attention(q, k, v)
+        return self.o(a.transpose(1, 2).reshape(b, s, -1))
+
+    def _attn_forward(self, vid_emb, text_emb, seq_metadata: SequenceMetadata):
+        """Each segment i attends over [text_i, frames 12i .. 12(i+1)] (13 frames, 1 shared with its
+        neighbour); the shared frame's outputs are averaged (reference :163-211)."""
+        tl, tpf = seq_metadata.text_length, seq_metadata.tokens_per_frame
+        out_vid = torch.zeros_like(vid_emb)
+        out_txt = torch.zeros_like(text_emb)
+        count = torch.zeros_like(vid_emb[..., :1])
+        for i in range(seq_metadata.num_chunks):
+            lo = i * self.attn_length * tpf
+            hi = (self.prefix_temporal_length + (i + 1) * self.attn_length) * tpf
+            seg = torch.cat((text_emb[:, i * tl:(i + 1) * tl], vid_emb[:, lo:hi]), dim=1)
+            o = self._segment(seg, tl)
+            out_txt[:, i * tl:(i + 1) * tl] = o[:, :tl]
+            out_vid[:, lo:hi] += o[:, tl:]
+            count[:, lo:hi] += 1
+        return torch.cat((out_txt, out_vid / count), dim=1)
+
+    # -- bidirectional TTT ------------------------------------------------------------------------
+    @staticmethod
+    def _reverse_text_chunks(text_emb, num_chunks):
+        b, n, e = text_emb.shape
+        return text_emb.view(b, num_chunks, n // num_chunks, e).flip(1).reshape(b, n, e)
+
+    def _gate(self, text_gate, video_gate, residual, ssm_output, n_text):
+        return residual + torch.cat((text_gate(ssm_output[:, :n_text]), video_gate(ssm_output[:, n_text:])), dim=1)
+
+    def _flip_sequence(self, emb, n_text, meta):
+        """Time-reverse: flip all video tokens, reverse the order of the per-scene text chunks."""
+        txt = emb[:, :n_text]
+        if meta.is_multiscene:
+            txt = self._reverse_text_chunks(txt, meta.num_chunks)
+        return torch.cat((txt, emb[:, n_text:].flip(1)), dim=1)
+
+    def _ssm_forward(self, emb, seq_metadata: SequenceMetadata):
+        """forward TTT -> gated residual -> time-reversed TTT with the same weights -> gated residual
+        (reference :224-266)."""
+        n_text = seq_metadata.seq_text_length
+        fwd = _ckpt(self.ssm, self.do_forward_ssm_remat)
+        rev = _ckpt(self.ssm, self.do_reverse_ssm_remat)
+        emb = self._gate(self.forward_ssm_gating_text, self.forward_ssm_gating_video, emb, fwd(emb, seq_metadata), n_text)
+        y = rev(self._flip_sequence(emb, n_text, seq_metadata), seq_metadata)
+        y = self._flip_sequence(y, n_text, seq_metadata)
+        return self._gate(self.backward_ssm_gating_text, self.backward_ssm_gating_video, emb, y, n_text)
+
+    def forward(self, vid_emb, text_emb, seq_metadata: SequenceMetadata):
+        x = _ckpt(self._attn_forward, self.do_attn_remat)(vid_emb, text_emb, seq_metadata)
+        x = self._ssm_forward(x, seq_metadata)
+        n_text = seq_metadata.seq_text_length
+        return x[:, n_text:], x[:, :n_text]
+
+
+class TransformerLayer(nn.Module):
+    """AdaLN-modulated sequence block + AdaLN-modulated MLP, separate modulation for video and text
+    tokens (reference :281-382)."""
+
+    def __init__(self, config):
+        super().__init__()
+        train = config.adapter_method == "sft"
+        self.remat_seq_modeling_block = config.remat_seq_modeling_block
+        self.tp_mesh = None
+        D = config.model_dim
+        self.pre_seq_layernorm = nn.LayerNorm(D, eps=config.layer_norm_eps).requires_grad_(train)
+        self.pre_seq_adaLN_modulation = nn.Sequential(nn.SiLU(), nn.Linear(config.time_embed_dim, 6 * D, bias=True).requires_grad_(train))
+        self.seq_modeling_block = SeqModelingBlock(config)
+        self.pre_mlp_layernorm = nn.LayerNorm(D, eps=config.layer_norm_eps).requires_grad_(train)
+        self.pre_mlp_adaLN_modulation = nn.Sequential(nn.SiLU(), nn.Linear(config.time_embed_dim, 6 * D, bias=True).requires_grad_(train))
+        self.mlp = MLP(config)
+
+    def forward(self, vid_emb, text_emb, seq_metadata: SequenceMetadata):
+        n_text = seq_metadata.seq_text_length
+        t = seq_metadata.t_emb
+        sh_v, sc_v, g_v, sh_t, sc_t, g_t = self.pre_seq_adaLN_modulation(t).chunk(6, dim=1)
+        block = _ckpt(self.seq_modeling_block, self.remat_seq_modeling_block)
+        v_out, t_out = block(modulate(self.pre_seq_layernorm(vid_emb), sh_v, sc_v),
+                             modulate(self.pre_seq_layernorm(text_emb), sh_t, sc_t), seq_metadata)
+        vid_emb = vid_emb + g_v.unsqueeze(1) * v_out
+        text_emb = text_emb + g_t.unsqueeze(1) * t_out
+
+        sh_v, sc_v, g_v, sh_t, sc_t, g_t = self.pre_mlp_adaLN_modulation(t).chunk(6, dim=1)
+        x = torch.cat((modulate(self.pre_mlp_layernorm(text_emb), sh_t, sc_t),
+                       modulate(self.pre_mlp_layernorm(vid_emb), sh_v, sc_v)), dim=1)
+        y = self.mlp(x)
+        vid_emb = vid_emb + g_v.unsqueeze(1) * y[:, n_text:]
+        text_emb = text_emb + g_t.unsqueeze(1) * y[:, :n_text]
+        return vid_emb, text_emb
+
+
+class FinalLayer(nn.Module):
+    """AdaLN + Linear to patch pixels + unpatchify (reference :385-418)."""
+
+    def __init__(self, config: ModelConfig):
+        super().__init__()
+        train = config.adapter_method == "sft"
+        self.out_channels = config.out_channels
+        self.patch_size = config.patch_size
+        self.adaLN_modulation = nn.Sequential(nn.SiLU(), nn.Linear(config.time_embed_dim, 2 * config.model_dim, bias=True).requires_grad_(train))
+        self.norm = nn.LayerNorm(config.model_dim, elementwise_affine=True, eps=config.layer_norm_eps).requires_grad_(train)
+        self.linear = nn.Linear(config.model_dim, config.patch_size * config.patch_size * self.out_channels, bias=True).requires_grad_(train)
+
+    def forward(self, vid_emb, seq_metadata: SequenceMetadata):
+        shift, scale = self.adaLN_modulation(seq_metadata.t_emb).chunk(2, dim=1)
+        x = self.linear(modulate(self.norm(vid_emb), shift, scale))
+        return unpatchify(x, c=self.out_channels, p=self.patch_size, w=seq_metadata.latent_width // self.patch_size,
+                          h=seq_metadata.latent_height // self.patch_size)
+
+
+class DiffusionTransformer(nn.Module):
+    """forward(video [B,T,16,H,W], text [B,n_scenes,S,text_dim], timesteps [B]) -> [B,T,16,H,W]
+    (reference :421-505).  Layers are re-materialised in groups of
+    ``remat_transformer_layer_group_size`` during backward."""
+
+    def __init__(self, config):
+        super().__init__()
+        train = config.adapter_method == "sft"
+        self.frames_per_chunk = config.attn_length
+        self.remat_transformer_layer_group_size = config.remat_transformer_layer_group_size
+        assert config.num_layers % self.remat_transformer_layer_group_size == 0, "Remat group size must be divisible into num layers"
+        self.model_dim = config.model_dim
+        self.shard_transformer_inputs = config.shard_transformer_inputs
+        self.time_embed = nn.Sequential(
+            nn.Linear(config.model_dim, config.time_embed_dim, bias=True).requires_grad_(train), nn.SiLU(),
+            nn.Linear(config.time_embed_dim, config.time_embed_dim, bias=True).requires_grad_(train))
+        self.patch_embedding = PatchEmbedding(config)
+        self.layers = nn.ModuleList([TransformerLayer(config) for _ in range(config.num_layers)])
+        self.transformer_norm = nn.LayerNorm(config.model_dim, eps=config.layer_norm_eps).requires_grad_(train)
+        self.final_layer = FinalLayer(config)
+
+    def _run_group(self, start, vid_emb, text_emb, seq_metadata):
+        for layer in self.layers[start:start + self.remat_transformer_layer_group_size]:
+            vid_emb, text_emb = layer(vid_emb, text_emb, seq_metadata)
+        return vid_emb, text_emb
+
+    def forward(self, video, text, timesteps):
+        num_frames, height, width = video.shape[1], video.shape[3], video.shape[4]
+        t_emb = self.time_embed(timestep_embedding(timesteps, self.model_dim, dtype=video.dtype))
+        text_emb, vid_emb = self.patch_embedding(video, text)      # [B,n,S,D], [B,T*h*w,D]
+        n_scenes, text_len = text_emb.shape[1], text.shape[-2]
+        meta = SequenceMetadata(text_length=text_len, seq_text_length=text_len * n_scenes, num_frames=num_frames,
+                                num_chunks=n_scenes, tokens_per_frame=vid_emb.shape[1] // num_frames,
+                                latent_height=height, latent_width=width, t_emb=t_emb)
+        if meta.is_multiscene:
+            meta.init_multiscene_offsets()
+        text_emb = text_emb.flatten(1, 2)
+        for i in range(0, len(self.layers), self.remat_transformer_layer_group_size):
+            if torch.is_grad_enabled():
+                vid_emb, text_emb = checkpoint(self._run_group, i, vid_emb, text_emb, meta, use_reentrant=False)
+            else:
+                vid_emb, text_emb = self._run_group(i, vid_emb, text_emb, meta)
+        return self.final_layer(self.transformer_norm(vid_emb), meta)

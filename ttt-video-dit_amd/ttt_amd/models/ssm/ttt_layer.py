@@ -1,0 +1,295 @@
+"""TTT layer modules: ``TTTWrapper`` -> ``TTTMLP`` | ``TTTLinear`` (on ``TTTBase``).
+
+Public surface, constructor arguments, parameter names/shapes (state-dict keys) and numerical
+behaviour follow the reference's ``ttt/models/ssm/ttt_layer.py`` (TTTWrapper :17-50, TTTBase
+:53-334, TTTLinear :337-398, TTTMLP :401-473) so reference checkpoints load unchanged.  The scan
+itself runs on the gfx950 HIP kernels behind ``TkMLP`` / ``HipLinear`` (``use_kernel=True``, the
+default) or, on explicit request, in dual form in PyTorch (``use_kernel=False``).
+
+MI355X-first differences in how the same math is organised:
+  * the multi-scene interleave / undo-interleave (reference :157-217) are single gathers through
+    a cached permutation instead of chunk/cat chains, and the same permutation yields the
+    per-mini-batch eta row directly;
+  * on the kernel path eta is never expanded to the ``[CS,CS]`` tile (64x redundant; the kernels
+    read one row, mlp_tk.py:105): only ``[B,NH,NC,1,CS]`` is produced.  The full tile is built
+    only for ``use_kernel=False``, whose dual form consumes it.
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ttt_amd.models.cogvideo.utils import SequenceMetadata
+from ttt_amd.models.configs import ModelConfig
+from ttt_amd.models.ssm.linear_hip import HipLinear, TritonLinear  # noqa: F401
+from ttt_amd.models.ssm.mlp_tk import TkMLP
+from ttt_amd.models.ssm.ops import ttt_linear, ttt_mlp
+from ttt_amd.models.ssm.utils import apply_rotary_emb, precompute_freqs_cis_3d
+
+
+class TTTWrapper(nn.Module):
+    """Selects the TTT variant from ``config.ssm_layer`` and owns the 3-D RoPE table (reference :17-50)."""
+
+    def __init__(self, config: ModelConfig):
+        super().__init__()
+        self.model_dim = config.model_dim
+        self.num_heads = config.num_heads
+        self.rope_theta = config.rope_theta
+        self.latent_height = config.latent_height
+        self.latent_width = config.latent_width
+        self.compressed_num_frames = config.compressed_num_frames
+        if config.ssm_layer == "ttt_linear":
+            self.ttt = TTTLinear(config)
+        elif config.ssm_layer == "ttt_mlp":
+            self.ttt = TTTMLP(config)
+        else:
+            raise TypeError(f"No ttt layer of type {config.ssm_layer}")
+        self.register_buffer("freqs_cis", self._precompute_freqs_cis_3d(), persistent=False)
+
+    def _precompute_freqs_cis_3d(self) -> torch.Tensor:
+        # stored as fp32 (cos, sin) pairs rather than complex64: same values, safe under .to(dtype)
+        return precompute_freqs_cis_3d(self.model_dim // self.num_heads, self.latent_height, self.latent_width,
+                                       self.compressed_num_frames, self.rope_theta, as_real=True)
+
+    def _apply(self, fn, recurse=True):
+        table = self.freqs_cis
+        super()._apply(fn, recurse)
+        if self.freqs_cis.dtype != torch.float32 and not self.freqs_cis.is_meta:   # follow device moves, refuse down-casts
+            self.freqs_cis = table.to(self.freqs_cis.device)
+        return self
+
+    def init_freqs(self):
+        self.freqs_cis.copy_(self._precompute_freqs_cis_3d())
+
+    def forward(self, x: torch.Tensor, seq_metadata: SequenceMetadata):
+        return self.ttt(x, self.freqs_cis, seq_metadata)
+
+
+def scene_permutation(meta: SequenceMetadata, seq_len: int) -> torch.Tensor:
+    """Index ``p`` with ``interleaved = tokens[p]``: [text_0..text_n, video] -> [text_0 video_0 text_1
+    video_1 ...] where scene 0 owns the remainder frame(s) (reference interleave :157-186 with the
+    offsets of cogvideo/utils.py:16-26)."""
+    n, tl = meta.num_chunks, meta.text_length
+    first = meta.init_offset - tl              # video tokens of scene 0
+    rest = meta.base_offset - tl               # video tokens of every later scene
+    txt = n * tl
+    parts, v = [], txt
+    for s in range(n):
+        parts.append(torch.arange(s * tl, (s + 1) * tl))
+        nv = first if s == 0 else rest
+        parts.append(torch.arange(v, v + nv))
+        v += nv
+    p = torch.cat(parts)
+    if p.numel() != seq_len or v != seq_len:
+        raise ValueError("sequence length does not match the scene layout in SequenceMetadata")
+    return p
+
+
+class TTTBase(nn.Module):
+    def __init__(self, config: ModelConfig):
+        super().__init__()
+        self.config = config
+        self.width = config.model_dim
+        self.num_heads = config.num_heads
+        self.head_dim = config.model_dim // config.num_heads
+        self.mini_batch_size = config.mini_batch_size
+        self.ttt_base_lr = config.ttt_base_lr
+        self.scan_checkpoint_group_size = config.scan_checkpoint_group_size
+        self.tp_mesh = None
+        self.use_kernel = True
+
+        D, NH, Fh = self.width, self.num_heads, self.head_dim
+        self.wq = nn.Linear(D, NH * Fh, bias=True)
+        self.wk = nn.Linear(D, NH * Fh, bias=True)
+        self.wv = nn.Linear(D, NH * Fh, bias=True)
+        self.wo = nn.Linear(D, NH * Fh, bias=True)
+        # per-head learning-rate gate: one Linear(D,1) per head, stacked (reference :91-106)
+        self.learnable_ttt_lr_weight = nn.Parameter(torch.normal(0, 0.02, size=(NH, 1, D)))
+        self.learnable_ttt_lr_bias = nn.Parameter(torch.zeros(NH, 1))
+        # per-head LayerNorm affine of the inner loop (reference :108-112)
+        self.ttt_norm_weight = nn.Parameter(torch.ones(NH, Fh))
+        self.ttt_norm_bias = nn.Parameter(torch.zeros(NH, Fh))
+        self.post_norm = nn.LayerNorm(D, eps=1e-6)
+        self._perm_cache: Dict[tuple, tuple] = {}
+
+    # -- initialisation -------------------------------------------------------------------------
+    def init_weights(self):
+        """Re-initialise after meta-device construction (reference :74-83)."""
+        for lin in (self.wq, self.wk, self.wv, self.wo):
+            nn.init.normal_(lin.weight, mean=0.0, std=0.02)
+        self.post_norm.reset_parameters()
+        nn.init.ones_(self.ttt_norm_weight)
+        nn.init.zeros_(self.ttt_norm_bias)
+        nn.init.normal_(self.learnable_ttt_lr_weight, mean=0.0, std=0.02)
+        nn.init.zeros_(self.learnable_ttt_lr_bias)
+
+    def init_device_mesh(self, tp_mesh):
+        raise NotImplementedError("head-sharded tensor parallelism is a next-row item (SURVEY.md 8f #2); "
+                                  "the MI355X target runs FSDP-only (288 GB HBM per GPU)")
+
+    # -- pieces of process_input ------------------------------------------------------------------
+    def get_qkv_projections(self, hidden_states):
+        return self.wq(hidden_states), self.wk(hidden_states), self.wv(hidden_states)
+
+    def get_eta(self, X):
+        """Per-token inner-loop learning rate ``base_lr * sigmoid(x.w_h + b_h) / head_dim`` as
+        ``[B, NH, NC, 1, CS]`` from mini-batched ``X [B, NC, CS, D]`` (reference :143-155)."""
+        w = self.learnable_ttt_lr_weight.squeeze(1)                    # [NH, D]
+        logits = F.linear(X, w.to(X.dtype), self.learnable_ttt_lr_bias.reshape(-1).to(X.dtype))   # [B,NC,CS,NH]
+        lr = torch.sigmoid(logits).permute(0, 3, 1, 2).unsqueeze(3)    # [B,NH,NC,1,CS]
+        return self.ttt_base_lr * lr / self.head_dim
+
+    def _perm(self, meta: SequenceMetadata, L: int, device):
+        key = (meta.num_chunks, meta.text_length, meta.init_offset, meta.base_offset, L, str(device))
+        hit = self._perm_cache.get(key)
+        if hit is None:
+            p = scene_permutation(meta, L)
+            inv = torch.empty_like(p)
+            inv[p] = torch.arange(L)
+            hit = (p.to(device), inv.to(device))
+            self._perm_cache[key] = hit
+        return hit
+
+    def interleave(self, x: torch.Tensor, seq_metadata: SequenceMetadata):
+        """[B,NH,NC,CS,*] tokens in [texts, video] order -> scene-interleaved order (reference :157-186)."""
+        B, H, NC, C, HD = x.shape
+        p, _ = self._perm(seq_metadata, NC * C, x.device)
+        return x.reshape(B, H, NC * C, HD).index_select(2, p).reshape(B, H, NC, C, HD)
+
+    def undo_interleave(self, x: torch.Tensor, seq_metadata: SequenceMetadata):
+        """[B,L,D] scene-interleaved -> [texts, video] order (reference :188-217)."""
+        _, inv = self._perm(seq_metadata, x.shape[1], x.device)
+        return x.index_select(1, inv)
+
+    def ln_reconstruction_target(self, XV, XK):
+        """``gamma_h * LN(XV - XK) + beta_h + XK`` with *unbiased* std and eps added to the std
+        (reference :219-235).  XV/XK are [B, L, NH, F]; computed in fp32, returned in XV's dtype."""
+        d = XV.float() - XK.float()
+        mean = d.mean(dim=-1, keepdim=True)
+        std = d.std(dim=-1, keepdim=True)
+        d = (d - mean) / (std + 1e-8)
+        out = self.ttt_norm_weight.float()[None, None] * d + self.ttt_norm_bias.float()[None, None] + XK.float()
+        return out.to(XV.dtype)
+
+    def reshape_to_mini_batch(self, X, XQ, XK, XV):
+        """[B,L,NH,F] -> [B,NH,NC,CS,F] and X -> [B,NC,CS,D] (reference :237-250)."""
+        B, L = X.shape[:2]
+        NC, CS = L // self.mini_batch_size, self.mini_batch_size
+        mb = lambda t: t.transpose(1, 2).reshape(B, self.num_heads, NC, CS, self.head_dim)
+        return X.reshape(B, NC, CS, self.width), mb(XQ), mb(XK), mb(XV)
+
+    def process_input(self, hidden_states, freqs_cis, seq_metadata: SequenceMetadata):
+        """Projections, L2-norm, 3-D RoPE on video tokens, LN reconstruction target, mini-batching,
+        eta, scene interleave (reference :252-306).  Returns XQ/XK/XV [B,NH,NC,CS,F] and eta -
+        ``[B,NH,NC,1,CS]`` on the kernel path, the full ``[B,NH,NC,CS,CS]`` tile otherwise."""
+        n_text = seq_metadata.seq_text_length
+        B, L = hidden_states.shape[:2]
+        CS = self.mini_batch_size
+        XQ, XK, XV = self.get_qkv_projections(hidden_states)
+        XQ = F.normalize(XQ.view(B, L, -1, self.head_dim), p=2, dim=-1)
+        XK = F.normalize(XK.view(B, L, -1, self.head_dim), p=2, dim=-1)
+        XV = XV.view(B, L, -1, self.head_dim)
+
+        rq, rk = apply_rotary_emb(XQ[:, n_text:], XK[:, n_text:], freqs_cis=freqs_cis)
+        XQ = torch.cat((XQ[:, :n_text], rq), dim=1)
+        XK = torch.cat((XK[:, :n_text], rk), dim=1)
+        XV = self.ln_reconstruction_target(XV, XK)
+
+        X, XQ, XK, XV = self.reshape_to_mini_batch(hidden_states, XQ, XK, XV)
+        eta_row = self.get_eta(X) / CS                                   # [B,NH,NC,1,CS]  (reference :288)
+        NC = eta_row.shape[2]
+
+        if seq_metadata.is_multiscene:
+            XQ = self.interleave(XQ, seq_metadata)
+            XK = self.interleave(XK, seq_metadata)
+            XV = self.interleave(XV, seq_metadata)
+            # The reference interleaves the ROWS of the tiled eta (:294): the token landing at row i of
+            # new mini-batch m brings the lr row of the mini-batch it came from.
+            p, _ = self._perm(seq_metadata, L, XQ.device)
+            src_mb = torch.div(p, CS, rounding_mode="floor")             # [L] original mini-batch of each slot
+            if self.use_kernel:
+                eta = eta_row.index_select(2, src_mb[CS - 1::CS])        # last row of every new tile
+            else:
+                eta = eta_row.squeeze(3).index_select(2, src_mb).reshape(B, self.num_heads, NC, CS, CS)
+        else:
+            eta = eta_row if self.use_kernel else eta_row.expand(-1, -1, -1, CS, -1)
+        return {"XQ": XQ, "XK": XK, "XV": XV, "eta": eta}
+
+    def ttt(self, inputs):
+        raise NotImplementedError("ttt method must be implemented in TTTBase subclasses.")
+
+    def forward(self, hidden_states: torch.Tensor, freqs_cis: torch.Tensor, seq_metadata: SequenceMetadata):
+        assert hidden_states.size(1) % self.config.mini_batch_size == 0, "Sequence len must be multiple of mini batch size."
+        y = self.ttt(self.process_input(hidden_states, freqs_cis, seq_metadata))
+        y = self.wo(self.post_norm(y))
+        if seq_metadata.is_multiscene:
+            y = self.undo_interleave(y, seq_metadata)
+        return y
+
+    # helpers shared by the two variants
+    def _group_size(self, num_mini_batch: int) -> int:
+        return min(max(self.config.scan_checkpoint_group_size, 1), num_mini_batch)   # reference :368,:439
+
+    @staticmethod
+    def _per_batch(p: torch.Tensor, B: int) -> torch.Tensor:
+        return p.unsqueeze(0).expand(B, *p.shape)   # kernels read it; no need to materialise B copies
+
+
+class TTTLinear(TTTBase):
+    def __init__(self, config: ModelConfig, use_kernel: bool = True):
+        super().__init__(config)
+        self.W1 = nn.Parameter(torch.normal(0, 0.02, size=(self.num_heads, self.head_dim, self.head_dim)))
+        self.b1 = nn.Parameter(torch.zeros(self.num_heads, 1, self.head_dim))
+        self.use_kernel = use_kernel
+
+    def init_weights(self):
+        super().init_weights()
+        nn.init.normal_(self.W1, mean=0.0, std=0.02)
+        nn.init.zeros_(self.b1)
+
+    def ttt(self, inputs):
+        B, _, NC, CS, _ = inputs["XV"].shape
+        W1, b1 = self._per_batch(self.W1, B), self._per_batch(self.b1, B)
+        G = self._group_size(NC)
+        if self.use_kernel:
+            out = HipLinear.apply(self.ttt_norm_weight, self.ttt_norm_bias, W1, b1, inputs["XQ"], inputs["XV"],
+                                  inputs["XK"], inputs["eta"], G)
+            out = out.permute(0, 2, 3, 1, 4)
+        else:
+            out = ttt_linear(inputs["XK"], inputs["XQ"], inputs["XV"], inputs["eta"], self.ttt_norm_weight,
+                             self.ttt_norm_bias, W1, b1, G)
+        return out.reshape(B, NC * CS, self.width)
+
+
+class TTTMLP(TTTBase):
+    def __init__(self, config: ModelConfig, use_kernel: bool = True):
+        super().__init__(config)
+        NH, Fh = self.num_heads, self.head_dim
+        self.W1 = nn.Parameter(torch.normal(0, 0.02, size=(NH, Fh, 4 * Fh)))
+        self.b1 = nn.Parameter(torch.zeros(NH, 1, 4 * Fh))
+        self.W2 = nn.Parameter(torch.normal(0, 0.02, size=(NH, 4 * Fh, Fh)))
+        self.b2 = nn.Parameter(torch.zeros(NH, 1, Fh))
+        self.use_kernel = use_kernel
+
+    def init_weights(self):
+        super().init_weights()
+        nn.init.normal_(self.W1, mean=0.0, std=0.02)
+        nn.init.zeros_(self.b1)
+        nn.init.normal_(self.W2, mean=0.0, std=0.02)
+        nn.init.zeros_(self.b2)
+
+    def ttt(self, inputs):
+        B, _, NC, CS, _ = inputs["XV"].shape
+        st = [self._per_batch(p, B) for p in (self.W1, self.b1, self.W2, self.b2)]
+        G = self._group_size(NC)
+        if self.use_kernel:
+            out = TkMLP.apply(self.ttt_norm_weight, self.ttt_norm_bias, *st, inputs["XQ"], inputs["XV"], inputs["XK"],
+                              inputs["eta"], G)
+            out = out.permute(0, 2, 3, 1, 4)
+        else:
+            out = ttt_mlp(inputs["XK"], inputs["XQ"], inputs["XV"], inputs["eta"], self.ttt_norm_weight,
+                          self.ttt_norm_bias, *st, G)
+        return out.reshape(B, NC * CS, self.width)
