@@ -126,10 +126,15 @@ def _check(t: torch.Tensor, name: str, shape, dtype) -> None:
         raise RuntimeError(f"{name}: tensor must live on a HIP device (got {t.device}); there is no CPU path")
     if t.dtype != dtype:
         raise RuntimeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
-    if tuple(t.shape) != tuple(shape):
+    if shape is not None and tuple(t.shape) != tuple(shape):
         raise RuntimeError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
     if not t.is_contiguous():
         raise RuntimeError(f"{name}: tensor must be contiguous")
+
+
+def _check5(XQ) -> None:
+    if not isinstance(XQ, torch.Tensor) or XQ.ndim != 5:
+        raise RuntimeError("XQ: expected a 5-D tensor [B, NH, NC, CS, F]")
 
 
 def _dims(B, NH, NC, CS, F, G, act_dtype) -> _Dims:
@@ -168,6 +173,7 @@ def resolved_impl(B, NH, NC, CS, F, G, act_dtype=torch.bfloat16, mlp=True, backw
 def ttt_forward(XQ, XK, XV, last_eta, ttt_norm_weight, ttt_norm_bias, W1_init, b1_init, W2_init, b2_init,
                 W1_checkpoints, b1_checkpoints, W2_checkpoints, b2_checkpoints, XQW_batch, checkpoint_group_size):
     """TTT-MLP forward scan; argument list of the reference call site mlp_tk.py:116-133."""
+    _check5(XQ)
     B, NH, NC, CS, F = XQ.shape
     G = int(checkpoint_group_size)
     K = -(-NC // G)
@@ -195,6 +201,7 @@ def ttt_backward(XQ, XK, XV, last_eta, ttt_norm_weight, ttt_norm_bias, W1_checkp
                  grad_L_ttt_norm_bias, grad_L_W1_init, grad_L_b1_init, grad_L_W2_init, grad_L_b2_init, grad_L_last_eta,
                  grad_L_XQ, grad_L_XK, grad_L_XV, checkpoint_group_size):
     """TTT-MLP backward; the 42 tensors + 1 int of the reference call site mlp_tk.py:227-275."""
+    _check5(XQ)
     B, NH, NC, CS, F = XQ.shape
     G = int(checkpoint_group_size)
     K = -(-NC // G)
@@ -236,6 +243,7 @@ def ttt_backward(XQ, XK, XV, last_eta, ttt_norm_weight, ttt_norm_bias, W1_checkp
 def ttt_linear_forward(XQ, XK, XV, last_eta, ttt_norm_weight, ttt_norm_bias, W1_init, b1_init, W1_checkpoints,
                        b1_checkpoints, XQW_batch, checkpoint_group_size):
     """TTT-Linear forward scan (replaces ttt_linear_scan_forward, linear_triton.py:98-129)."""
+    _check5(XQ)
     B, NH, NC, CS, F = XQ.shape
     G = int(checkpoint_group_size)
     K = -(-NC // G)
@@ -257,6 +265,7 @@ def ttt_linear_backward(XQ, XK, XV, last_eta, ttt_norm_weight, ttt_norm_bias, W1
                         grad_L_ttt_norm_weight, grad_L_ttt_norm_bias, grad_L_W1_init, grad_L_b1_init, grad_L_last_eta,
                         grad_L_XQ, grad_L_XK, grad_L_XV, checkpoint_group_size):
     """TTT-Linear backward (replaces ttt_linear_scan_backward, linear_triton.py:203-246)."""
+    _check5(XQ)
     B, NH, NC, CS, F = XQ.shape
     G = int(checkpoint_group_size)
     K = -(-NC // G)
