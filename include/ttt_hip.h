@@ -143,6 +143,10 @@ int ttt_hip_linear_backward(const ttt_dims* d, const ttt_linear_bwd_args* a, voi
 /* Which implementation TTT_IMPL_AUTO resolves to for these dims (returns TTT_IMPL_GENERIC/MFMA). */
 int ttt_hip_resolve_impl(const ttt_dims* d, int is_mlp, int is_backward);
 
+/* DEBUG: when given a device buffer of 16 zero-initialised uint64, the MFMA kernels' workgroup 0 adds
+ * per-phase shader-cycle totals into it (NULL switches the instrumentation off). */
+void        ttt_hip_debug_timing(void* device_buffer);
+
 int         ttt_hip_abi_version(void);
 const char* ttt_hip_last_error(void);
 

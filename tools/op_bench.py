@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--g", type=int, default=16)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--fwd-only", action="store_true")
+    ap.add_argument("--phases", action="store_true", help="also print per-phase cycle totals of workgroup 0")
     a = ap.parse_args()
     import test_time_training as ext
     from ttt_amd.models.ssm.linear_hip import HipLinear
@@ -90,6 +91,15 @@ def main():
         res[k] = {"impl": ext.resolved_impl(B, NH, NC, CS, F, G, torch.bfloat16, a.kind == "mlp", k == "bwd"),
                   "avg_ms": avg, "min_ms": ms[0], "us_per_step": 1e3 * avg / NC, "tflops": fl / (avg * 1e-3) / 1e12,
                   "frac_mfma_peak": fl / (avg * 1e-3) / 2.5e15, "frac_occupied_cu_peak": fl / (avg * 1e-3) / (2.5e15 * min(B * NH, 256) / 256)}
+    if a.phases:
+        buf = torch.zeros(16, dtype=torch.int64, device=dev)
+        ext.debug_timing(buf)
+        out = fwd()
+        if not a.fwd_only:
+            out.backward(dOut)
+        torch.cuda.synchronize()
+        ext.debug_timing(None)
+        res["phase_cycles_per_step"] = [round(v / NC, 1) for v in buf.tolist()]
     print(json.dumps(res))
 
 

@@ -46,6 +46,7 @@ static int post_launch(const char* what) {
 extern "C" {
 
 int ttt_hip_abi_version(void) { return TTT_HIP_ABI_VERSION; }
+void ttt_hip_debug_timing(void* device_buffer) { ttt::mfma::set_debug_timing(device_buffer); }
 const char* ttt_hip_last_error(void) { return g_err; }
 
 int ttt_hip_resolve_impl(const ttt_dims* d, int is_mlp, int is_backward) {

@@ -1,0 +1,711 @@
+// MFMA TTT-MLP backward for gfx950: the sequential reverse sweep.
+//
+// The backward of the scan is split MI355X-first into
+//   (A) group recompute  - mlp_scan_kernel<SAVE> (ttt_mfma.hip): one workgroup per (b, h, checkpoint
+//       group), i.e. K-fold more workgroups than the scan, filling the CUs a 48-workgroup scan
+//       cannot use; re-runs the forward of its group and stores every intermediate as register
+//       images into per-step "slots";
+//   (B) this kernel      - one workgroup per (b, h) walks the steps of a chunk in reverse, carrying
+//       dW1/dW2 (fp32 MFMA accumulator tiles, hidden-sliced over the 4 waves exactly like the
+//       forward state) and db1/db2/dgamma/dbeta, and emits dXQ, dXK, dXV, d(eta).
+// Chunks of `chunk_groups` groups are processed from the end of the sequence to its start; the
+// state gradient travels between chunks through a small fp32 carry area.
+//
+// Math: SURVEY.md Appendix A backward (oracle/ttt_oracle.py:_mlp_step_bwd is the executable spec),
+// arranged so that every contraction is over a register (row) index - see ttt_mfma_dev.h:
+//   B1 owners : LN backward of the output LayerNorm                       -> dZ2b  [t][f] (LDS)
+//   B2 waves  : dW2' += X2b^T dZ2b ; dZ1b = (dZ2b W2'^T) * gelu'(Z1b) ; dW1' += Q^T dZ1b ;
+//               partial dQ^T = W1'[:,H_w] dZ1b^T                           -> red
+//   B3 owners : dQ = dOut + sum partials                                  -> dXQ
+//      waves  : A2 = gZ2 dW2'^T ; E1 = K dW1' + db1' ; dgZ1 = -eta E1 ; u = dgZ1*D1 ;
+//               d(eta) partial = -rowsum(X2*A2 + gZ1*E1) ; dW2 += u^T gZ2 ;
+//               partial dgZ2^T = -eta (dW2'^T X2^T) + W2^T u^T              -> red
+//   B4 owners : dgZ2 -> backward of the fused LN/L2 gradient -> dZ2, dV, dgamma, dbeta, d(eta)
+//   B5 waves  : dX2 = -eta A2 + dZ2 W2^T ; dZ1 = dgZ1*gX2*gelu''(Z1) + dX2*D1 ; dW2 += X2^T dZ2 ;
+//               dW1 += K^T dZ1 ; partial dK^T = -eta (dW1'^T gZ1^T) + W1 dZ1^T  -> red
+//   B6 owners : dK = sum partials - dt                                    -> dXK
+#include "ttt_mfma.h"
+#include "ttt_mfma_dev.h"
+#include "ttt_mfma_int.h"
+
+namespace ttt {
+namespace mfma {
+using namespace ttt::mf;
+
+constexpr int BL_TILES = 4 * TILE_ELEMS * 2;                 // K, Q, dOut, gZ2
+constexpr int BL_WORK = 2 * TILE_ELEMS * 2;                  // dZ2b, dZ2
+constexpr int BL_RED = 4 * 64 * PS * 4;
+constexpr int BL_SMALL = (64 + 64 + 64 + 4 * 64) * 4;        // eta, db2, gamma, etaP[4][64]
+constexpr int LDS_BWD = BL_TILES + BL_WORK + BL_RED + BL_SMALL;
+
+// carry area per (b,h), floats
+constexpr size_t CARRY_DW1 = 0, CARRY_DW2 = 64 * 256, CARRY_DB1 = 2 * 64 * 256, CARRY_DB2 = CARRY_DB1 + 256,
+                 CARRY_DG = CARRY_DB2 + 64, CARRY_DBT = CARRY_DG + 4 * 64 * 16, CARRY_FLOATS = CARRY_DBT + 4 * 64 * 16;
+
+struct SweepParams {
+    const __bf16 *XQ, *XK, *dOut, *eta;
+    const float* ln_w;
+    const float *uW1, *ub1, *uW2, *ub2;     // upstream state gradient (first processed chunk)
+    char* slots; size_t slot_stride_bh;
+    float* carry;                           // [B*NH][CARRY_FLOATS]
+    __bf16 *dXQ, *dXK, *dXV, *deta;
+    float *dW1, *db1, *dW2, *db2, *dlnw, *dlnb;   // final outputs (last processed chunk)
+    int NH, NC, chunk_lo, chunk_hi, first, last;
+};
+
+struct BPrefetch {
+    uint4 v[8];
+    float eta;
+};
+
+__device__ __forceinline__ void bprefetch_issue(BPrefetch& pf, const SweepParams& p, size_t tile, const char* slot) {
+    const size_t base = tile * 4096;
+    const __bf16* g = reinterpret_cast<const __bf16*>(slot + SLOT_FR + SLOT_OWN);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = threadIdx.x + NT * j;
+        const size_t off = (size_t)(q >> 3) * 64 + (q & 7) * 8;
+        pf.v[0 + j] = *reinterpret_cast<const uint4*>(p.XK + base + off);
+        pf.v[2 + j] = *reinterpret_cast<const uint4*>(p.XQ + base + off);
+        pf.v[4 + j] = *reinterpret_cast<const uint4*>(p.dOut + base + off);
+        pf.v[6 + j] = *reinterpret_cast<const uint4*>(g + off);
+    }
+    pf.eta = (threadIdx.x < 64) ? (float)p.eta[tile * 64 + threadIdx.x] : 0.f;
+}
+__device__ __forceinline__ void bprefetch_park(const BPrefetch& pf, __bf16* tiles, float* etaL) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = threadIdx.x + NT * j;
+        const int o = (q >> 3) * TS + (q & 7) * 8;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *reinterpret_cast<uint4*>(tiles + k * TILE_ELEMS + o) = pf.v[2 * k + j];
+    }
+    if (threadIdx.x < 64) etaL[threadIdx.x] = pf.eta;
+}
+
+// natural-layout fp32 matrix slice <-> hidden-sliced accumulator tiles
+__device__ __forceinline__ void load_dW(const float* g1, const float* g2, f32x16 (&d1)[2][2], f32x16 (&d2)[2][2], int w, int h, int c) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                d1[a][b][r] = g1[(size_t)(32 * a + row_of(r, h)) * 256 + 64 * w + 32 * b + c];
+                d2[a][b][r] = g2[(size_t)(64 * w + 32 * a + row_of(r, h)) * 64 + 32 * b + c];
+            }
+}
+__device__ __forceinline__ void store_dW(float* g1, float* g2, const f32x16 (&d1)[2][2], const f32x16 (&d2)[2][2], int w, int h, int c) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                g1[(size_t)(32 * a + row_of(r, h)) * 256 + 64 * w + 32 * b + c] = d1[a][b][r];
+                g2[(size_t)(64 * w + 32 * a + row_of(r, h)) * 64 + 32 * b + c] = d2[a][b][r];
+            }
+}
+
+__device__ __forceinline__ f32x16 ld_tile(const char* wave_base, int arr, int a, int b, int lane) {
+    return unpack2(ld_frag(wave_base, arr, fr_idx(a, b, 0), lane), ld_frag(wave_base, arr, fr_idx(a, b, 1), lane));
+}
+__device__ __forceinline__ float tile_colsum(const f32x16& t) {   // sum over the 32 rows of a tile, per lane column
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += t[r];
+    return xor_add(s, 32);
+}
+
+__global__ __launch_bounds__(NT, 1) void mlp_bwd_sweep_kernel(SweepParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __bf16* tiles = reinterpret_cast<__bf16*>(smem);
+    __bf16* Kt = tiles + 0 * TILE_ELEMS;
+    __bf16* Qt = tiles + 1 * TILE_ELEMS;
+    __bf16* dOt = tiles + 2 * TILE_ELEMS;
+    __bf16* Gt = tiles + 3 * TILE_ELEMS;
+    __bf16* At = tiles + 4 * TILE_ELEMS;     // dZ2b [t][f]
+    __bf16* Bt = tiles + 5 * TILE_ELEMS;     // dZ2  [t][f]
+    float* red = reinterpret_cast<float*>(smem + BL_TILES + BL_WORK);
+    float* etaL = reinterpret_cast<float*>(smem + BL_TILES + BL_WORK + BL_RED);
+    float* db2L = etaL + 64;
+    float* gamL = db2L + 64;
+    float* etaP = gamL + 64;                 // [4][64]
+
+    const int bh = blockIdx.x, head = bh % p.NH;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, h = l >> 5, c = l & 31;
+    const int NC = p.NC;
+    char* slots = p.slots + (size_t)bh * p.slot_stride_bh;
+    float* carry = p.carry + (size_t)bh * CARRY_FLOATS;
+    const int ot = 16 * w + (l & 15), of0 = 16 * (l >> 4);
+    const bf16x8 I0 = ident_pi(0, h, c), I1 = ident_pi(1, h, c);
+
+    // ---- carried state gradient -----------------------------------------------------------------
+    f32x16 dW1t[2][2], dW2t[2][2];
+    float db1v[2], db2v[2], dgam[16], dbet[16];
+    if (p.first) {
+        load_dW(p.uW1 + (size_t)bh * 64 * 256, p.uW2 + (size_t)bh * 256 * 64, dW1t, dW2t, w, h, c);
+        db1v[0] = p.ub1[(size_t)bh * 256 + 64 * w + c];
+        db1v[1] = p.ub1[(size_t)bh * 256 + 64 * w + 32 + c];
+        db2v[0] = p.ub2[(size_t)bh * 64 + c];
+        db2v[1] = p.ub2[(size_t)bh * 64 + 32 + c];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { dgam[j] = 0.f; dbet[j] = 0.f; }
+    } else {
+        load_dW(carry + CARRY_DW1, carry + CARRY_DW2, dW1t, dW2t, w, h, c);
+        db1v[0] = carry[CARRY_DB1 + 64 * w + c];
+        db1v[1] = carry[CARRY_DB1 + 64 * w + 32 + c];
+        db2v[0] = carry[CARRY_DB2 + c];
+        db2v[1] = carry[CARRY_DB2 + 32 + c];
+        load16_f32(carry + CARRY_DG + (size_t)threadIdx.x * 16, dgam);
+        load16_f32(carry + CARRY_DBT + (size_t)threadIdx.x * 16, dbet);
+    }
+    if (threadIdx.x < 64) gamL[threadIdx.x] = p.ln_w[(size_t)head * 64 + threadIdx.x];
+    if (w == 0 && h == 0) { db2L[c] = db2v[0]; db2L[32 + c] = db2v[1]; }
+
+    BPrefetch pf;
+    bprefetch_issue(pf, p, (size_t)bh * NC + p.chunk_hi - 1, slots + (size_t)(p.chunk_hi - 1 - p.chunk_lo) * SLOT_BYTES);
+    bprefetch_park(pf, tiles, etaL);
+    __syncthreads();
+
+    for (int i = p.chunk_hi - 1; i >= p.chunk_lo; --i) {
+        const size_t tile = (size_t)bh * NC + i;
+        char* slot = slots + (size_t)(i - p.chunk_lo) * SLOT_BYTES;
+        char* slot_w = slot + (size_t)w * SLOT_WAVE_FR;
+        const char* next_w = slot + SLOT_BYTES + (size_t)w * SLOT_WAVE_FR;      // post-update state W' = state entering i+1
+        const char* own_w = slot + SLOT_FR + (size_t)w * SLOT_OWN_WAVE;
+        const bool more = (i > p.chunk_lo);
+        if (more) bprefetch_issue(pf, p, tile - 1, slot - SLOT_BYTES);
+
+        // ================= B1: owners - backward of the output LayerNorm ============================
+        {
+            float d[16], xl[16], g[16];
+            load16_bf16(dOt + ot * TS + of0, d);
+            ld_own16(own_w, 2, xl, l);
+            const float rstdl = own_stats(const_cast<char*>(own_w), l)[1];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                dgam[j] += d[j] * xl[j];
+                dbet[j] += d[j];
+                g[j] = d[j] * gamL[of0 + j];
+                s1 += g[j]; s2 += g[j] * xl[j];
+            }
+            s1 = quad_add(s1); s2 = quad_add(s2);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) g[j] = (64.0f * g[j] - s1 - xl[j] * s2) * rstdl * (1.0f / 64.0f);
+            store16_bf16(At + ot * TS + of0, g);
+        }
+        __syncthreads();   // bar1
+
+        // ================= B2: second-layer / output-path gradients, partial dQ =======================
+        {
+            bf16x8 Dpi[2][2][2];      // [ti][fj][s]  dZ2b (m=t, k=f)
+            bf16x8 DcF[2][2][2];      // [ti][fj][s]  dZ2b tile (rows=t, lane=f)
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int fj = 0; fj < 2; ++fj) {
+                    Dpi[ti][fj][0] = pi_read(At + (32 * ti + c) * TS, 32 * fj, 0, h);
+                    Dpi[ti][fj][1] = pi_read(At + (32 * ti + c) * TS, 32 * fj, 1, h);
+                    const f32x16 dc = transpose_tile(Dpi[ti][fj][0], Dpi[ti][fj][1], I0, I1);
+                    db2v[fj] += tile_colsum(dc);
+                    DcF[ti][fj][0] = pack(dc, 0);
+                    DcF[ti][fj][1] = pack(dc, 1);
+                }
+            if (w == 0 && h == 0) { db2L[c] = db2v[0]; db2L[32 + c] = db2v[1]; }
+            // dW2' += X2b^T dZ2b
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const bf16x8 xa = ld_frag(slot_w, FR_X2B, fr_idx(ti, ni, s), l);
+                        dW2t[ni][0] = mma(xa, DcF[ti][0][s], dW2t[ni][0]);
+                        dW2t[ni][1] = mma(xa, DcF[ti][1][s], dW2t[ni][1]);
+                    }
+            // W2'^T
+            bf16x8 WTn[2][2][2];      // [fj][ni][s]  (rows=f, lane=n)
+#pragma unroll
+            for (int fj = 0; fj < 2; ++fj)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const f32x16 wt = transpose_tile(ld_frag(next_w, FR_W2, fr_idx(ni, fj, 0), l), ld_frag(next_w, FR_W2, fr_idx(ni, fj, 1), l), I0, I1);
+                    WTn[fj][ni][0] = pack(wt, 0);
+                    WTn[fj][ni][1] = pack(wt, 1);
+                }
+            // dZ1b = (dZ2b W2'^T) * gelu'(Z1b)   (rows=t, lane=n)
+            bf16x8 dZbF[2][2][2];     // [ti][nj][s]
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int nj = 0; nj < 2; ++nj) {
+                    f32x16 dx = zero16();
+#pragma unroll
+                    for (int fj = 0; fj < 2; ++fj)
+#pragma unroll
+                        for (int s = 0; s < 2; ++s) dx = mma(Dpi[ti][fj][s], WTn[fj][nj][s], dx);
+                    const f32x16 d1b = ld_tile(slot_w, FR_D1B, ti, nj, l);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dx[r] *= d1b[r];
+                    db1v[nj] += tile_colsum(dx);
+                    dZbF[ti][nj][0] = pack(dx, 0);
+                    dZbF[ti][nj][1] = pack(dx, 1);
+                }
+            // dW1' += Q^T dZ1b
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int fi = 0; fi < 2; ++fi) {
+                    const f32x16 qc = transpose_tile(pi_read(Qt + (32 * ti + c) * TS, 32 * fi, 0, h),
+                                                     pi_read(Qt + (32 * ti + c) * TS, 32 * fi, 1, h), I0, I1);   // Q (rows=t, lane=f)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const bf16x8 qa = pack(qc, s);
+                        dW1t[fi][0] = mma(qa, dZbF[ti][0][s], dW1t[fi][0]);
+                        dW1t[fi][1] = mma(qa, dZbF[ti][1][s], dW1t[fi][1]);
+                    }
+                }
+            // partial dQ^T[f,t] = sum_{n in H_w} W1'[f,n] dZ1b[t,n]
+            f32x16 P[2][2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) P[a][b] = zero16();
+#pragma unroll
+            for (int nj = 0; nj < 2; ++nj) {
+                bf16x8 W1Tn[2][2];    // [fj][s]  W1'^T tile (rows=n, lane=f)
+#pragma unroll
+                for (int fj = 0; fj < 2; ++fj) {
+                    const f32x16 wt = transpose_tile(ld_frag(next_w, FR_W1, fr_idx(fj, nj, 0), l), ld_frag(next_w, FR_W1, fr_idx(fj, nj, 1), l), I0, I1);
+                    W1Tn[fj][0] = pack(wt, 0);
+                    W1Tn[fj][1] = pack(wt, 1);
+                }
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti) {
+                    const f32x16 zt = transpose_tile(dZbF[ti][nj][0], dZbF[ti][nj][1], I0, I1);   // dZ1b^T (rows=n, lane=t)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const bf16x8 zb = pack(zt, s);
+                        P[0][ti] = mma(W1Tn[0][s], zb, P[0][ti]);
+                        P[1][ti] = mma(W1Tn[1][s], zb, P[1][ti]);
+                    }
+                }
+            }
+            write_partial(red + (size_t)w * 64 * PS, P, h, c);
+        }
+        __syncthreads();   // bar2
+
+        // ================= B3: owners dQ ; waves: A2, E1, dgZ1, u, d(eta) partial, partial dgZ2 =======
+        {
+            float z[16], d[16];
+            gather_partial(red, nullptr, ot, of0, z);
+            load16_bf16(dOt + ot * TS + of0, d);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) z[j] += d[j];
+            store16_bf16(p.dXQ + tile * 4096 + (size_t)ot * 64 + of0, z);
+        }
+        {
+            bf16x8 dW2F[2][2][2];     // [ni][fj][s]  dW2' packed (rows=n, lane=f)
+            bf16x8 dWT[2][2][2];      // [fj][ni][s]  dW2'^T (rows=f, lane=n)
+            bf16x8 dW1F[2][2][2];     // [fi][nj][s]  dW1' packed (rows=f, lane=n)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        dW2F[a][b][s] = pack(dW2t[a][b], s);
+                        dW1F[a][b][s] = pack(dW1t[a][b], s);
+                    }
+#pragma unroll
+            for (int fj = 0; fj < 2; ++fj)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const f32x16 t = transpose_tile(dW2F[ni][fj][0], dW2F[ni][fj][1], I0, I1);
+                    dWT[fj][ni][0] = pack(t, 0);
+                    dWT[fj][ni][1] = pack(t, 1);
+                }
+            f32x16 PE[2][2];          // [fj][ti]  partial dgZ2^T (rows=f, lane=t)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) PE[a][b] = zero16();
+            // -eta * (dW2'^T X2^T)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const bf16x8 xt = ld_frag(slot_w, FR_XT, fr_idx(ni, ti, s), l);
+                        PE[0][ti] = mma(dW2F[ni][0][s], xt, PE[0][ti]);
+                        PE[1][ti] = mma(dW2F[ni][1][s], xt, PE[1][ti]);
+                    }
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                const float el = -etaL[32 * ti + c];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { PE[0][ti][r] *= el; PE[1][ti][r] *= el; }
+            }
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                const f32x16 etaR = rows_from_lds(etaL, 32 * ti, h);
+                bf16x8 Gpi[2][2], GcF[2][2], Kpi[2][2];   // [fj][s]
+#pragma unroll
+                for (int fj = 0; fj < 2; ++fj) {
+                    Gpi[fj][0] = pi_read(Gt + (32 * ti + c) * TS, 32 * fj, 0, h);
+                    Gpi[fj][1] = pi_read(Gt + (32 * ti + c) * TS, 32 * fj, 1, h);
+                    const f32x16 gc = transpose_tile(Gpi[fj][0], Gpi[fj][1], I0, I1);   // gZ2 (rows=t, lane=f)
+                    GcF[fj][0] = pack(gc, 0);
+                    GcF[fj][1] = pack(gc, 1);
+                    Kpi[fj][0] = pi_read(Kt + (32 * ti + c) * TS, 32 * fj, 0, h);
+                    Kpi[fj][1] = pi_read(Kt + (32 * ti + c) * TS, 32 * fj, 1, h);
+                }
+                float se = 0.f;       // rowsum over this wave's hidden slice, per token (lane = t after the transposes)
+#pragma unroll
+                for (int nj = 0; nj < 2; ++nj) {
+                    f32x16 a2 = zero16(), e1 = zero16();
+#pragma unroll
+                    for (int fj = 0; fj < 2; ++fj)
+#pragma unroll
+                        for (int s = 0; s < 2; ++s) {
+                            a2 = mma(Gpi[fj][s], dWT[fj][nj][s], a2);       // A2 = gZ2 dW2'^T
+                            e1 = mma(Kpi[fj][s], dW1F[fj][nj][s], e1);      // K dW1'
+                        }
+                    const f32x16 x2 = ld_tile(slot_w, FR_X2, ti, nj, l);
+                    const f32x16 g1 = ld_tile(slot_w, FR_GZ1, ti, nj, l);
+                    const f32x16 d1 = ld_tile(slot_w, FR_D1, ti, nj, l);
+                    const f32x16 d2 = ld_tile(slot_w, FR_D2, ti, nj, l);
+                    const f32x16 gx = ld_tile(slot_w, FR_GX2, ti, nj, l);
+                    f32x16 y, u, dx2, dz1;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float e = e1[r] + db1v[nj];
+                        y[r] = x2[r] * a2[r] + g1[r] * e;
+                        const float dg = -etaR[r] * e;                        // dgZ1
+                        u[r] = dg * d1[r];
+                        dz1[r] = dg * gx[r] * d2[r];                          // first part of dZ1
+                        dx2[r] = -etaR[r] * a2[r];                            // first part of dX2
+                    }
+                    // park the two partial tiles in the (now dead) GX2 / D2 slot arrays for B5
+                    st_frag(slot_w, FR_GX2, fr_idx(ti, nj, 0), pack(dz1, 0), l);
+                    st_frag(slot_w, FR_GX2, fr_idx(ti, nj, 1), pack(dz1, 1), l);
+                    st_frag(slot_w, FR_D2, fr_idx(ti, nj, 0), pack(dx2, 0), l);
+                    st_frag(slot_w, FR_D2, fr_idx(ti, nj, 1), pack(dx2, 1), l);
+                    const bf16x8 u0 = pack(u, 0), u1 = pack(u, 1);
+                    // d(eta): rowsum over n needs the lane index reduced -> transpose, then sum registers
+                    const f32x16 yt = transpose_tile(pack(y, 0), pack(y, 1), I0, I1);           // (rows=n, lane=t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) se += yt[r];
+                    // dW2 += u^T gZ2
+                    dW2t[nj][0] = mma(u0, GcF[0][0], dW2t[nj][0]);
+                    dW2t[nj][0] = mma(u1, GcF[0][1], dW2t[nj][0]);
+                    dW2t[nj][1] = mma(u0, GcF[1][0], dW2t[nj][1]);
+                    dW2t[nj][1] = mma(u1, GcF[1][1], dW2t[nj][1]);
+                    // partial dgZ2^T += W2^T u^T
+                    const f32x16 ut = transpose_tile(u0, u1, I0, I1);                            // u^T (rows=n, lane=t)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const bf16x8 ub = pack(ut, s);
+                        PE[0][ti] = mma(ld_frag(slot_w, FR_W2, fr_idx(nj, 0, s), l), ub, PE[0][ti]);
+                        PE[1][ti] = mma(ld_frag(slot_w, FR_W2, fr_idx(nj, 1, s), l), ub, PE[1][ti]);
+                    }
+                }
+                se = xor_add(se, 32);
+                if (h == 0) etaP[w * 64 + 32 * ti + c] = -se;
+            }
+            __syncthreads();   // bar3: owners finished reading the dQ partials
+            write_partial(red + (size_t)w * 64 * PS, PE, h, c);
+        }
+        __syncthreads();   // bar4
+
+        // ================= B4: owners - backward of the fused LN / L2 gradient =======================
+        float dyv[16];     // dy = -dt, needed again in B6 (dK -= dt)
+        {
+            float G_[16], xh[16], go[16];
+            gather_partial(red, nullptr, ot, of0, G_);
+            ld_own16(own_w, 0, xh, l);
+            ld_own16(own_w, 1, go, l);
+            const float r = own_stats(const_cast<char*>(own_w), l)[0];
+            const float eta_t = etaL[ot];
+            float gxh[16], gz[16];
+            float s1g = 0.f, s2g = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                gxh[j] = go[j] * gamL[of0 + j];
+                s1g += gxh[j]; s2g += gxh[j] * xh[j];
+            }
+            s1g = quad_add(s1g); s2g = quad_add(s2g);
+            float se = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                gz[j] = (64.0f * gxh[j] - s1g - xh[j] * s2g) * r * (1.0f / 64.0f);     // gZ2 (fp32)
+                const float db2 = db2L[of0 + j];
+                se += gz[j] * db2;
+                G_[j] -= eta_t * db2;                                                   // dgZ2 complete
+                const float m = -G_[j] * r;
+                s1 += m; s2 += m * xh[j];
+            }
+            se = quad_add(se); s1 = quad_add(s1); s2 = quad_add(s2);
+            float a1 = 0.f, a2 = 0.f, dxh[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float g = gamL[of0 + j];
+                const float m = -G_[j] * r;
+                const float dgxh = r * G_[j] + (s1 + xh[j] * s2) * (1.0f / 64.0f);
+                const float dy = g * dgxh;
+                dgam[j] += go[j] * dgxh + dy * xh[j];
+                dbet[j] += dy;
+                dyv[j] = dy;
+                dxh[j] = dy * g + (gxh[j] * s2 + s2g * m) * (1.0f / 64.0f);
+                const float dstd = -dxh[j] * xh[j] * r - G_[j] * gz[j] * r;
+                a1 += dxh[j]; a2 += dstd;
+            }
+            a1 = quad_add(a1); a2 = quad_add(a2);
+            float dv[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                G_[j] = dxh[j] * r - a1 * r * (1.0f / 64.0f) + a2 * xh[j] * (1.0f / 64.0f);   // dZ2
+                dv[j] = -dyv[j];
+            }
+            store16_bf16(Bt + ot * TS + of0, G_);
+            store16_bf16(p.dXV + tile * 4096 + (size_t)ot * 64 + of0, dv);
+            if ((l >> 4) == 0) {
+                const float de = -se + etaP[0 * 64 + ot] + etaP[1 * 64 + ot] + etaP[2 * 64 + ot] + etaP[3 * 64 + ot];
+                p.deta[tile * 64 + ot] = (__bf16)de;
+            }
+        }
+        __syncthreads();   // bar5
+
+        // ================= B5: first-layer gradients, partial dK ======================================
+        {
+            bf16x8 Zpi[2][2][2], ZcF[2][2][2];    // [ti][fj][s]
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int fj = 0; fj < 2; ++fj) {
+                    Zpi[ti][fj][0] = pi_read(Bt + (32 * ti + c) * TS, 32 * fj, 0, h);
+                    Zpi[ti][fj][1] = pi_read(Bt + (32 * ti + c) * TS, 32 * fj, 1, h);
+                    const f32x16 zc = transpose_tile(Zpi[ti][fj][0], Zpi[ti][fj][1], I0, I1);   // dZ2 (rows=t, lane=f)
+                    db2v[fj] += tile_colsum(zc);
+                    ZcF[ti][fj][0] = pack(zc, 0);
+                    ZcF[ti][fj][1] = pack(zc, 1);
+                }
+            // dW2 += X2^T dZ2
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const bf16x8 xa = ld_frag(slot_w, FR_X2, fr_idx(ti, ni, s), l);
+                        dW2t[ni][0] = mma(xa, ZcF[ti][0][s], dW2t[ni][0]);
+                        dW2t[ni][1] = mma(xa, ZcF[ti][1][s], dW2t[ni][1]);
+                    }
+            // W2^T of the entering state
+            bf16x8 WT[2][2][2];       // [fj][ni][s]
+#pragma unroll
+            for (int fj = 0; fj < 2; ++fj)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const f32x16 t = transpose_tile(ld_frag(slot_w, FR_W2, fr_idx(ni, fj, 0), l), ld_frag(slot_w, FR_W2, fr_idx(ni, fj, 1), l), I0, I1);
+                    WT[fj][ni][0] = pack(t, 0);
+                    WT[fj][ni][1] = pack(t, 1);
+                }
+            f32x16 PA[2][2];          // [fj][ti]  partial dK^T
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) PA[a][b] = zero16();
+            // -eta * (dW1'^T gZ1^T)   (dW1' = value before this step's K^T dZ1 term)
+#pragma unroll
+            for (int nj = 0; nj < 2; ++nj) {
+                bf16x8 dWt1[2][2];    // [fj][s]  dW1'^T (rows=n, lane=f)
+#pragma unroll
+                for (int fj = 0; fj < 2; ++fj) {
+                    const f32x16 t = transpose_tile(pack(dW1t[fj][nj], 0), pack(dW1t[fj][nj], 1), I0, I1);
+                    dWt1[fj][0] = pack(t, 0);
+                    dWt1[fj][1] = pack(t, 1);
+                }
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const bf16x8 gt = ld_frag(slot_w, FR_GZ1T, fr_idx(nj, ti, s), l);
+                        PA[0][ti] = mma(dWt1[0][s], gt, PA[0][ti]);
+                        PA[1][ti] = mma(dWt1[1][s], gt, PA[1][ti]);
+                    }
+            }
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                const float el = -etaL[32 * ti + c];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { PA[0][ti][r] *= el; PA[1][ti][r] *= el; }
+            }
+            // dX2 = -eta A2 + dZ2 W2^T ; dZ1 = part + dX2 * D1 ; dW1 += K^T dZ1 ; partial dK^T += W1 dZ1^T
+#pragma unroll
+            for (int nj = 0; nj < 2; ++nj) {
+                bf16x8 W1T[2][2];     // [fj][s]  W1^T (rows=n, lane=f), entering state
+#pragma unroll
+                for (int fj = 0; fj < 2; ++fj) {
+                    const f32x16 t = transpose_tile(ld_frag(slot_w, FR_W1, fr_idx(fj, nj, 0), l), ld_frag(slot_w, FR_W1, fr_idx(fj, nj, 1), l), I0, I1);
+                    W1T[fj][0] = pack(t, 0);
+                    W1T[fj][1] = pack(t, 1);
+                }
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti) {
+                    f32x16 dx = ld_tile(slot_w, FR_D2, ti, nj, l);              // -eta A2 (parked in B3)
+#pragma unroll
+                    for (int fj = 0; fj < 2; ++fj)
+#pragma unroll
+                        for (int s = 0; s < 2; ++s) dx = mma(Zpi[ti][fj][s], WT[fj][nj][s], dx);
+                    const f32x16 d1 = ld_tile(slot_w, FR_D1, ti, nj, l);
+                    f32x16 dz = ld_tile(slot_w, FR_GX2, ti, nj, l);              // dgZ1*gX2*gelu''(Z1) (parked in B3)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dz[r] += dx[r] * d1[r];
+                    db1v[nj] += tile_colsum(dz);
+                    const bf16x8 z0 = pack(dz, 0), z1 = pack(dz, 1);
+                    // dW1 += K^T dZ1
+#pragma unroll
+                    for (int fi = 0; fi < 2; ++fi) {
+                        const f32x16 kc = transpose_tile(pi_read(Kt + (32 * ti + c) * TS, 32 * fi, 0, h),
+                                                         pi_read(Kt + (32 * ti + c) * TS, 32 * fi, 1, h), I0, I1);   // K (rows=t, lane=f)
+                        dW1t[fi][nj] = mma(pack(kc, 0), z0, dW1t[fi][nj]);
+                        dW1t[fi][nj] = mma(pack(kc, 1), z1, dW1t[fi][nj]);
+                    }
+                    const f32x16 zt = transpose_tile(z0, z1, I0, I1);             // dZ1^T (rows=n, lane=t)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const bf16x8 zb = pack(zt, s);
+                        PA[0][ti] = mma(W1T[0][s], zb, PA[0][ti]);
+                        PA[1][ti] = mma(W1T[1][s], zb, PA[1][ti]);
+                    }
+                }
+            }
+            write_partial(red + (size_t)w * 64 * PS, PA, h, c);   // B4's reads of `red` finished before bar5
+        }
+        __syncthreads();   // bar6
+
+        // ================= B6: owners dK ===============================================================
+        {
+            float z[16];
+            gather_partial(red, nullptr, ot, of0, z);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) z[j] += dyv[j];      // dK -= dt, dt = -dy
+            store16_bf16(p.dXK + tile * 4096 + (size_t)ot * 64 + of0, z);
+        }
+        if (w == 0 && h == 0) { db2L[c] = db2v[0]; db2L[32 + c] = db2v[1]; }
+        __syncthreads();   // bar7: every read of this step's tiles / red is complete
+        if (more) {
+            bprefetch_park(pf, tiles, etaL);
+            __syncthreads();   // bar8
+        }
+    }
+
+    // ---- hand the state gradient to the next chunk, or emit the final results ---------------------
+    if (!p.last) {
+        store_dW(carry + CARRY_DW1, carry + CARRY_DW2, dW1t, dW2t, w, h, c);
+        if (h == 0) { carry[CARRY_DB1 + 64 * w + c] = db1v[0]; carry[CARRY_DB1 + 64 * w + 32 + c] = db1v[1]; }
+        if (w == 0 && h == 0) { carry[CARRY_DB2 + c] = db2v[0]; carry[CARRY_DB2 + 32 + c] = db2v[1]; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 a = {dgam[4 * q], dgam[4 * q + 1], dgam[4 * q + 2], dgam[4 * q + 3]};
+            f32x4 b = {dbet[4 * q], dbet[4 * q + 1], dbet[4 * q + 2], dbet[4 * q + 3]};
+            *reinterpret_cast<f32x4*>(carry + CARRY_DG + (size_t)threadIdx.x * 16 + 4 * q) = a;
+            *reinterpret_cast<f32x4*>(carry + CARRY_DBT + (size_t)threadIdx.x * 16 + 4 * q) = b;
+        }
+    } else {
+        store_dW(p.dW1 + (size_t)bh * 64 * 256, p.dW2 + (size_t)bh * 256 * 64, dW1t, dW2t, w, h, c);
+        if (h == 0) { p.db1[(size_t)bh * 256 + 64 * w + c] = db1v[0]; p.db1[(size_t)bh * 256 + 64 * w + 32 + c] = db1v[1]; }
+        if (w == 0 && h == 0) { p.db2[(size_t)bh * 64 + c] = db2v[0]; p.db2[(size_t)bh * 64 + 32 + c] = db2v[1]; }
+        // dgamma/dbeta: owner lane (w, tt, fq) holds features 16*fq..+15 of its token slot: reduce over tt and waves
+        float* sg = red;                 // [256 threads][16]
+        float* sb = red + NT * 16;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { sg[threadIdx.x * 16 + j] = dgam[j]; sb[threadIdx.x * 16 + j] = dbet[j]; }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const int f = threadIdx.x, fq = f >> 4, j = f & 15;
+            float a = 0.f, b = 0.f;
+            for (int ww = 0; ww < 4; ++ww)
+                for (int tt = 0; tt < 16; ++tt) {
+                    const int thr = ww * 64 + fq * 16 + tt;
+                    a += sg[thr * 16 + j];
+                    b += sb[thr * 16 + j];
+                }
+            p.dlnw[(size_t)bh * 64 + f] = a;
+            p.dlnb[(size_t)bh * 64 + f] = b;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+bool bwd_available() { return true; }
+
+static int groups_per_chunk(const ttt_dims* d) {
+    const int nbh = d->B * d->NH;
+    const int K = (d->NC + d->G - 1) / d->G;
+    int g = (256 + nbh - 1) / nbh;            // enough recompute workgroups to cover the 256 CUs
+    // bound the slot area to ~4 GiB
+    const size_t per_group = (size_t)nbh * d->G * SLOT_BYTES;
+    const size_t cap = (size_t)4 << 30;
+    while (g > 1 && per_group * g > cap) --g;
+    if (g > K) g = K;
+    return g < 1 ? 1 : g;
+}
+
+size_t workspace_bytes(const ttt_dims* d, bool mlp, bool backward) {
+    if (!mlp || !backward) return 0;
+    const size_t nbh = (size_t)d->B * d->NH;
+    const size_t slots = (size_t)groups_per_chunk(d) * d->G + 1;
+    return nbh * (slots * SLOT_BYTES + CARRY_FLOATS * sizeof(float));
+}
+
+void mlp_backward(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hipStream_t s) {
+    const int nbh = d->B * d->NH, G = d->G, NC = d->NC;
+    const int K = (NC + G - 1) / G;
+    const int gpc = groups_per_chunk(d);
+    const size_t slot_stride = ((size_t)gpc * G + 1) * SLOT_BYTES;
+    char* slots = (char*)ws;
+    float* carry = (float*)(slots + (size_t)nbh * slot_stride);
+
+    ScanParams sp = {};
+    sp.XQ = (const __bf16*)a->XQ; sp.XK = (const __bf16*)a->XK; sp.XV = (const __bf16*)a->XV; sp.eta = (const __bf16*)a->last_eta;
+    sp.ln_w = a->ttt_norm_weight; sp.ln_b = a->ttt_norm_bias;
+    sp.W1c = const_cast<float*>(a->W1_checkpoints); sp.b1c = const_cast<float*>(a->b1_checkpoints);
+    sp.W2c = const_cast<float*>(a->W2_checkpoints); sp.b2c = const_cast<float*>(a->b2_checkpoints);
+    sp.NH = d->NH; sp.NC = NC; sp.G = G; sp.K = K; sp.eps = d->eps;
+    sp.slots = slots; sp.slot_stride_bh = slot_stride;
+
+    SweepParams bp = {};
+    bp.XQ = (const __bf16*)a->XQ; bp.XK = (const __bf16*)a->XK; bp.dOut = (const __bf16*)a->grad_L_XQW; bp.eta = (const __bf16*)a->last_eta;
+    bp.ln_w = a->ttt_norm_weight;
+    bp.uW1 = a->grad_L_W1_last; bp.ub1 = a->grad_L_b1_last; bp.uW2 = a->grad_L_W2_last; bp.ub2 = a->grad_L_b2_last;
+    bp.slots = slots; bp.slot_stride_bh = slot_stride; bp.carry = carry;
+    bp.dXQ = (__bf16*)a->grad_L_XQ; bp.dXK = (__bf16*)a->grad_L_XK; bp.dXV = (__bf16*)a->grad_L_XV; bp.deta = (__bf16*)a->grad_L_last_eta;
+    bp.dW1 = a->grad_L_W1_init; bp.db1 = a->grad_L_b1_init; bp.dW2 = a->grad_L_W2_init; bp.db2 = a->grad_L_b2_init;
+    bp.dlnw = a->grad_L_ttt_norm_weight; bp.dlnb = a->grad_L_ttt_norm_bias;
+    bp.NH = d->NH; bp.NC = NC;
+
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)mlp_bwd_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BWD);
+        attr = true;
+    }
+    const int nchunks = (K + gpc - 1) / gpc;
+    for (int ch = nchunks - 1; ch >= 0; --ch) {
+        const int g0 = ch * gpc, ng = (K - g0 < gpc) ? K - g0 : gpc;
+        sp.chunk_group0 = g0; sp.chunk_groups = ng; sp.chunk_lo = g0 * G;
+        launch_group_recompute(sp, nbh, s);
+        bp.chunk_lo = g0 * G;
+        bp.chunk_hi = ((g0 + ng) * G < NC) ? (g0 + ng) * G : NC;
+        bp.first = (ch == nchunks - 1);
+        bp.last = (ch == 0);
+        hipLaunchKernelGGL(mlp_bwd_sweep_kernel, dim3(nbh), dim3(NT), LDS_BWD, s, bp);
+    }
+}
+
+}  // namespace mfma
+}  // namespace ttt

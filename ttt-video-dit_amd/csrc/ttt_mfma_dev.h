@@ -102,5 +102,144 @@ __device__ __forceinline__ void gelu_fwd_grad(float x, float& y, float& dy) {
 }
 __device__ __forceinline__ float gelu_fwd(float x) { return x * sigmoid2u(x, x * x); }
 
+__device__ __forceinline__ float gelu_grad_only(float x) {
+    float y, dy;
+    gelu_fwd_grad(x, y, dy);
+    return dy;
+}
+// y = gelu, dy = gelu', d2y = gelu''   (gelu'' = q u' + x q (u''/2 - t u'^2), q = 1 - t^2)
+__device__ __forceinline__ void gelu_fwd_grad2(float x, float& y, float& dy, float& d2y) {
+    const float x2 = x * x;
+    const float s = sigmoid2u(x, x2);
+    const float t = 2.0f * s - 1.0f;
+    const float q = 4.0f * s * (1.0f - s);
+    const float du = GELU_A + GELU_3AC * x2;
+    const float d2u = 2.0f * GELU_3AC * x;
+    y = x * s;
+    dy = s + 0.5f * x * q * du;
+    d2y = q * du + 0.5f * x * q * (d2u - 2.0f * t * du * du);
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS geometry shared by the scan kernels
+constexpr int NT = 256;
+constexpr int TILE_ELEMS = 64 * TS;                          // one padded [64][64] bf16 tile
+
+// write one wave's partial [f][t] tiles (rows=f, lane=t) to red[w][t][f]
+__device__ __forceinline__ void write_partial(float* redw, const f32x16 (&P)[2][2], int h, int c) {
+#pragma unroll
+    for (int fj = 0; fj < 2; ++fj)
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v = {P[fj][ti][4 * q], P[fj][ti][4 * q + 1], P[fj][ti][4 * q + 2], P[fj][ti][4 * q + 3]};
+                *reinterpret_cast<f32x4*>(redw + (32 * ti + c) * PS + 32 * fj + 8 * q + 4 * h) = v;
+            }
+}
+
+// owner lane (token t, 16 features f0..f0+15): z = sum of the four partials (+ bias[f] if given)
+__device__ __forceinline__ void gather_partial(const float* red, const float* bias, int t, int f0, float (&z)[16]) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) z[j] = bias ? bias[f0 + j] : 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(red + ((size_t)w * 64 + t) * PS + f0 + 4 * q);
+            z[4 * q] += v[0]; z[4 * q + 1] += v[1]; z[4 * q + 2] += v[2]; z[4 * q + 3] += v[3];
+        }
+}
+
+// sum over the 4 lanes (l, l^16, l^32, l^48) that share an owner token
+__device__ __forceinline__ float quad_add(float v) { return xor_add(xor_add(v, 16), 32); }
+
+// LayerNorm statistics of a 64-wide row spread over 4 lanes, 16 values each
+__device__ __forceinline__ void row_stats(const float (&z)[16], float eps, float& mu, float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s += z[j];
+    mu = quad_add(s) * (1.0f / 64.0f);
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { const float d = z[j] - mu; v += d * d; }
+    rstd = 1.0f / sqrtf(quad_add(v) * (1.0f / 64.0f) + eps);
+}
+
+__device__ __forceinline__ void load16_bf16(const __bf16* p, float (&o)[16]) {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
+    const bf16x8 b = *reinterpret_cast<const bf16x8*>(p + 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { o[j] = (float)a[j]; o[8 + j] = (float)b[j]; }
+}
+__device__ __forceinline__ void store16_bf16(__bf16* p, const float (&v)[16]) {
+    bf16x8 a, b;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { a[j] = (__bf16)v[j]; b[j] = (__bf16)v[8 + j]; }
+    *reinterpret_cast<bf16x8*>(p) = a;
+    *reinterpret_cast<bf16x8*>(p + 8) = b;
+}
+__device__ __forceinline__ void load16_f32(const float* p, float (&o)[16]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p + 4 * q);
+        o[4 * q] = v[0]; o[4 * q + 1] = v[1]; o[4 * q + 2] = v[2]; o[4 * q + 3] = v[3];
+    }
+}
+
+// per-register row values: o[r] = src[base + row_of(r,h)]  (src fp32 in LDS, 16-B aligned groups)
+__device__ __forceinline__ f32x16 rows_from_lds(const float* src, int base, int h) {
+    f32x16 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + base + 8 * q + 4 * h);
+        o[4 * q] = v[0]; o[4 * q + 1] = v[1]; o[4 * q + 2] = v[2]; o[4 * q + 3] = v[3];
+    }
+    return o;
+}
+__device__ __forceinline__ f32x16 unpack2(bf16x8 lo, bf16x8 hi) {   // inverse of pack(.,0), pack(.,1)
+    f32x16 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { o[e] = (float)lo[e]; o[8 + e] = (float)hi[e]; }
+    return o;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward workspace: one "slot" per scan step holds everything the reverse sweep needs, written
+// by the (parallel) group-recompute kernel as register images (16 B per lane per fragment).
+enum { FR_W1 = 0, FR_W2, FR_X2, FR_XT, FR_D1, FR_D2, FR_GX2, FR_GZ1, FR_GZ1T, FR_X2B, FR_D1B, FR_COUNT };
+constexpr size_t FRAG_BYTES = 64 * 16;
+constexpr size_t SLOT_WAVE_FR = (size_t)FR_COUNT * 8 * FRAG_BYTES;      // 88 KiB per wave
+constexpr size_t SLOT_FR = 4 * SLOT_WAVE_FR;
+constexpr size_t SLOT_OWN_WAVE = 12 * FRAG_BYTES + 64 * 8;              // xh, go, xhl (4 x float4 each) + (rstd, rstdl)
+constexpr size_t SLOT_OWN = 4 * SLOT_OWN_WAVE;
+constexpr size_t SLOT_G = 64 * 64 * 2;                                   // gZ2 tile, bf16 row-major
+constexpr size_t SLOT_BYTES = SLOT_FR + SLOT_OWN + SLOT_G;
+
+__device__ __forceinline__ int fr_idx(int a, int b, int s) { return (a * 2 + b) * 2 + s; }
+__device__ __forceinline__ void st_frag(char* wave_base, int arr, int idx, bf16x8 v, int lane) {
+    *reinterpret_cast<bf16x8*>(wave_base + ((size_t)(arr * 8 + idx) * 64 + lane) * 16) = v;
+}
+__device__ __forceinline__ bf16x8 ld_frag(const char* wave_base, int arr, int idx, int lane) {
+    return *reinterpret_cast<const bf16x8*>(wave_base + ((size_t)(arr * 8 + idx) * 64 + lane) * 16);
+}
+__device__ __forceinline__ void st_own16(char* own_wave, int arr, const float (&v)[16], int lane) {   // arr: 0 xh, 1 go, 2 xhl
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x4 x = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+        *reinterpret_cast<f32x4*>(own_wave + ((size_t)(arr * 4 + q) * 64 + lane) * 16) = x;
+    }
+}
+__device__ __forceinline__ void ld_own16(const char* own_wave, int arr, float (&v)[16], int lane) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(own_wave + ((size_t)(arr * 4 + q) * 64 + lane) * 16);
+        v[4 * q] = x[0]; v[4 * q + 1] = x[1]; v[4 * q + 2] = x[2]; v[4 * q + 3] = x[3];
+    }
+}
+__device__ __forceinline__ float* own_stats(char* own_wave, int lane) {
+    return reinterpret_cast<float*>(own_wave + 12 * FRAG_BYTES) + 2 * lane;
+}
+
 }  // namespace mf
 }  // namespace ttt

@@ -1,0 +1,29 @@
+// Internal interface between the MFMA translation units (scan/recompute kernel and reverse sweep).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+namespace ttt {
+namespace mfma {
+
+struct ScanParams {
+    const __bf16 *XQ, *XK, *XV, *eta;
+    const float *ln_w, *ln_b;
+    const float *W1, *b1, *W2, *b2;        // initial state (forward only)
+    float *W1c, *b1c, *W2c, *b2c;          // checkpoints: written by the forward, read by the recompute
+    __bf16* out;                           // XQW (forward only)
+    int NH, NC, G, K;
+    float eps;
+    // group-recompute (SAVE) mode: groups [chunk_group0, chunk_group0 + chunk_groups) -> slots
+    char* slots;                           // base of the slot area; slot s of (b,h) <-> step chunk_lo + s
+    size_t slot_stride_bh;                 // bytes between consecutive (b,h) slot areas
+    int chunk_group0, chunk_groups, chunk_lo;
+    unsigned long long* dbg;               // optional per-phase cycle totals of workgroup 0
+};
+
+void launch_scan_forward(const ScanParams& p, int n_bh, hipStream_t s);
+void launch_group_recompute(const ScanParams& p, int n_bh, hipStream_t s);
+bool bwd_available();
+
+}  // namespace mfma
+}  // namespace ttt

@@ -67,6 +67,7 @@ EXPORTED_SYMBOLS = (
     "ttt_hip_mlp_forward_workspace", "ttt_hip_mlp_backward_workspace", "ttt_hip_linear_forward_workspace",
     "ttt_hip_linear_backward_workspace", "ttt_hip_mlp_forward", "ttt_hip_mlp_backward", "ttt_hip_linear_forward",
     "ttt_hip_linear_backward", "ttt_hip_resolve_impl", "ttt_hip_abi_version", "ttt_hip_last_error",
+    "ttt_hip_debug_timing",
 )
 
 _lib: Optional[ctypes.CDLL] = None
@@ -99,6 +100,13 @@ def load_library() -> ctypes.CDLL:
         raise RuntimeError("test_time_training: libttt_hip.so ABI version mismatch")
     _lib = lib
     return lib
+
+
+def debug_timing(buf: Optional[torch.Tensor]) -> None:
+    """DEBUG: per-phase cycle counters of workgroup 0 are accumulated into ``buf`` (16 x int64, zeroed, on device)."""
+    lib = load_library()
+    lib.ttt_hip_debug_timing.argtypes = [ctypes.c_void_p]
+    lib.ttt_hip_debug_timing(buf.data_ptr() if buf is not None else None)
 
 
 def set_impl(name: str) -> None:

@@ -158,7 +158,8 @@ class Rotary3DPositionEmbedding(nn.Module):
 
     def forward(self, t):  # t [B, NH, S, D]
         n = t.shape[2]
-        cos, sin = self.freqs_cos[:n], self.freqs_sin[:n]
+        # computed in the activation dtype, like the reference after cast_rotary_freqs (train.py:71-72)
+        cos, sin = self.freqs_cos[:n].to(t.dtype), self.freqs_sin[:n].to(t.dtype)
         pairs = to_local(t).unflatten(-1, (-1, 2))
         rot = torch.stack((-pairs[..., 1], pairs[..., 0]), dim=-1).flatten(-2)
         return t * cos + place_into(rot, t) * sin
