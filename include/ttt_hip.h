@@ -146,6 +146,9 @@ int ttt_hip_resolve_impl(const ttt_dims* d, int is_mlp, int is_backward);
 /* DEBUG: when given a device buffer of 16 zero-initialised uint64, the MFMA kernels' workgroup 0 adds
  * per-phase shader-cycle totals into it (NULL switches the instrumentation off). */
 void        ttt_hip_debug_timing(void* device_buffer);
+/* DEBUG: force the number of checkpoint groups the MFMA backward re-materialises per chunk (0 = automatic,
+ * sized to cover the 256 CUs); lets tests exercise the chunk-to-chunk gradient hand-over at small sizes. */
+void        ttt_hip_debug_groups_per_chunk(int groups);
 
 int         ttt_hip_abi_version(void);
 const char* ttt_hip_last_error(void);

@@ -8,6 +8,7 @@ namespace mfma {
 bool   supports(const ttt_dims* d, bool mlp, bool backward);
 size_t workspace_bytes(const ttt_dims* d, bool mlp, bool backward);
 void set_debug_timing(void* device_buffer_16_u64);
+void set_debug_groups_per_chunk(int groups);   // 0 = automatic
 void mlp_forward(const ttt_dims* d, const ttt_mlp_fwd_args* a, void* ws, hipStream_t s);
 void mlp_backward(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hipStream_t s);
 void linear_forward(const ttt_dims* d, const ttt_linear_fwd_args* a, void* ws, hipStream_t s);

@@ -644,10 +644,14 @@ __global__ __launch_bounds__(NT, 1) void mlp_bwd_sweep_kernel(SweepParams p) {
 // ---------------------------------------------------------------------------------------------------
 bool bwd_available() { return true; }
 
+static int g_forced_gpc = 0;
+void set_debug_groups_per_chunk(int g) { g_forced_gpc = g; }
+
 static int groups_per_chunk(const ttt_dims* d) {
     const int nbh = d->B * d->NH;
     const int K = (d->NC + d->G - 1) / d->G;
     int g = (256 + nbh - 1) / nbh;            // enough recompute workgroups to cover the 256 CUs
+    if (g_forced_gpc > 0) g = g_forced_gpc;   // DEBUG knob (tests exercise the chunk hand-over at small sizes)
     // bound the slot area to ~4 GiB
     const size_t per_group = (size_t)nbh * d->G * SLOT_BYTES;
     const size_t cap = (size_t)4 << 30;

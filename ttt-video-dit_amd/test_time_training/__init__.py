@@ -67,7 +67,7 @@ EXPORTED_SYMBOLS = (
     "ttt_hip_mlp_forward_workspace", "ttt_hip_mlp_backward_workspace", "ttt_hip_linear_forward_workspace",
     "ttt_hip_linear_backward_workspace", "ttt_hip_mlp_forward", "ttt_hip_mlp_backward", "ttt_hip_linear_forward",
     "ttt_hip_linear_backward", "ttt_hip_resolve_impl", "ttt_hip_abi_version", "ttt_hip_last_error",
-    "ttt_hip_debug_timing",
+    "ttt_hip_debug_timing", "ttt_hip_debug_groups_per_chunk",
 )
 
 _lib: Optional[ctypes.CDLL] = None
@@ -107,6 +107,13 @@ def debug_timing(buf: Optional[torch.Tensor]) -> None:
     lib = load_library()
     lib.ttt_hip_debug_timing.argtypes = [ctypes.c_void_p]
     lib.ttt_hip_debug_timing(buf.data_ptr() if buf is not None else None)
+
+
+def debug_groups_per_chunk(groups: int) -> None:
+    """DEBUG: force the MFMA backward's chunk size in checkpoint groups (0 = automatic)."""
+    lib = load_library()
+    lib.ttt_hip_debug_groups_per_chunk.argtypes = [ctypes.c_int]
+    lib.ttt_hip_debug_groups_per_chunk(int(groups))
 
 
 def set_impl(name: str) -> None:
