@@ -149,6 +149,11 @@ void        ttt_hip_debug_timing(void* device_buffer);
 /* DEBUG: force the number of checkpoint groups the MFMA backward re-materialises per chunk (0 = automatic,
  * sized to cover the 256 CUs); lets tests exercise the chunk-to-chunk gradient hand-over at small sizes. */
 void        ttt_hip_debug_groups_per_chunk(int groups);
+/* DEBUG: select the MFMA forward-scan kernel revision (2 = current 8-wave kernel, 1 = first 4-wave kernel,
+ * kept for A/B measurements). */
+void        ttt_hip_debug_variant(int revision);
+/* DEBUG: device buffer (>= 120000 floats) receiving the step-0 intermediates of workgroup 0 (NULL = off). */
+void        ttt_hip_debug_dump(float* device_buffer);
 
 int         ttt_hip_abi_version(void);
 const char* ttt_hip_last_error(void);

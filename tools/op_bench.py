@@ -30,12 +30,14 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--fwd-only", action="store_true")
     ap.add_argument("--phases", action="store_true", help="also print per-phase cycle totals of workgroup 0")
+    ap.add_argument("--variant", type=int, default=2, help="MFMA forward kernel revision (2 = current, 1 = first)")
     a = ap.parse_args()
     import test_time_training as ext
     from ttt_amd.models.ssm.linear_hip import HipLinear
     from ttt_amd.models.ssm.mlp_tk import TkMLP
     ext.load_library()
     ext.set_impl(a.impl)
+    ext.debug_variant(a.variant)
     dev = torch.device("cuda:0")
     B, NH, NC, CS, F, G = a.b, a.nh, a.nc, a.cs, 64, a.g
     H = 4 * F if a.kind == "mlp" else F
@@ -81,7 +83,7 @@ def main():
     torch.cuda.synchronize()
     g = 2.0 * CS * F * H
     nfl = {"fwd": (7 if a.kind == "mlp" else 3) * g, "bwd": (14 if a.kind == "mlp" else 6) * g}
-    res = {"kind": a.kind, "impl_requested": a.impl, "shape": [B, NH, NC, CS, F], "G": G}
+    res = {"kind": a.kind, "impl_requested": a.impl, "variant": a.variant, "shape": [B, NH, NC, CS, F], "G": G}
     for k, ev in times.items():
         if not ev:
             continue

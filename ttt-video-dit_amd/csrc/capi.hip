@@ -48,6 +48,8 @@ extern "C" {
 int ttt_hip_abi_version(void) { return TTT_HIP_ABI_VERSION; }
 void ttt_hip_debug_timing(void* device_buffer) { ttt::mfma::set_debug_timing(device_buffer); }
 void ttt_hip_debug_groups_per_chunk(int groups) { ttt::mfma::set_debug_groups_per_chunk(groups); }
+void ttt_hip_debug_variant(int v) { ttt::mfma::set_debug_variant(v); }
+void ttt_hip_debug_dump(float* buf) { ttt::mfma::set_debug_dump(buf); }
 const char* ttt_hip_last_error(void) { return g_err; }
 
 int ttt_hip_resolve_impl(const ttt_dims* d, int is_mlp, int is_backward) {

@@ -504,7 +504,8 @@ void mlp_forward(const ttt_dims* d, const ttt_mlp_fwd_args* a, void*, hipStream_
     p.W1c = a->W1_checkpoints; p.b1c = a->b1_checkpoints; p.W2c = a->W2_checkpoints; p.b2c = a->b2_checkpoints;
     p.out = (__bf16*)a->XQW;
     p.NH = d->NH; p.NC = d->NC; p.G = d->G; p.K = (d->NC + d->G - 1) / d->G; p.eps = d->eps;
-    launch_scan_forward(p, d->B * d->NH, s);
+    if (get_debug_variant() == 1) launch_scan_forward(p, d->B * d->NH, s);
+    else launch_scan_forward_v2(p, d->B * d->NH, g_dbg, s);
 }
 void linear_forward(const ttt_dims*, const ttt_linear_fwd_args*, void*, hipStream_t) {}
 void linear_backward(const ttt_dims*, const ttt_linear_bwd_args*, void*, hipStream_t) {}

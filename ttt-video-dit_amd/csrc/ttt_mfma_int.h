@@ -19,11 +19,16 @@ struct ScanParams {
     size_t slot_stride_bh;                 // bytes between consecutive (b,h) slot areas
     int chunk_group0, chunk_groups, chunk_lo;
     unsigned long long* dbg;               // optional per-phase cycle totals of workgroup 0
+    float* dump;                           // DEBUG: intermediates of workgroup 0, step 0 (revision-2 forward)
 };
 
 void launch_scan_forward(const ScanParams& p, int n_bh, hipStream_t s);
 void launch_group_recompute(const ScanParams& p, int n_bh, hipStream_t s);
 bool bwd_available();
+// revision-2 forward scan (ttt_mfma2.hip): 8 waves per (b,h), VGPR-form MFMA, LDS transposed reads
+void launch_scan_forward_v2(const ScanParams& p, int n_bh, unsigned long long* dbg, hipStream_t s);
+void set_debug_dump(float* buf);
+int get_debug_variant();
 
 }  // namespace mfma
 }  // namespace ttt

@@ -67,7 +67,7 @@ EXPORTED_SYMBOLS = (
     "ttt_hip_mlp_forward_workspace", "ttt_hip_mlp_backward_workspace", "ttt_hip_linear_forward_workspace",
     "ttt_hip_linear_backward_workspace", "ttt_hip_mlp_forward", "ttt_hip_mlp_backward", "ttt_hip_linear_forward",
     "ttt_hip_linear_backward", "ttt_hip_resolve_impl", "ttt_hip_abi_version", "ttt_hip_last_error",
-    "ttt_hip_debug_timing", "ttt_hip_debug_groups_per_chunk",
+    "ttt_hip_debug_timing", "ttt_hip_debug_groups_per_chunk", "ttt_hip_debug_variant", "ttt_hip_debug_dump",
 )
 
 _lib: Optional[ctypes.CDLL] = None
@@ -114,6 +114,20 @@ def debug_groups_per_chunk(groups: int) -> None:
     lib = load_library()
     lib.ttt_hip_debug_groups_per_chunk.argtypes = [ctypes.c_int]
     lib.ttt_hip_debug_groups_per_chunk(int(groups))
+
+
+def debug_variant(revision: int) -> None:
+    """DEBUG: MFMA forward-scan kernel revision (2 = current, 1 = first 4-wave kernel)."""
+    lib = load_library()
+    lib.ttt_hip_debug_variant.argtypes = [ctypes.c_int]
+    lib.ttt_hip_debug_variant(int(revision))
+
+
+def debug_dump(buf: Optional[torch.Tensor]) -> None:
+    """DEBUG: step-0 intermediates of workgroup 0 of the revision-2 forward go to ``buf`` (>= 120000 fp32 on device)."""
+    lib = load_library()
+    lib.ttt_hip_debug_dump.argtypes = [ctypes.c_void_p]
+    lib.ttt_hip_debug_dump(buf.data_ptr() if buf is not None else None)
 
 
 def set_impl(name: str) -> None:
