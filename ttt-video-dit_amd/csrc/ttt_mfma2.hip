@@ -120,12 +120,13 @@ __device__ __forceinline__ void write_partial2(float* redw, const f32x16& P, int
 }
 
 #define TTT_STAMP2(k)                                                        \
-    if (p.dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {           \
+    if (DBG && p.dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {    \
         const unsigned long long _t = __builtin_readcyclecounter();          \
         p.dbg[k] += _t - t_last;                                             \
         t_last = _t;                                                         \
     }
 
+template <bool DBG>
 __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __bf16* Kt = reinterpret_cast<__bf16*>(smem + L_K);
@@ -201,17 +202,27 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
         if (tid < 64) etaL[tid] = pfE;
     }
     // packed operands of the entering state (re-made after every update, carried across steps)
-    bf16x8 W1F[2][2], W2F[2][2];
+    bf16x8 W1F[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) { W1F[a][s] = pack(W1t[a], s); W2F[a][s] = pack(W2t[a], s); }
+        for (int s = 0; s < 2; ++s) W1F[a][s] = pack(W1t[a], s);
     __syncthreads();
 
     unsigned long long t_last = __builtin_readcyclecounter();
     for (int i = 0; i < NC; ++i) {
         const size_t tile = tile0 + i;
         const bool more = (i + 1 < NC);
+        // Per-iteration opaque copies of the lane / thread index: every LDS and global address below is a pure
+        // function of them, and hipcc otherwise hoists ~80 loop-invariant address registers out of the loop,
+        // spills them, and each reload's vmcnt(0) then waits for the prefetch loads in flight.  Recomputing an
+        // address costs one VALU op; a scratch reload costs an HBM round trip.
+        int l_op = tid & 63, tid_op = tid;
+        asm volatile("" : "+v"(l_op), "+v"(tid_op));
+        const int l = l_op, h = l >> 5, c = l & 31;
+        const int tid = tid_op;
+        const int ot = tid >> 3, of0 = 8 * (tid & 7);
+        const int prow = tid >> 3, pcol = (tid & 7) * 8;
 
         if (i % G == 0) {   // checkpoint: state entering step i (mlp_tk.py:95-98)
             const size_t ck = (size_t)bh * p.K + i / G;
@@ -228,18 +239,19 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
             if (h == 0) p.b1c[ck * 256 + nO + c] = b1v;
             if (w == 0 && h == 0) p.b2c[ck * 64 + fO + c] = b2v;
         }
-        {   // this step's Q and the next step's K, V, eta: in flight until they are parked below
-            const size_t off = tile * 4096 + (size_t)prow * 64 + pcol;
-            pfQ = *reinterpret_cast<const uint4*>(p.XQ + off);
-            if (more) {
-                pfK = *reinterpret_cast<const uint4*>(p.XK + off + 4096);
-                pfV = *reinterpret_cast<const uint4*>(p.XV + off + 4096);
-                if (tid < 64) pfE = (float)p.eta[(tile + 1) * 64 + tid];
-            }
+        // Tile traffic.  Register-staged prefetch across a whole step is not affordable at 256 VGPRs (hipcc spills
+        // the staged tiles at once, i.e. waits for HBM at the top of every step), so: (1) here, one dword per 128-byte
+        // line of the NEXT step's K / V / Q tiles is touched to pull them into L2 (waves 0..2, one tile each; the
+        // value is only "used" after B3); (2) the real 16-byte loads are issued after B3 - L2 hits by then - and
+        // parked before B5 (K, V, eta) or after the next B0 (Q), live only across the low-pressure tail of the step.
+        unsigned touch = 0;
+        if (more && wv < 3) {
+            const __bf16* src = (wv == 0 ? p.XK : wv == 1 ? p.XV : p.XQ) + (tile + 1) * 4096 + (size_t)l * 64;
+            touch = *reinterpret_cast<const unsigned*>(src);
         }
+        if (i == 0) pfQ = *reinterpret_cast<const uint4*>(p.XQ + tile * 4096 + (size_t)prow * 64 + pcol);
 
         // ================= A1: Z1 = K W1 + b1 ; X2, D1 ; X2 image ================================
-        bf16x8 X2F[2][2];             // [ti][s]  X2 tile (rows=t, lane=n) packed: (outer=n, k=t)
         f32x16 D1[2];                 // gelu'(Z1)
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti) {
@@ -256,30 +268,35 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
                 Z[r] = y;
                 D1[ti][r] = dy;
             }
+            // pin gelu' here: hipcc otherwise sinks half of its arithmetic into phase C and keeps Z1 (+ temporaries,
+            // ~56 registers) alive across A2 / P3 instead of these 16
+            asm volatile("" : "+v"(D1[ti]));
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                X2F[ti][s] = pack(Z, s);
-                st_image(X2img + (nO + c) * TS, 32 * ti, s, h, X2F[ti][s]);
-            }
+            for (int s = 0; s < 2; ++s) st_image(X2img + (nO + c) * TS, 32 * ti, s, h, pack(Z, s));
         }
         TTT_STAMP2(0)
         __syncthreads();              // B0: X2 image complete; every P6 read of step i-1 (red, Qt, b2L) is done
         TTT_STAMP2(8)
-        if (p.dump && blockIdx.x == 0 && i == 0)
+        if (DBG && p.dump && blockIdx.x == 0 && i == 0)
             for (int e = tid; e < 256 * 64; e += NT2) p.dump[e] = (float)X2img[(e >> 6) * TS + (e & 63)];
 
         // ================= A2: partial Z2^T[Fp, t] over the hidden slice ==========================
         {
-            f32x16 P[2] = {zero16(), zero16()};
+            bf16x8 W2F[2][2];         // operands of the entering W2 (packed here and again in E: not worth 16 live registers)
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
+            for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int ti = 0; ti < 2; ++ti) {
-                    P[ti] = mma(W2F[0][s], tr_frag_pi(X2img, TS, nO, s, 32 * ti, l), P[ti]);
-                    P[ti] = mma(W2F[1][s], tr_frag_pi(X2img, TS, nX, s, 32 * ti, l), P[ti]);
+                for (int s = 0; s < 2; ++s) W2F[a][s] = pack(W2t[a], s);
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                f32x16 P = zero16();
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    P = mma(W2F[0][s], tr_frag_pi(X2img, TS, nO, s, 32 * ti, l), P);
+                    P = mma(W2F[1][s], tr_frag_pi(X2img, TS, nX, s, 32 * ti, l), P);
                 }
-            write_partial2(red + (size_t)w * 64 * PS, P[0], 0, pp, h, c);
-            write_partial2(red + (size_t)w * 64 * PS, P[1], 1, pp, h, c);
+                write_partial2(red + (size_t)w * 64 * PS, P, ti, pp, h, c);
+            }
         }
         *reinterpret_cast<uint4*>(Qt + prow * TS + pcol) = pfQ;   // Q of this step (read only after B2)
         TTT_STAMP2(1)
@@ -292,7 +309,7 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
             load8_f32(b2L + of0, z);
 #pragma unroll
             for (int ww = 0; ww < 4; ++ww) add8_f32(red + ((size_t)ww * 64 + ot) * PS + of0, z);
-            if (p.dump && blockIdx.x == 0 && i == 0) {
+            if (DBG && p.dump && blockIdx.x == 0 && i == 0) {
                 for (int j = 0; j < 8; ++j) p.dump[16384 + ot * 64 + of0 + j] = z[j];
                 for (int ww = 0; ww < 4; ++ww)
                     for (int j = 0; j < 8; ++j) p.dump[45376 + (ww * 64 + ot) * 64 + of0 + j] = red[((size_t)ww * 64 + ot) * PS + of0 + j];
@@ -305,7 +322,7 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const float d = z[j] - mu; v += d * d; }
             const float rstd = __builtin_amdgcn_rsqf(sum8(v) * (1.0f / 64.0f) + p.eps);
-            if (p.dump && blockIdx.x == 0 && i == 0 && (tid & 7) == 0) { p.dump[60000 + ot] = mu; p.dump[60064 + ot] = rstd; }
+            if (DBG && p.dump && blockIdx.x == 0 && i == 0 && (tid & 7) == 0) { p.dump[60000 + ot] = mu; p.dump[60064 + ot] = rstd; }
             load8_bf16(Kt + ot * TS + of0, kk);
             load8_bf16(Vt + ot * TS + of0, vv);
             float s1 = 0.f, s2 = 0.f, gx[8];
@@ -328,7 +345,7 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
         TTT_STAMP2(2)
         __syncthreads();              // B2: Gs visible
         TTT_STAMP2(10)
-        if (p.dump && blockIdx.x == 0 && i == 0)
+        if (DBG && p.dump && blockIdx.x == 0 && i == 0)
             for (int e = tid; e < 64 * 64; e += NT2) p.dump[20480 + e] = (float)Gs[(e >> 6) * TS + (e & 63)];
 
         // ================= C: state updates, f3, f4 ===============================================
@@ -339,21 +356,29 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) W2TF[a][s] = pack(W2Tt[a], s);
+            // b2' = b2 + colsum_t Gs (ones MFMA: every row of the product is the column sum); two waves only
+            if (w == 0) {
+                f32x16 acc = zero16();
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) acc = mma(ONES, tr_frag_pi(Gs, TS, 32 * ti, s, fO, l), acc);
+                b2v += acc[0];
+            }
             // f5 + W2^T update.  Gs^T fragments (outer=f, k=t) by transposed reads: own half of f (also f5's B
-            // operand), then the partner's half.  X2: own half in place, partner half from the image.
-            f32x16 acc = zero16();
+            // operand), then the partner's half.  X2 (outer=n, k=t) is re-read from the image for both halves
+            // (cheaper than keeping the in-place fragments of A1 alive across A2 / P3).
 #pragma unroll
             for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const bf16x8 gO = tr_frag_pi(Gs, TS, 32 * ti, s, fO, l);
-                    W2t[0] = mma(X2F[ti][s], gO, W2t[0]);                                          // f5, own hidden half
+                    const bf16x8 xO = pi_read(X2img + (nO + c) * TS, 32 * ti, s, h);
+                    W2t[0] = mma(xO, gO, W2t[0]);                                                  // f5, own hidden half
                     W2t[1] = mma(pi_read(X2img + (nX + c) * TS, 32 * ti, s, h), gO, W2t[1]);       // f5, partner's half
-                    W2Tt[0] = mma(gO, X2F[ti][s], W2Tt[0]);
-                    W2Tt[1] = mma(tr_frag_pi(Gs, TS, 32 * ti, s, fX, l), X2F[ti][s], W2Tt[1]);
-                    if (w == 0) acc = mma(ONES, gO, acc);   // b2' = b2 + colsum_t Gs (every product row is the column sum)
+                    W2Tt[0] = mma(gO, xO, W2Tt[0]);
+                    W2Tt[1] = mma(tr_frag_pi(Gs, TS, 32 * ti, s, fX, l), xO, W2Tt[1]);
                 }
-            if (w == 0) b2v += acc[0];
             // f3: gX2s = Gs W2^T ; gZ1s = gX2s * D1   (rows=t, lane=n) ; f4: W1[f, n in Hp] += K[:, f]^T gZ1s
             float sb = 0.f;
 #pragma unroll
@@ -375,7 +400,7 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
             }
             b1v += xor_add(sb, 32);   // b1' = b1 - sum_t eta gZ1
         }
-        if (p.dump && blockIdx.x == 0 && i == 0) {
+        if (DBG && p.dump && blockIdx.x == 0 && i == 0) {
             if (h == 0) p.dump[24576 + nO + c] = b1v;
             if (w == 0 && h == 0) p.dump[24832 + fO + c] = b2v;
             for (int r = 0; r < 16; ++r) {
@@ -408,7 +433,7 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
                         zb = mma(W1F[a][s], pi_read(Qt + (32 * ti + c) * TS, 32 * a, s, h), zb);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) zb[r] = gelu_fwd(zb[r]);
-                if (p.dump && blockIdx.x == 0 && i == 0)
+                if (DBG && p.dump && blockIdx.x == 0 && i == 0)
                     for (int r = 0; r < 16; ++r) p.dump[28992 + (size_t)(nO + row_of(r, h)) * 64 + 32 * ti + c] = zb[r];
                 X2bF[ti][0] = pack(zb, 0);
                 X2bF[ti][1] = pack(zb, 1);
@@ -417,37 +442,46 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
         TTT_STAMP2(4)
         __syncthreads();              // B3: every read of the X2 image, of Kt and of Vt / etaL is done
         TTT_STAMP2(11)
+        asm volatile("" :: "v"(touch));
+        if (more) {
+            const size_t off = (tile + 1) * 4096 + (size_t)prow * 64 + pcol;
+            pfK = *reinterpret_cast<const uint4*>(p.XK + off);
+            pfV = *reinterpret_cast<const uint4*>(p.XV + off);
+            pfQ = *reinterpret_cast<const uint4*>(p.XQ + off);
+            if (tid < 64) pfE = (float)p.eta[(tile + 1) * 64 + tid];
+        }
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
             for (int s = 0; s < 2; ++s)
                 *reinterpret_cast<bf16x8*>(exch + ((size_t)(wv * 4 + ti * 2 + s) * 64 + l) * 16) = X2bF[ti][s];
-        if (more) {
-            *reinterpret_cast<uint4*>(Kt + prow * TS + pcol) = pfK;
-            *reinterpret_cast<uint4*>(Vt + prow * TS + pcol) = pfV;
-            if (tid < 64) etaL[tid] = pfE;
-        }
         if (w == 0 && h == 0) b2L[fO + c] = b2v;
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) W2F[a][s] = pack(W2t[a], s);
         __syncthreads();              // B4: exchange visible
         TTT_STAMP2(12)
 
         // ================= E: partial Z2b^T[Fp, t] ================================================
         {
-            f32x16 P[2] = {zero16(), zero16()};
+            bf16x8 W2F[2][2];
 #pragma unroll
-            for (int ti = 0; ti < 2; ++ti)
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) W2F[a][s] = pack(W2t[a], s);
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                f32x16 P = zero16();
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const bf16x8 xo = *reinterpret_cast<const bf16x8*>(exch + ((size_t)((wv ^ 1) * 4 + ti * 2 + s) * 64 + l) * 16);
-                    P[ti] = mma(W2F[0][s], X2bF[ti][s], P[ti]);
-                    P[ti] = mma(W2F[1][s], xo, P[ti]);
+                    P = mma(W2F[0][s], X2bF[ti][s], P);
+                    P = mma(W2F[1][s], xo, P);
                 }
-            write_partial2(red + (size_t)w * 64 * PS, P[0], 0, pp, h, c);
-            write_partial2(red + (size_t)w * 64 * PS, P[1], 1, pp, h, c);
+                write_partial2(red + (size_t)w * 64 * PS, P, ti, pp, h, c);
+            }
+        }
+        if (more) {                   // next step's K, V, eta (their last readers finished before B3)
+            *reinterpret_cast<uint4*>(Kt + prow * TS + pcol) = pfK;
+            *reinterpret_cast<uint4*>(Vt + prow * TS + pcol) = pfV;
+            if (tid < 64) etaL[tid] = pfE;
         }
         TTT_STAMP2(5)
         __syncthreads();              // B5
@@ -459,7 +493,7 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
             load8_f32(b2L + of0, z);
 #pragma unroll
             for (int ww = 0; ww < 4; ++ww) add8_f32(red + ((size_t)ww * 64 + ot) * PS + of0, z);
-            if (p.dump && blockIdx.x == 0 && i == 0)
+            if (DBG && p.dump && blockIdx.x == 0 && i == 0)
                 for (int j = 0; j < 8; ++j) p.dump[24896 + ot * 64 + of0 + j] = z[j];
             float s = 0.f;
 #pragma unroll
@@ -482,7 +516,8 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
 static void set_attr_once() {
     static bool done = false;
     if (!done) {
-        (void)hipFuncSetAttribute((const void*)mlp_scan8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_V2);
+        (void)hipFuncSetAttribute((const void*)mlp_scan8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_V2);
+        (void)hipFuncSetAttribute((const void*)mlp_scan8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_V2);
         done = true;
     }
 }
@@ -500,7 +535,8 @@ void launch_scan_forward_v2(const ScanParams& p0, int n_bh, unsigned long long* 
     p.dbg = dbg;
     p.dump = g_dump;
     v2::set_attr_once();
-    hipLaunchKernelGGL(v2::mlp_scan8_kernel, dim3(n_bh), dim3(v2::NT2), v2::LDS_V2, s, p);
+    if (p.dbg || p.dump) hipLaunchKernelGGL(v2::mlp_scan8_kernel<true>, dim3(n_bh), dim3(v2::NT2), v2::LDS_V2, s, p);
+    else hipLaunchKernelGGL(v2::mlp_scan8_kernel<false>, dim3(n_bh), dim3(v2::NT2), v2::LDS_V2, s, p);
 }
 
 }  // namespace mfma

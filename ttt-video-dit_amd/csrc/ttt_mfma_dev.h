@@ -88,19 +88,23 @@ __device__ __forceinline__ f32x16 transpose_tile(bf16x8 a0, bf16x8 a1, bf16x8 i0
 
 __device__ __forceinline__ float xor_add(float v, int mask) { return v + __shfl_xor(v, mask, 64); }
 
-// fast tanh-GELU pieces (same constants as the reference, ops/utils.py:51-54)
-__device__ __forceinline__ float sigmoid2u(float x, float x2) {   // sigmoid(2u), u = a*x*(1+c*x^2)
-    const float u2 = 2.0f * GELU_A * x * (1.0f + GELU_C * x2);
-    return __builtin_amdgcn_rcpf(1.0f + __expf(-u2));
+// fast tanh-GELU pieces (same constants as the reference, ops/utils.py:51-54).  With u = a x (1 + c x^2):
+//   gelu(x) = x * sig(2u),  sig(2u) = 1 / (1 + 2^(x * (k0 + k1 x^2))),  k0 = -2 a log2(e), k1 = k0 * c
+//   gelu'(x) = s + x s (1 - s) * 2 u' = s + (y - y s) (2a + 6ac x^2)
+constexpr float GELU_K0 = -2.0f * GELU_A * 1.4426950408889634f;
+constexpr float GELU_K1 = GELU_K0 * GELU_C;
+__device__ __forceinline__ float sig2u(float x, float x2) {
+    const float e = __builtin_amdgcn_exp2f(x * __builtin_fmaf(x2, GELU_K1, GELU_K0));
+    return __builtin_amdgcn_rcpf(1.0f + e);
 }
+__device__ __forceinline__ float sigmoid2u(float x, float x2) { return sig2u(x, x2); }
 __device__ __forceinline__ void gelu_fwd_grad(float x, float& y, float& dy) {
     const float x2 = x * x;
-    const float s = sigmoid2u(x, x2);            // (1+tanh u)/2
+    const float s = sig2u(x, x2);                // (1 + tanh u) / 2
     y = x * s;
-    // gelu' = s + x * (1 - t^2)/2 * u' ,  (1 - t^2) = 4 s (1 - s),  u' = a + 3ac x^2
-    dy = s + 2.0f * x * s * (1.0f - s) * (GELU_A + GELU_3AC * x2);
+    dy = __builtin_fmaf(__builtin_fmaf(-y, s, y), __builtin_fmaf(x2, 2.0f * GELU_3AC, 2.0f * GELU_A), s);
 }
-__device__ __forceinline__ float gelu_fwd(float x) { return x * sigmoid2u(x, x * x); }
+__device__ __forceinline__ float gelu_fwd(float x) { return x * sig2u(x, x * x); }
 
 __device__ __forceinline__ float gelu_grad_only(float x) {
     float y, dy;
