@@ -140,6 +140,36 @@ int ttt_hip_mlp_backward(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* wor
 int ttt_hip_linear_forward(const ttt_dims* d, const ttt_linear_fwd_args* a, void* workspace, size_t workspace_bytes, void* stream);
 int ttt_hip_linear_backward(const ttt_dims* d, const ttt_linear_bwd_args* a, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- Fused pre- / post-processing of the TTT layer (bf16 activations, head_dim 64) ---------------------------
+ * These replace chains of PyTorch elementwise kernels around the scan; tensors are named after the reference code.
+ *   pre : ttt/models/ssm/ttt_layer.py:252-306 (process_input) - L2-normalise XQ, XK per head (:264-266), 3-D RoPE on
+ *         video tokens (ssm/utils.py:82-108), LayerNorm reconstruction target for XV (:219-235), re-layout
+ *         [B,L,NH*F] -> [B,NH,NC,CS,F] (:237-250) and the token permutation `src` (scene interleave :157-186 and/or
+ *         the time reversal of the bidirectional pass, cogvideo/dit.py:247-263): scan position t reads token src[t]
+ *         and is rotated by rope[pos[t]] (pos[t] < 0: text token, no rotation).  src/pos may be NULL (identity / none).
+ *   post: ttt_layer.py:327-334 - [B,NH,NC,CS,F] -> [B,L,D], inverse permutation, post_norm LayerNorm(D, eps).
+ *   gate: cogvideo/dit.py:219-222 - out = residual + tanh(alpha_text | alpha_video) * y (text = first n_text tokens).
+ * Parameter gradients are returned as per-block partial sums [P, ...] (P from the *_partials queries); the caller
+ * reduces over P. */
+int ttt_hip_pre_forward(int B, int L, int NH, int F, const void* XQ_raw, const void* XK_raw, const void* XV_raw,
+                        const float* rope /* [n_pos, F/2, 2] (cos, sin) */, const int32_t* src, const int32_t* pos,
+                        const float* ln_w, const float* ln_b /* [NH, F] */, void* XQ, void* XK, void* XV, void* stream);
+int ttt_hip_pre_backward_partials(int NH);
+int ttt_hip_pre_backward(int B, int L, int NH, int F, const void* XQ_raw, const void* XK_raw, const void* XV_raw,
+                         const float* rope, const int32_t* src, const int32_t* pos, const float* ln_w,
+                         const void* dXQ, const void* dXK, const void* dXV, void* dXQ_raw, void* dXK_raw, void* dXV_raw,
+                         float* dlnw_part, float* dlnb_part /* [P, NH*F] */, void* stream);
+int ttt_hip_post_partials(int B, int L);
+int ttt_hip_post_forward(int B, int L, int NH, int F, float eps, const void* Y, const int32_t* src, const float* w, const float* b,
+                         void* out, void* stream);
+int ttt_hip_post_backward(int B, int L, int NH, int F, float eps, const void* Y, const void* dOut, const int32_t* src, const float* w,
+                          void* dY, float* dw_part, float* db_part /* [P, NH*F] */, void* stream);
+int ttt_hip_gate_forward(int B, int L, int D, int n_text, const void* res, const void* y, const float* tanh_text,
+                         const float* tanh_video, void* out, void* stream);
+int ttt_hip_gate_backward_partials(int D);
+int ttt_hip_gate_backward(int B, int L, int D, int n_text, const void* g, const void* y, const float* tanh_text,
+                          const float* tanh_video, void* dy, float* dtanh_part /* [P, 2, D] */, void* stream);
+
 /* Which implementation TTT_IMPL_AUTO resolves to for these dims (returns TTT_IMPL_GENERIC/MFMA). */
 int ttt_hip_resolve_impl(const ttt_dims* d, int is_mlp, int is_backward);
 

@@ -6,6 +6,7 @@
 #include "../../include/ttt_hip.h"
 #include "ttt_generic.h"
 #include "ttt_mfma.h"
+#include "ttt_prepost.h"
 
 static thread_local char g_err[512] = "";
 
@@ -126,6 +127,74 @@ int ttt_hip_linear_backward(const ttt_dims* d, const ttt_linear_bwd_args* a, voi
     if (r == TTT_IMPL_MFMA) ttt::mfma::linear_backward(d, a, ws, (hipStream_t)stream);
     else ttt::generic::linear_backward(d, a, ws, (hipStream_t)stream);
     return post_launch("linear_backward");
+}
+
+/* ---- fused pre / post-processing of the TTT layer (ttt_prepost.hip) --------------------------------- */
+static int check_pp(int B, int L, int NH, int F) {
+    if (B <= 0 || L <= 0 || NH <= 0) return fail("ttt_hip: non-positive dimension");
+    if (F != 64) return fail("ttt_hip: fused pre/post kernels need head_dim 64");
+    if (NH * 8 > 1024) return fail("ttt_hip: too many heads for the post kernels");
+    return 0;
+}
+
+int ttt_hip_pre_forward(int B, int L, int NH, int F, const void* XQ_raw, const void* XK_raw, const void* XV_raw,
+                        const float* rope, const int32_t* src, const int32_t* pos, const float* ln_w, const float* ln_b,
+                        void* XQ, void* XK, void* XV, void* stream) {
+    if (check_pp(B, L, NH, F)) return -1;
+    if (!XQ_raw || !XK_raw || !XV_raw || !ln_w || !ln_b || !XQ || !XK || !XV) return fail("ttt_hip: pre_forward: null pointer");
+    if (pos && !rope) return fail("ttt_hip: pre_forward: positions without a rotation table");
+    ttt::prepost::PreArgs a = {(const __bf16*)XQ_raw, (const __bf16*)XK_raw, (const __bf16*)XV_raw, rope, src, pos, ln_w, ln_b,
+                               (__bf16*)XQ, (__bf16*)XK, (__bf16*)XV, B, L, NH};
+    ttt::prepost::pre_forward(a, (hipStream_t)stream);
+    return post_launch("pre_forward");
+}
+int ttt_hip_pre_backward_partials(int NH) { return ttt::prepost::pre_backward_partials(NH); }
+int ttt_hip_pre_backward(int B, int L, int NH, int F, const void* XQ_raw, const void* XK_raw, const void* XV_raw,
+                         const float* rope, const int32_t* src, const int32_t* pos, const float* ln_w,
+                         const void* dXQ, const void* dXK, const void* dXV, void* dXQ_raw, void* dXK_raw, void* dXV_raw,
+                         float* dlnw_part, float* dlnb_part, void* stream) {
+    if (check_pp(B, L, NH, F)) return -1;
+    if (!XQ_raw || !XK_raw || !XV_raw || !ln_w || !dXQ || !dXK || !dXV || !dXQ_raw || !dXK_raw || !dXV_raw || !dlnw_part || !dlnb_part)
+        return fail("ttt_hip: pre_backward: null pointer");
+    ttt::prepost::PreBwdArgs a = {(const __bf16*)XQ_raw, (const __bf16*)XK_raw, (const __bf16*)XV_raw, rope, src, pos, ln_w,
+                                  (const __bf16*)dXQ, (const __bf16*)dXK, (const __bf16*)dXV,
+                                  (__bf16*)dXQ_raw, (__bf16*)dXK_raw, (__bf16*)dXV_raw, dlnw_part, dlnb_part, B, L, NH};
+    ttt::prepost::pre_backward(a, (hipStream_t)stream);
+    return post_launch("pre_backward");
+}
+int ttt_hip_post_partials(int B, int L) { return ttt::prepost::post_blocks(B, L); }
+int ttt_hip_post_forward(int B, int L, int NH, int F, float eps, const void* Y, const int32_t* src, const float* w, const float* b,
+                         void* out, void* stream) {
+    if (check_pp(B, L, NH, F)) return -1;
+    if (!Y || !w || !b || !out) return fail("ttt_hip: post_forward: null pointer");
+    ttt::prepost::PostArgs a = {(const __bf16*)Y, src, w, b, (__bf16*)out, B, L, NH, eps};
+    ttt::prepost::post_forward(a, (hipStream_t)stream);
+    return post_launch("post_forward");
+}
+int ttt_hip_post_backward(int B, int L, int NH, int F, float eps, const void* Y, const void* dOut, const int32_t* src, const float* w,
+                          void* dY, float* dw_part, float* db_part, void* stream) {
+    if (check_pp(B, L, NH, F)) return -1;
+    if (!Y || !dOut || !w || !dY || !dw_part || !db_part) return fail("ttt_hip: post_backward: null pointer");
+    ttt::prepost::PostBwdArgs a = {(const __bf16*)Y, (const __bf16*)dOut, src, w, (__bf16*)dY, dw_part, db_part, B, L, NH, eps};
+    ttt::prepost::post_backward(a, (hipStream_t)stream);
+    return post_launch("post_backward");
+}
+int ttt_hip_gate_forward(int B, int L, int D, int n_text, const void* res, const void* y, const float* tanh_text,
+                         const float* tanh_video, void* out, void* stream) {
+    if (B <= 0 || L <= 0 || D <= 0 || D % 8) return fail("ttt_hip: gate_forward: bad dimensions");
+    if (!res || !y || !tanh_text || !tanh_video || !out) return fail("ttt_hip: gate_forward: null pointer");
+    ttt::prepost::GateArgs a = {(const __bf16*)res, (const __bf16*)y, tanh_text, tanh_video, (__bf16*)out, B, L, D, n_text};
+    ttt::prepost::gate_forward(a, (hipStream_t)stream);
+    return post_launch("gate_forward");
+}
+int ttt_hip_gate_backward_partials(int D) { return ttt::prepost::gate_backward_partials(D); }
+int ttt_hip_gate_backward(int B, int L, int D, int n_text, const void* g, const void* y, const float* tanh_text,
+                          const float* tanh_video, void* dy, float* dtanh_part, void* stream) {
+    if (B <= 0 || L <= 0 || D <= 0 || D % 8) return fail("ttt_hip: gate_backward: bad dimensions");
+    if (!g || !y || !tanh_text || !tanh_video || !dy || !dtanh_part) return fail("ttt_hip: gate_backward: null pointer");
+    ttt::prepost::GateBwdArgs a = {(const __bf16*)g, (const __bf16*)y, tanh_text, tanh_video, (__bf16*)dy, dtanh_part, B, L, D, n_text};
+    ttt::prepost::gate_backward(a, (hipStream_t)stream);
+    return post_launch("gate_backward");
 }
 
 }  // extern "C"

@@ -68,6 +68,9 @@ EXPORTED_SYMBOLS = (
     "ttt_hip_linear_backward_workspace", "ttt_hip_mlp_forward", "ttt_hip_mlp_backward", "ttt_hip_linear_forward",
     "ttt_hip_linear_backward", "ttt_hip_resolve_impl", "ttt_hip_abi_version", "ttt_hip_last_error",
     "ttt_hip_debug_timing", "ttt_hip_debug_groups_per_chunk", "ttt_hip_debug_variant", "ttt_hip_debug_dump",
+    "ttt_hip_pre_forward", "ttt_hip_pre_backward_partials", "ttt_hip_pre_backward", "ttt_hip_post_partials",
+    "ttt_hip_post_forward", "ttt_hip_post_backward", "ttt_hip_gate_forward", "ttt_hip_gate_backward_partials",
+    "ttt_hip_gate_backward",
 )
 
 _lib: Optional[ctypes.CDLL] = None
@@ -315,3 +318,87 @@ def ttt_linear_backward(XQ, XK, XV, last_eta, ttt_norm_weight, ttt_norm_bias, W1
         _check(t[k], k, shape, dt)
     args = _LinBwd(*[t[k].data_ptr() for k in LIN_BWD_FIELDS])
     _launch("ttt_hip_linear_backward", _dims(B, NH, NC, CS, F, G, act), args, XQ.device)
+
+
+# ------------------------------------------------------------------------------------------------
+# Fused pre- / post-processing kernels (include/ttt_hip.h, "Fused pre- / post-processing").  Thin wrappers: the
+# caller (ttt_amd/models/ssm/fused.py) allocates every tensor; bf16 activations, fp32 parameters / tables.
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _req(t, name, dtype):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != dtype or not t.is_contiguous():
+        raise RuntimeError(f"{name}: expected a contiguous {dtype} tensor on a HIP device")
+
+
+def _call(fn, *args, device):
+    lib = load_library()
+    f = getattr(lib, fn)
+    f.restype = ctypes.c_int
+    stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    with torch.cuda.device(device):
+        rc = f(*args, stream)
+    if rc != 0:
+        raise RuntimeError(lib.ttt_hip_last_error().decode())
+
+
+def pre_forward(XQ_raw, XK_raw, XV_raw, rope, src, pos, ln_w, ln_b, XQ, XK, XV, NH):
+    B, L, D = XQ_raw.shape
+    for t, n in ((XQ_raw, "XQ_raw"), (XK_raw, "XK_raw"), (XV_raw, "XV_raw"), (XQ, "XQ"), (XK, "XK"), (XV, "XV")):
+        _req(t, n, torch.bfloat16)
+    for t, n in ((ln_w, "ln_w"), (ln_b, "ln_b")):
+        _req(t, n, torch.float32)
+    _call("ttt_hip_pre_forward", B, L, NH, D // NH, _p(XQ_raw), _p(XK_raw), _p(XV_raw), _p(rope), _p(src), _p(pos), _p(ln_w), _p(ln_b),
+          _p(XQ), _p(XK), _p(XV), device=XQ_raw.device)
+
+
+def pre_backward_partials(NH):
+    return load_library().ttt_hip_pre_backward_partials(int(NH))
+
+
+def pre_backward(XQ_raw, XK_raw, XV_raw, rope, src, pos, ln_w, dXQ, dXK, dXV, dXQ_raw, dXK_raw, dXV_raw, dlnw_part, dlnb_part, NH):
+    B, L, D = XQ_raw.shape
+    for t, n in ((XQ_raw, "XQ_raw"), (XK_raw, "XK_raw"), (XV_raw, "XV_raw"), (dXQ, "dXQ"), (dXK, "dXK"), (dXV, "dXV"),
+                 (dXQ_raw, "dXQ_raw"), (dXK_raw, "dXK_raw"), (dXV_raw, "dXV_raw")):
+        _req(t, n, torch.bfloat16)
+    for t, n in ((ln_w, "ln_w"), (dlnw_part, "dlnw_part"), (dlnb_part, "dlnb_part")):
+        _req(t, n, torch.float32)
+    _call("ttt_hip_pre_backward", B, L, NH, D // NH, _p(XQ_raw), _p(XK_raw), _p(XV_raw), _p(rope), _p(src), _p(pos), _p(ln_w),
+          _p(dXQ), _p(dXK), _p(dXV), _p(dXQ_raw), _p(dXK_raw), _p(dXV_raw), _p(dlnw_part), _p(dlnb_part), device=XQ_raw.device)
+
+
+def post_partials(B, L):
+    return load_library().ttt_hip_post_partials(int(B), int(L))
+
+
+def post_forward(Y, src, w, b, out, eps):
+    B, NH, L, F = Y.shape
+    _req(Y, "Y", torch.bfloat16); _req(out, "out", torch.bfloat16); _req(w, "w", torch.float32); _req(b, "b", torch.float32)
+    _call("ttt_hip_post_forward", B, L, NH, F, ctypes.c_float(eps), _p(Y), _p(src), _p(w), _p(b), _p(out), device=Y.device)
+
+
+def post_backward(Y, dOut, src, w, dY, dw_part, db_part, eps):
+    B, NH, L, F = Y.shape
+    _req(Y, "Y", torch.bfloat16); _req(dOut, "dOut", torch.bfloat16); _req(dY, "dY", torch.bfloat16)
+    _req(w, "w", torch.float32); _req(dw_part, "dw_part", torch.float32); _req(db_part, "db_part", torch.float32)
+    _call("ttt_hip_post_backward", B, L, NH, F, ctypes.c_float(eps), _p(Y), _p(dOut), _p(src), _p(w), _p(dY), _p(dw_part), _p(db_part),
+          device=Y.device)
+
+
+def gate_forward(res, y, tanh_text, tanh_video, out, n_text):
+    B, L, D = res.shape
+    _req(res, "res", torch.bfloat16); _req(y, "y", torch.bfloat16); _req(out, "out", torch.bfloat16)
+    _req(tanh_text, "tanh_text", torch.float32); _req(tanh_video, "tanh_video", torch.float32)
+    _call("ttt_hip_gate_forward", B, L, D, int(n_text), _p(res), _p(y), _p(tanh_text), _p(tanh_video), _p(out), device=res.device)
+
+
+def gate_backward_partials(D):
+    return load_library().ttt_hip_gate_backward_partials(int(D))
+
+
+def gate_backward(g, y, tanh_text, tanh_video, dy, dtanh_part, n_text):
+    B, L, D = g.shape
+    _req(g, "g", torch.bfloat16); _req(y, "y", torch.bfloat16); _req(dy, "dy", torch.bfloat16)
+    _req(tanh_text, "tanh_text", torch.float32); _req(tanh_video, "tanh_video", torch.float32); _req(dtanh_part, "dtanh_part", torch.float32)
+    _call("ttt_hip_gate_backward", B, L, D, int(n_text), _p(g), _p(y), _p(tanh_text), _p(tanh_video), _p(dy), _p(dtanh_part), device=g.device)

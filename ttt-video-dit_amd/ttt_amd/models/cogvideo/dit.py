@@ -18,6 +18,7 @@ from torch.utils.checkpoint import checkpoint
 from ttt_amd.models.cogvideo.utils import (Rotary3DPositionEmbedding, SequenceMetadata, modulate,
                                            timestep_embedding, unpatchify)
 from ttt_amd.models.configs import ModelConfig
+from ttt_amd.models.ssm.fused import FusedGate, fused_available
 from ttt_amd.models.ssm.ttt_layer import TTTWrapper
 
 
@@ -139,30 +140,20 @@ class SeqModelingBlock(nn.Module):
         return torch.cat((out_txt, out_vid / count), dim=1)
 
     # -- bidirectional TTT ------------------------------------------------------------------------
-    @staticmethod
-    def _reverse_text_chunks(text_emb, num_chunks):
-        b, n, e = text_emb.shape
-        return text_emb.view(b, num_chunks, n // num_chunks, e).flip(1).reshape(b, n, e)
-
     def _gate(self, text_gate, video_gate, residual, ssm_output, n_text):
+        if fused_available(residual, 64) and residual.shape[-1] % 8 == 0:     # one HIP pass instead of mul, mul, cat, add
+            return FusedGate.apply(residual, ssm_output, text_gate.gating_alpha, video_gate.gating_alpha, n_text)
         return residual + torch.cat((text_gate(ssm_output[:, :n_text]), video_gate(ssm_output[:, n_text:])), dim=1)
-
-    def _flip_sequence(self, emb, n_text, meta):
-        """Time-reverse: flip all video tokens, reverse the order of the per-scene text chunks."""
-        txt = emb[:, :n_text]
-        if meta.is_multiscene:
-            txt = self._reverse_text_chunks(txt, meta.num_chunks)
-        return torch.cat((txt, emb[:, n_text:].flip(1)), dim=1)
 
     def _ssm_forward(self, emb, seq_metadata: SequenceMetadata):
         """forward TTT -> gated residual -> time-reversed TTT with the same weights -> gated residual
-        (reference :224-266)."""
+        (reference :224-266).  The time reversal is delegated to the TTT layer (``reverse=True``), whose fused
+        pre/post kernels fold it into their token maps instead of materialising flipped copies."""
         n_text = seq_metadata.seq_text_length
         fwd = _ckpt(self.ssm, self.do_forward_ssm_remat)
         rev = _ckpt(self.ssm, self.do_reverse_ssm_remat)
-        emb = self._gate(self.forward_ssm_gating_text, self.forward_ssm_gating_video, emb, fwd(emb, seq_metadata), n_text)
-        y = rev(self._flip_sequence(emb, n_text, seq_metadata), seq_metadata)
-        y = self._flip_sequence(y, n_text, seq_metadata)
+        emb = self._gate(self.forward_ssm_gating_text, self.forward_ssm_gating_video, emb, fwd(emb, seq_metadata, False), n_text)
+        y = rev(emb, seq_metadata, True)
         return self._gate(self.backward_ssm_gating_text, self.backward_ssm_gating_video, emb, y, n_text)
 
     def forward(self, vid_emb, text_emb, seq_metadata: SequenceMetadata):

@@ -1,0 +1,109 @@
+"""Autograd boundaries around the fused pre- / post-processing HIP kernels of the TTT layer
+(``csrc/ttt_prepost.hip`` behind ``include/ttt_hip.h``): the MI355X replacement for the chains of
+elementwise PyTorch ops in the reference's ``TTTBase.process_input`` (``ttt_layer.py:252-306``), its
+``post_norm`` + re-layout tail (``:327-334``) and the gated residual of ``SeqModelingBlock._gate``
+(``cogvideo/dit.py:219-222``).  Used only for bf16 activations on a HIP device; every other case keeps the
+plain PyTorch path in ``ttt_layer.py`` (which is also the parity reference of these kernels in the tests)."""
+from __future__ import annotations
+
+import torch
+
+_BF16, _F32 = torch.bfloat16, torch.float32
+
+
+def _ext():
+    import test_time_training
+    return test_time_training
+
+
+def fused_available(x: torch.Tensor, head_dim: int) -> bool:
+    return x.is_cuda and x.dtype == _BF16 and head_dim == 64
+
+
+class FusedPre(torch.autograd.Function):
+    """(XQ_raw, XK_raw, XV_raw [B,L,NH*64], ln_w, ln_b [NH,64], rope [n,32,2] | None, src, pos [L] int32 | None)
+    -> XQ, XK, XV [B,NH,L,64] in scan order (token permutation, L2-norm, RoPE, LayerNorm target fused)."""
+
+    @staticmethod
+    def forward(ctx, XQ_raw, XK_raw, XV_raw, ln_w, ln_b, rope, src, pos, NH):
+        ext = _ext()
+        B, L, D = XQ_raw.shape
+        q, k, v = XQ_raw.contiguous(), XK_raw.contiguous(), XV_raw.contiguous()
+        w32, b32 = ln_w.detach().to(_F32).contiguous(), ln_b.detach().to(_F32).contiguous()
+        outs = [torch.empty(B, NH, L, D // NH, device=q.device, dtype=_BF16) for _ in range(3)]
+        ext.pre_forward(q, k, v, rope, src, pos, w32, b32, *outs, NH)
+        ctx.save_for_backward(q, k, v, w32, rope, src, pos)
+        ctx.NH, ctx.param_dtype = NH, ln_w.dtype
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, dXQ, dXK, dXV):
+        ext = _ext()
+        q, k, v, w32, rope, src, pos = ctx.saved_tensors
+        NH = ctx.NH
+        P = ext.pre_backward_partials(NH)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        pw = torch.empty(P, q.shape[-1], device=q.device, dtype=_F32)
+        pb = torch.empty_like(pw)
+        ext.pre_backward(q, k, v, rope, src, pos, w32, dXQ.contiguous(), dXK.contiguous(), dXV.contiguous(), dq, dk, dv, pw, pb, NH)
+        dw = pw.sum(0).view(NH, -1).to(ctx.param_dtype)
+        db = pb.sum(0).view(NH, -1).to(ctx.param_dtype)
+        return dq, dk, dv, dw, db, None, None, None, None
+
+
+class FusedPost(torch.autograd.Function):
+    """(Y [B,NH,L,64] scan order, weight, bias [D], src | None, eps) -> LayerNorm_D(Y) as [B,L,D] in token order."""
+
+    @staticmethod
+    def forward(ctx, Y, weight, bias, src, eps):
+        ext = _ext()
+        B, NH, L, F = Y.shape
+        y = Y.contiguous()
+        w32, b32 = weight.detach().to(_F32).contiguous(), bias.detach().to(_F32).contiguous()
+        out = torch.empty(B, L, NH * F, device=y.device, dtype=_BF16)
+        ext.post_forward(y, src, w32, b32, out, float(eps))
+        ctx.save_for_backward(y, w32, src)
+        ctx.eps, ctx.param_dtype = float(eps), weight.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ext = _ext()
+        y, w32, src = ctx.saved_tensors
+        B, NH, L, F = y.shape
+        P = ext.post_partials(B, L)
+        dY = torch.empty_like(y)
+        pw = torch.empty(P, NH * F, device=y.device, dtype=_F32)
+        pb = torch.empty_like(pw)
+        ext.post_backward(y, g.contiguous(), src, w32, dY, pw, pb, ctx.eps)
+        return dY, pw.sum(0).to(ctx.param_dtype), pb.sum(0).to(ctx.param_dtype), None, None
+
+
+class FusedGate(torch.autograd.Function):
+    """residual + tanh(alpha_text | alpha_video) * y with the first ``n_text`` tokens using the text gate."""
+
+    @staticmethod
+    def forward(ctx, res, y, alpha_text, alpha_video, n_text):
+        ext = _ext()
+        r, yy = res.contiguous(), y.contiguous()
+        tt, tv = torch.tanh(alpha_text.detach().to(_F32)).contiguous(), torch.tanh(alpha_video.detach().to(_F32)).contiguous()
+        out = torch.empty_like(r)
+        ext.gate_forward(r, yy, tt, tv, out, n_text)
+        ctx.save_for_backward(yy, tt, tv)
+        ctx.n_text, ctx.param_dtype = n_text, alpha_text.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ext = _ext()
+        yy, tt, tv = ctx.saved_tensors
+        g = g.contiguous()
+        D = g.shape[-1]
+        P = ext.gate_backward_partials(D)
+        dy = torch.empty_like(g)
+        part = torch.empty(P, 2, D, device=g.device, dtype=_F32)
+        ext.gate_backward(g, yy, tt, tv, dy, part, ctx.n_text)
+        dt = part.sum(0)                                   # d/d tanh(alpha)
+        da_t = (dt[0] * (1 - tt * tt)).to(ctx.param_dtype)
+        da_v = (dt[1] * (1 - tv * tv)).to(ctx.param_dtype)
+        return g, dy, da_t, da_v, None

@@ -24,6 +24,7 @@ from torch import nn
 
 from ttt_amd.models.cogvideo.utils import SequenceMetadata
 from ttt_amd.models.configs import ModelConfig
+from ttt_amd.models.ssm.fused import FusedPost, FusedPre, fused_available
 from ttt_amd.models.ssm.linear_hip import HipLinear, TritonLinear  # noqa: F401
 from ttt_amd.models.ssm.mlp_tk import TkMLP
 from ttt_amd.models.ssm.ops import ttt_linear, ttt_mlp
@@ -64,8 +65,11 @@ class TTTWrapper(nn.Module):
     def init_freqs(self):
         self.freqs_cis.copy_(self._precompute_freqs_cis_3d())
 
-    def forward(self, x: torch.Tensor, seq_metadata: SequenceMetadata):
-        return self.ttt(x, self.freqs_cis, seq_metadata)
+    def forward(self, x: torch.Tensor, seq_metadata: SequenceMetadata, reverse: bool = False):
+        """``reverse=True`` runs the layer on the time-reversed sequence and returns the result in the original
+        token order - the second half of the bidirectional pass (reference cogvideo/dit.py:247-263 flips around the
+        call; here the fused pre/post kernels absorb the flips into their token maps)."""
+        return self.ttt(x, self.freqs_cis, seq_metadata, reverse)
 
 
 def scene_permutation(meta: SequenceMetadata, seq_len: int) -> torch.Tensor:
@@ -88,6 +92,26 @@ def scene_permutation(meta: SequenceMetadata, seq_len: int) -> torch.Tensor:
     return p
 
 
+def flip_sequence(emb: torch.Tensor, meta: SequenceMetadata) -> torch.Tensor:
+    """Time reversal of a [texts, video] token sequence: all video tokens flipped, the per-scene text chunks in
+    reverse order (reference cogvideo/dit.py:213-217, 247-263).  An involution."""
+    n_text = meta.seq_text_length
+    txt = emb[:, :n_text]
+    if meta.is_multiscene:
+        b, n, e = txt.shape
+        txt = txt.view(b, meta.num_chunks, n // meta.num_chunks, e).flip(1).reshape(b, n, e)
+    return torch.cat((txt, emb[:, n_text:].flip(1)), dim=1)
+
+
+def reversal_map(meta: SequenceMetadata, seq_len: int) -> torch.Tensor:
+    """Index r of the time-reversed sequence -> index of the same token in the original sequence."""
+    n_text, tl = meta.seq_text_length, meta.text_length
+    r = torch.arange(n_text)
+    if meta.is_multiscene:
+        r = (meta.num_chunks - 1 - r // tl) * tl + r % tl
+    return torch.cat((r, torch.arange(seq_len - 1, n_text - 1, -1)))
+
+
 class TTTBase(nn.Module):
     def __init__(self, config: ModelConfig):
         super().__init__()
@@ -100,6 +124,7 @@ class TTTBase(nn.Module):
         self.scan_checkpoint_group_size = config.scan_checkpoint_group_size
         self.tp_mesh = None
         self.use_kernel = True
+        self.use_fused = True          # fused HIP pre/post-processing when the activations are bf16 on a HIP device
 
         D, NH, Fh = self.width, self.num_heads, self.head_dim
         self.wq = nn.Linear(D, NH * Fh, bias=True)
@@ -221,13 +246,57 @@ class TTTBase(nn.Module):
     def ttt(self, inputs):
         raise NotImplementedError("ttt method must be implemented in TTTBase subclasses.")
 
-    def forward(self, hidden_states: torch.Tensor, freqs_cis: torch.Tensor, seq_metadata: SequenceMetadata):
+    def forward(self, hidden_states: torch.Tensor, freqs_cis: torch.Tensor, seq_metadata: SequenceMetadata, reverse: bool = False):
         assert hidden_states.size(1) % self.config.mini_batch_size == 0, "Sequence len must be multiple of mini batch size."
+        if self.use_kernel and self.use_fused and fused_available(hidden_states, self.head_dim) and not freqs_cis.is_complex():
+            return self._forward_fused(hidden_states, freqs_cis, seq_metadata, reverse)
+        if reverse:
+            hidden_states = flip_sequence(hidden_states, seq_metadata)
         y = self.ttt(self.process_input(hidden_states, freqs_cis, seq_metadata))
         y = self.wo(self.post_norm(y))
         if seq_metadata.is_multiscene:
             y = self.undo_interleave(y, seq_metadata)
-        return y
+        return flip_sequence(y, seq_metadata) if reverse else y
+
+    # -- fused path: HIP pre/post kernels around the scan (bf16 on a HIP device) ------------------------------
+    def _token_maps(self, meta: SequenceMetadata, L: int, device, reverse: bool):
+        """int32 maps for the fused kernels: scan position t reads token ``src[t]`` of the input sequence and is
+        rotated with ``rope[pos[t]]`` (-1: text token); ``rev`` = reversal map or None."""
+        key = ("maps", meta.num_chunks, meta.text_length, meta.seq_text_length, meta.init_offset, meta.base_offset, L, str(device), reverse)
+        hit = self._perm_cache.get(key)
+        if hit is None:
+            n_text = meta.seq_text_length
+            seq = scene_permutation(meta, L) if meta.is_multiscene else torch.arange(L)   # scan pos -> index in the (reversed) sequence
+            pos = torch.where(seq >= n_text, seq - n_text, torch.full_like(seq, -1))
+            rev = reversal_map(meta, L) if reverse else None
+            src = rev[seq] if reverse else seq
+            to = lambda t: None if t is None else t.to(device=device, dtype=torch.int32).contiguous()
+            hit = (to(src), to(pos), None if rev is None else rev.to(device))
+            self._perm_cache[key] = hit
+        return hit
+
+    def _forward_fused(self, x, freqs_cis, meta: SequenceMetadata, reverse: bool):
+        B, L, _ = x.shape
+        NH, Fh, CS = self.num_heads, self.head_dim, self.mini_batch_size
+        NC = L // CS
+        src, pos, rev = self._token_maps(meta, L, x.device, reverse)
+        XQr, XKr, XVr = self.get_qkv_projections(x)
+        rope = freqs_cis if freqs_cis.dtype == torch.float32 and freqs_cis.is_contiguous() else freqs_cis.float().contiguous()
+        XQ, XK, XV = FusedPre.apply(XQr, XKr, XVr, self.ttt_norm_weight, self.ttt_norm_bias, rope, src, pos, NH)
+        mb = lambda t: t.view(B, NH, NC, CS, Fh)
+        # eta (tiny: [B, L, NH]): per-token learning rate in the order of the (reversed) sequence, then the
+        # reference's tile bookkeeping - the kernels read the row of the mini-batch the LAST token of a tile came from
+        w = self.learnable_ttt_lr_weight.squeeze(1)
+        lr = torch.sigmoid(F.linear(x, w.to(x.dtype), self.learnable_ttt_lr_bias.reshape(-1).to(x.dtype)))      # [B, L, NH]
+        if rev is not None:
+            lr = lr.index_select(1, rev)
+        eta = (self.ttt_base_lr * lr.view(B, NC, CS, NH).permute(0, 3, 1, 2).unsqueeze(3) / Fh) / CS               # [B,NH,NC,1,CS]
+        if meta.is_multiscene:
+            p, _ = self._perm(meta, L, x.device)
+            eta = eta.index_select(2, torch.div(p, CS, rounding_mode="floor")[CS - 1::CS])
+        Y = self.ttt_raw({"XQ": mb(XQ), "XK": mb(XK), "XV": mb(XV), "eta": eta})                                  # [B,NH,NC,CS,F]
+        y = FusedPost.apply(Y.reshape(B, NH, L, Fh), self.post_norm.weight, self.post_norm.bias, src, self.post_norm.eps)
+        return self.wo(y)
 
     # helpers shared by the two variants
     def _group_size(self, num_mini_batch: int) -> int:
@@ -249,6 +318,12 @@ class TTTLinear(TTTBase):
         super().init_weights()
         nn.init.normal_(self.W1, mean=0.0, std=0.02)
         nn.init.zeros_(self.b1)
+
+    def ttt_raw(self, inputs):
+        """Scan on the HIP kernels, result left in the kernel layout [B,NH,NC,CS,F]."""
+        B, _, NC, _, _ = inputs["XV"].shape
+        return HipLinear.apply(self.ttt_norm_weight, self.ttt_norm_bias, self._per_batch(self.W1, B), self._per_batch(self.b1, B),
+                               inputs["XQ"], inputs["XV"], inputs["XK"], inputs["eta"], self._group_size(NC))
 
     def ttt(self, inputs):
         B, _, NC, CS, _ = inputs["XV"].shape
@@ -280,6 +355,13 @@ class TTTMLP(TTTBase):
         nn.init.zeros_(self.b1)
         nn.init.normal_(self.W2, mean=0.0, std=0.02)
         nn.init.zeros_(self.b2)
+
+    def ttt_raw(self, inputs):
+        """Scan on the HIP kernels, result left in the kernel layout [B,NH,NC,CS,F]."""
+        B, _, NC, _, _ = inputs["XV"].shape
+        st = [self._per_batch(p, B) for p in (self.W1, self.b1, self.W2, self.b2)]
+        return TkMLP.apply(self.ttt_norm_weight, self.ttt_norm_bias, *st, inputs["XQ"], inputs["XV"], inputs["XK"],
+                           inputs["eta"], self._group_size(NC))
 
     def ttt(self, inputs):
         B, _, NC, CS, _ = inputs["XV"].shape
