@@ -87,6 +87,24 @@ class KernelTimer:
         return out
 
 
+def pmc_traffic(kernel, video_length):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*pmc_traffic.json: FETCH_SIZE
+    and WRITE_SIZE collected in separate --pmc runs of tools/op_bench.py at the same geometry, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  PMC passes cannot run inside the timed region; None when no summary
+    for this kernel / geometry is committed."""
+    import glob
+    if video_length != "3sec":
+        return None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), reverse=True):
+        try:
+            k = json.load(open(f))["kernels"].get(kernel)
+        except Exception:
+            continue
+        if k:
+            return k.get("traffic_bytes_per_backward") or (k.get("fetch_bytes", 0) + k.get("write_bytes", 0))
+    return None
+
+
 def cpu_baseline(ssm_layer):
     """CPU port of the same workload on the host cores: ONE 5B-geometry TransformerLayer (torch CPU fp32,
     TTT scan by the oracle through oracle/cpu_ext.py), fwd+bwd, at a bounded sequence (1 latent frame +
@@ -230,8 +248,9 @@ def main():
             ach = per_launch / (ks[dom]["avg_ms"] * 1e-3) / 1e12
             impl = ext.resolved_impl(B, NH, NC, CS, F, min(cfg.scan_checkpoint_group_size, NC), torch.bfloat16,
                                      mlp=args.ssm_layer == "ttt_mlp", backward=dom == "bwd")
-            roof = {"bound": "mfma", "kernel": f"{args.ssm_layer}_{dom}_scan[{impl}]", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+            kname = f"{args.ssm_layer}_{dom}_scan[{impl}]"
+            roof = {"bound": "mfma", "kernel": kname, "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": pmc_traffic(kname, args.video_length),
                     "flops_per_launch": per_launch, "avg_launch_ms": ks[dom]["avg_ms"], "launches_timed": ks[dom]["launches"],
                     "occupied_cu_frac": ach / (MFMA_BF16_PEAK_TFLOPS * min(B * NH, 256) / 256.0),
                     "other": {k: {"avg_ms": v["avg_ms"], "launches": v["launches"],
