@@ -170,6 +170,48 @@ int ttt_hip_gate_backward_partials(int D);
 int ttt_hip_gate_backward(int B, int L, int D, int n_text, const void* g, const void* y, const float* tanh_text,
                           const float* tanh_video, void* dy, float* dtanh_part /* [P, 2, D] */, void* stream);
 
+/* ---- Segment self-attention (head_dim 64, bf16) -----------------------------------------------------------------
+ * Replaces F.scaled_dot_product_attention(q, k, v) (non-causal, no mask, no dropout) of the reference's local attention,
+ * ttt/models/cogvideo/dit.py:196-198, and its autograd backward.  Every tensor is described by a base pointer and
+ * element strides (batch, head, token); the head dimension (64) is contiguous, so both the reference's [B,NH,S,D]
+ * views of [B,S,NH*D] projections and contiguous tensors are consumed without copies.  O = softmax(Q K^T * scale) V;
+ * LSE [B,NH,S] fp32 = log-sum-exp of the scaled scores (saved for the backward).  The backward needs a caller-allocated
+ * fp32 workspace Delta [B,NH,S]. */
+typedef struct ttt_attn_tensor {
+    void*   ptr;
+    int64_t stride_b, stride_h, stride_s;   /* in elements */
+} ttt_attn_tensor;
+typedef struct ttt_attn_fwd_args {
+    ttt_attn_tensor Q, K, V, O;             /* bf16 */
+    float*  LSE;                            /* [B,NH,S] fp32, out (may be NULL for inference) */
+    int32_t B, NH, S, D;                    /* D must be 64 */
+    float   scale;                          /* 1/sqrt(D) in the reference */
+} ttt_attn_fwd_args;
+typedef struct ttt_attn_bwd_args {
+    ttt_attn_tensor Q, K, V, O, dO;         /* bf16, in  */
+    ttt_attn_tensor dQ, dK, dV;             /* bf16, out */
+    const float* LSE;                       /* [B,NH,S] from the forward */
+    float*  Delta;                          /* [B,NH,S] fp32 workspace */
+    int32_t B, NH, S, D;
+    float   scale;
+} ttt_attn_bwd_args;
+int ttt_hip_attn_forward(const ttt_attn_fwd_args* a, void* stream);
+int ttt_hip_attn_backward(const ttt_attn_bwd_args* a, void* stream);
+
+/* Fused per-head LayerNorm(64, eps) + 3-D RoPE of the attention's q and k (reference cogvideo/dit.py:184-195,
+ * cogvideo/utils.py:424-437): q_raw / k_raw / q / k / dq_raw / dk_raw are contiguous [B, S, NH*64] bf16; tokens
+ * s >= n_text are rotated by row (s - n_text) of the [n_pos, 64] fp32 cos / sin tables; LayerNorm parameters [64] fp32.
+ * The backward takes dq / dk as strided [B,NH,S,64] views and returns parameter-gradient partial sums
+ * [P, 4, 64] (dw_q, db_q, dw_k, db_k), P = ttt_hip_attn_pre_partials(B, S, NH); the caller reduces over P. */
+int ttt_hip_attn_pre_forward(int B, int S, int NH, int n_text, float eps, const void* q_raw, const void* k_raw,
+                             const float* wq, const float* bq, const float* wk, const float* bk,
+                             const float* cos_table, const float* sin_table, void* q, void* k, void* stream);
+int ttt_hip_attn_pre_partials(int B, int S, int NH);
+int ttt_hip_attn_pre_backward(int B, int S, int NH, int n_text, float eps, const void* q_raw, const void* k_raw,
+                              const ttt_attn_tensor* dq, const ttt_attn_tensor* dk, const float* wq, const float* wk,
+                              const float* cos_table, const float* sin_table, void* dq_raw, void* dk_raw, float* part,
+                              void* stream);
+
 /* Which implementation TTT_IMPL_AUTO resolves to for these dims (returns TTT_IMPL_GENERIC/MFMA). */
 int ttt_hip_resolve_impl(const ttt_dims* d, int is_mlp, int is_backward);
 

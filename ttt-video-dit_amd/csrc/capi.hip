@@ -7,6 +7,7 @@
 #include "ttt_generic.h"
 #include "ttt_mfma.h"
 #include "ttt_prepost.h"
+#include "attn.h"
 
 static thread_local char g_err[512] = "";
 
@@ -195,6 +196,89 @@ int ttt_hip_gate_backward(int B, int L, int D, int n_text, const void* g, const 
     ttt::prepost::GateBwdArgs a = {(const __bf16*)g, (const __bf16*)y, tanh_text, tanh_video, (__bf16*)dy, dtanh_part, B, L, D, n_text};
     ttt::prepost::gate_backward(a, (hipStream_t)stream);
     return post_launch("gate_backward");
+}
+
+
+static int check_attn_tensor(const ttt_attn_tensor& t, const char* name) {
+    if (!t.ptr) return fail("ttt_hip: attention: null tensor %s", name);
+    if (((uintptr_t)t.ptr & 15) || (t.stride_b & 7) || (t.stride_h & 7) || (t.stride_s & 7))
+        return fail("ttt_hip: attention: tensor %s must be 16-byte aligned with strides that are multiples of 8 elements", name);
+    return 0;
+}
+
+int ttt_hip_attn_forward(const ttt_attn_fwd_args* a, void* stream) {
+    if (!a) return fail("ttt_hip: null args");
+    if (a->D != 64) return fail("ttt_hip: attention: head_dim must be 64");
+    if (a->B <= 0 || a->NH <= 0 || a->S <= 0) return fail("ttt_hip: attention: non-positive dimension");
+    if (check_attn_tensor(a->Q, "Q") || check_attn_tensor(a->K, "K") || check_attn_tensor(a->V, "V") || check_attn_tensor(a->O, "O")) return -1;
+    ttt::attn::FwdParams p = {};
+    p.Q = (const __bf16*)a->Q.ptr; p.K = (const __bf16*)a->K.ptr; p.V = (const __bf16*)a->V.ptr; p.O = (__bf16*)a->O.ptr;
+    p.LSE = a->LSE;
+    p.q_sb = a->Q.stride_b; p.q_sh = a->Q.stride_h; p.q_ss = a->Q.stride_s;
+    p.k_sb = a->K.stride_b; p.k_sh = a->K.stride_h; p.k_ss = a->K.stride_s;
+    p.v_sb = a->V.stride_b; p.v_sh = a->V.stride_h; p.v_ss = a->V.stride_s;
+    p.o_sb = a->O.stride_b; p.o_sh = a->O.stride_h; p.o_ss = a->O.stride_s;
+    p.B = a->B; p.NH = a->NH; p.S = a->S; p.scale = a->scale;
+    ttt::attn::launch_forward(p, (hipStream_t)stream);
+    return post_launch("attn_forward");
+}
+
+int ttt_hip_attn_backward(const ttt_attn_bwd_args* a, void* stream) {
+    if (!a) return fail("ttt_hip: null args");
+    if (a->D != 64) return fail("ttt_hip: attention: head_dim must be 64");
+    if (a->B <= 0 || a->NH <= 0 || a->S <= 0) return fail("ttt_hip: attention: non-positive dimension");
+    if (!a->LSE || !a->Delta) return fail("ttt_hip: attention backward: null LSE / Delta");
+    if (check_attn_tensor(a->Q, "Q") || check_attn_tensor(a->K, "K") || check_attn_tensor(a->V, "V") || check_attn_tensor(a->O, "O") ||
+        check_attn_tensor(a->dO, "dO") || check_attn_tensor(a->dQ, "dQ") || check_attn_tensor(a->dK, "dK") || check_attn_tensor(a->dV, "dV")) return -1;
+    ttt::attn::BwdParams p = {};
+    p.Q = (const __bf16*)a->Q.ptr; p.K = (const __bf16*)a->K.ptr; p.V = (const __bf16*)a->V.ptr; p.O = (const __bf16*)a->O.ptr;
+    p.dO = (const __bf16*)a->dO.ptr; p.dQ = (__bf16*)a->dQ.ptr; p.dK = (__bf16*)a->dK.ptr; p.dV = (__bf16*)a->dV.ptr;
+    p.LSE = a->LSE; p.Delta = a->Delta;
+    p.q_sb = a->Q.stride_b; p.q_sh = a->Q.stride_h; p.q_ss = a->Q.stride_s;
+    p.k_sb = a->K.stride_b; p.k_sh = a->K.stride_h; p.k_ss = a->K.stride_s;
+    p.v_sb = a->V.stride_b; p.v_sh = a->V.stride_h; p.v_ss = a->V.stride_s;
+    p.o_sb = a->O.stride_b; p.o_sh = a->O.stride_h; p.o_ss = a->O.stride_s;
+    p.do_sb = a->dO.stride_b; p.do_sh = a->dO.stride_h; p.do_ss = a->dO.stride_s;
+    p.dq_sb = a->dQ.stride_b; p.dq_sh = a->dQ.stride_h; p.dq_ss = a->dQ.stride_s;
+    p.dk_sb = a->dK.stride_b; p.dk_sh = a->dK.stride_h; p.dk_ss = a->dK.stride_s;
+    p.dv_sb = a->dV.stride_b; p.dv_sh = a->dV.stride_h; p.dv_ss = a->dV.stride_s;
+    p.B = a->B; p.NH = a->NH; p.S = a->S; p.scale = a->scale;
+    ttt::attn::launch_backward(p, (hipStream_t)stream);
+    return post_launch("attn_backward");
+}
+
+
+int ttt_hip_attn_pre_partials(int B, int S, int NH) { return ttt::attn::pre_blocks((long)B * S * NH); }
+
+int ttt_hip_attn_pre_forward(int B, int S, int NH, int n_text, float eps, const void* q_raw, const void* k_raw,
+                             const float* wq, const float* bq, const float* wk, const float* bk,
+                             const float* cos_table, const float* sin_table, void* q, void* k, void* stream) {
+    if (B <= 0 || S <= 0 || NH <= 0 || n_text < 0) return fail("ttt_hip: attn_pre: bad dimension");
+    if (!q_raw || !k_raw || !wq || !bq || !wk || !bk || !q || !k) return fail("ttt_hip: attn_pre_forward: null pointer");
+    if (n_text < S && (!cos_table || !sin_table)) return fail("ttt_hip: attn_pre_forward: null rope table");
+    ttt::attn::PreParams p = {(const __bf16*)q_raw, (const __bf16*)k_raw, wq, bq, wk, bk, cos_table, sin_table,
+                              (__bf16*)q, (__bf16*)k, B, S, NH, n_text, eps};
+    ttt::attn::launch_pre_forward(p, (hipStream_t)stream);
+    return post_launch("attn_pre_forward");
+}
+
+int ttt_hip_attn_pre_backward(int B, int S, int NH, int n_text, float eps, const void* q_raw, const void* k_raw,
+                              const ttt_attn_tensor* dq, const ttt_attn_tensor* dk, const float* wq, const float* wk,
+                              const float* cos_table, const float* sin_table, void* dq_raw, void* dk_raw, float* part,
+                              void* stream) {
+    if (B <= 0 || S <= 0 || NH <= 0 || n_text < 0) return fail("ttt_hip: attn_pre: bad dimension");
+    if (!q_raw || !k_raw || !dq || !dk || !wq || !wk || !dq_raw || !dk_raw || !part) return fail("ttt_hip: attn_pre_backward: null pointer");
+    if (n_text < S && (!cos_table || !sin_table)) return fail("ttt_hip: attn_pre_backward: null rope table");
+    if (check_attn_tensor(*dq, "dq") || check_attn_tensor(*dk, "dk")) return -1;
+    ttt::attn::PreBwdParams p = {};
+    p.q_raw = (const __bf16*)q_raw; p.k_raw = (const __bf16*)k_raw; p.dq = (const __bf16*)dq->ptr; p.dk = (const __bf16*)dk->ptr;
+    p.dq_sb = dq->stride_b; p.dq_sh = dq->stride_h; p.dq_ss = dq->stride_s;
+    p.dk_sb = dk->stride_b; p.dk_sh = dk->stride_h; p.dk_ss = dk->stride_s;
+    p.wq = wq; p.wk = wk; p.cos = cos_table; p.sin = sin_table;
+    p.dq_raw = (__bf16*)dq_raw; p.dk_raw = (__bf16*)dk_raw; p.part = part;
+    p.B = B; p.S = S; p.NH = NH; p.n_text = n_text; p.eps = eps;
+    ttt::attn::launch_pre_backward(p, (hipStream_t)stream);
+    return post_launch("attn_pre_backward");
 }
 
 }  // extern "C"

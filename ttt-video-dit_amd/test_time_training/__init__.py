@@ -70,7 +70,8 @@ EXPORTED_SYMBOLS = (
     "ttt_hip_debug_timing", "ttt_hip_debug_groups_per_chunk", "ttt_hip_debug_variant", "ttt_hip_debug_dump",
     "ttt_hip_pre_forward", "ttt_hip_pre_backward_partials", "ttt_hip_pre_backward", "ttt_hip_post_partials",
     "ttt_hip_post_forward", "ttt_hip_post_backward", "ttt_hip_gate_forward", "ttt_hip_gate_backward_partials",
-    "ttt_hip_gate_backward",
+    "ttt_hip_gate_backward", "ttt_hip_attn_forward", "ttt_hip_attn_backward",
+    "ttt_hip_attn_pre_forward", "ttt_hip_attn_pre_partials", "ttt_hip_attn_pre_backward",
 )
 
 _lib: Optional[ctypes.CDLL] = None
@@ -402,3 +403,78 @@ def gate_backward(g, y, tanh_text, tanh_video, dy, dtanh_part, n_text):
     _req(g, "g", torch.bfloat16); _req(y, "y", torch.bfloat16); _req(dy, "dy", torch.bfloat16)
     _req(tanh_text, "tanh_text", torch.float32); _req(tanh_video, "tanh_video", torch.float32); _req(dtanh_part, "dtanh_part", torch.float32)
     _call("ttt_hip_gate_backward", B, L, D, int(n_text), _p(g), _p(y), _p(tanh_text), _p(tanh_video), _p(dy), _p(dtanh_part), device=g.device)
+
+
+# ------------------------------------------------------------------------------------------------
+# Segment self-attention (include/ttt_hip.h, "Segment self-attention"): strided [B, NH, S, 64] bf16 views, no copies.
+class _AttnTensor(ctypes.Structure):
+    _fields_ = [("ptr", ctypes.c_void_p), ("stride_b", ctypes.c_int64), ("stride_h", ctypes.c_int64), ("stride_s", ctypes.c_int64)]
+
+
+class _AttnFwd(ctypes.Structure):
+    _fields_ = [("Q", _AttnTensor), ("K", _AttnTensor), ("V", _AttnTensor), ("O", _AttnTensor), ("LSE", ctypes.c_void_p),
+                ("B", ctypes.c_int32), ("NH", ctypes.c_int32), ("S", ctypes.c_int32), ("D", ctypes.c_int32), ("scale", ctypes.c_float)]
+
+
+class _AttnBwd(ctypes.Structure):
+    _fields_ = [(n, _AttnTensor) for n in ("Q", "K", "V", "O", "dO", "dQ", "dK", "dV")] + [
+        ("LSE", ctypes.c_void_p), ("Delta", ctypes.c_void_p),
+        ("B", ctypes.c_int32), ("NH", ctypes.c_int32), ("S", ctypes.c_int32), ("D", ctypes.c_int32), ("scale", ctypes.c_float)]
+
+
+def _attn_tensor(t, name, shape):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.bfloat16:
+        raise RuntimeError(f"{name}: expected a bfloat16 tensor on a HIP device (there is no CPU path)")
+    if tuple(t.shape) != tuple(shape):
+        raise RuntimeError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    if t.stride(3) != 1:
+        raise RuntimeError(f"{name}: the head dimension must be contiguous")
+    return _AttnTensor(t.data_ptr(), t.stride(0), t.stride(1), t.stride(2))
+
+
+def attn_forward(q, k, v, out, lse, scale):
+    """O = softmax(q k^T * scale) v for [B, NH, S, 64] bf16 views (any batch/head/token strides); lse [B,NH,S] fp32 or None."""
+    B, NH, S, D = q.shape
+    a = _AttnFwd(_attn_tensor(q, "q", (B, NH, S, D)), _attn_tensor(k, "k", (B, NH, S, D)), _attn_tensor(v, "v", (B, NH, S, D)),
+                 _attn_tensor(out, "out", (B, NH, S, D)), lse.data_ptr() if lse is not None else None, B, NH, S, D, float(scale))
+    if lse is not None:
+        _req(lse, "lse", torch.float32)
+    _call("ttt_hip_attn_forward", ctypes.byref(a), device=q.device)
+
+
+def attn_backward(q, k, v, out, dout, lse, delta, dq, dk, dv, scale):
+    B, NH, S, D = q.shape
+    sh = (B, NH, S, D)
+    _req(lse, "lse", torch.float32); _req(delta, "delta", torch.float32)
+    a = _AttnBwd(_attn_tensor(q, "q", sh), _attn_tensor(k, "k", sh), _attn_tensor(v, "v", sh), _attn_tensor(out, "out", sh),
+                 _attn_tensor(dout, "dout", sh), _attn_tensor(dq, "dq", sh), _attn_tensor(dk, "dk", sh), _attn_tensor(dv, "dv", sh),
+                 lse.data_ptr(), delta.data_ptr(), B, NH, S, D, float(scale))
+    _call("ttt_hip_attn_backward", ctypes.byref(a), device=q.device)
+
+
+def attn_pre_forward(q_raw, k_raw, wq, bq, wk, bk, cos, sin, q, k, NH, n_text, eps):
+    """Fused per-head LayerNorm(64) + RoPE of the attention's q and k; [B, S, NH*64] bf16 in and out."""
+    B, S, D = q_raw.shape
+    for t, n in ((q_raw, "q_raw"), (k_raw, "k_raw"), (q, "q"), (k, "k")):
+        _req(t, n, torch.bfloat16)
+    for t, n in ((wq, "wq"), (bq, "bq"), (wk, "wk"), (bk, "bk"), (cos, "cos"), (sin, "sin")):
+        _req(t, n, torch.float32)
+    if D != NH * 64 or cos.shape[-1] != 64 or cos.shape[0] < S - n_text:
+        raise RuntimeError("attn_pre_forward: head_dim must be 64 and the rope tables must cover the video tokens")
+    _call("ttt_hip_attn_pre_forward", B, S, NH, int(n_text), ctypes.c_float(eps), _p(q_raw), _p(k_raw), _p(wq), _p(bq), _p(wk), _p(bk),
+          _p(cos), _p(sin), _p(q), _p(k), device=q_raw.device)
+
+
+def attn_pre_partials(B, S, NH):
+    return load_library().ttt_hip_attn_pre_partials(int(B), int(S), int(NH))
+
+
+def attn_pre_backward(q_raw, k_raw, dq, dk, wq, wk, cos, sin, dq_raw, dk_raw, part, NH, n_text, eps):
+    B, S, D = q_raw.shape
+    for t, n in ((q_raw, "q_raw"), (k_raw, "k_raw"), (dq_raw, "dq_raw"), (dk_raw, "dk_raw")):
+        _req(t, n, torch.bfloat16)
+    for t, n in ((wq, "wq"), (wk, "wk"), (cos, "cos"), (sin, "sin"), (part, "part")):
+        _req(t, n, torch.float32)
+    tq, tk = _attn_tensor(dq, "dq", (B, NH, S, 64)), _attn_tensor(dk, "dk", (B, NH, S, 64))
+    _call("ttt_hip_attn_pre_backward", B, S, NH, int(n_text), ctypes.c_float(eps), _p(q_raw), _p(k_raw), ctypes.byref(tq), ctypes.byref(tk),
+          _p(wq), _p(wk), _p(cos), _p(sin), _p(dq_raw), _p(dk_raw), _p(part), device=q_raw.device)

@@ -5,8 +5,8 @@ behaviour follow the reference's ``ttt/models/cogvideo/dit.py`` (PatchEmbedding 
 :385-418, DiffusionTransformer :421-505).
 
 Dense projections / MLP GEMMs go to hipBLASLt through PyTorch; the TTT scan goes to the
-hand-written gfx950 kernels (``ttt_amd.models.ssm``); local attention goes through
-``segment_attention`` below.
+hand-written gfx950 kernels (``ttt_amd.models.ssm``); the local attention (q/k LayerNorm + RoPE, QK^T /
+softmax / PV and their backward) goes to the MFMA kernels behind ``ttt_amd.models.cogvideo.attention``.
 """
 from __future__ import annotations
 
@@ -15,6 +15,7 @@ import torch.nn.functional as F
 from torch import nn
 from torch.utils.checkpoint import checkpoint
 
+from ttt_amd.models.cogvideo.attention import AttnPre, attn_pre_available, segment_attention
 from ttt_amd.models.cogvideo.utils import (Rotary3DPositionEmbedding, SequenceMetadata, modulate,
                                            timestep_embedding, unpatchify)
 from ttt_amd.models.configs import ModelConfig
@@ -26,11 +27,6 @@ def _ckpt(fn, enabled: bool):
     if not enabled:
         return fn
     return lambda *a: checkpoint(fn, *a, use_reentrant=False)
-
-
-def segment_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
-    """Non-causal self-attention over one 3-second segment, [B, NH, S, D] (reference dit.py:196-198)."""
-    return F.scaled_dot_product_attention(q, k, v, attn_mask=None, dropout_p=0.0, is_causal=False)
 
 
 class PatchEmbedding(nn.Module):
@@ -115,10 +111,16 @@ class SeqModelingBlock(nn.Module):
         """q/k/v projections, per-head LayerNorm on q,k, 3-D RoPE on the video tokens, SDPA, o."""
         b, s, _ = emb.shape
         heads = lambda t: t.view(b, s, self.num_heads, self.head_dim).transpose(1, 2)   # [b, h, s, d]
-        q, k, v = heads(self.q(emb)), heads(self.k(emb)), heads(self.v(emb))
-        q, k = self.q_norm(q), self.k_norm(k)
-        q = torch.cat((q[:, :, :n_text], self.rotary(q[:, :, n_text:])), dim=2)
-        k = torch.cat((k[:, :, :n_text], self.rotary(k[:, :, n_text:])), dim=2)
+        if attn_pre_available(emb, self.head_dim):      # HIP: LayerNorm + RoPE fused, layout kept, strided views downstream
+            cos, sin = self.rotary.tables_f32()
+            q, k = AttnPre.apply(self.q(emb), self.k(emb), self.q_norm.weight, self.q_norm.bias, self.k_norm.weight,
+                                 self.k_norm.bias, cos, sin, self.num_heads, n_text, self.q_norm.eps)
+            v = heads(self.v(emb))
+        else:
+            q, k, v = heads(self.q(emb)), heads(self.k(emb)), heads(self.v(emb))
+            q, k = self.q_norm(q), self.k_norm(k)
+            q = torch.cat((q[:, :, :n_text], self.rotary(q[:, :, n_text:])), dim=2)
+            k = torch.cat((k[:, :, :n_text], self.rotary(k[:, :, n_text:])), dim=2)
         a = segment_attention(q, k, v)
         return self.o(a.transpose(1, 2).reshape(b, s, -1))
 
@@ -126,6 +128,8 @@ class SeqModelingBlock(nn.Module):
         """Each segment i attends over [text_i, frames 12i .. 12(i+1)] (13 frames, 1 shared with its
         neighbour); the shared frame's outputs are averaged (reference :163-211)."""
         tl, tpf = seq_metadata.text_length, seq_metadata.tokens_per_frame
+        if seq_metadata.num_chunks == 1:     # one segment: nothing overlaps, the accumulate / average below is the identity
+            return self._segment(torch.cat((text_emb, vid_emb), dim=1), tl)
         out_vid = torch.zeros_like(vid_emb)
         out_txt = torch.zeros_like(text_emb)
         count = torch.zeros_like(vid_emb[..., :1])

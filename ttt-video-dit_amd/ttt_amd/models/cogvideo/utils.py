@@ -156,6 +156,15 @@ class Rotary3DPositionEmbedding(nn.Module):
             self.freqs_sin = replicate_tensor(self.freqs_sin, self.tp_mesh)
             self.freqs_cos = replicate_tensor(self.freqs_cos, self.tp_mesh)
 
+    def tables_f32(self):
+        """(cos, sin) as contiguous fp32 [n_pos, head_dim] for the fused HIP kernel (which applies the bf16 rounding of
+        ``forward`` itself); cached per buffer identity."""
+        key = (self.freqs_cos.data_ptr(), self.freqs_cos.dtype, self.freqs_cos.device)
+        if getattr(self, "_f32_key", None) != key:
+            self._f32 = (to_local(self.freqs_cos).float().contiguous(), to_local(self.freqs_sin).float().contiguous())
+            self._f32_key = key
+        return self._f32
+
     def forward(self, t):  # t [B, NH, S, D]
         n = t.shape[2]
         # computed in the activation dtype, like the reference after cast_rotary_freqs (train.py:71-72)
