@@ -145,7 +145,7 @@ __global__ __launch_bounds__(NT, 1) void mlp_scan_kernel(ScanParams p) {
         const size_t tile = (size_t)bh * NC + i;
         char* slot = SAVE ? slots + (size_t)(i - p.chunk_lo) * SLOT_BYTES : nullptr;
         char* slot_w = SAVE ? slot + (size_t)w * SLOT_WAVE_FR : nullptr;
-        char* own_w = SAVE ? slot + SLOT_FR + (size_t)w * SLOT_OWN_WAVE : nullptr;
+        char* own = SAVE ? slot + SLOT_FR : nullptr;
 
         if (!SAVE && i % G == 0) {   // checkpoint: state entering step i (mlp_tk.py:95-98)
             const size_t ck = (size_t)bh * p.K + i / G;
@@ -220,6 +220,11 @@ __global__ __launch_bounds__(NT, 1) void mlp_scan_kernel(ScanParams p) {
                             st_frag(slot_w, FR_D1, fr_idx(ti, nj, s), pack(D1[ti][nj], s), l);
                             st_frag(slot_w, FR_D2, fr_idx(ti, nj, s), pack(d2, s), l);
                         }
+                        if (p.slot_v2) {      // gelu'(Z1) also in (rows=n, lane=t) orientation for the revision-2 sweep
+                            const f32x16 dn = transpose_tile(pack(D1[ti][nj], 0), pack(D1[ti][nj], 1), I0, I1);
+                            st_frag(slot_w, FR_D1N, fr_idx(nj, ti, 0), pack(dn, 0), l);
+                            st_frag(slot_w, FR_D1N, fr_idx(nj, ti, 1), pack(dn, 1), l);
+                        }
                     }
                 }
         }
@@ -265,6 +270,10 @@ __global__ __launch_bounds__(NT, 1) void mlp_scan_kernel(ScanParams p) {
                     const f32x16 wt = transpose_tile(W2F[ni][fj][0], W2F[ni][fj][1], I0, I1);   // (rows=f, lane=n)
                     WTF[fj][ni][0] = pack(wt, 0);
                     WTF[fj][ni][1] = pack(wt, 1);
+                    if (SAVE && p.slot_v2) {
+                        st_frag(slot_w, FR_W2T, fr_idx(fj, ni, 0), WTF[fj][ni][0], l);
+                        st_frag(slot_w, FR_W2T, fr_idx(fj, ni, 1), WTF[fj][ni][1], l);
+                    }
                 }
         }
         TTT_STAMP(1)
@@ -295,9 +304,9 @@ __global__ __launch_bounds__(NT, 1) void mlp_scan_kernel(ScanParams p) {
             for (int j = 0; j < 16; ++j) gx[j] = (64.0f * gx[j] - s1 - z[j] * s2) * rstd * (1.0f / 64.0f);
             store16_bf16(G1 + ot * TS + of0, gx);
             if (SAVE) {
-                st_own16(own_w, 0, z, l);
-                st_own16(own_w, 1, go, l);
-                own_stats(own_w, l)[0] = rstd;
+                st_own<16>(own, 0, ot, of0, z);
+                st_own<16>(own, 1, ot, of0, go);
+                own_stats(own, ot)[0] = rstd;
                 store16_bf16(reinterpret_cast<__bf16*>(slot + SLOT_FR + SLOT_OWN) + ot * 64 + of0, gx);
             }
         }
@@ -343,10 +352,19 @@ __global__ __launch_bounds__(NT, 1) void mlp_scan_kernel(ScanParams p) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) g1[r] = gx[r] * D1[ti][nj][r];   // gZ1, unscaled
                     const bf16x8 g1a = pack(g1, 0), g1b = pack(g1, 1);
-                    st_frag(slot_w, FR_GX2, fr_idx(ti, nj, 0), pack(gx, 0), l);
-                    st_frag(slot_w, FR_GX2, fr_idx(ti, nj, 1), pack(gx, 1), l);
-                    st_frag(slot_w, FR_GZ1, fr_idx(ti, nj, 0), g1a, l);
-                    st_frag(slot_w, FR_GZ1, fr_idx(ti, nj, 1), g1b, l);
+                    if (p.slot_v2) {          // revision-2 sweep consumes the product M = gX2 * gelu''(Z1) only
+                        const f32x16 d2 = unpack2(ld_frag(slot_w, FR_D2, fr_idx(ti, nj, 0), l), ld_frag(slot_w, FR_D2, fr_idx(ti, nj, 1), l));
+                        f32x16 mm;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) mm[r] = gx[r] * d2[r];
+                        st_frag(slot_w, FR_GX2, fr_idx(ti, nj, 0), pack(mm, 0), l);
+                        st_frag(slot_w, FR_GX2, fr_idx(ti, nj, 1), pack(mm, 1), l);
+                    } else {
+                        st_frag(slot_w, FR_GX2, fr_idx(ti, nj, 0), pack(gx, 0), l);
+                        st_frag(slot_w, FR_GX2, fr_idx(ti, nj, 1), pack(gx, 1), l);
+                        st_frag(slot_w, FR_GZ1, fr_idx(ti, nj, 0), g1a, l);
+                        st_frag(slot_w, FR_GZ1, fr_idx(ti, nj, 1), g1b, l);
+                    }
                     const f32x16 g1t = transpose_tile(g1a, g1b, I0, I1);          // gZ1^T (rows=n, lane=t)
                     st_frag(slot_w, FR_GZ1T, fr_idx(nj, ti, 0), pack(g1t, 0), l);
                     st_frag(slot_w, FR_GZ1T, fr_idx(nj, ti, 1), pack(g1t, 1), l);
@@ -441,8 +459,8 @@ __global__ __launch_bounds__(NT, 1) void mlp_scan_kernel(ScanParams p) {
             if (SAVE) {
 #pragma unroll
                 for (int j = 0; j < 16; ++j) z[j] = (z[j] - mu) * rstd;
-                st_own16(own_w, 2, z, l);
-                own_stats(own_w, l)[1] = rstd;
+                st_own<16>(own, 2, ot, of0, z);
+                own_stats(own, ot)[1] = rstd;
             } else {
                 load16_bf16(Qt + ot * TS + of0, q);
 #pragma unroll
@@ -464,6 +482,16 @@ __global__ __launch_bounds__(NT, 1) void mlp_scan_kernel(ScanParams p) {
                     st_frag(slot_w, FR_W1, fr_idx(a, b, s), pack(W1t[a][b], s), l);
                     st_frag(slot_w, FR_W2, fr_idx(a, b, s), pack(W2t[a][b], s), l);
                 }
+        if (p.slot_v2) {
+#pragma unroll
+            for (int fj = 0; fj < 2; ++fj)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const f32x16 wt = transpose_tile(pack(W2t[ni][fj], 0), pack(W2t[ni][fj], 1), I0, I1);
+                    st_frag(slot_w, FR_W2T, fr_idx(fj, ni, 0), pack(wt, 0), l);
+                    st_frag(slot_w, FR_W2T, fr_idx(fj, ni, 1), pack(wt, 1), l);
+                }
+        }
     }
 }
 

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(NT, 1) void mlp_bwd_sweep_kernel(SweepParams p) {
         char* slot = slots + (size_t)(i - p.chunk_lo) * SLOT_BYTES;
         char* slot_w = slot + (size_t)w * SLOT_WAVE_FR;
         const char* next_w = slot + SLOT_BYTES + (size_t)w * SLOT_WAVE_FR;      // post-update state W' = state entering i+1
-        const char* own_w = slot + SLOT_FR + (size_t)w * SLOT_OWN_WAVE;
+        char* own = slot + SLOT_FR;
         const bool more = (i > p.chunk_lo);
         if (more) bprefetch_issue(pf, p, tile - 1, slot - SLOT_BYTES);
 
@@ -181,8 +181,8 @@ __global__ __launch_bounds__(NT, 1) void mlp_bwd_sweep_kernel(SweepParams p) {
         {
             float d[16], xl[16], g[16];
             load16_bf16(dOt + ot * TS + of0, d);
-            ld_own16(own_w, 2, xl, l);
-            const float rstdl = own_stats(const_cast<char*>(own_w), l)[1];
+            ld_own<16>(own, 2, ot, of0, xl);
+            const float rstdl = own_stats(own, ot)[1];
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
@@ -426,9 +426,9 @@ __global__ __launch_bounds__(NT, 1) void mlp_bwd_sweep_kernel(SweepParams p) {
         {
             float G_[16], xh[16], go[16];
             gather_partial(red, nullptr, ot, of0, G_);
-            ld_own16(own_w, 0, xh, l);
-            ld_own16(own_w, 1, go, l);
-            const float r = own_stats(const_cast<char*>(own_w), l)[0];
+            ld_own<16>(own, 0, ot, of0, xh);
+            ld_own<16>(own, 1, ot, of0, go);
+            const float r = own_stats(own, ot)[0];
             const float eta_t = etaL[ot];
             float gxh[16], gz[16];
             float s1g = 0.f, s2g = 0.f;
@@ -647,7 +647,7 @@ bool bwd_available() { return true; }
 static int g_forced_gpc = 0;
 void set_debug_groups_per_chunk(int g) { g_forced_gpc = g; }
 
-static int groups_per_chunk(const ttt_dims* d) {
+int groups_per_chunk(const ttt_dims* d) {
     const int nbh = d->B * d->NH;
     const int K = (d->NC + d->G - 1) / d->G;
     int g = (256 + nbh - 1) / nbh;            // enough recompute workgroups to cover the 256 CUs
@@ -664,10 +664,13 @@ size_t workspace_bytes(const ttt_dims* d, bool mlp, bool backward) {
     if (!mlp || !backward) return 0;
     const size_t nbh = (size_t)d->B * d->NH;
     const size_t slots = (size_t)groups_per_chunk(d) * d->G + 1;
-    return nbh * (slots * SLOT_BYTES + CARRY_FLOATS * sizeof(float));
+    const size_t v1 = nbh * (slots * SLOT_BYTES + CARRY_FLOATS * sizeof(float));
+    const size_t v2 = workspace_bytes_v2(d);
+    return v1 > v2 ? v1 : v2;
 }
 
 void mlp_backward(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hipStream_t s) {
+    if (get_debug_variant() != 1) { mlp_backward_v2(d, a, ws, s); return; }   // revision 2 (default): ttt_mfma_bwd2.hip
     const int nbh = d->B * d->NH, G = d->G, NC = d->NC;
     const int K = (NC + G - 1) / G;
     const int gpc = groups_per_chunk(d);

@@ -1,0 +1,777 @@
+// MFMA TTT-MLP backward for gfx950, revision 2: 8-wave reverse sweep + parallel dK / dQ tail kernel.
+//
+// Why a second revision (profiles/r1b): the 4-wave / 512-register sweep (ttt_mfma_bwd.hip) spends 70 % of its wave
+// cycles waiting (one wave per SIMD: every slot load and every barrier is exposed), 10 % of the occupied SIMDs' MFMA
+// time is used, 20 of its MFMAs per wave-step are layout transposes, and it carries work that does not depend on the
+// sequential state at all.  Here
+//   * the sequential kernel is 8 waves (2 per SIMD, <= 256 VGPRs, VGPR-form MFMA), wave (w, p) owning the 32 hidden
+//     units Hp = [64w + 32p, +32): dW1[:, Hp] as tiles (rows = f, lane = n) and dW2[Hp, :] in BOTH orientations
+//     (rows = n, lane = f) and (rows = f, lane = n), each updated by its own MFMAs - so every contraction of the step
+//     runs over a tile's row index (in-place operand re-use, ttt_mfma_dev.h) with no transposes;
+//   * everything elementwise is evaluated in the orientation its consumer contracts over: the (K dW1) and (gZ2 dW2^T)
+//     products are formed twice, (rows = n, lane = t) for the token-wise reductions / the contraction over hidden units
+//     and (rows = t, lane = n) for the contractions over tokens - an MFMA is cheaper than any cross-lane shuffle;
+//   * the contraction over the 256 hidden units of d(gZ2) is reduced over the 4 hidden slices through LDS partials
+//     (pairs (w,0),(w,1) first exchange the 32-unit operand fragments they miss: u^T and the packed dW2 block);
+//   * dK and dQ leave the sequential kernel: they need the carried dW1 and dZ1 of their step but nothing downstream
+//     needs them, so the sweep stores those two (bf16 fragment images) and a fully parallel tail kernel (one workgroup
+//     per step) finishes dK = -eta (gZ1 dW1'^T) + dZ1 W1^T - dt and dQ = dOut + dZ1b W1'^T.
+// Math: SURVEY.md Appendix A backward; oracle/ttt_oracle.py:_mlp_step_bwd is the executable spec.
+//
+// Per step i of the sweep (5 workgroup barriers; "step j" = i - 1 is the next one to be processed):
+//   S1  E1^T = dW1^T K^T, A2^T = dW2 gZ2^T (rows = n, lane = t); u^T = -eta (E1 + db1) gelu'(Z1);
+//       d(eta) partial = -colsum(X2^T A2^T + gZ1^T (E1^T + db1)); first half of d(gZ2)^T = -eta (dW2^T X2^T);
+//       publish u^T fragments                                                                              | Ba
+//   S2  d(gZ2)^T partial += W2^T u^T (own + partner fragments) -> LDS partials                              | Bb
+//   S3  owners: reduce 4 partials, backward of the fused LN / L2 gradient -> dZ2 (LDS), dV, d(eta), dgamma, dbeta;
+//       output LayerNorm backward of step j -> dZ2b_j (LDS).  Waves: E1, A2 again in (rows = t, lane = n)  | Bc
+//   S4a u = -eta (E1 + db1) gelu'(Z1); dX2 = -eta A2 + dZ2 W2^T; dZ1 = dgZ1 M + dX2 gelu'(Z1);
+//       dW1 += K^T dZ1; dW2 += u^T gZ2 + X2^T dZ2 (both orientations); db1, db2; dZ1 -> slot                | Bd
+//   S4b step j's output path: dZ1b = (dZ2b W2'^T) gelu'(Z1b); dW1 += Q^T dZ1b; dW2 += X2b^T dZ2b; db1, db2;
+//       dZ1b and the now complete dW1 -> slot j (tail kernel + next S1); publish dW2 block; park K, gZ2, eta | Be
+#include "ttt_mfma.h"
+#include "ttt_mfma_dev.h"
+#include "ttt_mfma_int.h"
+
+namespace ttt {
+namespace mfma {
+using namespace ttt::mf;
+
+namespace b2 {
+
+constexpr int NT2 = 512;
+typedef __attribute__((address_space(3))) bf16x4 lds_b4;
+
+// ---- helpers shared with the revision-2 forward (same idioms) --------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float sum8(float v) {
+    v += dpp_f<0xB1>(v);
+    v += dpp_f<0x4E>(v);
+    v += dpp_f<0x141>(v);
+    return v;
+}
+__device__ __forceinline__ bf16x8 tr_frag(const __bf16* img, int stride, int r0, int r1, int col0, int l) {
+    const int i = l & 15, g1 = (l >> 4) & 1;
+    const int off = (i >> 2) * stride + col0 + 16 * g1 + 4 * (i & 3);
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(img + r0 * stride + off));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(img + r1 * stride + off));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+// operand fragment (outer = column in [col0, col0+32), contraction = rows of the 32-row block at row0, pi slot order s)
+__device__ __forceinline__ bf16x8 tr_pi(const __bf16* img, int row0, int s, int col0, int l) {
+    const int h = l >> 5;
+    return tr_frag(img, TS, row0 + 16 * s + 4 * h, row0 + 16 * s + 8 + 4 * h, col0, l);
+}
+// operand fragment (outer = row 32 ti + c, contraction = columns col0 + pi slots of s)
+__device__ __forceinline__ bf16x8 row_pi(const __bf16* img, int ti, int col0, int s, int l) {
+    return pi_read(img + (32 * ti + (l & 31)) * TS, col0, s, l >> 5);
+}
+__device__ __forceinline__ void load8_bf16(const __bf16* p, float (&o)[8]) {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (float)a[j];
+}
+__device__ __forceinline__ void store8_bf16(__bf16* p, const float (&v)[8]) {
+    bf16x8 a;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = (__bf16)v[j];
+    *reinterpret_cast<bf16x8*>(p) = a;
+}
+__device__ __forceinline__ void load8_f32(const float* p, float (&o)[8]) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+}
+__device__ __forceinline__ void add8_f32(const float* p, float (&o)[8]) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+    o[0] += a[0]; o[1] += a[1]; o[2] += a[2]; o[3] += a[3]; o[4] += b[0]; o[5] += b[1]; o[6] += b[2]; o[7] += b[3];
+}
+// one wave's partial tile (rows = f in Fp, lane = t of tile ti) -> red[w][t][f]
+__device__ __forceinline__ void write_partial2(float* redw, const f32x16& P, int ti, int p, int h, int c) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x4 v = {P[4 * q], P[4 * q + 1], P[4 * q + 2], P[4 * q + 3]};
+        *reinterpret_cast<f32x4*>(redw + (32 * ti + c) * PS + 32 * p + 8 * q + 4 * h) = v;
+    }
+}
+__device__ __forceinline__ f32x16 ld_tile(const char* wave_base, int arr, int a, int b, int lane) {
+    return unpack2(ld_frag(wave_base, arr, fr_idx(a, b, 0), lane), ld_frag(wave_base, arr, fr_idx(a, b, 1), lane));
+}
+__device__ __forceinline__ float tile_colsum(const f32x16& t) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += t[r];
+    return xor_add(s, 32);
+}
+
+// ---- LDS map ------------------------------------------------------------------------------------------------------------
+constexpr int TILE_B = TILE_ELEMS * 2;                    // 9216 bytes
+constexpr int L_K = 0;                                    // K_i          [t][f]
+constexpr int L_G = L_K + TILE_B;                         // gZ2_i        [t][f]
+constexpr int L_Q = L_G + TILE_B;                         // Q_j          [t][f]   (j = i - 1)
+constexpr int L_A = L_Q + TILE_B;                         // dZ2b_j       [t][f]
+constexpr int L_XU = L_A + TILE_B;                        // u^T exchange (8 waves x 4 fragments x 1 KiB); later dZ2_i [t][f]
+constexpr int XU_BYTES = 8 * 4 * 1024;
+constexpr int L_XD = L_XU + XU_BYTES;                     // dW2 block exchange (8 waves x 2 fragments)
+constexpr int XD_BYTES = 8 * 2 * 1024;
+constexpr int L_RED = L_XD + XD_BYTES;                    // [4][64][PS] fp32
+constexpr int RED_B = 4 * 64 * PS * 4;
+constexpr int L_SM = L_RED + RED_B;                       // eta[64], db1[256], db2[64], gamma[64], etaP[8][64]
+constexpr int LDS_SWEEP = L_SM + (64 + 256 + 64 + 64 + 8 * 64) * 4;
+static_assert(LDS_SWEEP <= 160 * 1024, "LDS budget");
+static_assert(TILE_B <= XU_BYTES, "dZ2 tile aliases the u exchange");
+
+// carry area per (b,h), floats: natural-layout dW1 [64][256], dW2 [256][64], db1 [256], db2 [64], then per-thread dgamma / dbeta
+constexpr size_t C_DW1 = 0, C_DW2 = 64 * 256, C_DB1 = 2 * 64 * 256, C_DB2 = C_DB1 + 256, C_DG = C_DB2 + 64, C_DBT = C_DG + NT2 * 8,
+                 CARRY_FLOATS2 = C_DBT + NT2 * 8;
+
+struct SweepParams2 {
+    const __bf16 *XQ, *XK, *dOut, *eta;
+    const float* ln_w;
+    const float *uW1, *ub1, *uW2, *ub2;
+    char* slots; size_t slot_stride_bh;
+    float* carry;
+    __bf16 *dXV, *deta;
+    float *dW1, *db1, *dW2, *db2, *dlnw, *dlnb;
+    int NH, NC, chunk_lo, chunk_hi, first, last;
+};
+
+struct Stage {            // next step's tiles, register-staged: one 16-byte chunk per thread per tile
+    uint4 k, g, q;
+    float eta;
+};
+
+__global__ __launch_bounds__(NT2) void mlp_bwd_sweep8_kernel(SweepParams2 p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __bf16* Kt = reinterpret_cast<__bf16*>(smem + L_K);
+    __bf16* Gt = reinterpret_cast<__bf16*>(smem + L_G);
+    __bf16* Qt = reinterpret_cast<__bf16*>(smem + L_Q);
+    __bf16* At = reinterpret_cast<__bf16*>(smem + L_A);
+    __bf16* Bt = reinterpret_cast<__bf16*>(smem + L_XU);
+    char* exu = smem + L_XU;
+    char* exd = smem + L_XD;
+    float* red = reinterpret_cast<float*>(smem + L_RED);
+    float* etaL = reinterpret_cast<float*>(smem + L_SM);
+    float* db1L = etaL + 64;
+    float* db2L = db1L + 256;
+    float* gamL = db2L + 64;
+    float* etaP = gamL + 64;
+
+    const int tid = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = wv >> 1, pp = wv & 1;
+    const int nO = 64 * w + 32 * pp;
+    const int fO = 32 * pp, fX = 32 * (1 - pp);
+    const int bh = blockIdx.x, head = bh % p.NH;
+    const int NC = p.NC;
+    char* slots = p.slots + (size_t)bh * p.slot_stride_bh;
+    float* carry = p.carry + (size_t)bh * CARRY_FLOATS2;
+
+    // ---- carried state gradient ---------------------------------------------------------------------------------------
+    f32x16 dW1t[2];      // [a]  dW1[f in 32a.., n in Hp]                 (rows = f, lane = n)
+    f32x16 dW2t[2];      // [0] dW2[n in Hp, f in Fp], [1] dW2[n in Hp, f in Fx]      (rows = n, lane = f)
+    f32x16 dW2Tt[2];     // same blocks transposed                                      (rows = f, lane = n)
+    float db1v, db2v = 0.f;   // db1[nO + c] ; db2[fO + c] (waves with w == 0)
+    float dgam[8], dbet[8];
+    {
+        const int l = tid & 63, h = l >> 5, c = l & 31;
+        const float* g1 = p.first ? p.uW1 + (size_t)bh * 64 * 256 : carry + C_DW1;
+        const float* g2 = p.first ? p.uW2 + (size_t)bh * 256 * 64 : carry + C_DW2;
+        const float* gb1 = p.first ? p.ub1 + (size_t)bh * 256 : carry + C_DB1;
+        const float* gb2 = p.first ? p.ub2 + (size_t)bh * 64 : carry + C_DB2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ro = row_of(r, h);
+            dW1t[0][r] = g1[(size_t)ro * 256 + nO + c];
+            dW1t[1][r] = g1[(size_t)(32 + ro) * 256 + nO + c];
+            dW2t[0][r] = g2[(size_t)(nO + ro) * 64 + fO + c];
+            dW2t[1][r] = g2[(size_t)(nO + ro) * 64 + fX + c];
+            dW2Tt[0][r] = g2[(size_t)(nO + c) * 64 + fO + ro];
+            dW2Tt[1][r] = g2[(size_t)(nO + c) * 64 + fX + ro];
+        }
+        db1v = gb1[nO + c];
+        if (w == 0) db2v = gb2[fO + c];
+        if (p.first) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { dgam[j] = 0.f; dbet[j] = 0.f; }
+        } else {
+            load8_f32(carry + C_DG + (size_t)tid * 8, dgam);
+            load8_f32(carry + C_DBT + (size_t)tid * 8, dbet);
+        }
+        if (tid < 64) gamL[tid] = p.ln_w[(size_t)head * 64 + tid];
+    }
+    bf16x8 ONES;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ONES[e] = (__bf16)1.0f;
+
+    // ---- staging helpers (lambdas keep the index arithmetic in one place) ---------------------------------------------
+    auto stage_issue = [&](Stage& st, int step, bool with_kg, bool with_q) {
+        const int prow = tid >> 3, pcol = (tid & 7) * 8;
+        const size_t off = ((size_t)bh * NC + step) * 4096 + (size_t)prow * 64 + pcol;
+        if (with_kg) {
+            st.k = *reinterpret_cast<const uint4*>(p.XK + off);
+            const __bf16* g = reinterpret_cast<const __bf16*>(slots + (size_t)(step - p.chunk_lo) * SLOT_BYTES + SLOT_FR + SLOT_OWN);
+            st.g = *reinterpret_cast<const uint4*>(g + (size_t)prow * 64 + pcol);
+            st.eta = tid < 64 ? (float)p.eta[((size_t)bh * NC + step) * 64 + tid] : 0.f;
+        }
+        if (with_q) st.q = *reinterpret_cast<const uint4*>(p.XQ + off);
+    };
+    auto park_kg = [&](const Stage& st) {
+        const int prow = tid >> 3, pcol = (tid & 7) * 8;
+        *reinterpret_cast<uint4*>(Kt + prow * TS + pcol) = st.k;
+        *reinterpret_cast<uint4*>(Gt + prow * TS + pcol) = st.g;
+        if (tid < 64) etaL[tid] = st.eta;
+    };
+    auto park_q = [&](const Stage& st) {
+        const int prow = tid >> 3, pcol = (tid & 7) * 8;
+        *reinterpret_cast<uint4*>(Qt + prow * TS + pcol) = st.q;
+    };
+    // owners: backward of the output LayerNorm of step j -> dZ2b_j tile (At), dgamma / dbeta contributions
+    auto owner_out_ln = [&](int j) {
+        const int ot = tid >> 3, of0 = 8 * (tid & 7);
+        char* own = slots + (size_t)(j - p.chunk_lo) * SLOT_BYTES + SLOT_FR;
+        float d[8], xl[8], g[8];
+        load8_bf16(p.dOut + ((size_t)bh * NC + j) * 4096 + (size_t)ot * 64 + of0, d);
+        ld_own<8>(own, 2, ot, of0, xl);
+        const float rstdl = own_stats(own, ot)[1];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            dgam[k] += d[k] * xl[k];
+            dbet[k] += d[k];
+            g[k] = d[k] * gamL[of0 + k];
+            s1 += g[k]; s2 += g[k] * xl[k];
+        }
+        s1 = sum8(s1); s2 = sum8(s2);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) g[k] = (64.0f * g[k] - s1 - xl[k] * s2) * rstdl * (1.0f / 64.0f);
+        store8_bf16(At + ot * TS + of0, g);
+    };
+    // waves: output path of step j, W2' = state entering step j + 1 (slot j + 1), X2b / gelu'(Z1b) from slot j
+    auto add_output_path = [&](int j) {
+        const int l = tid & 63, h = l >> 5, c = l & 31;
+        char* sj = slots + (size_t)(j - p.chunk_lo) * SLOT_BYTES + (size_t)w * SLOT_WAVE_FR;
+        const char* sn = sj + SLOT_BYTES;
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+            f32x16 dz = zero16();
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                dz = mma(row_pi(At, ti, fO, s, l), ld_frag(sn, FR_W2T, fr_idx(pp, pp, s), l), dz);
+                dz = mma(row_pi(At, ti, fX, s, l), ld_frag(sn, FR_W2T, fr_idx(1 - pp, pp, s), l), dz);
+            }
+            const f32x16 d1b = ld_tile(sj, FR_D1B, ti, pp, l);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dz[r] *= d1b[r];
+            db1v += tile_colsum(dz);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 zf = pack(dz, s);                       // dZ1b (k = t rows, j = n lane)
+                st_frag(sj, FR_DZ1B, fr_idx(ti, pp, s), zf, l);
+                dW1t[0] = mma(tr_pi(Qt, 32 * ti, s, 0, l), zf, dW1t[0]);
+                dW1t[1] = mma(tr_pi(Qt, 32 * ti, s, 32, l), zf, dW1t[1]);
+                const bf16x8 xb = ld_frag(sj, FR_X2B, fr_idx(ti, pp, s), l);   // X2b (m = n lane, k = t rows)
+                const bf16x8 aO = tr_pi(At, 32 * ti, s, fO, l), aX = tr_pi(At, 32 * ti, s, fX, l);
+                dW2t[0] = mma(xb, aO, dW2t[0]);
+                dW2t[1] = mma(xb, aX, dW2t[1]);
+                dW2Tt[0] = mma(aO, xb, dW2Tt[0]);
+                dW2Tt[1] = mma(aX, xb, dW2Tt[1]);
+                if (w == 0) {                                         // db2 += column sums of dZ2b (ones MFMA)
+                    f32x16 acc = mma(ONES, aO, zero16());
+                    db2v += acc[0];
+                }
+            }
+        }
+        (void)h; (void)c;
+    };
+    // publish what the next S1 needs from this wave: complete dW1 (slot j, also the tail kernel's operand), db1, db2,
+    // the dW2 block the partner contracts over
+    auto publish_state = [&](int j) {
+        const int l = tid & 63, h = l >> 5, c = l & 31;
+        char* sj = slots + (size_t)(j - p.chunk_lo) * SLOT_BYTES + (size_t)w * SLOT_WAVE_FR;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) st_frag(sj, FR_DW1, fr_idx(a, pp, s), pack(dW1t[a], s), l);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) *reinterpret_cast<bf16x8*>(exd + ((size_t)(wv * 2 + s) * 64 + l) * 16) = pack(dW2t[1], s);
+        if (h == 0) db1L[nO + c] = db1v;
+        if (w == 0 && h == 0) db2L[fO + c] = db2v;
+    };
+
+    // ---- prologue: tiles of the first step, its output path, published state ---------------------------------------------
+    const int i0 = p.chunk_hi - 1;
+    Stage st;
+    stage_issue(st, i0, true, true);
+    park_kg(st);
+    park_q(st);
+    __syncthreads();
+    owner_out_ln(i0);
+    __syncthreads();
+    add_output_path(i0);
+    publish_state(i0);
+    __syncthreads();
+
+    for (int i = i0; i >= p.chunk_lo; --i) {
+        int l_op = tid & 63;
+        asm volatile("" : "+v"(l_op));           // opaque lane id: keeps address arithmetic inside the loop (no hoist + spill)
+        const int l = l_op, h = l >> 5, c = l & 31;
+        const bool more = i > p.chunk_lo;
+        const size_t tile = (size_t)bh * NC + i;
+        char* slot = slots + (size_t)(i - p.chunk_lo) * SLOT_BYTES;
+        char* slot_w = slot + (size_t)w * SLOT_WAVE_FR;
+        if (more) stage_issue(st, i - 1, false, true);          // Q_j now (parked after S2); K, gZ2, eta of step j at S3
+
+        // ================= S1 : (rows = n, lane = t) products, u^T, d(eta) partial, first half of d(gZ2)^T ==============
+        // Three operand-set blocks, each walking both token tiles, fenced by sched_barriers: hipcc otherwise interleaves
+        // everything for ILP and the live set (state 96 + operands 48 + 6 tiles) no longer fits 256 registers.
+        f32x16 P[2];                       // [ti]  d(gZ2)^T partial (rows = f in Fp, lane = t)
+        bf16x8 uN[2][2];                   // [ti][s]  u^T (k = n rows, j = t lane)
+        float se2[2];
+        {
+            bf16x8 dW1F[2][2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) dW1F[a][s] = pack(dW1t[a], s);
+            const f32x16 db1R = rows_from_lds(db1L + nO, 0, h);
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                f32x16 e1 = db1R;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    e1 = mma(dW1F[0][s], row_pi(Kt, ti, 0, s, l), e1);
+                    e1 = mma(dW1F[1][s], row_pi(Kt, ti, 32, s, l), e1);
+                }
+                const float ec = -etaL[32 * ti + c];
+                const f32x16 g1 = ld_tile(slot_w, FR_GZ1T, pp, ti, l);
+                const f32x16 d1 = ld_tile(slot_w, FR_D1N, pp, ti, l);
+                float se = 0.f;
+                f32x16 u;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    se += g1[r] * e1[r];
+                    u[r] = ec * e1[r] * d1[r];
+                }
+                se2[ti] = se;
+                uN[ti][0] = pack(u, 0);
+                uN[ti][1] = pack(u, 1);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) *reinterpret_cast<bf16x8*>(exu + ((size_t)(wv * 4 + ti * 2 + s) * 64 + l) * 16) = uN[ti][s];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        {
+            bf16x8 dW2TF[2][2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) dW2TF[a][s] = pack(dW2Tt[a], s);
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                f32x16 a2 = zero16();
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    a2 = mma(dW2TF[0][s], row_pi(Gt, ti, fO, s, l), a2);
+                    a2 = mma(dW2TF[1][s], row_pi(Gt, ti, fX, s, l), a2);
+                }
+                const f32x16 x2 = ld_tile(slot_w, FR_XT, pp, ti, l);
+                float se = se2[ti];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) se += x2[r] * a2[r];
+                se = xor_add(se, 32);
+                if (h == 0) etaP[wv * 64 + 32 * ti + c] = -se;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        {
+            const bf16x8 D2o0 = pack(dW2t[0], 0), D2o1 = pack(dW2t[0], 1);
+            const bf16x8 D2x0 = *reinterpret_cast<const bf16x8*>(exd + ((size_t)((wv ^ 1) * 2 + 0) * 64 + l) * 16);
+            const bf16x8 D2x1 = *reinterpret_cast<const bf16x8*>(exd + ((size_t)((wv ^ 1) * 2 + 1) * 64 + l) * 16);
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                f32x16 pa = zero16();
+                pa = mma(D2o0, ld_frag(slot_w, FR_XT, fr_idx(pp, ti, 0), l), pa);
+                pa = mma(D2o1, ld_frag(slot_w, FR_XT, fr_idx(pp, ti, 1), l), pa);
+                pa = mma(D2x0, ld_frag(slot_w, FR_XT, fr_idx(1 - pp, ti, 0), l), pa);
+                pa = mma(D2x1, ld_frag(slot_w, FR_XT, fr_idx(1 - pp, ti, 1), l), pa);
+                const float ec = -etaL[32 * ti + c];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pa[r] *= ec;
+                P[ti] = pa;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();                   // Ba: u^T fragments visible
+
+        // ================= S2 : second half of d(gZ2)^T partial -> LDS ===============================================
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 ux = *reinterpret_cast<const bf16x8*>(exu + ((size_t)((wv ^ 1) * 4 + ti * 2 + s) * 64 + l) * 16);
+                P[ti] = mma(ld_frag(slot_w, FR_W2, fr_idx(pp, pp, s), l), uN[ti][s], P[ti]);
+                P[ti] = mma(ld_frag(slot_w, FR_W2, fr_idx(1 - pp, pp, s), l), ux, P[ti]);
+            }
+            write_partial2(red + (size_t)w * 64 * PS, P[ti], ti, pp, h, c);
+        }
+        if (more) park_q(st);              // Q_j: its buffer was last read in the previous S4b
+        __syncthreads();                   // Bb: partials visible; every read of the u exchange is done
+
+        // ================= S3 : owners ====================================================================================
+        if (more) stage_issue(st, i - 1, true, false);           // K_j, gZ2_j, eta_j: parked in S4b
+        {
+            const int ot = tid >> 3, of0 = 8 * (tid & 7);
+            char* own = slot + SLOT_FR;
+            float G_[8], xh[8], go[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) G_[k] = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) add8_f32(red + ((size_t)ww * 64 + ot) * PS + of0, G_);
+            ld_own<8>(own, 0, ot, of0, xh);
+            ld_own<8>(own, 1, ot, of0, go);
+            const float r = own_stats(own, ot)[0];
+            const float eta_t = etaL[ot];
+            float gxh[8], gz[8];
+            float s1g = 0.f, s2g = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                gxh[k] = go[k] * gamL[of0 + k];
+                s1g += gxh[k]; s2g += gxh[k] * xh[k];
+            }
+            s1g = sum8(s1g); s2g = sum8(s2g);
+            float se = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                gz[k] = (64.0f * gxh[k] - s1g - xh[k] * s2g) * r * (1.0f / 64.0f);      // gZ2 (fp32)
+                const float db2 = db2L[of0 + k];
+                se += gz[k] * db2;
+                G_[k] -= eta_t * db2;                                                    // d(gZ2) complete
+                const float m = -G_[k] * r;
+                s1 += m; s2 += m * xh[k];
+            }
+            se = sum8(se); s1 = sum8(s1); s2 = sum8(s2);
+            float a1 = 0.f, a2 = 0.f, dxh[8], dyv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float g = gamL[of0 + k];
+                const float m = -G_[k] * r;
+                const float dgxh = r * G_[k] + (s1 + xh[k] * s2) * (1.0f / 64.0f);
+                const float dy = g * dgxh;
+                dgam[k] += go[k] * dgxh + dy * xh[k];
+                dbet[k] += dy;
+                dyv[k] = -dy;                                                            // dt = -dy ; dV = dt
+                dxh[k] = dy * g + (gxh[k] * s2 + s2g * m) * (1.0f / 64.0f);
+                const float dstd = -dxh[k] * xh[k] * r - G_[k] * gz[k] * r;
+                a1 += dxh[k]; a2 += dstd;
+            }
+            a1 = sum8(a1); a2 = sum8(a2);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) G_[k] = dxh[k] * r - a1 * r * (1.0f / 64.0f) + a2 * xh[k] * (1.0f / 64.0f);   // dZ2
+            store8_bf16(Bt + ot * TS + of0, G_);
+            store8_bf16(p.dXV + tile * 4096 + (size_t)ot * 64 + of0, dyv);
+            if ((tid & 7) == 0) {
+                float de = -se;
+#pragma unroll
+                for (int ww = 0; ww < 8; ++ww) de += etaP[ww * 64 + ot];
+                p.deta[tile * 64 + ot] = (__bf16)de;
+            }
+            if (more) owner_out_ln(i - 1);
+        }
+        __syncthreads();                   // Bc: dZ2 (Bt) and dZ2b_j (At) visible
+
+        // ================= S4a : first-layer gradients and this step's state updates ====================================
+        // Per token tile: (rows = t, lane = n) products E1 = K dW1, A2 = gZ2 dW2^T (operands packed just in time), the
+        // elementwise chain, then every MFMA that consumes this tile's u / dZ1 / X2.  db1 is read (old value) by both tiles
+        // before either adds to it.
+        {
+            const float db1_old = db1v;
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                const f32x16 etaR = rows_from_lds(etaL, 32 * ti, h);
+                f32x16 e1 = zero16();
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    e1 = mma(row_pi(Kt, ti, 0, s, l), pack(dW1t[0], s), e1);
+                    e1 = mma(row_pi(Kt, ti, 32, s, l), pack(dW1t[1], s), e1);
+                }
+                const f32x16 d1 = ld_tile(slot_w, FR_D1, ti, pp, l);
+                f32x16 dz;
+                bf16x8 uf[2];
+                {
+                    const f32x16 mm = ld_tile(slot_w, FR_GX2, ti, pp, l);
+                    f32x16 u;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float dg = -etaR[r] * (e1[r] + db1_old);      // d(gZ1)
+                        u[r] = dg * d1[r];
+                        dz[r] = dg * mm[r];
+                    }
+                    uf[0] = pack(u, 0);                                     // u (m = n lane, k = t rows)
+                    uf[1] = pack(u, 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    f32x16 dx = zero16();
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        dx = mma(row_pi(Gt, ti, fO, s, l), pack(dW2Tt[0], s), dx);
+                        dx = mma(row_pi(Gt, ti, fX, s, l), pack(dW2Tt[1], s), dx);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dx[r] *= -etaR[r];          // -eta A2
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        dx = mma(row_pi(Bt, ti, fO, s, l), ld_frag(slot_w, FR_W2T, fr_idx(pp, pp, s), l), dx);
+                        dx = mma(row_pi(Bt, ti, fX, s, l), ld_frag(slot_w, FR_W2T, fr_idx(1 - pp, pp, s), l), dx);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dz[r] += dx[r] * d1[r];     // dZ1
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                db1v += tile_colsum(dz);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const bf16x8 zf = pack(dz, s);                        // dZ1 (k = t rows, j = n lane)
+                    st_frag(slot_w, FR_DZ1, fr_idx(ti, pp, s), zf, l);
+                    dW1t[0] = mma(tr_pi(Kt, 32 * ti, s, 0, l), zf, dW1t[0]);
+                    dW1t[1] = mma(tr_pi(Kt, 32 * ti, s, 32, l), zf, dW1t[1]);
+                    const bf16x8 gO = tr_pi(Gt, 32 * ti, s, fO, l), gX = tr_pi(Gt, 32 * ti, s, fX, l);
+                    dW2t[0] = mma(uf[s], gO, dW2t[0]);
+                    dW2t[1] = mma(uf[s], gX, dW2t[1]);
+                    dW2Tt[0] = mma(gO, uf[s], dW2Tt[0]);
+                    dW2Tt[1] = mma(gX, uf[s], dW2Tt[1]);
+                    const bf16x8 xf = ld_frag(slot_w, FR_X2, fr_idx(ti, pp, s), l);     // X2 (m = n lane, k = t rows)
+                    const bf16x8 zO = tr_pi(Bt, 32 * ti, s, fO, l), zX = tr_pi(Bt, 32 * ti, s, fX, l);
+                    dW2t[0] = mma(xf, zO, dW2t[0]);
+                    dW2t[1] = mma(xf, zX, dW2t[1]);
+                    dW2Tt[0] = mma(zO, xf, dW2Tt[0]);
+                    dW2Tt[1] = mma(zX, xf, dW2Tt[1]);
+                    if (w == 0) {
+                        f32x16 acc = mma(ONES, zO, zero16());
+                        db2v += acc[0];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();                   // Bd: every read of K_i, gZ2_i, dZ2_i, eta_i is done
+
+        // ================= S4b : output path of step j, publish, park ====================================================
+        if (more) {
+            add_output_path(i - 1);
+            publish_state(i - 1);
+            park_kg(st);
+        }
+        __syncthreads();                   // Be
+    }
+
+    // ---- hand the state gradient to the next chunk, or emit the final results ---------------------------------------------
+    {
+        const int l = tid & 63, h = l >> 5, c = l & 31;
+        float* o1 = p.last ? p.dW1 + (size_t)bh * 64 * 256 : carry + C_DW1;
+        float* o2 = p.last ? p.dW2 + (size_t)bh * 256 * 64 : carry + C_DW2;
+        float* ob1 = p.last ? p.db1 + (size_t)bh * 256 : carry + C_DB1;
+        float* ob2 = p.last ? p.db2 + (size_t)bh * 64 : carry + C_DB2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ro = row_of(r, h);
+            o1[(size_t)ro * 256 + nO + c] = dW1t[0][r];
+            o1[(size_t)(32 + ro) * 256 + nO + c] = dW1t[1][r];
+            o2[(size_t)(nO + ro) * 64 + fO + c] = dW2t[0][r];
+            o2[(size_t)(nO + ro) * 64 + fX + c] = dW2t[1][r];
+        }
+        if (h == 0) ob1[nO + c] = db1v;
+        if (w == 0 && h == 0) ob2[fO + c] = db2v;
+        if (!p.last) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                f32x4 a = {dgam[4 * q], dgam[4 * q + 1], dgam[4 * q + 2], dgam[4 * q + 3]};
+                f32x4 b = {dbet[4 * q], dbet[4 * q + 1], dbet[4 * q + 2], dbet[4 * q + 3]};
+                *reinterpret_cast<f32x4*>(carry + C_DG + (size_t)tid * 8 + 4 * q) = a;
+                *reinterpret_cast<f32x4*>(carry + C_DBT + (size_t)tid * 8 + 4 * q) = b;
+            }
+        } else {
+            // dgamma / dbeta: thread (token ot, octet o) holds features 8 o .. 8 o + 7: reduce over the 64 tokens
+            float* sg = red;                 // [512][8]
+            float* sb = red + NT2 * 8;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { sg[tid * 8 + k] = dgam[k]; sb[tid * 8 + k] = dbet[k]; }
+            __syncthreads();
+            if (tid < 64) {
+                const int o = tid >> 3, k = tid & 7;
+                float a = 0.f, b = 0.f;
+                for (int t = 0; t < 64; ++t) { a += sg[(t * 8 + o) * 8 + k]; b += sb[(t * 8 + o) * 8 + k]; }
+                p.dlnw[(size_t)bh * 64 + tid] = a;
+                p.dlnb[(size_t)bh * 64 + tid] = b;
+            }
+        }
+    }
+}
+
+// =========================================================================================================================
+// Tail kernel: one workgroup (4 waves, wave w <-> hidden slice H_w as in the slot images) per (b, h, step of the chunk):
+//   dK = -eta (gZ1 dW1'^T) + dZ1 W1^T - dV        dQ = dOut + dZ1b W1'^T      (W1' = state entering the next step)
+struct TailParams {
+    const __bf16 *dOut, *eta, *dXV;
+    char* slots; size_t slot_stride_bh;
+    __bf16 *dXQ, *dXK;
+    int NC, chunk_lo, chunk_n;
+};
+constexpr int LDS_TAIL = 4 * 64 * PS * 4;
+
+__global__ __launch_bounds__(NT) void mlp_bwd_tail_kernel(TailParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, h = l >> 5, c = l & 31;
+    const int bh = blockIdx.x / p.chunk_n, si = blockIdx.x % p.chunk_n;
+    const int i = p.chunk_lo + si;
+    const size_t tile = (size_t)bh * p.NC + i;
+    const char* slot_w = p.slots + (size_t)bh * p.slot_stride_bh + (size_t)si * SLOT_BYTES + (size_t)w * SLOT_WAVE_FR;
+    const char* next_w = slot_w + SLOT_BYTES;
+    const bf16x8 I0 = ident_pi(0, h, c), I1 = ident_pi(1, h, c);
+    const int ot = 16 * w + (l & 15), of0 = 16 * (l >> 4);
+
+    for (int pass = 0; pass < 2; ++pass) {           // 0: dK, 1: dQ
+        f32x16 PA[2][2];                             // [fj][ti]  partial (rows = f, lane = t) over this wave's hidden slice
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) PA[a][b] = zero16();
+        if (pass == 0) {
+            // -eta * (dW1'^T)^T-contraction: A = dW1'^T tile (rows = n, lane = f) in place, B = gZ1^T (k = n, j = t)
+#pragma unroll
+            for (int nj = 0; nj < 2; ++nj) {
+                bf16x8 dWt[2][2];
+#pragma unroll
+                for (int fj = 0; fj < 2; ++fj) {
+                    const f32x16 t = transpose_tile(ld_frag(slot_w, FR_DW1, fr_idx(fj, nj, 0), l), ld_frag(slot_w, FR_DW1, fr_idx(fj, nj, 1), l), I0, I1);
+                    dWt[fj][0] = pack(t, 0);
+                    dWt[fj][1] = pack(t, 1);
+                }
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const bf16x8 gt = ld_frag(slot_w, FR_GZ1T, fr_idx(nj, ti, s), l);
+                        PA[0][ti] = mma(dWt[0][s], gt, PA[0][ti]);
+                        PA[1][ti] = mma(dWt[1][s], gt, PA[1][ti]);
+                    }
+            }
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                const float el = -(float)p.eta[tile * 64 + 32 * ti + c];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { PA[0][ti][r] *= el; PA[1][ti][r] *= el; }
+            }
+        }
+        // + W^T-contraction with dZ^T:  pass 0: W1 (entering state), dZ1 ; pass 1: W1' (next slot), dZ1b
+        const char* wsrc = pass == 0 ? slot_w : next_w;
+        const int zarr = pass == 0 ? FR_DZ1 : FR_DZ1B;
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj) {
+            bf16x8 W1T[2][2];
+#pragma unroll
+            for (int fj = 0; fj < 2; ++fj) {
+                const f32x16 t = transpose_tile(ld_frag(wsrc, FR_W1, fr_idx(fj, nj, 0), l), ld_frag(wsrc, FR_W1, fr_idx(fj, nj, 1), l), I0, I1);
+                W1T[fj][0] = pack(t, 0);
+                W1T[fj][1] = pack(t, 1);
+            }
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                const f32x16 zt = transpose_tile(ld_frag(slot_w, zarr, fr_idx(ti, nj, 0), l), ld_frag(slot_w, zarr, fr_idx(ti, nj, 1), l), I0, I1);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const bf16x8 zb = pack(zt, s);
+                    PA[0][ti] = mma(W1T[0][s], zb, PA[0][ti]);
+                    PA[1][ti] = mma(W1T[1][s], zb, PA[1][ti]);
+                }
+            }
+        }
+        if (pass == 1) __syncthreads();              // owners of pass 0 finished reading `red`
+        write_partial(red + (size_t)w * 64 * PS, PA, h, c);
+        __syncthreads();
+        {
+            float z[16], d[16];
+            gather_partial(red, nullptr, ot, of0, z);
+            const size_t off = tile * 4096 + (size_t)ot * 64 + of0;
+            if (pass == 0) {
+                load16_bf16(p.dXV + off, d);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) z[j] -= d[j];                // dK -= dt, dt = dV
+                store16_bf16(p.dXK + off, z);
+            } else {
+                load16_bf16(p.dOut + off, d);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) z[j] += d[j];
+                store16_bf16(p.dXQ + off, z);
+            }
+        }
+    }
+}
+
+}  // namespace b2
+
+// ---------------------------------------------------------------------------------------------------------------------------
+size_t workspace_bytes_v2(const ttt_dims* d) {
+    const size_t nbh = (size_t)d->B * d->NH;
+    const size_t slots = (size_t)groups_per_chunk(d) * d->G + 1;
+    return nbh * (slots * SLOT_BYTES + b2::CARRY_FLOATS2 * sizeof(float));
+}
+
+void mlp_backward_v2(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hipStream_t s) {
+    const int nbh = d->B * d->NH, G = d->G, NC = d->NC;
+    const int K = (NC + G - 1) / G;
+    const int gpc = groups_per_chunk(d);
+    const size_t slot_stride = ((size_t)gpc * G + 1) * SLOT_BYTES;
+    char* slots = (char*)ws;
+    float* carry = (float*)(slots + (size_t)nbh * slot_stride);
+
+    ScanParams sp = {};
+    sp.XQ = (const __bf16*)a->XQ; sp.XK = (const __bf16*)a->XK; sp.XV = (const __bf16*)a->XV; sp.eta = (const __bf16*)a->last_eta;
+    sp.ln_w = a->ttt_norm_weight; sp.ln_b = a->ttt_norm_bias;
+    sp.W1c = const_cast<float*>(a->W1_checkpoints); sp.b1c = const_cast<float*>(a->b1_checkpoints);
+    sp.W2c = const_cast<float*>(a->W2_checkpoints); sp.b2c = const_cast<float*>(a->b2_checkpoints);
+    sp.NH = d->NH; sp.NC = NC; sp.G = G; sp.K = K; sp.eps = d->eps;
+    sp.slots = slots; sp.slot_stride_bh = slot_stride; sp.slot_v2 = 1;
+
+    b2::SweepParams2 bp = {};
+    bp.XQ = (const __bf16*)a->XQ; bp.XK = (const __bf16*)a->XK; bp.dOut = (const __bf16*)a->grad_L_XQW; bp.eta = (const __bf16*)a->last_eta;
+    bp.ln_w = a->ttt_norm_weight;
+    bp.uW1 = a->grad_L_W1_last; bp.ub1 = a->grad_L_b1_last; bp.uW2 = a->grad_L_W2_last; bp.ub2 = a->grad_L_b2_last;
+    bp.slots = slots; bp.slot_stride_bh = slot_stride; bp.carry = carry;
+    bp.dXV = (__bf16*)a->grad_L_XV; bp.deta = (__bf16*)a->grad_L_last_eta;
+    bp.dW1 = a->grad_L_W1_init; bp.db1 = a->grad_L_b1_init; bp.dW2 = a->grad_L_W2_init; bp.db2 = a->grad_L_b2_init;
+    bp.dlnw = a->grad_L_ttt_norm_weight; bp.dlnb = a->grad_L_ttt_norm_bias;
+    bp.NH = d->NH; bp.NC = NC;
+
+    b2::TailParams tp = {};
+    tp.dOut = (const __bf16*)a->grad_L_XQW; tp.eta = (const __bf16*)a->last_eta; tp.dXV = (const __bf16*)a->grad_L_XV;
+    tp.slots = slots; tp.slot_stride_bh = slot_stride;
+    tp.dXQ = (__bf16*)a->grad_L_XQ; tp.dXK = (__bf16*)a->grad_L_XK; tp.NC = NC;
+
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)b2::mlp_bwd_sweep8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, b2::LDS_SWEEP);
+        (void)hipFuncSetAttribute((const void*)b2::mlp_bwd_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, b2::LDS_TAIL);
+        attr = true;
+    }
+    const int nchunks = (K + gpc - 1) / gpc;
+    for (int ch = nchunks - 1; ch >= 0; --ch) {
+        const int g0 = ch * gpc, ng = (K - g0 < gpc) ? K - g0 : gpc;
+        sp.chunk_group0 = g0; sp.chunk_groups = ng; sp.chunk_lo = g0 * G;
+        launch_group_recompute(sp, nbh, s);
+        bp.chunk_lo = g0 * G;
+        bp.chunk_hi = ((g0 + ng) * G < NC) ? (g0 + ng) * G : NC;
+        bp.first = (ch == nchunks - 1);
+        bp.last = (ch == 0);
+        hipLaunchKernelGGL(b2::mlp_bwd_sweep8_kernel, dim3(nbh), dim3(b2::NT2), b2::LDS_SWEEP, s, bp);
+        tp.chunk_lo = bp.chunk_lo; tp.chunk_n = bp.chunk_hi - bp.chunk_lo;
+        hipLaunchKernelGGL(b2::mlp_bwd_tail_kernel, dim3(nbh * tp.chunk_n), dim3(NT), b2::LDS_TAIL, s, tp);
+    }
+}
+
+}  // namespace mfma
+}  // namespace ttt

@@ -211,12 +211,27 @@ __device__ __forceinline__ f32x16 unpack2(bf16x8 lo, bf16x8 hi) {   // inverse o
 // ------------------------------------------------------------------------------------------------
 // Backward workspace: one "slot" per scan step holds everything the reverse sweep needs, written
 // by the (parallel) group-recompute kernel as register images (16 B per lane per fragment).
-enum { FR_W1 = 0, FR_W2, FR_X2, FR_XT, FR_D1, FR_D2, FR_GX2, FR_GZ1, FR_GZ1T, FR_X2B, FR_D1B, FR_COUNT };
+// Fragment arrays are laid out per wave w of the 4-wave decomposition (hidden slice H_w = [64w, 64w+64)), 8 fragments
+// each, index fr_idx(a, b, s); layouts: T = tile (rows = t, lane = n), N = tile (rows = n, lane = t).
+//   FR_W1   [fi][nj][s]  W1 (rows=f, lane=n)            FR_W2   [ni][fj][s]  W2 (rows=n, lane=f)
+//   FR_X2   [ti][nj][s]  X2, T                          FR_XT   [ni][ti][s]  X2, N
+//   FR_D1   [ti][nj][s]  gelu'(Z1), T                   FR_D2   [ti][nj][s]  gelu''(Z1), T        (revision-1 sweep only)
+//   FR_GX2  [ti][nj][s]  gX2, T (revision 1) / M = gX2*gelu''(Z1), T (revision 2)
+//   FR_GZ1  [ti][nj][s]  gZ1, T (revision 1 only)       FR_GZ1T [nj][ti][s]  gZ1, N
+//   FR_X2B  [ti][nj][s]  X2b, T                         FR_D1B  [ti][nj][s]  gelu'(Z1b), T
+//   revision 2 additions -
+//   FR_W2T  [fj][ni][s]  W2^T (rows=f, lane=n)          FR_D1N  [nj][ti][s]  gelu'(Z1), N
+//   written by the revision-2 sweep for the parallel dK / dQ tail kernel:
+//   FR_DZ1  [ti][nj][s]  dZ1, T      FR_DZ1B [ti][nj][s]  dZ1b, T      FR_DW1 [fi][nj][s]  dW1' complete (rows=f, lane=n)
+enum { FR_W1 = 0, FR_W2, FR_X2, FR_XT, FR_D1, FR_D2, FR_GX2, FR_GZ1, FR_GZ1T, FR_X2B, FR_D1B,
+       FR_W2T, FR_D1N, FR_DZ1, FR_DZ1B, FR_DW1, FR_COUNT };
 constexpr size_t FRAG_BYTES = 64 * 16;
-constexpr size_t SLOT_WAVE_FR = (size_t)FR_COUNT * 8 * FRAG_BYTES;      // 88 KiB per wave
+constexpr size_t SLOT_WAVE_FR = (size_t)FR_COUNT * 8 * FRAG_BYTES;      // 128 KiB per wave
 constexpr size_t SLOT_FR = 4 * SLOT_WAVE_FR;
-constexpr size_t SLOT_OWN_WAVE = 12 * FRAG_BYTES + 64 * 8;              // xh, go, xhl (4 x float4 each) + (rstd, rstdl)
-constexpr size_t SLOT_OWN = 4 * SLOT_OWN_WAVE;
+// owner data: three row-major fp32 [64 t][64 f] arrays (0 = x_hat of the inner LN, 1 = go = y - target, 2 = x_hat of
+// the output LN) + per-token (rstd, rstd_out)
+constexpr size_t SLOT_OWN_ARR = 64 * 64 * 4;
+constexpr size_t SLOT_OWN = 3 * SLOT_OWN_ARR + 64 * 8;
 constexpr size_t SLOT_G = 64 * 64 * 2;                                   // gZ2 tile, bf16 row-major
 constexpr size_t SLOT_BYTES = SLOT_FR + SLOT_OWN + SLOT_G;
 
@@ -227,22 +242,27 @@ __device__ __forceinline__ void st_frag(char* wave_base, int arr, int idx, bf16x
 __device__ __forceinline__ bf16x8 ld_frag(const char* wave_base, int arr, int idx, int lane) {
     return *reinterpret_cast<const bf16x8*>(wave_base + ((size_t)(arr * 8 + idx) * 64 + lane) * 16);
 }
-__device__ __forceinline__ void st_own16(char* own_wave, int arr, const float (&v)[16], int lane) {   // arr: 0 xh, 1 go, 2 xhl
+// owner rows: `own` = slot + SLOT_FR; token ot, features of0 .. of0 + N - 1
+template <int N>
+__device__ __forceinline__ void st_own(char* own, int arr, int ot, int of0, const float (&v)[N]) {
+    float* p = reinterpret_cast<float*>(own + (size_t)arr * SLOT_OWN_ARR) + ot * 64 + of0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < N / 4; ++q) {
         f32x4 x = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
-        *reinterpret_cast<f32x4*>(own_wave + ((size_t)(arr * 4 + q) * 64 + lane) * 16) = x;
+        *reinterpret_cast<f32x4*>(p + 4 * q) = x;
     }
 }
-__device__ __forceinline__ void ld_own16(const char* own_wave, int arr, float (&v)[16], int lane) {
+template <int N>
+__device__ __forceinline__ void ld_own(const char* own, int arr, int ot, int of0, float (&v)[N]) {
+    const float* p = reinterpret_cast<const float*>(own + (size_t)arr * SLOT_OWN_ARR) + ot * 64 + of0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const f32x4 x = *reinterpret_cast<const f32x4*>(own_wave + ((size_t)(arr * 4 + q) * 64 + lane) * 16);
+    for (int q = 0; q < N / 4; ++q) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(p + 4 * q);
         v[4 * q] = x[0]; v[4 * q + 1] = x[1]; v[4 * q + 2] = x[2]; v[4 * q + 3] = x[3];
     }
 }
-__device__ __forceinline__ float* own_stats(char* own_wave, int lane) {
-    return reinterpret_cast<float*>(own_wave + 12 * FRAG_BYTES) + 2 * lane;
+__device__ __forceinline__ float* own_stats(char* own, int ot) {
+    return reinterpret_cast<float*>(own + 3 * SLOT_OWN_ARR) + 2 * ot;
 }
 
 }  // namespace mf

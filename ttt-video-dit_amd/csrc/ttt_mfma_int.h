@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
+#include "../../include/ttt_hip.h"
 
 namespace ttt {
 namespace mfma {
@@ -18,6 +19,7 @@ struct ScanParams {
     char* slots;                           // base of the slot area; slot s of (b,h) <-> step chunk_lo + s
     size_t slot_stride_bh;                 // bytes between consecutive (b,h) slot areas
     int chunk_group0, chunk_groups, chunk_lo;
+    int slot_v2;                           // group-recompute: write the revision-2 slot contents (ttt_mfma_dev.h)
     unsigned long long* dbg;               // optional per-phase cycle totals of workgroup 0
     float* dump;                           // DEBUG: intermediates of workgroup 0, step 0 (revision-2 forward)
 };
@@ -25,6 +27,10 @@ struct ScanParams {
 void launch_scan_forward(const ScanParams& p, int n_bh, hipStream_t s);
 void launch_group_recompute(const ScanParams& p, int n_bh, hipStream_t s);
 bool bwd_available();
+// revision-2 backward (ttt_mfma_bwd2.hip): 8-wave reverse sweep + parallel dK/dQ tail kernel
+void mlp_backward_v2(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hipStream_t s);
+size_t workspace_bytes_v2(const ttt_dims* d);
+int groups_per_chunk(const ttt_dims* d);
 // revision-2 forward scan (ttt_mfma2.hip): 8 waves per (b,h), VGPR-form MFMA, LDS transposed reads
 void launch_scan_forward_v2(const ScanParams& p, int n_bh, unsigned long long* dbg, hipStream_t s);
 void set_debug_dump(float* buf);
