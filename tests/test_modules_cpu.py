@@ -132,3 +132,24 @@ def test_hip_path_fails_loudly_without_gpu():
     m, meta = _build_wrapper(g, use_kernel=True)
     with pytest.raises(RuntimeError):
         m(g["x"], meta)
+
+
+def test_remat_free_layers_changes_memory_policy_only():
+    """Keeping activations for the first layers (remat_free_layers, the 288-GB setting) vs re-materialising every layer
+    (the reference's setting): identical outputs and gradients."""
+    g = load_golden("dit_lin_1scene.pt")
+    res = []
+    for n_free in (0, 1, 99):
+        m = DiffusionTransformer(ModelConfig(**g["cfg"]))
+        m.load_state_dict(g["state_dict"], strict=True)
+        for mod in m.modules():
+            if hasattr(mod, "use_kernel"):
+                mod.use_kernel = False
+        m.remat_free_layers = n_free
+        out = m(g["video"], g["text"], g["timesteps"])
+        out.backward(g["dout"])
+        res.append((out.detach(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
+    for out, grads in res[1:]:
+        assert torch.equal(out, res[0][0])
+        for k, v in grads.items():
+            assert torch.equal(v, res[0][1][k]), k

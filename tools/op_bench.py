@@ -94,7 +94,7 @@ def main():
                   "avg_ms": avg, "min_ms": ms[0], "us_per_step": 1e3 * avg / NC, "tflops": fl / (avg * 1e-3) / 1e12,
                   "frac_mfma_peak": fl / (avg * 1e-3) / 2.5e15, "frac_occupied_cu_peak": fl / (avg * 1e-3) / (2.5e15 * min(B * NH, 256) / 256)}
     if a.phases:
-        buf = torch.zeros(16, dtype=torch.int64, device=dev)
+        buf = torch.zeros(32, dtype=torch.int64, device=dev)
         ext.debug_timing(buf)
         out = fwd()
         if not a.fwd_only:

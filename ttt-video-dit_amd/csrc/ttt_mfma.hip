@@ -39,6 +39,7 @@ constexpr int LDS_FWD = LDS_TILES + LDS_RED + LDS_G1 + LDS_SMALL;
 
 static unsigned long long* g_dbg = nullptr;
 void set_debug_timing(void* buf) { g_dbg = (unsigned long long*)buf; }
+unsigned long long* get_debug_timing() { return g_dbg; }
 
 #define TTT_STAMP(k)                                                         \
     if (p.dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {           \

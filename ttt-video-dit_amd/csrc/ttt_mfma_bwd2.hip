@@ -136,13 +136,44 @@ struct SweepParams2 {
     __bf16 *dXV, *deta;
     float *dW1, *db1, *dW2, *db2, *dlnw, *dlnb;
     int NH, NC, chunk_lo, chunk_hi, first, last;
+    unsigned long long* dbg;                // optional: per-stage cycle totals of workgroup 0 (entries 16..25)
 };
+
+#define TTT_STAMP3(k)                                                        \
+    if (DBG && p.dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {    \
+        const unsigned long long _t = __builtin_readcyclecounter();          \
+        p.dbg[16 + (k)] += _t - t_last;                                      \
+        t_last = _t;                                                         \
+    }
 
 struct Stage {            // next step's tiles, register-staged: one 16-byte chunk per thread per tile
     uint4 k, g, q;
     float eta;
 };
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// Slot / tensor accesses of the sweep go through buffer instructions: wave-uniform base (SRD) + wave-uniform byte offset
+// in an SGPR + ONE per-lane offset register (lane * 16 or thread * 16/32).  With flat addressing hipcc materialises a
+// 64-bit address pair for each of the ~60 distinct slot accesses of a step at the top of the iteration and spills them.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const void* base, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(bytes > 0x7fffffffull ? 0x7fffffffull : bytes), 0x00020000);
+}
+__device__ __forceinline__ bf16x8 bld8(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void bst8(__amdgpu_buffer_rsrc_t r, int voff, int soff, bf16x8 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
+}
+__device__ __forceinline__ f32x4 bld4f(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void bld8f(__amdgpu_buffer_rsrc_t r, int voff, int soff, float (&o)[8]) {
+    const f32x4 a = bld4f(r, voff, soff), b = bld4f(r, voff + 16, soff);
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+}
+constexpr int fro(int arr, int idx) { return (arr * 8 + idx) * (int)FRAG_BYTES; }       // byte offset of a fragment in a wave region
+
+template <bool DBG>
 __global__ __launch_bounds__(NT2) void mlp_bwd_sweep8_kernel(SweepParams2 p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __bf16* Kt = reinterpret_cast<__bf16*>(smem + L_K);
@@ -168,6 +199,14 @@ __global__ __launch_bounds__(NT2) void mlp_bwd_sweep8_kernel(SweepParams2 p) {
     const int NC = p.NC;
     char* slots = p.slots + (size_t)bh * p.slot_stride_bh;
     float* carry = p.carry + (size_t)bh * CARRY_FLOATS2;
+    const __amdgpu_buffer_rsrc_t rS = make_srd(slots, p.slot_stride_bh);                       // this (b,h)'s slot area
+    const size_t act_bytes = (size_t)NC * 4096 * 2;
+    const __amdgpu_buffer_rsrc_t rK = make_srd(p.XK + (size_t)bh * NC * 4096, act_bytes);
+    const __amdgpu_buffer_rsrc_t rQ = make_srd(p.XQ + (size_t)bh * NC * 4096, act_bytes);
+    const __amdgpu_buffer_rsrc_t rO = make_srd(p.dOut + (size_t)bh * NC * 4096, act_bytes);
+    const __amdgpu_buffer_rsrc_t rV = make_srd(p.dXV + (size_t)bh * NC * 4096, act_bytes);
+    const int WREG = w * (int)SLOT_WAVE_FR;                                                     // this wave pair's fragment region
+    auto slot_off = [&](int step) { return (step - p.chunk_lo) * (int)SLOT_BYTES; };
 
     // ---- carried state gradient ---------------------------------------------------------------------------------------
     f32x16 dW1t[2];      // [a]  dW1[f in 32a.., n in Hp]                 (rows = f, lane = n)
@@ -208,15 +247,13 @@ __global__ __launch_bounds__(NT2) void mlp_bwd_sweep8_kernel(SweepParams2 p) {
 
     // ---- staging helpers (lambdas keep the index arithmetic in one place) ---------------------------------------------
     auto stage_issue = [&](Stage& st, int step, bool with_kg, bool with_q) {
-        const int prow = tid >> 3, pcol = (tid & 7) * 8;
-        const size_t off = ((size_t)bh * NC + step) * 4096 + (size_t)prow * 64 + pcol;
+        const int t16 = tid * 16;                  // a [64][64] bf16 tile is 512 threads x 16 contiguous bytes
         if (with_kg) {
-            st.k = *reinterpret_cast<const uint4*>(p.XK + off);
-            const __bf16* g = reinterpret_cast<const __bf16*>(slots + (size_t)(step - p.chunk_lo) * SLOT_BYTES + SLOT_FR + SLOT_OWN);
-            st.g = *reinterpret_cast<const uint4*>(g + (size_t)prow * 64 + pcol);
+            st.k = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rK, t16, step * 8192, 0));
+            st.g = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rS, t16, slot_off(step) + (int)(SLOT_FR + SLOT_OWN), 0));
             st.eta = tid < 64 ? (float)p.eta[((size_t)bh * NC + step) * 64 + tid] : 0.f;
         }
-        if (with_q) st.q = *reinterpret_cast<const uint4*>(p.XQ + off);
+        if (with_q) st.q = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rQ, t16, step * 8192, 0));
     };
     auto park_kg = [&](const Stage& st) {
         const int prow = tid >> 3, pcol = (tid & 7) * 8;
@@ -231,11 +268,15 @@ __global__ __launch_bounds__(NT2) void mlp_bwd_sweep8_kernel(SweepParams2 p) {
     // owners: backward of the output LayerNorm of step j -> dZ2b_j tile (At), dgamma / dbeta contributions
     auto owner_out_ln = [&](int j) {
         const int ot = tid >> 3, of0 = 8 * (tid & 7);
-        char* own = slots + (size_t)(j - p.chunk_lo) * SLOT_BYTES + SLOT_FR;
+        const int so = slot_off(j) + (int)SLOT_FR;
         float d[8], xl[8], g[8];
-        load8_bf16(p.dOut + ((size_t)bh * NC + j) * 4096 + (size_t)ot * 64 + of0, d);
-        ld_own<8>(own, 2, ot, of0, xl);
-        const float rstdl = own_stats(own, ot)[1];
+        {
+            const bf16x8 dv = bld8(rO, tid * 16, j * 8192);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) d[k] = (float)dv[k];
+        }
+        bld8f(rS, tid * 32, so + 2 * (int)SLOT_OWN_ARR, xl);
+        const float rstdl = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rS, ot * 8 + 4, so + 3 * (int)SLOT_OWN_ARR, 0));
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -252,27 +293,26 @@ __global__ __launch_bounds__(NT2) void mlp_bwd_sweep8_kernel(SweepParams2 p) {
     // waves: output path of step j, W2' = state entering step j + 1 (slot j + 1), X2b / gelu'(Z1b) from slot j
     auto add_output_path = [&](int j) {
         const int l = tid & 63, h = l >> 5, c = l & 31;
-        char* sj = slots + (size_t)(j - p.chunk_lo) * SLOT_BYTES + (size_t)w * SLOT_WAVE_FR;
-        const char* sn = sj + SLOT_BYTES;
+        const int sj = slot_off(j) + WREG, sn = sj + (int)SLOT_BYTES, l16 = l * 16;
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti) {
             f32x16 dz = zero16();
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                dz = mma(row_pi(At, ti, fO, s, l), ld_frag(sn, FR_W2T, fr_idx(pp, pp, s), l), dz);
-                dz = mma(row_pi(At, ti, fX, s, l), ld_frag(sn, FR_W2T, fr_idx(1 - pp, pp, s), l), dz);
+                dz = mma(row_pi(At, ti, fO, s, l), bld8(rS, l16, sn + fro(FR_W2T, fr_idx(pp, pp, s))), dz);
+                dz = mma(row_pi(At, ti, fX, s, l), bld8(rS, l16, sn + fro(FR_W2T, fr_idx(1 - pp, pp, s))), dz);
             }
-            const f32x16 d1b = ld_tile(sj, FR_D1B, ti, pp, l);
+            const f32x16 d1b = unpack2(bld8(rS, l16, sj + fro(FR_D1B, fr_idx(ti, pp, 0))), bld8(rS, l16, sj + fro(FR_D1B, fr_idx(ti, pp, 1))));
 #pragma unroll
             for (int r = 0; r < 16; ++r) dz[r] *= d1b[r];
             db1v += tile_colsum(dz);
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const bf16x8 zf = pack(dz, s);                       // dZ1b (k = t rows, j = n lane)
-                st_frag(sj, FR_DZ1B, fr_idx(ti, pp, s), zf, l);
+                bst8(rS, l16, sj + fro(FR_DZ1B, fr_idx(ti, pp, s)), zf);
                 dW1t[0] = mma(tr_pi(Qt, 32 * ti, s, 0, l), zf, dW1t[0]);
                 dW1t[1] = mma(tr_pi(Qt, 32 * ti, s, 32, l), zf, dW1t[1]);
-                const bf16x8 xb = ld_frag(sj, FR_X2B, fr_idx(ti, pp, s), l);   // X2b (m = n lane, k = t rows)
+                const bf16x8 xb = bld8(rS, l16, sj + fro(FR_X2B, fr_idx(ti, pp, s)));   // X2b (m = n lane, k = t rows)
                 const bf16x8 aO = tr_pi(At, 32 * ti, s, fO, l), aX = tr_pi(At, 32 * ti, s, fX, l);
                 dW2t[0] = mma(xb, aO, dW2t[0]);
                 dW2t[1] = mma(xb, aX, dW2t[1]);
@@ -290,11 +330,11 @@ __global__ __launch_bounds__(NT2) void mlp_bwd_sweep8_kernel(SweepParams2 p) {
     // the dW2 block the partner contracts over
     auto publish_state = [&](int j) {
         const int l = tid & 63, h = l >> 5, c = l & 31;
-        char* sj = slots + (size_t)(j - p.chunk_lo) * SLOT_BYTES + (size_t)w * SLOT_WAVE_FR;
+        const int sj = slot_off(j) + WREG;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) st_frag(sj, FR_DW1, fr_idx(a, pp, s), pack(dW1t[a], s), l);
+            for (int s = 0; s < 2; ++s) bst8(rS, l * 16, sj + fro(FR_DW1, fr_idx(a, pp, s)), pack(dW1t[a], s));
 #pragma unroll
         for (int s = 0; s < 2; ++s) *reinterpret_cast<bf16x8*>(exd + ((size_t)(wv * 2 + s) * 64 + l) * 16) = pack(dW2t[1], s);
         if (h == 0) db1L[nO + c] = db1v;
@@ -314,15 +354,19 @@ __global__ __launch_bounds__(NT2) void mlp_bwd_sweep8_kernel(SweepParams2 p) {
     publish_state(i0);
     __syncthreads();
 
+    unsigned long long t_last = __builtin_readcyclecounter();
     for (int i = i0; i >= p.chunk_lo; --i) {
         int l_op = tid & 63;
         asm volatile("" : "+v"(l_op));           // opaque lane id: keeps address arithmetic inside the loop (no hoist + spill)
         const int l = l_op, h = l >> 5, c = l & 31;
         const bool more = i > p.chunk_lo;
         const size_t tile = (size_t)bh * NC + i;
-        char* slot = slots + (size_t)(i - p.chunk_lo) * SLOT_BYTES;
-        char* slot_w = slot + (size_t)w * SLOT_WAVE_FR;
+        const int sI = slot_off(i), sw = sI + WREG, l16 = l * 16;     // byte offsets of slot i / this wave's region in it
         if (more) stage_issue(st, i - 1, false, true);          // Q_j now (parked after S2); K, gZ2, eta of step j at S3
+        // (An L2 prefetch of step j's slot was tried here in two forms - dword touches kept in registers and LDS-DMA touches
+        // without destination registers - and both lose: a step reads ~430 KiB of slot data, and ONE CU sustains only ~10
+        // bytes/cycle of HBM misses (~64 lines in flight x ~900 cycles), so the prefetch itself costs ~40 k cycles per step.
+        // The sweep is bound by per-CU miss parallelism, not by exposed latency: see DESIGN.md 4.)
 
         // ================= S1 : (rows = n, lane = t) products, u^T, d(eta) partial, first half of d(gZ2)^T ==============
         // Three operand-set blocks, each walking both token tiles, fenced by sched_barriers: hipcc otherwise interleaves
@@ -331,56 +375,51 @@ __global__ __launch_bounds__(NT2) void mlp_bwd_sweep8_kernel(SweepParams2 p) {
         bf16x8 uN[2][2];                   // [ti][s]  u^T (k = n rows, j = t lane)
         float se2[2];
         {
-            bf16x8 dW1F[2][2];
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) dW1F[a][s] = pack(dW1t[a], s);
             const f32x16 db1R = rows_from_lds(db1L + nO, 0, h);
 #pragma unroll
             for (int ti = 0; ti < 2; ++ti) {
                 f32x16 e1 = db1R;
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    e1 = mma(dW1F[0][s], row_pi(Kt, ti, 0, s, l), e1);
-                    e1 = mma(dW1F[1][s], row_pi(Kt, ti, 32, s, l), e1);
+                    e1 = mma(pack(dW1t[0], s), row_pi(Kt, ti, 0, s, l), e1);
+                    e1 = mma(pack(dW1t[1], s), row_pi(Kt, ti, 32, s, l), e1);
                 }
                 const float ec = -etaL[32 * ti + c];
-                const f32x16 g1 = ld_tile(slot_w, FR_GZ1T, pp, ti, l);
-                const f32x16 d1 = ld_tile(slot_w, FR_D1N, pp, ti, l);
                 float se = 0.f;
-                f32x16 u;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    se += g1[r] * e1[r];
-                    u[r] = ec * e1[r] * d1[r];
+                for (int s = 0; s < 2; ++s) {      // fragment by fragment: 8 rows of the tile at a time
+                    const bf16x8 g1 = bld8(rS, l16, sw + fro(FR_GZ1T, fr_idx(pp, ti, s)));
+                    const bf16x8 d1 = bld8(rS, l16, sw + fro(FR_D1N, fr_idx(pp, ti, s)));
+                    bf16x8 uf;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float ev = e1[8 * s + e];
+                        se += (float)g1[e] * ev;
+                        uf[e] = (__bf16)(ec * ev * (float)d1[e]);
+                    }
+                    uN[ti][s] = uf;
+                    *reinterpret_cast<bf16x8*>(exu + ((size_t)(wv * 4 + ti * 2 + s) * 64 + l) * 16) = uf;
                 }
                 se2[ti] = se;
-                uN[ti][0] = pack(u, 0);
-                uN[ti][1] = pack(u, 1);
-#pragma unroll
-                for (int s = 0; s < 2; ++s) *reinterpret_cast<bf16x8*>(exu + ((size_t)(wv * 4 + ti * 2 + s) * 64 + l) * 16) = uN[ti][s];
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         {
-            bf16x8 dW2TF[2][2];
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) dW2TF[a][s] = pack(dW2Tt[a], s);
 #pragma unroll
             for (int ti = 0; ti < 2; ++ti) {
                 f32x16 a2 = zero16();
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    a2 = mma(dW2TF[0][s], row_pi(Gt, ti, fO, s, l), a2);
-                    a2 = mma(dW2TF[1][s], row_pi(Gt, ti, fX, s, l), a2);
+                    a2 = mma(pack(dW2Tt[0], s), row_pi(Gt, ti, fO, s, l), a2);
+                    a2 = mma(pack(dW2Tt[1], s), row_pi(Gt, ti, fX, s, l), a2);
                 }
-                const f32x16 x2 = ld_tile(slot_w, FR_XT, pp, ti, l);
                 float se = se2[ti];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) se += x2[r] * a2[r];
+                for (int s = 0; s < 2; ++s) {
+                    const bf16x8 x2 = bld8(rS, l16, sw + fro(FR_XT, fr_idx(pp, ti, s)));
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) se += (float)x2[e] * a2[8 * s + e];
+                }
                 se = xor_add(se, 32);
                 if (h == 0) etaP[wv * 64 + 32 * ti + c] = -se;
                 __builtin_amdgcn_sched_barrier(0);
@@ -393,10 +432,10 @@ __global__ __launch_bounds__(NT2) void mlp_bwd_sweep8_kernel(SweepParams2 p) {
 #pragma unroll
             for (int ti = 0; ti < 2; ++ti) {
                 f32x16 pa = zero16();
-                pa = mma(D2o0, ld_frag(slot_w, FR_XT, fr_idx(pp, ti, 0), l), pa);
-                pa = mma(D2o1, ld_frag(slot_w, FR_XT, fr_idx(pp, ti, 1), l), pa);
-                pa = mma(D2x0, ld_frag(slot_w, FR_XT, fr_idx(1 - pp, ti, 0), l), pa);
-                pa = mma(D2x1, ld_frag(slot_w, FR_XT, fr_idx(1 - pp, ti, 1), l), pa);
+                pa = mma(D2o0, bld8(rS, l16, sw + fro(FR_XT, fr_idx(pp, ti, 0))), pa);
+                pa = mma(D2o1, bld8(rS, l16, sw + fro(FR_XT, fr_idx(pp, ti, 1))), pa);
+                pa = mma(D2x0, bld8(rS, l16, sw + fro(FR_XT, fr_idx(1 - pp, ti, 0))), pa);
+                pa = mma(D2x1, bld8(rS, l16, sw + fro(FR_XT, fr_idx(1 - pp, ti, 1))), pa);
                 const float ec = -etaL[32 * ti + c];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) pa[r] *= ec;
@@ -404,7 +443,9 @@ __global__ __launch_bounds__(NT2) void mlp_bwd_sweep8_kernel(SweepParams2 p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        TTT_STAMP3(0)
         __syncthreads();                   // Ba: u^T fragments visible
+        TTT_STAMP3(1)
 
         // ================= S2 : second half of d(gZ2)^T partial -> LDS ===============================================
 #pragma unroll
@@ -412,27 +453,28 @@ __global__ __launch_bounds__(NT2) void mlp_bwd_sweep8_kernel(SweepParams2 p) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const bf16x8 ux = *reinterpret_cast<const bf16x8*>(exu + ((size_t)((wv ^ 1) * 4 + ti * 2 + s) * 64 + l) * 16);
-                P[ti] = mma(ld_frag(slot_w, FR_W2, fr_idx(pp, pp, s), l), uN[ti][s], P[ti]);
-                P[ti] = mma(ld_frag(slot_w, FR_W2, fr_idx(1 - pp, pp, s), l), ux, P[ti]);
+                P[ti] = mma(bld8(rS, l16, sw + fro(FR_W2, fr_idx(pp, pp, s))), uN[ti][s], P[ti]);
+                P[ti] = mma(bld8(rS, l16, sw + fro(FR_W2, fr_idx(1 - pp, pp, s))), ux, P[ti]);
             }
             write_partial2(red + (size_t)w * 64 * PS, P[ti], ti, pp, h, c);
         }
         if (more) park_q(st);              // Q_j: its buffer was last read in the previous S4b
+        TTT_STAMP3(2)
         __syncthreads();                   // Bb: partials visible; every read of the u exchange is done
 
+        TTT_STAMP3(3)
         // ================= S3 : owners ====================================================================================
-        if (more) stage_issue(st, i - 1, true, false);           // K_j, gZ2_j, eta_j: parked in S4b
         {
             const int ot = tid >> 3, of0 = 8 * (tid & 7);
-            char* own = slot + SLOT_FR;
+            const int so = sI + (int)SLOT_FR;
             float G_[8], xh[8], go[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) G_[k] = 0.f;
 #pragma unroll
             for (int ww = 0; ww < 4; ++ww) add8_f32(red + ((size_t)ww * 64 + ot) * PS + of0, G_);
-            ld_own<8>(own, 0, ot, of0, xh);
-            ld_own<8>(own, 1, ot, of0, go);
-            const float r = own_stats(own, ot)[0];
+            bld8f(rS, tid * 32, so, xh);
+            bld8f(rS, tid * 32, so + (int)SLOT_OWN_ARR, go);
+            const float r = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rS, ot * 8, so + 3 * (int)SLOT_OWN_ARR, 0));
             const float eta_t = etaL[ot];
             float gxh[8], gz[8];
             float s1g = 0.f, s2g = 0.f;
@@ -471,7 +513,12 @@ __global__ __launch_bounds__(NT2) void mlp_bwd_sweep8_kernel(SweepParams2 p) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) G_[k] = dxh[k] * r - a1 * r * (1.0f / 64.0f) + a2 * xh[k] * (1.0f / 64.0f);   // dZ2
             store8_bf16(Bt + ot * TS + of0, G_);
-            store8_bf16(p.dXV + tile * 4096 + (size_t)ot * 64 + of0, dyv);
+            {
+                bf16x8 dv;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) dv[k] = (__bf16)dyv[k];
+                bst8(rV, tid * 16, i * 8192, dv);
+            }
             if ((tid & 7) == 0) {
                 float de = -se;
 #pragma unroll
@@ -480,12 +527,15 @@ __global__ __launch_bounds__(NT2) void mlp_bwd_sweep8_kernel(SweepParams2 p) {
             }
             if (more) owner_out_ln(i - 1);
         }
+        TTT_STAMP3(4)
         __syncthreads();                   // Bc: dZ2 (Bt) and dZ2b_j (At) visible
+        TTT_STAMP3(5)
 
         // ================= S4a : first-layer gradients and this step's state updates ====================================
         // Per token tile: (rows = t, lane = n) products E1 = K dW1, A2 = gZ2 dW2^T (operands packed just in time), the
         // elementwise chain, then every MFMA that consumes this tile's u / dZ1 / X2.  db1 is read (old value) by both tiles
         // before either adds to it.
+        if (more) stage_issue(st, i - 1, true, false);           // K_j, gZ2_j, eta_j (L2 hits: touched in S1); parked in S4b
         {
             const float db1_old = db1v;
 #pragma unroll
@@ -497,20 +547,18 @@ __global__ __launch_bounds__(NT2) void mlp_bwd_sweep8_kernel(SweepParams2 p) {
                     e1 = mma(row_pi(Kt, ti, 0, s, l), pack(dW1t[0], s), e1);
                     e1 = mma(row_pi(Kt, ti, 32, s, l), pack(dW1t[1], s), e1);
                 }
-                const f32x16 d1 = ld_tile(slot_w, FR_D1, ti, pp, l);
+                bf16x8 d1f[2], uf[2];                                       // gelu'(Z1) fragments ; u (m = n lane, k = t rows)
                 f32x16 dz;
-                bf16x8 uf[2];
-                {
-                    const f32x16 mm = ld_tile(slot_w, FR_GX2, ti, pp, l);
-                    f32x16 u;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float dg = -etaR[r] * (e1[r] + db1_old);      // d(gZ1)
-                        u[r] = dg * d1[r];
-                        dz[r] = dg * mm[r];
+                for (int s = 0; s < 2; ++s) {
+                    d1f[s] = bld8(rS, l16, sw + fro(FR_D1, fr_idx(ti, pp, s)));
+                    const bf16x8 mm = bld8(rS, l16, sw + fro(FR_GX2, fr_idx(ti, pp, s)));
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float dg = -etaR[8 * s + e] * (e1[8 * s + e] + db1_old);      // d(gZ1)
+                        uf[s][e] = (__bf16)(dg * (float)d1f[s][e]);
+                        dz[8 * s + e] = dg * (float)mm[e];
                     }
-                    uf[0] = pack(u, 0);                                     // u (m = n lane, k = t rows)
-                    uf[1] = pack(u, 1);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 {
@@ -524,18 +572,18 @@ __global__ __launch_bounds__(NT2) void mlp_bwd_sweep8_kernel(SweepParams2 p) {
                     for (int r = 0; r < 16; ++r) dx[r] *= -etaR[r];          // -eta A2
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
-                        dx = mma(row_pi(Bt, ti, fO, s, l), ld_frag(slot_w, FR_W2T, fr_idx(pp, pp, s), l), dx);
-                        dx = mma(row_pi(Bt, ti, fX, s, l), ld_frag(slot_w, FR_W2T, fr_idx(1 - pp, pp, s), l), dx);
+                        dx = mma(row_pi(Bt, ti, fO, s, l), bld8(rS, l16, sw + fro(FR_W2T, fr_idx(pp, pp, s))), dx);
+                        dx = mma(row_pi(Bt, ti, fX, s, l), bld8(rS, l16, sw + fro(FR_W2T, fr_idx(1 - pp, pp, s))), dx);
                     }
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) dz[r] += dx[r] * d1[r];     // dZ1
+                    for (int r = 0; r < 16; ++r) dz[r] += dx[r] * (float)d1f[r >> 3][r & 7];     // dZ1
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 db1v += tile_colsum(dz);
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const bf16x8 zf = pack(dz, s);                        // dZ1 (k = t rows, j = n lane)
-                    st_frag(slot_w, FR_DZ1, fr_idx(ti, pp, s), zf, l);
+                    bst8(rS, l16, sw + fro(FR_DZ1, fr_idx(ti, pp, s)), zf);
                     dW1t[0] = mma(tr_pi(Kt, 32 * ti, s, 0, l), zf, dW1t[0]);
                     dW1t[1] = mma(tr_pi(Kt, 32 * ti, s, 32, l), zf, dW1t[1]);
                     const bf16x8 gO = tr_pi(Gt, 32 * ti, s, fO, l), gX = tr_pi(Gt, 32 * ti, s, fX, l);
@@ -543,7 +591,7 @@ __global__ __launch_bounds__(NT2) void mlp_bwd_sweep8_kernel(SweepParams2 p) {
                     dW2t[1] = mma(uf[s], gX, dW2t[1]);
                     dW2Tt[0] = mma(gO, uf[s], dW2Tt[0]);
                     dW2Tt[1] = mma(gX, uf[s], dW2Tt[1]);
-                    const bf16x8 xf = ld_frag(slot_w, FR_X2, fr_idx(ti, pp, s), l);     // X2 (m = n lane, k = t rows)
+                    const bf16x8 xf = bld8(rS, l16, sw + fro(FR_X2, fr_idx(ti, pp, s)));     // X2 (m = n lane, k = t rows)
                     const bf16x8 zO = tr_pi(Bt, 32 * ti, s, fO, l), zX = tr_pi(Bt, 32 * ti, s, fX, l);
                     dW2t[0] = mma(xf, zO, dW2t[0]);
                     dW2t[1] = mma(xf, zX, dW2t[1]);
@@ -557,7 +605,9 @@ __global__ __launch_bounds__(NT2) void mlp_bwd_sweep8_kernel(SweepParams2 p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        TTT_STAMP3(6)
         __syncthreads();                   // Bd: every read of K_i, gZ2_i, dZ2_i, eta_i is done
+        TTT_STAMP3(7)
 
         // ================= S4b : output path of step j, publish, park ====================================================
         if (more) {
@@ -565,7 +615,9 @@ __global__ __launch_bounds__(NT2) void mlp_bwd_sweep8_kernel(SweepParams2 p) {
             publish_state(i - 1);
             park_kg(st);
         }
+        TTT_STAMP3(8)
         __syncthreads();                   // Be
+        TTT_STAMP3(9)
     }
 
     // ---- hand the state gradient to the next chunk, or emit the final results ---------------------------------------------
@@ -754,7 +806,8 @@ void mlp_backward_v2(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hip
 
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)b2::mlp_bwd_sweep8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, b2::LDS_SWEEP);
+        (void)hipFuncSetAttribute((const void*)b2::mlp_bwd_sweep8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, b2::LDS_SWEEP);
+        (void)hipFuncSetAttribute((const void*)b2::mlp_bwd_sweep8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, b2::LDS_SWEEP);
         (void)hipFuncSetAttribute((const void*)b2::mlp_bwd_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, b2::LDS_TAIL);
         attr = true;
     }
@@ -767,7 +820,9 @@ void mlp_backward_v2(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hip
         bp.chunk_hi = ((g0 + ng) * G < NC) ? (g0 + ng) * G : NC;
         bp.first = (ch == nchunks - 1);
         bp.last = (ch == 0);
-        hipLaunchKernelGGL(b2::mlp_bwd_sweep8_kernel, dim3(nbh), dim3(b2::NT2), b2::LDS_SWEEP, s, bp);
+        bp.dbg = get_debug_timing();
+        if (bp.dbg) hipLaunchKernelGGL(b2::mlp_bwd_sweep8_kernel<true>, dim3(nbh), dim3(b2::NT2), b2::LDS_SWEEP, s, bp);
+        else hipLaunchKernelGGL(b2::mlp_bwd_sweep8_kernel<false>, dim3(nbh), dim3(b2::NT2), b2::LDS_SWEEP, s, bp);
         tp.chunk_lo = bp.chunk_lo; tp.chunk_n = bp.chunk_hi - bp.chunk_lo;
         hipLaunchKernelGGL(b2::mlp_bwd_tail_kernel, dim3(nbh * tp.chunk_n), dim3(NT), b2::LDS_TAIL, s, tp);
     }

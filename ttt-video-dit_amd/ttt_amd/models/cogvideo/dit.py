@@ -225,13 +225,15 @@ class FinalLayer(nn.Module):
 class DiffusionTransformer(nn.Module):
     """forward(video [B,T,16,H,W], text [B,n_scenes,S,text_dim], timesteps [B]) -> [B,T,16,H,W]
     (reference :421-505).  Layers are re-materialised in groups of
-    ``remat_transformer_layer_group_size`` during backward."""
+    ``remat_transformer_layer_group_size`` during backward, except the first ``remat_free_layers`` layers, which keep
+    their activations (288 GB of HBM3E per MI355X make that the better trade; same arithmetic, same results)."""
 
     def __init__(self, config):
         super().__init__()
         train = config.adapter_method == "sft"
         self.frames_per_chunk = config.attn_length
         self.remat_transformer_layer_group_size = config.remat_transformer_layer_group_size
+        self.remat_free_layers = getattr(config, "remat_free_layers", 0)
         assert config.num_layers % self.remat_transformer_layer_group_size == 0, "Remat group size must be divisible into num layers"
         self.model_dim = config.model_dim
         self.shard_transformer_inputs = config.shard_transformer_inputs
@@ -260,7 +262,7 @@ class DiffusionTransformer(nn.Module):
             meta.init_multiscene_offsets()
         text_emb = text_emb.flatten(1, 2)
         for i in range(0, len(self.layers), self.remat_transformer_layer_group_size):
-            if torch.is_grad_enabled():
+            if torch.is_grad_enabled() and i >= self.remat_free_layers:
                 vid_emb, text_emb = checkpoint(self._run_group, i, vid_emb, text_emb, meta, use_reentrant=False)
             else:
                 vid_emb, text_emb = self._run_group(i, vid_emb, text_emb, meta)

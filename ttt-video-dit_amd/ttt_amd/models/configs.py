@@ -54,6 +54,9 @@ class ModelConfig:
 
     # activation re-materialisation
     remat_transformer_layer_group_size: int = 1
+    # MI355X (288 GB HBM3E): the first `remat_free_layers` transformer layers keep their activations instead of being
+    # re-materialised in backward (0 = the reference's behaviour: every layer group is checkpointed, dit.py:493-499).
+    remat_free_layers: int = 0
     remat_forward_ssm: bool = False
     remat_reverse_ssm: bool = False
     remat_attention: bool = False
