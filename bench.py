@@ -233,18 +233,36 @@ def main():
             step()
             torch.cuda.synchronize()
             per_layer = max((torch.cuda.max_memory_allocated() - peak0) / probe, 1.0)
-            n_free = int(max(0, min(cfg.num_layers, (0.80 * total_mem - peak0) // per_layer)))
+            n_free = int(max(0, min(cfg.num_layers, (0.88 * total_mem - peak0) // per_layer)))
         if world > 1:       # every rank must take the same decision
             t = torch.tensor([n_free], device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             n_free = int(t)
     else:
         n_free = int(args.remat_free_layers)
-    dit.remat_free_layers = n_free
-    torch.cuda.reset_peak_memory_stats()
-
-    for _ in range(args.warmup):
-        step()
+    # warm-up with the chosen setting; if the caching allocator's fragmentation pushes it over the edge, back off and retry
+    # (still untimed).  With an explicit --remat-free-layers N an out-of-memory error is fatal, as it should be.
+    while True:
+        dit.remat_free_layers = n_free
+        torch.cuda.reset_peak_memory_stats()
+        try:
+            for _ in range(max(args.warmup, 1 if args.remat_free_layers == "auto" else 0)):
+                step()
+            torch.cuda.synchronize()
+            ok = 1
+        except torch.cuda.OutOfMemoryError:
+            if args.remat_free_layers != "auto":
+                raise
+            ok = 0
+        if world > 1:
+            t = torch.tensor([ok], device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            ok = int(t)
+        if ok:
+            break
+        opt.zero_grad(set_to_none=True)
+        torch.cuda.empty_cache()
+        n_free = int(n_free * 0.8)
     dist.barrier(device_ids=[local_rank])
     torch.cuda.synchronize()
     timer.active = True

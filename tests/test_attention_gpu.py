@@ -145,3 +145,32 @@ def test_attn_pre_vs_oracle_and_unfused(B, S, NH, n_text):
     print(errs)
     assert max(errs["q"], errs["k"]) < 1e-2, errs                # bf16 output rounding (three roundings on rotated tokens)
     assert max(v for n, v in errs.items() if n.startswith("d")) < 2e-2, errs
+
+
+def test_fused_attention_node_equals_two_nodes():
+    """FusedSegmentAttention (keeps raw q/k only, re-derives them in backward) == AttnPre followed by SegmentAttention."""
+    from ttt_amd.models.cogvideo.attention import AttnPre, FusedSegmentAttention, SegmentAttention
+    from ttt_amd.models.cogvideo.utils import Rotary3DPositionEmbedding
+    g = torch.Generator().manual_seed(9)
+    B, S, NH, n_text = 2, 333, 4, 21
+    rot = Rotary3DPositionEmbedding(4, 10, 10, 64)
+    cos, sin = rot.freqs_cos.float().contiguous().to(DEV), rot.freqs_sin.float().contiguous().to(DEV)
+    mk = lambda: torch.randn(B, S, NH * 64, generator=g).bfloat16().to(DEV)
+    base = [mk(), mk(), mk()]
+    par0 = [(1 + 0.2 * torch.randn(64, generator=g)).to(DEV) for _ in range(4)]
+    do = torch.randn(B, NH, S, 64, generator=g).bfloat16().to(DEV)
+    res = []
+    for fused in (False, True):
+        qr, kr, vr = (t.clone().requires_grad_(True) for t in base)
+        par = [t.clone().requires_grad_(True) for t in par0]
+        v = vr.view(B, S, NH, 64).transpose(1, 2)
+        if fused:
+            out = FusedSegmentAttention.apply(qr, kr, v, *par, cos, sin, NH, n_text, 1e-6)
+        else:
+            q, k = AttnPre.apply(qr, kr, *par, cos, sin, NH, n_text, 1e-6)
+            out = SegmentAttention.apply(q, k, v)
+        out.backward(do)
+        torch.cuda.synchronize()
+        res.append([out.detach()] + [t.grad for t in (qr, kr, vr)] + [t.grad for t in par])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)

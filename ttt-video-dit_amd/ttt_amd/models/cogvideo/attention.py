@@ -96,3 +96,56 @@ class AttnPre(torch.autograd.Function):
 
 def attn_pre_available(x: torch.Tensor, head_dim: int) -> bool:
     return x.is_cuda and x.dtype == torch.bfloat16 and head_dim == 64
+
+
+class FusedSegmentAttention(torch.autograd.Function):
+    """``AttnPre`` + ``SegmentAttention`` as ONE autograd node that keeps only the raw q / k projections (plus v, the
+    output and the log-sum-exp): the normalised / rotated q, k are re-derived in the backward (one ~0.2 ms pass) instead
+    of living from forward to backward - activation memory bounds ``remat_free_layers`` on the 288-GB MI355X.
+
+    (q_raw, k_raw [B,S,NH*64], v [B,NH,S,64] view, q_norm w/b, k_norm w/b [64], cos, sin, NH, n_text, eps) -> out [B,NH,S,64]
+    (a view of a [B,S,NH,64] buffer)."""
+
+    @staticmethod
+    def forward(ctx, q_raw, k_raw, v, wq, bq, wk, bk, cos, sin, NH, n_text, eps):
+        ext = _ext()
+        B, S, D = q_raw.shape
+        Dh = D // NH
+        qr, kr = q_raw.contiguous(), k_raw.contiguous()
+        v = v if v.stride(3) == 1 else v.contiguous()
+        f32 = lambda t: t.detach().to(torch.float32).contiguous()
+        p32 = (f32(wq), f32(bq), f32(wk), f32(bk))
+        q, k = torch.empty_like(qr), torch.empty_like(kr)
+        ext.attn_pre_forward(qr, kr, *p32, cos, sin, q, k, NH, n_text, float(eps))
+        view = lambda t: t.view(B, S, NH, Dh).transpose(1, 2)
+        scale = 1.0 / math.sqrt(Dh)
+        out = torch.empty(B, S, NH, Dh, device=qr.device, dtype=qr.dtype).transpose(1, 2)
+        lse = torch.empty(B, NH, S, device=qr.device, dtype=torch.float32)
+        ext.attn_forward(view(q), view(k), v, out, lse, scale)
+        ctx.save_for_backward(qr, kr, v, out, lse, *p32, cos, sin)
+        ctx.meta = (NH, n_text, float(eps), scale, wq.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ext = _ext()
+        qr, kr, v, out, lse, wq32, bq32, wk32, bk32, cos, sin = ctx.saved_tensors
+        NH, n_text, eps, scale, pdt = ctx.meta
+        B, S, D = qr.shape
+        Dh = D // NH
+        q, k = torch.empty_like(qr), torch.empty_like(kr)
+        ext.attn_pre_forward(qr, kr, wq32, bq32, wk32, bk32, cos, sin, q, k, NH, n_text, eps)      # re-derive q, k
+        view = lambda t: t.view(B, S, NH, Dh).transpose(1, 2)
+        if dout.stride(3) != 1:
+            dout = dout.contiguous()
+        mk = lambda: torch.empty(B, S, NH, Dh, device=qr.device, dtype=qr.dtype).transpose(1, 2)
+        dq, dk, dv = mk(), mk(), mk()
+        delta = torch.empty(B, NH, S, device=qr.device, dtype=torch.float32)
+        ext.attn_backward(view(q), view(k), v, out, dout, lse, delta, dq, dk, dv, scale)
+        del q, k
+        dq_raw, dk_raw = torch.empty_like(qr), torch.empty_like(kr)
+        P = ext.attn_pre_partials(B, S, NH)
+        part = torch.empty(P, 4, 64, device=qr.device, dtype=torch.float32)
+        ext.attn_pre_backward(qr, kr, dq, dk, wq32, wk32, cos, sin, dq_raw, dk_raw, part, NH, n_text, eps)
+        g = part.sum(0).to(pdt)
+        return dq_raw, dk_raw, dv, g[0], g[1], g[2], g[3], None, None, None, None, None

@@ -107,3 +107,83 @@ class FusedGate(torch.autograd.Function):
         da_t = (dt[0] * (1 - tt * tt)).to(ctx.param_dtype)
         da_v = (dt[1] * (1 - tv * tv)).to(ctx.param_dtype)
         return g, dy, da_t, da_v, None
+
+
+class FusedPreScanMLP(torch.autograd.Function):
+    """``FusedPre`` followed by the TTT-MLP scan (``TkMLP``) as ONE autograd node that keeps only the raw projections:
+    the processed XQ / XK / XV (3 x [B,L,D] per call) are re-derived in the backward by re-running the pre kernel
+    (~0.2 ms) instead of living from forward to backward.  Activation memory is what bounds how many transformer
+    layers can skip re-materialisation on a 288-GB MI355X (``remat_free_layers``).
+
+    (XQ_raw, XK_raw, XV_raw [B,L,NH*64], ln_w, ln_b [NH,64], rope, src, pos, NH, W1, b1, W2, b2 [B,NH,..] fp32 views,
+     eta [B,NH,NC,1,CS], G) -> XQW [B,NH,NC,CS,64]."""
+
+    @staticmethod
+    def forward(ctx, XQ_raw, XK_raw, XV_raw, ln_w, ln_b, rope, src, pos, NH, W1, b1, W2, b2, eta, G):
+        import math
+        ext = _ext()
+        B, L, D = XQ_raw.shape
+        Fh = D // NH
+        q, k, v = XQ_raw.contiguous(), XK_raw.contiguous(), XV_raw.contiguous()
+        w32, b32 = ln_w.detach().to(_F32).contiguous(), ln_b.detach().to(_F32).contiguous()
+        XQ, XK, XV = (torch.empty(B, NH, L, Fh, device=q.device, dtype=_BF16) for _ in range(3))
+        ext.pre_forward(q, k, v, rope, src, pos, w32, b32, XQ, XK, XV, NH)
+        CS = eta.shape[-1]
+        NC = L // CS
+        K = math.ceil(NC / G)
+        mb = lambda t: t.view(B, NH, NC, CS, Fh)
+        last_eta = eta.to(_BF16)[:, :, :, -1, :, None].contiguous()
+        lw, lb = w32.reshape(1, NH, 1, Fh), b32.reshape(1, NH, 1, Fh)
+        state = [t.to(_F32).contiguous() for t in (W1, b1, W2, b2)]
+        out = torch.empty(B, NH, NC, CS, Fh, device=q.device, dtype=_BF16)
+        cks = (torch.empty(B, NH, K, Fh, 4 * Fh, device=q.device, dtype=_F32), torch.empty(B, NH, K, 1, 4 * Fh, device=q.device, dtype=_F32),
+               torch.empty(B, NH, K, 4 * Fh, Fh, device=q.device, dtype=_F32), torch.empty(B, NH, K, 1, Fh, device=q.device, dtype=_F32))
+        ext.ttt_forward(mb(XQ), mb(XK), mb(XV), last_eta, lw, lb, *state, *cks, out, G)
+        ctx.save_for_backward(q, k, v, w32, b32, rope, src, pos, last_eta, *cks)
+        ctx.meta = (NH, G, tuple(eta.shape), ln_w.dtype, W1.dtype, eta.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        ext = _ext()
+        q, k, v, w32, b32, rope, src, pos, last_eta, W1c, b1c, W2c, b2c = ctx.saved_tensors
+        NH, G, eta_shape, ln_dt, st_dt, eta_dt = ctx.meta
+        B, L, D = q.shape
+        Fh = D // NH
+        CS = eta_shape[-1]
+        NC = L // CS
+        H, dev = 4 * Fh, q.device
+        XQ, XK, XV = (torch.empty(B, NH, L, Fh, device=dev, dtype=_BF16) for _ in range(3))
+        ext.pre_forward(q, k, v, rope, src, pos, w32, b32, XQ, XK, XV, NH)              # re-derive the scan inputs
+        mb = lambda t: t.view(B, NH, NC, CS, Fh)
+        z32 = lambda *s: torch.zeros(*s, device=dev, dtype=_F32)
+        e32 = lambda *s: torch.empty(*s, device=dev, dtype=_F32)
+        e16 = lambda *s: torch.empty(*s, device=dev, dtype=_BF16)
+        up = (z32(B, NH, Fh, H), z32(B, NH, 1, H), z32(B, NH, H, Fh), z32(B, NH, 1, Fh))
+        g_out = grad_out.to(_BF16).contiguous()
+        remat = (e32(B, NH, G, Fh, H), e32(B, NH, G, 1, H), e32(B, NH, G, H, Fh), e32(B, NH, G, 1, Fh),
+                 e16(B, NH, G, CS, Fh), e32(B, NH, G, CS, 1),
+                 e16(B, NH, G, CS, H), e16(B, NH, G, CS, H), e16(B, NH, G, CS, H), e16(B, NH, G, CS, H),
+                 e16(B, NH, G, CS, Fh), e16(B, NH, G, CS, H), e16(B, NH, G, CS, Fh), e16(B, NH, G, CS, Fh), e16(B, NH, G, CS, Fh),
+                 e32(B, NH, G, CS, 1))
+        d_lnw, d_lnb = e32(B, NH, 1, Fh), e32(B, NH, 1, Fh)
+        d_state = (e32(B, NH, Fh, H), e32(B, NH, 1, H), e32(B, NH, H, Fh), e32(B, NH, 1, Fh))
+        d_eta = torch.empty(B, NH, NC, CS, 1, device=dev, dtype=_BF16)
+        dQ, dK, dV = (torch.empty(B, NH, NC, CS, Fh, device=dev, dtype=_BF16) for _ in range(3))
+        lw, lb = w32.reshape(1, NH, 1, Fh), b32.reshape(1, NH, 1, Fh)
+        ext.ttt_backward(mb(XQ), mb(XK), mb(XV), last_eta, lw, lb, W1c, b1c, W2c, b2c, g_out, *remat, *up, g_out,
+                         d_lnw, d_lnb, *d_state, d_eta, dQ, dK, dV, G)
+        del XQ, XK, XV
+        # pre backward (re-uses the raw projections)
+        P = ext.pre_backward_partials(NH)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        pw = torch.empty(P, D, device=dev, dtype=_F32)
+        pb = torch.empty_like(pw)
+        flat = lambda t: t.view(B, NH, L, Fh)
+        ext.pre_backward(q, k, v, rope, src, pos, w32, flat(dQ), flat(dK), flat(dV), dq, dk, dv, pw, pb, NH)
+        g_w = (pw.sum(0).view(NH, Fh) + d_lnw.sum(dim=0).squeeze(1)).to(ln_dt)
+        g_b = (pb.sum(0).view(NH, Fh) + d_lnb.sum(dim=0).squeeze(1)).to(ln_dt)
+        row = d_eta.transpose(-2, -1)
+        rows = eta_shape[-2]
+        d_eta_full = row if rows == 1 else torch.nn.functional.pad(row, (0, 0, rows - 1, 0))
+        return (dq, dk, dv, g_w, g_b, None, None, None, None, *(g.to(st_dt) for g in d_state), d_eta_full.to(eta_dt), None)

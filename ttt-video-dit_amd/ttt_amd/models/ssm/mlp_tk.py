@@ -55,7 +55,7 @@ class TkMLP(torch.autograd.Function):
                torch.empty(B, NH, K, 4 * F, F, device=dev, dtype=_F32), torch.empty(B, NH, K, 1, F, device=dev, dtype=_F32))
         ext.ttt_forward(XQ, XK, XV, last_eta, ln_w, ln_b, *state, *cks, out, G)
 
-        ctx.save_for_backward(XQ, XV, XK, last_eta, ln_w, ln_b, *cks, out)
+        ctx.save_for_backward(XQ, XV, XK, last_eta, ln_w, ln_b, *cks)   # XQW is not an input of the backward arithmetic
         ctx.G = G
         ctx.eta_shape = tuple(eta_batch.shape)
         ctx.param_dtypes = (ttt_norm_weight.dtype, W1_init.dtype)
@@ -64,7 +64,7 @@ class TkMLP(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         ext = _ext()
-        XQ, XV, XK, last_eta, ln_w, ln_b, W1c, b1c, W2c, b2c, out = ctx.saved_tensors
+        XQ, XV, XK, last_eta, ln_w, ln_b, W1c, b1c, W2c, b2c = ctx.saved_tensors
         B, NH, NC, CS, F = XQ.shape
         G, H, dev = ctx.G, 4 * XQ.shape[-1], XQ.device
         z32 = lambda *s: torch.zeros(*s, device=dev, dtype=_F32)
@@ -73,6 +73,7 @@ class TkMLP(torch.autograd.Function):
 
         up = (z32(B, NH, F, H), z32(B, NH, 1, H), z32(B, NH, H, F), z32(B, NH, 1, F))  # final state is not an output
         g_out = grad_out.to(_BF16).contiguous()
+        out = g_out                 # placeholder for the ABI's XQW slot (mlp_tk.py:236): same shape / dtype, never read
         # re-materialisation scratch, shapes/dtypes of mlp_tk.py:192-210
         remat = (e32(B, NH, G, F, H), e32(B, NH, G, 1, H), e32(B, NH, G, H, F), e32(B, NH, G, 1, F),
                  e16(B, NH, G, CS, F), e32(B, NH, G, CS, 1),

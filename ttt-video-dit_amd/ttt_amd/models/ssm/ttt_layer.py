@@ -24,7 +24,7 @@ from torch import nn
 
 from ttt_amd.models.cogvideo.utils import SequenceMetadata
 from ttt_amd.models.configs import ModelConfig
-from ttt_amd.models.ssm.fused import FusedPost, FusedPre, fused_available
+from ttt_amd.models.ssm.fused import FusedPost, FusedPre, FusedPreScanMLP, fused_available
 from ttt_amd.models.ssm.linear_hip import HipLinear, TritonLinear  # noqa: F401
 from ttt_amd.models.ssm.mlp_tk import TkMLP
 from ttt_amd.models.ssm.ops import ttt_linear, ttt_mlp
@@ -282,7 +282,6 @@ class TTTBase(nn.Module):
         src, pos, rev = self._token_maps(meta, L, x.device, reverse)
         XQr, XKr, XVr = self.get_qkv_projections(x)
         rope = freqs_cis if freqs_cis.dtype == torch.float32 and freqs_cis.is_contiguous() else freqs_cis.float().contiguous()
-        XQ, XK, XV = FusedPre.apply(XQr, XKr, XVr, self.ttt_norm_weight, self.ttt_norm_bias, rope, src, pos, NH)
         mb = lambda t: t.view(B, NH, NC, CS, Fh)
         # eta (tiny: [B, L, NH]): per-token learning rate in the order of the (reversed) sequence, then the
         # reference's tile bookkeeping - the kernels read the row of the mini-batch the LAST token of a tile came from
@@ -294,7 +293,13 @@ class TTTBase(nn.Module):
         if meta.is_multiscene:
             p, _ = self._perm(meta, L, x.device)
             eta = eta.index_select(2, torch.div(p, CS, rounding_mode="floor")[CS - 1::CS])
-        Y = self.ttt_raw({"XQ": mb(XQ), "XK": mb(XK), "XV": mb(XV), "eta": eta})                                  # [B,NH,NC,CS,F]
+        if isinstance(self, TTTMLP):       # pre + scan as one autograd node: only the raw projections stay alive for backward
+            st = [self._per_batch(p, B) for p in (self.W1, self.b1, self.W2, self.b2)]
+            Y = FusedPreScanMLP.apply(XQr, XKr, XVr, self.ttt_norm_weight, self.ttt_norm_bias, rope, src, pos, NH, *st, eta,
+                                      self._group_size(NC))
+        else:
+            XQ, XK, XV = FusedPre.apply(XQr, XKr, XVr, self.ttt_norm_weight, self.ttt_norm_bias, rope, src, pos, NH)
+            Y = self.ttt_raw({"XQ": mb(XQ), "XK": mb(XK), "XV": mb(XV), "eta": eta})                              # [B,NH,NC,CS,F]
         y = FusedPost.apply(Y.reshape(B, NH, L, Fh), self.post_norm.weight, self.post_norm.bias, src, self.post_norm.eps)
         return self.wo(y)
 
