@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--remat-free-layers", default="auto",
                     help="transformer layers that keep their activations instead of being re-materialised in backward: "
                          "'auto' (sized to the free HBM of this GPU), or an integer; 0 = the reference's 80-GB-GPU setting")
+    ap.add_argument("--reshard-after-forward", action="store_true",
+                    help="FSDP: free the gathered bf16 parameters after each layer's forward and all-gather them again in "
+                         "backward (the reference's 80-GB setting); default: keep them resident (14.5 GB of 288)")
     ap.add_argument("--layers", type=int, default=None, help="DEBUG: fewer layers (result flagged invalid)")
     return ap.parse_args()
 
@@ -63,11 +66,12 @@ class KernelTimer:
     (torch's current stream - the extension launches there)."""
 
     def __init__(self, ext):
-        self.ext, self.active, self.events = ext, False, {"fwd": [], "bwd": []}
+        self.ext, self.active, self.events = ext, False, {"fwd": [], "bwd": [], "attn_fwd": [], "attn_bwd": []}
         self._orig = {}
 
     def install(self):
-        for name, key in (("ttt_forward", "fwd"), ("ttt_backward", "bwd"), ("ttt_linear_forward", "fwd"), ("ttt_linear_backward", "bwd")):
+        for name, key in (("ttt_forward", "fwd"), ("ttt_backward", "bwd"), ("ttt_linear_forward", "fwd"), ("ttt_linear_backward", "bwd"),
+                          ("attn_forward", "attn_fwd"), ("attn_backward", "attn_bwd")):
             orig = getattr(self.ext, name)
             self._orig[name] = orig
 
@@ -189,7 +193,7 @@ def main():
 
     with torch.device("meta"):
         model = CogVideoX(cfg, effective_rank=rank, effective_world_size=world)
-    apply_fsdp(model, get_dp_mesh())                       # reference parallelisms.py:155-175
+    apply_fsdp(model, get_dp_mesh(), reshard_after_forward=args.reshard_after_forward)   # reference parallelisms.py:155-175
     model.to_empty(device=dev)
     torch.manual_seed(1234)                                # same init on every rank, then sharded
     with torch.no_grad():
@@ -242,6 +246,7 @@ def main():
         n_free = int(args.remat_free_layers)
     # warm-up with the chosen setting; if the caching allocator's fragmentation pushes it over the edge, back off and retry
     # (still untimed).  With an explicit --remat-free-layers N an out-of-memory error is fatal, as it should be.
+    refined = False
     while True:
         dit.remat_free_layers = n_free
         torch.cuda.reset_peak_memory_stats()
@@ -258,6 +263,18 @@ def main():
             t = torch.tensor([ok], device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             ok = int(t)
+        if ok and args.remat_free_layers == "auto" and not refined and 0 < n_free < cfg.num_layers:
+            # one refinement with the footprint measured at the chosen setting (the 4-layer probe over-estimates it)
+            refined = True
+            per_layer = max((torch.cuda.max_memory_allocated() - peak0) / n_free, 1.0)
+            better = int(max(0, min(cfg.num_layers, (0.88 * total_mem - peak0) // per_layer)))
+            if world > 1:
+                t = torch.tensor([better], device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                better = int(t)
+            if better > n_free:
+                n_free = better
+                continue
         if ok:
             break
         opt.zero_grad(set_to_none=True)
@@ -292,7 +309,12 @@ def main():
         else:
             gemm = 2.0 * CS * F * F
             flops = {"fwd": 3 * gemm, "bwd": 6 * gemm}
-        dom = max(ks, key=lambda k: ks[k]["total_ms"]) if ks else None
+        # local attention (hand-written MFMA kernels too): algorithmic 4 S^2 D NH forward, 2.5x that backward
+        seg_S = 13 * TOKENS_PER_FRAME + text_len
+        a_flops = 4.0 * seg_S * seg_S * cfg.head_dim * cfg.num_heads
+        flops["attn_fwd"], flops["attn_bwd"] = a_flops / (B * NH * NC), 2.5 * a_flops / (B * NH * NC)     # per (b,h,step) units like the scan
+        scan_keys = [k for k in ks if k in ("fwd", "bwd")]
+        dom = max(scan_keys, key=lambda k: ks[k]["total_ms"]) if scan_keys else None
         roof = None
         if dom:
             per_launch = B * NH * NC * flops[dom]
@@ -306,14 +328,16 @@ def main():
                     "occupied_cu_frac": ach / (MFMA_BF16_PEAK_TFLOPS * min(B * NH, 256) / 256.0),
                     "other": {k: {"avg_ms": v["avg_ms"], "launches": v["launches"],
                                   "achieved_tflops": B * NH * NC * flops[k] / (v["avg_ms"] * 1e-3) / 1e12} for k, v in ks.items() if k != dom},
-                    "scan_share_of_step": sum(v["total_ms"] for v in ks.values()) / (1e3 * dt)}
+                    "scan_share_of_step": sum(ks[k]["total_ms"] for k in scan_keys) / (1e3 * dt),
+                    "attention_share_of_step": sum(v["total_ms"] for k, v in ks.items() if k.startswith("attn")) / (1e3 * dt)}
         line = {"metric": "DiT+TTT fwd/bwd video-tokens/sec", "value": value, "unit": "video-tokens/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                 "config": {"workload": f"CogVideoX-5B+{args.ssm_layer} {args.video_length} training step (fwd+bwd+AdamW), "
                                        f"{cfg.num_layers} layers, L={L} tokens/sample, adapter=sft",
                            "global_batch": world, "seq_len": L, "parallelism": f"fsdp{world}", "ttt_impl": args.impl,
-                           "remat_free_layers": n_free, "valid": args.layers is None},
+                           "remat_free_layers": n_free, "fsdp_reshard_after_forward": bool(args.reshard_after_forward),
+                           "valid": args.layers is None},
                 "roofline": roof, "loss": loss_val, "peak_mem_gib": peak_mem, "total_tokens_per_s": world * L / (dt / args.steps)}
         if world == 1 and not args.no_cpu_baseline:
             try:

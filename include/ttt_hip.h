@@ -224,6 +224,9 @@ void        ttt_hip_debug_groups_per_chunk(int groups);
 /* DEBUG: select the MFMA forward-scan kernel revision (2 = current 8-wave kernel, 1 = first 4-wave kernel,
  * kept for A/B measurements). */
 void        ttt_hip_debug_variant(int revision);
+/* DEBUG: number of L2-prefetch helper workgroups per (batch, head) of the revision-2 backward sweep (-1 = automatic:
+ * 4 when B*NH is a multiple of 8 and everything is co-resident, else 0). */
+void        ttt_hip_debug_helpers(int helpers);
 /* DEBUG: device buffer (>= 120000 floats) receiving the step-0 intermediates of workgroup 0 (NULL = off). */
 void        ttt_hip_debug_dump(float* device_buffer);
 

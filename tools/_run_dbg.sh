@@ -1,7 +1,7 @@
 #!/bin/bash
-# DEBUG helper for gpurun: revision-2 backward correctness (vs revision 1 / oracle) + per-stage timing
+# DEBUG helper for gpurun: A/B timing of backward-sweep variants
 mkdir -p gpurun_out/dbg
-timeout 100 python tools/debug_bwd_v2.py > gpurun_out/dbg/debug_bwd2.log 2>&1
-grep -E "===|dXK|dW1 |dlast_eta|NaN" gpurun_out/dbg/debug_bwd2.log | head -30
-timeout 120 python tools/op_bench.py --phases --iters 3 > gpurun_out/dbg/op_phases.json 2>&1
-tail -1 gpurun_out/dbg/op_phases.json
+for v in 0 1 0 1; do
+  timeout 120 python tools/op_bench.py --phases --iters 5 --sweep-variant $v > gpurun_out/dbg/op_v$v.json 2>&1
+  tail -1 gpurun_out/dbg/op_v$v.json | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('variant $v', 'bwd ms', round(d['bwd']['avg_ms'],3), [int(x) for x in d['phase_cycles_per_step'][16:26]])"
+done

@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--fwd-only", action="store_true")
     ap.add_argument("--phases", action="store_true", help="also print per-phase cycle totals of workgroup 0")
+    ap.add_argument("--helpers", type=int, default=-1, help="backward sweep prefetch helpers per (b,h); -1 = automatic")
+    ap.add_argument("--sweep-variant", type=int, default=1, help="DEBUG A/B of the backward sweep: 1 = no scheduling fences (default), 0 = fenced")
     ap.add_argument("--variant", type=int, default=2, help="MFMA forward kernel revision (2 = current, 1 = first)")
     a = ap.parse_args()
     import test_time_training as ext
@@ -38,6 +40,8 @@ def main():
     ext.load_library()
     ext.set_impl(a.impl)
     ext.debug_variant(a.variant)
+    ext.debug_helpers(a.helpers)
+    ext.debug_helpers(-100 - a.sweep_variant)
     dev = torch.device("cuda:0")
     B, NH, NC, CS, F, G = a.b, a.nh, a.nc, a.cs, 64, a.g
     H = 4 * F if a.kind == "mlp" else F

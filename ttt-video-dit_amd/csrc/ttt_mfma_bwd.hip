@@ -650,7 +650,9 @@ void set_debug_groups_per_chunk(int g) { g_forced_gpc = g; }
 int groups_per_chunk(const ttt_dims* d) {
     const int nbh = d->B * d->NH;
     const int K = (d->NC + d->G - 1) / d->G;
-    int g = (256 + nbh - 1) / nbh;            // enough recompute workgroups to cover the 256 CUs
+    // recompute workgroups (one per (b,h,group), one per CU: 135 KiB of LDS) should fill the 256 CUs in ONE wave: with
+    // ceil(256/nbh) groups (288 workgroups at nbh = 48) the last 32 run alone and the launch takes twice as long
+    int g = nbh < 256 ? 256 / nbh : 1;
     if (g_forced_gpc > 0) g = g_forced_gpc;   // DEBUG knob (tests exercise the chunk hand-over at small sizes)
     // bound the slot area to ~4 GiB
     const size_t per_group = (size_t)nbh * d->G * SLOT_BYTES;

@@ -137,6 +137,8 @@ struct SweepParams2 {
     float *dW1, *db1, *dW2, *db2, *dlnw, *dlnb;
     int NH, NC, chunk_lo, chunk_hi, first, last;
     unsigned long long* dbg;                // optional: per-stage cycle totals of workgroup 0 (entries 16..25)
+    int* prog;                              // [B*NH] step the sweep of each (b,h) is working on (read by its prefetch helpers)
+    int nbh, helpers;                       // grid = nbh * (1 + helpers): blocks >= nbh are prefetch helpers of (b,h) = block % nbh
 };
 
 #define TTT_STAMP3(k)                                                        \
@@ -173,7 +175,7 @@ __device__ __forceinline__ void bld8f(__amdgpu_buffer_rsrc_t r, int voff, int so
 }
 constexpr int fro(int arr, int idx) { return (arr * 8 + idx) * (int)FRAG_BYTES; }       // byte offset of a fragment in a wave region
 
-template <bool DBG>
+template <bool DBG, int VAR>
 __global__ __launch_bounds__(NT2) void mlp_bwd_sweep8_kernel(SweepParams2 p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __bf16* Kt = reinterpret_cast<__bf16*>(smem + L_K);
@@ -195,7 +197,48 @@ __global__ __launch_bounds__(NT2) void mlp_bwd_sweep8_kernel(SweepParams2 p) {
     const int w = wv >> 1, pp = wv & 1;
     const int nO = 64 * w + 32 * pp;
     const int fO = 32 * pp, fX = 32 * (1 - pp);
-    const int bh = blockIdx.x, head = bh % p.NH;
+    const int bh = blockIdx.x % p.nbh, head = bh % p.NH;
+    // ---- prefetch helpers ------------------------------------------------------------------------------------------------
+    // A step reads ~430 KiB of slot data and ONE CU sustains only ~10 bytes/cycle of HBM misses (about 64 lines in flight
+    // x 900 cycles), which alone is 19 us per step; 208 of the 256 CUs are idle while the 48 scans run.  So `helpers`
+    // extra workgroups per (b,h) - launched so that they share the scan's XCD (block % 8, a speed-only assumption) - walk
+    // the same slots one step ahead of the scan and pull them into that XCD's L2 with their own miss parallelism; the scan
+    // then runs on L2 hits.  Helpers only read; the scan never waits for them; they follow its progress word with relaxed
+    // loads and give up after a bounded number of polls, so correctness and termination do not depend on them.
+    if (blockIdx.x >= p.nbh) {
+        const int hid = blockIdx.x / p.nbh - 1;                    // 0 .. helpers-1
+        const char* base = p.slots + (size_t)bh * p.slot_stride_bh;
+        const char* kq[3] = {reinterpret_cast<const char*>(p.XK), reinterpret_cast<const char*>(p.XQ), reinterpret_cast<const char*>(p.dOut)};
+        constexpr int FR_LINES = 4 * 10 * 64;                      // 4 wave regions x 10 arrays x 64 lines
+        constexpr int OWN_LINES = (int)((SLOT_OWN + SLOT_G) / 128);
+        constexpr int ALL_LINES = FR_LINES + OWN_LINES + 3 * 64;
+        unsigned sink = 0;
+        for (int t = p.chunk_hi - 1; t >= p.chunk_lo; --t) {
+            int polls = 0;
+            while (true) {                                         // stay at most one step ahead of the scan
+                const int cur = __hip_atomic_load(p.prog + bh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (cur <= t + 1 || ++polls > 200000) break;
+                __builtin_amdgcn_s_sleep(8);
+            }
+            const char* sl = base + (size_t)(t - p.chunk_lo) * SLOT_BYTES;
+            for (int ln = hid * NT2 + threadIdx.x; ln < ALL_LINES; ln += p.helpers * NT2) {
+                const char* a;
+                if (ln < FR_LINES) {
+                    const int wr = ln / 640, rem = ln % 640, ai = rem >> 6, li = rem & 63;
+                    const int arr = ai < 4 ? ai + 1 : ai == 4 ? 6 : ai + 3;      // FR_W2..FR_D1, FR_GX2, FR_GZ1T..FR_D1N
+                    a = sl + (size_t)wr * SLOT_WAVE_FR + (size_t)arr * 8 * FRAG_BYTES + (size_t)li * 128;
+                } else if (ln < FR_LINES + OWN_LINES) {
+                    a = sl + SLOT_FR + (size_t)(ln - FR_LINES) * 128;
+                } else {
+                    const int r = ln - FR_LINES - OWN_LINES;
+                    a = kq[r >> 6] + (((size_t)bh * p.NC + t) * 4096) * 2 + (size_t)(r & 63) * 128;
+                }
+                sink ^= *reinterpret_cast<const unsigned*>(a);
+            }
+        }
+        asm volatile("" :: "v"(sink));
+        return;
+    }
     const int NC = p.NC;
     char* slots = p.slots + (size_t)bh * p.slot_stride_bh;
     float* carry = p.carry + (size_t)bh * CARRY_FLOATS2;
@@ -343,6 +386,7 @@ __global__ __launch_bounds__(NT2) void mlp_bwd_sweep8_kernel(SweepParams2 p) {
 
     // ---- prologue: tiles of the first step, its output path, published state ---------------------------------------------
     const int i0 = p.chunk_hi - 1;
+    if (tid == 0 && p.helpers) __hip_atomic_store(p.prog + bh, i0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     Stage st;
     stage_issue(st, i0, true, true);
     park_kg(st);
@@ -362,6 +406,7 @@ __global__ __launch_bounds__(NT2) void mlp_bwd_sweep8_kernel(SweepParams2 p) {
         const bool more = i > p.chunk_lo;
         const size_t tile = (size_t)bh * NC + i;
         const int sI = slot_off(i), sw = sI + WREG, l16 = l * 16;     // byte offsets of slot i / this wave's region in it
+        if (tid == 0 && p.helpers) __hip_atomic_store(p.prog + bh, i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (more) stage_issue(st, i - 1, false, true);          // Q_j now (parked after S2); K, gZ2, eta of step j at S3
         // (An L2 prefetch of step j's slot was tried here in two forms - dword touches kept in registers and LDS-DMA touches
         // without destination registers - and both lose: a step reads ~430 KiB of slot data, and ONE CU sustains only ~10
@@ -401,7 +446,7 @@ __global__ __launch_bounds__(NT2) void mlp_bwd_sweep8_kernel(SweepParams2 p) {
                     *reinterpret_cast<bf16x8*>(exu + ((size_t)(wv * 4 + ti * 2 + s) * 64 + l) * 16) = uf;
                 }
                 se2[ti] = se;
-                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (VAR == 0) __builtin_amdgcn_sched_barrier(0);
             }
         }
         {
@@ -422,7 +467,7 @@ __global__ __launch_bounds__(NT2) void mlp_bwd_sweep8_kernel(SweepParams2 p) {
                 }
                 se = xor_add(se, 32);
                 if (h == 0) etaP[wv * 64 + 32 * ti + c] = -se;
-                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (VAR == 0) __builtin_amdgcn_sched_barrier(0);
             }
         }
         {
@@ -440,7 +485,7 @@ __global__ __launch_bounds__(NT2) void mlp_bwd_sweep8_kernel(SweepParams2 p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) pa[r] *= ec;
                 P[ti] = pa;
-                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (VAR == 0) __builtin_amdgcn_sched_barrier(0);
             }
         }
         TTT_STAMP3(0)
@@ -560,7 +605,7 @@ __global__ __launch_bounds__(NT2) void mlp_bwd_sweep8_kernel(SweepParams2 p) {
                         dz[8 * s + e] = dg * (float)mm[e];
                     }
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (VAR == 0) __builtin_amdgcn_sched_barrier(0);
                 {
                     f32x16 dx = zero16();
 #pragma unroll
@@ -578,7 +623,7 @@ __global__ __launch_bounds__(NT2) void mlp_bwd_sweep8_kernel(SweepParams2 p) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) dz[r] += dx[r] * (float)d1f[r >> 3][r & 7];     // dZ1
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (VAR == 0) __builtin_amdgcn_sched_barrier(0);
                 db1v += tile_colsum(dz);
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
@@ -602,7 +647,7 @@ __global__ __launch_bounds__(NT2) void mlp_bwd_sweep8_kernel(SweepParams2 p) {
                         db2v += acc[0];
                     }
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (VAR == 0) __builtin_amdgcn_sched_barrier(0);
             }
         }
         TTT_STAMP3(6)
@@ -620,6 +665,7 @@ __global__ __launch_bounds__(NT2) void mlp_bwd_sweep8_kernel(SweepParams2 p) {
         TTT_STAMP3(9)
     }
 
+    if (tid == 0 && p.helpers) __hip_atomic_store(p.prog + bh, -(1 << 30), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // release the helpers
     // ---- hand the state gradient to the next chunk, or emit the final results ---------------------------------------------
     {
         const int l = tid & 63, h = l >> 5, c = l & 31;
@@ -770,7 +816,7 @@ __global__ __launch_bounds__(NT) void mlp_bwd_tail_kernel(TailParams p) {
 size_t workspace_bytes_v2(const ttt_dims* d) {
     const size_t nbh = (size_t)d->B * d->NH;
     const size_t slots = (size_t)groups_per_chunk(d) * d->G + 1;
-    return nbh * (slots * SLOT_BYTES + b2::CARRY_FLOATS2 * sizeof(float));
+    return nbh * (slots * SLOT_BYTES + b2::CARRY_FLOATS2 * sizeof(float) + 64);       // + progress words
 }
 
 void mlp_backward_v2(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hipStream_t s) {
@@ -780,6 +826,11 @@ void mlp_backward_v2(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hip
     const size_t slot_stride = ((size_t)gpc * G + 1) * SLOT_BYTES;
     char* slots = (char*)ws;
     float* carry = (float*)(slots + (size_t)nbh * slot_stride);
+    int* prog = (int*)(carry + (size_t)nbh * b2::CARRY_FLOATS2);
+    // prefetch helpers: only when they can share the scans' XCDs (nbh % 8 == 0) and everything is co-resident (1 WG / CU)
+    int helpers = get_debug_helpers();
+    if (helpers < 0) helpers = (nbh % 8 == 0 && nbh * 3 <= 256) ? 2 : 0;      // measured: 2 helpers 9.70 ms, 4 helpers 9.97 ms, none 11.68 ms (3 s geometry)
+    if (nbh % 8 != 0 || nbh * (1 + helpers) > 256) helpers = 0;
 
     ScanParams sp = {};
     sp.XQ = (const __bf16*)a->XQ; sp.XK = (const __bf16*)a->XK; sp.XV = (const __bf16*)a->XV; sp.eta = (const __bf16*)a->last_eta;
@@ -806,8 +857,10 @@ void mlp_backward_v2(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hip
 
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)b2::mlp_bwd_sweep8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, b2::LDS_SWEEP);
-        (void)hipFuncSetAttribute((const void*)b2::mlp_bwd_sweep8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, b2::LDS_SWEEP);
+        (void)hipFuncSetAttribute((const void*)b2::mlp_bwd_sweep8_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, b2::LDS_SWEEP);
+        (void)hipFuncSetAttribute((const void*)b2::mlp_bwd_sweep8_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, b2::LDS_SWEEP);
+        (void)hipFuncSetAttribute((const void*)b2::mlp_bwd_sweep8_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, b2::LDS_SWEEP);
+        (void)hipFuncSetAttribute((const void*)b2::mlp_bwd_sweep8_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, b2::LDS_SWEEP);
         (void)hipFuncSetAttribute((const void*)b2::mlp_bwd_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, b2::LDS_TAIL);
         attr = true;
     }
@@ -821,8 +874,13 @@ void mlp_backward_v2(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hip
         bp.first = (ch == nchunks - 1);
         bp.last = (ch == 0);
         bp.dbg = get_debug_timing();
-        if (bp.dbg) hipLaunchKernelGGL(b2::mlp_bwd_sweep8_kernel<true>, dim3(nbh), dim3(b2::NT2), b2::LDS_SWEEP, s, bp);
-        else hipLaunchKernelGGL(b2::mlp_bwd_sweep8_kernel<false>, dim3(nbh), dim3(b2::NT2), b2::LDS_SWEEP, s, bp);
+        bp.prog = prog; bp.nbh = nbh; bp.helpers = helpers;
+        const dim3 grid(nbh * (1 + helpers)), blk(b2::NT2);
+        const bool v1 = get_debug_sweep_variant() == 1;     // DEBUG A/B: 1 = no scheduling fences inside the stages
+        if (bp.dbg) { if (v1) hipLaunchKernelGGL((b2::mlp_bwd_sweep8_kernel<true, 1>), grid, blk, b2::LDS_SWEEP, s, bp);
+                      else hipLaunchKernelGGL((b2::mlp_bwd_sweep8_kernel<true, 0>), grid, blk, b2::LDS_SWEEP, s, bp); }
+        else { if (v1) hipLaunchKernelGGL((b2::mlp_bwd_sweep8_kernel<false, 1>), grid, blk, b2::LDS_SWEEP, s, bp);
+               else hipLaunchKernelGGL((b2::mlp_bwd_sweep8_kernel<false, 0>), grid, blk, b2::LDS_SWEEP, s, bp); }
         tp.chunk_lo = bp.chunk_lo; tp.chunk_n = bp.chunk_hi - bp.chunk_lo;
         hipLaunchKernelGGL(b2::mlp_bwd_tail_kernel, dim3(nbh * tp.chunk_n), dim3(NT), b2::LDS_TAIL, s, tp);
     }

@@ -36,6 +36,9 @@ void launch_scan_forward_v2(const ScanParams& p, int n_bh, unsigned long long* d
 void set_debug_dump(float* buf);
 int get_debug_variant();
 unsigned long long* get_debug_timing();
+int get_debug_helpers();          // -1 = automatic
+int get_debug_sweep_variant();
+void set_debug_sweep_variant(int v);
 
 }  // namespace mfma
 }  // namespace ttt
