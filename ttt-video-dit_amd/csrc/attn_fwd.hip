@@ -133,10 +133,19 @@ __global__ __launch_bounds__(NTF) void attn_fwd_kernel(FwdParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) mt = fmaxf(mt, Sc[1][r]);
         mt = fmaxf(mt, half_swap(mt));
-        const float mn = fmaxf(m, mt);
-        const float alpha = __builtin_amdgcn_exp2f((m - mn) * sc);
-        m = mn;
-        const float msc = mn * sc;
+        // rescale only when some row of this wave saw a larger maximum (exact: alpha == 1 for every lane otherwise);
+        // after the first few tiles that is the rare case, and it saves 33 multiplies + an exp per lane and tile
+        if (__builtin_amdgcn_ballot_w64(mt > m) != 0) {
+            const float mn = fmaxf(m, mt);
+            const float alpha = __builtin_amdgcn_exp2f((m - mn) * sc);
+            m = mn;
+            lsum *= alpha;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) O[db][r] *= alpha;
+        }
+        const float msc = m * sc;
         float ps = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -146,11 +155,7 @@ __global__ __launch_bounds__(NTF) void attn_fwd_kernel(FwdParams p) {
                 Sc[kb][r] = e;
                 ps += e;
             }
-        lsum = lsum * alpha + ps;
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) O[db][r] *= alpha;
+        lsum += ps;
         // ---- O^T += V^T P^T ----------------------------------------------------------------------------------------
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
