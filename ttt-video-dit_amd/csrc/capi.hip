@@ -52,7 +52,11 @@ int ttt_hip_abi_version(void) { return TTT_HIP_ABI_VERSION; }
 void ttt_hip_debug_timing(void* device_buffer) { ttt::mfma::set_debug_timing(device_buffer); }
 void ttt_hip_debug_groups_per_chunk(int groups) { ttt::mfma::set_debug_groups_per_chunk(groups); }
 void ttt_hip_debug_variant(int v) { ttt::mfma::set_debug_variant(v); }
-void ttt_hip_debug_helpers(int n) { if (n <= -100) ttt::mfma::set_debug_sweep_variant(-100 - n); else ttt::mfma::set_debug_helpers(n); }
+void ttt_hip_debug_helpers(int n) {
+    if (n <= -200) ttt::mfma::set_debug_overlap(-200 - n);            // -200: recompute / sweep overlap off, -201: on
+    else if (n <= -100) ttt::mfma::set_debug_sweep_variant(-100 - n); // -100 / -101: sweep scheduling variant
+    else ttt::mfma::set_debug_helpers(n);
+}
 void ttt_hip_debug_dump(float* buf) { ttt::mfma::set_debug_dump(buf); }
 const char* ttt_hip_last_error(void) { return g_err; }
 

@@ -816,17 +816,39 @@ __global__ __launch_bounds__(NT) void mlp_bwd_tail_kernel(TailParams p) {
 size_t workspace_bytes_v2(const ttt_dims* d) {
     const size_t nbh = (size_t)d->B * d->NH;
     const size_t slots = (size_t)groups_per_chunk(d) * d->G + 1;
-    return nbh * (slots * SLOT_BYTES + b2::CARRY_FLOATS2 * sizeof(float) + 64);       // + progress words
+    return nbh * (2 * slots * SLOT_BYTES + b2::CARRY_FLOATS2 * sizeof(float) + 64);   // two slot buffers + carry + progress words
 }
+
+// Side stream for the group recompute of the NEXT chunk: it needs only the forward checkpoints, so it runs beside the
+// sweep of the current chunk on the ~110 CUs the 48 scans and their prefetch helpers leave idle (two slot buffers).  Fork /
+// join with events, so for the caller everything is ordered on `stream`; lower priority than the caller's stream so the
+// sweep (the critical path) gets its CUs first.  Handles are created once per process (one process per GPU).
+struct SideStream {
+    hipStream_t s2 = nullptr;
+    hipEvent_t in = nullptr, rec[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
+    bool ok = false;
+    SideStream() {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        ok = hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, lo) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&in, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; i < 2 && ok; ++i)
+            ok = hipEventCreateWithFlags(&rec[i], hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&done[i], hipEventDisableTiming) == hipSuccess;
+    }
+};
+static SideStream& side_stream() { static SideStream ss; return ss; }
 
 void mlp_backward_v2(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hipStream_t s) {
     const int nbh = d->B * d->NH, G = d->G, NC = d->NC;
     const int K = (NC + G - 1) / G;
     const int gpc = groups_per_chunk(d);
     const size_t slot_stride = ((size_t)gpc * G + 1) * SLOT_BYTES;
-    char* slots = (char*)ws;
-    float* carry = (float*)(slots + (size_t)nbh * slot_stride);
+    char* slots0 = (char*)ws;                                   // two slot buffers, used alternately by the chunks
+    const size_t buf_bytes = (size_t)nbh * slot_stride;
+    float* carry = (float*)(slots0 + 2 * buf_bytes);
     int* prog = (int*)(carry + (size_t)nbh * b2::CARRY_FLOATS2);
+    char* slots = slots0;
     // prefetch helpers: only when they can share the scans' XCDs (nbh % 8 == 0) and everything is co-resident (1 WG / CU)
     int helpers = get_debug_helpers();
     if (helpers < 0) helpers = (nbh % 8 == 0 && nbh * 3 <= 256) ? 2 : 0;      // measured: 2 helpers 9.70 ms, 4 helpers 9.97 ms, none 11.68 ms (3 s geometry)
@@ -865,10 +887,30 @@ void mlp_backward_v2(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hip
         attr = true;
     }
     const int nchunks = (K + gpc - 1) / gpc;
-    for (int ch = nchunks - 1; ch >= 0; --ch) {
-        const int g0 = ch * gpc, ng = (K - g0 < gpc) ? K - g0 : gpc;
+    SideStream& ss = side_stream();
+    const bool overlap = ss.ok && nchunks > 1 && get_debug_overlap() != 0;
+    auto chunk_range = [&](int ch, int& g0, int& ng) { g0 = ch * gpc; ng = (K - g0 < gpc) ? K - g0 : gpc; };
+    auto recompute = [&](int ch, hipStream_t st) {
+        int g0, ng;
+        chunk_range(ch, g0, ng);
+        sp.slots = slots0 + (size_t)(ch & 1) * buf_bytes;
         sp.chunk_group0 = g0; sp.chunk_groups = ng; sp.chunk_lo = g0 * G;
-        launch_group_recompute(sp, nbh, s);
+        launch_group_recompute(sp, nbh, st);
+    };
+    if (overlap) {
+        (void)hipEventRecord(ss.in, s);                           // fork: the side stream sees the caller's inputs
+        (void)hipStreamWaitEvent(ss.s2, ss.in, 0);
+        recompute(nchunks - 1, ss.s2);
+        (void)hipEventRecord(ss.rec[(nchunks - 1) & 1], ss.s2);
+    }
+    for (int ch = nchunks - 1; ch >= 0; --ch) {
+        int g0, ng;
+        chunk_range(ch, g0, ng);
+        const int buf = ch & 1;
+        slots = slots0 + (size_t)buf * buf_bytes;
+        if (overlap) (void)hipStreamWaitEvent(s, ss.rec[buf], 0);
+        else recompute(ch, s);
+        bp.slots = slots; tp.slots = slots;
         bp.chunk_lo = g0 * G;
         bp.chunk_hi = ((g0 + ng) * G < NC) ? (g0 + ng) * G : NC;
         bp.first = (ch == nchunks - 1);
@@ -881,9 +923,18 @@ void mlp_backward_v2(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hip
                       else hipLaunchKernelGGL((b2::mlp_bwd_sweep8_kernel<true, 0>), grid, blk, b2::LDS_SWEEP, s, bp); }
         else { if (v1) hipLaunchKernelGGL((b2::mlp_bwd_sweep8_kernel<false, 1>), grid, blk, b2::LDS_SWEEP, s, bp);
                else hipLaunchKernelGGL((b2::mlp_bwd_sweep8_kernel<false, 0>), grid, blk, b2::LDS_SWEEP, s, bp); }
+        if (overlap && ch > 0) {
+            // next chunk's recompute goes to the other buffer, free once the sweep + tail of chunk ch + 1 are done; enqueued
+            // AFTER this chunk's sweep so that the sweep's workgroups are dispatched first
+            if (ch + 1 <= nchunks - 1) (void)hipStreamWaitEvent(ss.s2, ss.done[buf ^ 1], 0);
+            recompute(ch - 1, ss.s2);
+            (void)hipEventRecord(ss.rec[buf ^ 1], ss.s2);
+        }
         tp.chunk_lo = bp.chunk_lo; tp.chunk_n = bp.chunk_hi - bp.chunk_lo;
         hipLaunchKernelGGL(b2::mlp_bwd_tail_kernel, dim3(nbh * tp.chunk_n), dim3(NT), b2::LDS_TAIL, s, tp);
+        if (overlap) (void)hipEventRecord(ss.done[buf], s);
     }
+    // join: every side-stream launch was consumed by a wait on `s` above (its last event is rec[0 or 1] of chunk 0)
 }
 
 }  // namespace mfma

@@ -15,6 +15,9 @@
 //   ("pi read").  Contraction over the LANE index is impossible in place; a 32x32 tile is
 //   transposed with two MFMAs against constant identity fragments:  X^T = (X as A) * I_pi.
 #pragma once
+#ifndef TTT_SLOT_STORE_SC1
+#define TTT_SLOT_STORE_SC1 0
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "ttt_common.h"
@@ -236,8 +239,16 @@ constexpr size_t SLOT_G = 64 * 64 * 2;                                   // gZ2 
 constexpr size_t SLOT_BYTES = SLOT_FR + SLOT_OWN + SLOT_G;
 
 __device__ __forceinline__ int fr_idx(int a, int b, int s) { return (a * 2 + b) * 2 + s; }
+// TTT_SLOT_STORE_SC1 = 1 makes the slot stores write-through (sc1: the line leaves the XCD's L2).  Measured slower (8.50 vs
+// 8.22 ms per backward at the 3 s geometry), kept as a build option for the record.
 __device__ __forceinline__ void st_frag(char* wave_base, int arr, int idx, bf16x8 v, int lane) {
-    *reinterpret_cast<bf16x8*>(wave_base + ((size_t)(arr * 8 + idx) * 64 + lane) * 16) = v;
+    bf16x8* p = reinterpret_cast<bf16x8*>(wave_base + ((size_t)(arr * 8 + idx) * 64 + lane) * 16);
+#if TTT_SLOT_STORE_SC1
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(__builtin_bit_cast(u32x4_t, v)) : "memory");
+#else
+    *p = v;
+#endif
 }
 __device__ __forceinline__ bf16x8 ld_frag(const char* wave_base, int arr, int idx, int lane) {
     return *reinterpret_cast<const bf16x8*>(wave_base + ((size_t)(arr * 8 + idx) * 64 + lane) * 16);

@@ -38,6 +38,8 @@ int get_debug_variant();
 unsigned long long* get_debug_timing();
 int get_debug_helpers();          // -1 = automatic
 int get_debug_sweep_variant();
+int get_debug_overlap();
+void set_debug_overlap(int v);
 void set_debug_sweep_variant(int v);
 
 }  // namespace mfma
