@@ -223,6 +223,9 @@ def main():
     # and keep as many layers un-checkpointed as fit under 80 % of the device memory.  Same arithmetic, same results.
     dit = model.dit if hasattr(model, "dit") else model
     total_mem = torch.cuda.get_device_properties(dev).total_memory
+    # share of the device memory the activations may fill: multi-rank runs stay further from the edge, because an
+    # out-of-memory error on ONE rank cannot be recovered from while the others sit in a collective
+    cap = 0.88 if world == 1 else 0.80
     if args.remat_free_layers == "auto":
         probe = 4 if cfg.num_layers >= 8 else 0
         torch.cuda.reset_peak_memory_stats()
@@ -237,7 +240,7 @@ def main():
             step()
             torch.cuda.synchronize()
             per_layer = max((torch.cuda.max_memory_allocated() - peak0) / probe, 1.0)
-            n_free = int(max(0, min(cfg.num_layers, (0.88 * total_mem - peak0) // per_layer)))
+            n_free = int(max(0, min(cfg.num_layers, (cap * total_mem - peak0) // per_layer)))
         if world > 1:       # every rank must take the same decision
             t = torch.tensor([n_free], device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
@@ -267,7 +270,7 @@ def main():
             # one refinement with the footprint measured at the chosen setting (the 4-layer probe over-estimates it)
             refined = True
             per_layer = max((torch.cuda.max_memory_allocated() - peak0) / n_free, 1.0)
-            better = int(max(0, min(cfg.num_layers, (0.88 * total_mem - peak0) // per_layer)))
+            better = int(max(0, min(cfg.num_layers, (cap * total_mem - peak0) // per_layer)))
             if world > 1:
                 t = torch.tensor([better], device=dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MIN)

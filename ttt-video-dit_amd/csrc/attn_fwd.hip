@@ -26,7 +26,12 @@ namespace attn {
 constexpr int QB = 256;          // query rows per workgroup
 constexpr int KB = 64;           // keys per tile
 constexpr int NTF = 512;
-constexpr int LDS_FWD = 2 * 2 * ATILE * 2;   // 2 buffers x (K, V) x [64][72] bf16
+// K tile: rows read as 16-byte fragments -> stride 72 elements (36 dwords: conflict-free ds_read_b128).  V tile: read only
+// through ds_read_b64_tr_b16, whose 32-lane groups cover 4 rows x 16 dwords -> stride 96 elements (48 dwords) puts the 4
+// rows on disjoint bank quarters; with stride 72 rows r and r+2 overlap (measured 28 % of the LDS cycles were conflicts).
+constexpr int VS = 96;
+constexpr int KT_ELEMS = ATILE, VT_ELEMS = 64 * VS, BUF_ELEMS = KT_ELEMS + VT_ELEMS;
+constexpr int LDS_FWD = 2 * BUF_ELEMS * 2;    // 2 buffers x (K [64][72], V [64][96]) bf16
 
 struct KVStage {
     uint4 k, v;
@@ -46,7 +51,7 @@ __device__ __forceinline__ void stage_issue(KVStage& st, const __bf16* Kp, const
 __device__ __forceinline__ void stage_park(const KVStage& st, __bf16* Kt, __bf16* Vt, int tid) {
     const int row = tid >> 3, col = (tid & 7) * 8;
     *reinterpret_cast<uint4*>(Kt + row * AS + col) = st.k;
-    *reinterpret_cast<uint4*>(Vt + row * AS + col) = st.v;
+    *reinterpret_cast<uint4*>(Vt + row * VS + col) = st.v;
 }
 
 __global__ __launch_bounds__(NTF) void attn_fwd_kernel(FwdParams p) {
@@ -100,12 +105,12 @@ __global__ __launch_bounds__(NTF) void attn_fwd_kernel(FwdParams p) {
     const int nt = (p.S + KB - 1) / KB;
     KVStage st;
     stage_issue(st, Kp, Vp, p.k_ss, p.v_ss, 0, p.S, tid);
-    stage_park(st, lds, lds + ATILE, tid);
+    stage_park(st, lds, lds + KT_ELEMS, tid);
     __syncthreads();
 
     for (int j = 0; j < nt; ++j) {
-        const __bf16* Kt = lds + (j & 1) * 2 * ATILE;
-        const __bf16* Vt = Kt + ATILE;
+        const __bf16* Kt = lds + (j & 1) * BUF_ELEMS;
+        const __bf16* Vt = Kt + KT_ELEMS;
         const bool more = j + 1 < nt;
         if (more) stage_issue(st, Kp, Vp, p.k_ss, p.v_ss, (j + 1) * KB, p.S, tid);
 
@@ -162,12 +167,12 @@ __global__ __launch_bounds__(NTF) void attn_fwd_kernel(FwdParams p) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const bf16x8 pf = pack(Sc[kb], s);
-                O[0] = mma(tr_frag_pi(Vt, AS, 32 * kb, s, 0, l), pf, O[0]);
-                O[1] = mma(tr_frag_pi(Vt, AS, 32 * kb, s, 32, l), pf, O[1]);
+                O[0] = mma(tr_frag_pi(Vt, VS, 32 * kb, s, 0, l), pf, O[0]);
+                O[1] = mma(tr_frag_pi(Vt, VS, 32 * kb, s, 32, l), pf, O[1]);
             }
         if (more) {
-            __bf16* Kn = lds + ((j + 1) & 1) * 2 * ATILE;
-            stage_park(st, Kn, Kn + ATILE, tid);
+            __bf16* Kn = lds + ((j + 1) & 1) * BUF_ELEMS;
+            stage_park(st, Kn, Kn + KT_ELEMS, tid);
         }
         __syncthreads();
     }

@@ -816,7 +816,8 @@ __global__ __launch_bounds__(NT) void mlp_bwd_tail_kernel(TailParams p) {
 size_t workspace_bytes_v2(const ttt_dims* d) {
     const size_t nbh = (size_t)d->B * d->NH;
     const size_t slots = (size_t)groups_per_chunk(d) * d->G + 1;
-    return nbh * (2 * slots * SLOT_BYTES + b2::CARRY_FLOATS2 * sizeof(float) + 64);   // two slot buffers + carry + progress words
+    const size_t nbuf = get_debug_overlap() ? 2 : 1;      // a second slot buffer only when recompute and sweep overlap
+    return nbh * (nbuf * slots * SLOT_BYTES + b2::CARRY_FLOATS2 * sizeof(float) + 64);   // slot buffer(s) + carry + progress words
 }
 
 // Side stream for the group recompute of the NEXT chunk: it needs only the forward checkpoints, so it runs beside the
@@ -846,7 +847,7 @@ void mlp_backward_v2(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hip
     const size_t slot_stride = ((size_t)gpc * G + 1) * SLOT_BYTES;
     char* slots0 = (char*)ws;                                   // two slot buffers, used alternately by the chunks
     const size_t buf_bytes = (size_t)nbh * slot_stride;
-    float* carry = (float*)(slots0 + 2 * buf_bytes);
+    float* carry = (float*)(slots0 + (get_debug_overlap() ? 2 : 1) * buf_bytes);
     int* prog = (int*)(carry + (size_t)nbh * b2::CARRY_FLOATS2);
     char* slots = slots0;
     // prefetch helpers: only when they can share the scans' XCDs (nbh % 8 == 0) and everything is co-resident (1 WG / CU)
@@ -893,7 +894,7 @@ void mlp_backward_v2(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hip
     auto recompute = [&](int ch, hipStream_t st) {
         int g0, ng;
         chunk_range(ch, g0, ng);
-        sp.slots = slots0 + (size_t)(ch & 1) * buf_bytes;
+        sp.slots = slots0 + (overlap ? (size_t)(ch & 1) * buf_bytes : 0);
         sp.chunk_group0 = g0; sp.chunk_groups = ng; sp.chunk_lo = g0 * G;
         launch_group_recompute(sp, nbh, st);
     };
@@ -907,7 +908,7 @@ void mlp_backward_v2(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hip
         int g0, ng;
         chunk_range(ch, g0, ng);
         const int buf = ch & 1;
-        slots = slots0 + (size_t)buf * buf_bytes;
+        slots = slots0 + (overlap ? (size_t)buf * buf_bytes : 0);
         if (overlap) (void)hipStreamWaitEvent(s, ss.rec[buf], 0);
         else recompute(ch, s);
         bp.slots = slots; tp.slots = slots;
