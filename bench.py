@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--remat-free-layers", default="auto",
                     help="transformer layers that keep their activations instead of being re-materialised in backward: "
                          "'auto' (sized to the free HBM of this GPU), or an integer; 0 = the reference's 80-GB-GPU setting")
+    ap.add_argument("--no-tuned-gemms", action="store_true", help="use hipBLASLt's default heuristic instead of the committed "
+                    "solution selections (ttt_amd/infra/gemm_tuning_gfx950.csv)")
     ap.add_argument("--reshard-after-forward", action="store_true",
                     help="FSDP: free the gathered bf16 parameters after each layer's forward and all-gather them again in "
                          "backward (the reference's 80-GB setting); default: keep them resident (14.5 GB of 288)")
@@ -174,13 +176,14 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     import test_time_training as ext
-    from ttt_amd.infra.parallelisms import apply_fsdp, get_dp_mesh, init_distributed, init_model_parameters
+    from ttt_amd.infra.parallelisms import apply_fsdp, enable_tuned_gemms, get_dp_mesh, init_distributed, init_model_parameters
     from ttt_amd.models.cogvideo.model import CogVideoX
     from ttt_amd.models.configs import ModelConfig
 
     ext.load_library()
     ext.set_impl(args.impl)
     init_distributed("nccl")
+    tuned = (not args.no_tuned_gemms) and enable_tuned_gemms()
 
     over = {}
     if args.layers is not None:
@@ -339,7 +342,7 @@ def main():
                 "config": {"workload": f"CogVideoX-5B+{args.ssm_layer} {args.video_length} training step (fwd+bwd+AdamW), "
                                        f"{cfg.num_layers} layers, L={L} tokens/sample, adapter=sft",
                            "global_batch": world, "seq_len": L, "parallelism": f"fsdp{world}", "ttt_impl": args.impl,
-                           "remat_free_layers": n_free, "fsdp_reshard_after_forward": bool(args.reshard_after_forward),
+                           "remat_free_layers": n_free, "fsdp_reshard_after_forward": bool(args.reshard_after_forward), "tuned_gemm_selections": bool(tuned),
                            "valid": args.layers is None},
                 "roofline": roof, "loss": loss_val, "peak_mem_gib": peak_mem, "total_tokens_per_s": world * L / (dt / args.steps)}
         if world == 1 and not args.no_cpu_baseline:

@@ -63,6 +63,27 @@ def apply_fsdp(model, dp_mesh, param_dtype=torch.bfloat16, reduce_dtype=torch.fl
     return model
 
 
+def enable_tuned_gemms(path: str | None = None) -> bool:
+    """Plain library GEMMs (projections, MLP) go to hipBLASLt / rocBLAS through PyTorch; this loads a committed
+    solution-selection file for the 5B / 3 s GEMM shapes on gfx950 (produced once with PyTorch TunableOp on an MI355X,
+    ``tools/_run_dbg.sh`` history: the default heuristic picks 0.39 ms kernels for the 18048x3072x3072 projections where
+    0.21 ms ones exist).  No tuning happens at run time; shapes that are not in the file, or a file written for another
+    library version (its validator lines are checked by PyTorch), fall back to the default heuristic.  Returns whether
+    the selections are active."""
+    path = path or os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_tuning_gfx950.csv")
+    try:
+        from torch.cuda import tunable
+        if not (torch.cuda.is_available() and os.path.exists(path)):
+            return False
+        import tempfile
+        tunable.enable(True)
+        tunable.tuning_enable(False)
+        tunable.set_filename(os.path.join(tempfile.gettempdir(), f"ttt_tunableop_{os.getpid()}.csv"))   # never write into the repo
+        return bool(tunable.read_file(path))
+    except Exception:
+        return False
+
+
 def init_model_parameters(model, initializer_range: float = 0.02):
     """N(0, 0.02) weights / zero biases everywhere except TTT modules, which initialise themselves
     (reference :178-196)."""
