@@ -212,6 +212,26 @@ int ttt_hip_attn_pre_backward(int B, int S, int NH, int n_text, float eps, const
                               const float* cos_table, const float* sin_table, void* dq_raw, void* dk_raw, float* part,
                               void* stream);
 
+/* ---- TransformerLayer glue (bf16 activations, fp32 parameter vectors) --------------------------------------------------
+ * adaln: out[B, Lt+Lv, D] = [ shift_t + LN(text) * scale1p_t | shift_v + LN(vid) * scale1p_v ]  - LayerNorm(D, eps) with
+ *        (w, b), per-(batch, group) modulation vectors shift / scale1p = 1 + scale laid out [B, 2, D] (group 0 = text,
+ *        1 = video): reference cogvideo/dit.py:353-357 and :366-371 (layernorm, modulate, torch.cat) in one pass.  The
+ *        backward returns d vid, d text and parameter-gradient partials [B*2*P, 4, D] (dw, db, d scale1p, d shift per
+ *        block; block index = (batch * 2 + group) * P + p), P = ttt_hip_adaln_backward_partials().
+ * resgate: new_vid = vid + gate_v * y[:, Lt:], new_text = text + gate_t * y[:, :Lt]  (dit.py:358-359, :372-373), gate
+ *        [B, 2, D]; the backward writes dy [B, Lt+Lv, D] and d gate partials [P, B, 2, D], P = ttt_hip_resgate_backward_partials(D)
+ *        (the residual gradients are the incoming gradients themselves). */
+int ttt_hip_adaln_forward(int B, int Lt, int Lv, int D, float eps, const void* vid, const void* text, const float* w, const float* b,
+                          const float* shift, const float* scale1p, void* out, void* stream);
+int ttt_hip_adaln_backward_partials(void);
+int ttt_hip_adaln_backward(int B, int Lt, int Lv, int D, float eps, const void* vid, const void* text, const void* dout,
+                           const float* w, const float* b, const float* scale1p, void* dvid, void* dtext, float* part, void* stream);
+int ttt_hip_resgate_forward(int B, int Lt, int Lv, int D, const void* vid, const void* text, const void* y, const float* gate,
+                            void* ovid, void* otext, void* stream);
+int ttt_hip_resgate_backward_partials(int D);
+int ttt_hip_resgate_backward(int B, int Lt, int Lv, int D, const void* dvid, const void* dtext, const void* y, const float* gate,
+                             void* dy, float* dgate_part, void* stream);
+
 /* Which implementation TTT_IMPL_AUTO resolves to for these dims (returns TTT_IMPL_GENERIC/MFMA). */
 int ttt_hip_resolve_impl(const ttt_dims* d, int is_mlp, int is_backward);
 

@@ -287,4 +287,46 @@ int ttt_hip_attn_pre_backward(int B, int S, int NH, int n_text, float eps, const
     return post_launch("attn_pre_backward");
 }
 
+
+static int check_glue_dims(int B, int Lt, int Lv, int D) {
+    if (B <= 0 || Lt < 0 || Lv < 0 || Lt + Lv <= 0 || D <= 0 || (D & 7)) return fail("ttt_hip: glue kernels: bad dimension (D must be a multiple of 8)");
+    if (D > 8 * 1024) return fail("ttt_hip: glue kernels: D too large for one block per token");
+    return 0;
+}
+int ttt_hip_adaln_backward_partials(void) { return ttt::prepost::adaln_backward_partials(); }
+int ttt_hip_adaln_forward(int B, int Lt, int Lv, int D, float eps, const void* vid, const void* text, const float* w, const float* b,
+                          const float* shift, const float* scale1p, void* out, void* stream) {
+    if (check_glue_dims(B, Lt, Lv, D)) return -1;
+    if ((Lv && !vid) || (Lt && !text) || !w || !b || !shift || !scale1p || !out) return fail("ttt_hip: adaln_forward: null pointer");
+    ttt::prepost::AdaLNArgs a = {(const __bf16*)vid, (const __bf16*)text, w, b, shift, scale1p, (__bf16*)out, B, Lt, Lv, D, eps};
+    ttt::prepost::adaln_forward(a, (hipStream_t)stream);
+    return post_launch("adaln_forward");
+}
+int ttt_hip_adaln_backward(int B, int Lt, int Lv, int D, float eps, const void* vid, const void* text, const void* dout,
+                           const float* w, const float* b, const float* scale1p, void* dvid, void* dtext, float* part, void* stream) {
+    if (check_glue_dims(B, Lt, Lv, D)) return -1;
+    if ((Lv && (!vid || !dvid)) || (Lt && (!text || !dtext)) || !dout || !w || !b || !scale1p || !part) return fail("ttt_hip: adaln_backward: null pointer");
+    ttt::prepost::AdaLNBwdArgs a = {(const __bf16*)vid, (const __bf16*)text, (const __bf16*)dout, w, b, scale1p,
+                                    (__bf16*)dvid, (__bf16*)dtext, part, B, Lt, Lv, D, 0, eps};
+    ttt::prepost::adaln_backward(a, (hipStream_t)stream);
+    return post_launch("adaln_backward");
+}
+int ttt_hip_resgate_backward_partials(int D) { return ttt::prepost::resgate_backward_partials(D); }
+int ttt_hip_resgate_forward(int B, int Lt, int Lv, int D, const void* vid, const void* text, const void* y, const float* gate,
+                            void* ovid, void* otext, void* stream) {
+    if (check_glue_dims(B, Lt, Lv, D)) return -1;
+    if ((Lv && (!vid || !ovid)) || (Lt && (!text || !otext)) || !y || !gate) return fail("ttt_hip: resgate_forward: null pointer");
+    ttt::prepost::ResGateArgs a = {(const __bf16*)vid, (const __bf16*)text, (const __bf16*)y, gate, (__bf16*)ovid, (__bf16*)otext, B, Lt, Lv, D};
+    ttt::prepost::resgate_forward(a, (hipStream_t)stream);
+    return post_launch("resgate_forward");
+}
+int ttt_hip_resgate_backward(int B, int Lt, int Lv, int D, const void* dvid, const void* dtext, const void* y, const float* gate,
+                             void* dy, float* dgate_part, void* stream) {
+    if (check_glue_dims(B, Lt, Lv, D)) return -1;
+    if ((Lv && !dvid) || (Lt && !dtext) || !y || !gate || !dy || !dgate_part) return fail("ttt_hip: resgate_backward: null pointer");
+    ttt::prepost::ResGateBwdArgs a = {(const __bf16*)dvid, (const __bf16*)dtext, (const __bf16*)y, gate, (__bf16*)dy, dgate_part, B, Lt, Lv, D};
+    ttt::prepost::resgate_backward(a, (hipStream_t)stream);
+    return post_launch("resgate_backward");
+}
+
 }  // extern "C"

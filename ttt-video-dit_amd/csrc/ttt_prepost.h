@@ -55,6 +55,36 @@ struct GateBwdArgs {
     int B, L, D, n_text;
 };
 
+struct AdaLNArgs {
+    const __bf16 *vid, *text;                 // [B, Lv, D], [B, Lt, D]
+    const float *w, *b;                       // LayerNorm [D]
+    const float *shift, *scale1p;             // [B, 2, D]: group 0 = text, 1 = video; scale1p = 1 + scale
+    __bf16* out;                              // [B, Lt + Lv, D] = [text | video]
+    int B, Lt, Lv, D;
+    float eps;
+};
+struct AdaLNBwdArgs {
+    const __bf16 *vid, *text, *dout;
+    const float *w, *b, *scale1p;
+    __bf16 *dvid, *dtext;
+    float* part;                              // [B * 2 * P, 4, D]: dw, db, d scale1p, d shift per block
+    int B, Lt, Lv, D, P;
+    float eps;
+};
+struct ResGateArgs {
+    const __bf16 *vid, *text, *y;             // residual streams and y = [text | video] [B, Lt + Lv, D]
+    const float* gate;                        // [B, 2, D]: group 0 = text, 1 = video
+    __bf16 *ovid, *otext;
+    int B, Lt, Lv, D;
+};
+struct ResGateBwdArgs {
+    const __bf16 *dvid, *dtext, *y;
+    const float* gate;
+    __bf16* dy;                               // [B, Lt + Lv, D]
+    float* dgate_part;                        // [P, B, 2, D]
+    int B, Lt, Lv, D;
+};
+
 void pre_forward(const PreArgs& a, hipStream_t s);
 int  pre_backward_partials(int NH);
 void pre_backward(const PreBwdArgs& a, hipStream_t s);
@@ -64,6 +94,12 @@ void post_backward(const PostBwdArgs& a, hipStream_t s);
 void gate_forward(const GateArgs& a, hipStream_t s);
 int  gate_backward_partials(int D);
 void gate_backward(const GateBwdArgs& a, hipStream_t s);
+void adaln_forward(const AdaLNArgs& a, hipStream_t s);
+int  adaln_backward_partials();
+void adaln_backward(const AdaLNBwdArgs& a, hipStream_t s);
+void resgate_forward(const ResGateArgs& a, hipStream_t s);
+int  resgate_backward_partials(int D);
+void resgate_backward(const ResGateBwdArgs& a, hipStream_t s);
 
 }  // namespace prepost
 }  // namespace ttt

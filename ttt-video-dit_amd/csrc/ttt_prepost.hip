@@ -357,6 +357,161 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(GateBwdArgs a) {
     for (int j = 0; j < 8; ++j) { pt[j] = at[j]; pv[j] = av[j]; }
 }
 
+// ------------------------------------------------------------------------------------------------ AdaLN (TransformerLayer glue)
+// out[b, :, :] = [ modulate(LN(text[b])) | modulate(LN(vid[b])) ],  modulate(y) = shift + y * scale1p  (scale1p = 1 + scale),
+// LN over D with (w, b, eps); shift / scale1p are per (batch, group) vectors.  Replaces, per call, two LayerNorm kernels, two
+// addcmul kernels and the concat copy of the reference's  modulate(layernorm(vid)), modulate(layernorm(text))  + torch.cat
+// (cogvideo/dit.py:353-371) by one pass: one block per token (blockDim = D/8 rounded up to whole waves, 8 features per thread).
+// Rounding mirrors the unfused bf16 path: the LayerNorm output is rounded to bf16 before the modulation.
+__global__ void adaln_fwd_kernel(AdaLNArgs a) {
+    __shared__ float sh[16];
+    const int D = a.D, nw = blockDim.x >> 6, L = a.Lt + a.Lv;
+    const int o8 = threadIdx.x * 8;
+    const bool act = o8 < D;
+    float w8[8], b8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { w8[j] = 0.f; b8[j] = 0.f; }
+    if (act) { ldf8(a.w + o8, w8); ldf8(a.b + o8, b8); }
+    for (long bt = blockIdx.x; bt < (long)a.B * L; bt += gridDim.x) {
+        const int t = bt % L, b = bt / L;
+        const int g = t < a.Lt ? 0 : 1;                                   // 0 = text, 1 = video
+        const __bf16* src = g == 0 ? a.text + ((size_t)b * a.Lt + t) * D : a.vid + ((size_t)b * a.Lv + (t - a.Lt)) * D;
+        float x[8], sf[8], sc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = 0.f;
+        if (act) ld8(src + o8, x);
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += x[j];
+        const float mean = block_sum(s, sh, nw) / D;
+        float vs = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { x[j] = act ? x[j] - mean : 0.f; vs += x[j] * x[j]; }
+        const float rstd = 1.0f / sqrtf(block_sum(vs, sh, nw) / D + a.eps);
+        if (act) {
+            ldf8(a.shift + ((size_t)b * 2 + g) * D + o8, sf);
+            ldf8(a.scale1p + ((size_t)b * 2 + g) * D + o8, sc);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = sf[j] + bf16_round(x[j] * rstd * w8[j] + b8[j]) * sc[j];
+            st8(a.out + ((size_t)b * L + t) * D + o8, x);
+        }
+    }
+}
+
+// backward: d_in = LN'(dOut * scale1p) ; parameter-gradient partials, one row per block:
+//   part[blk][0] = dw, [1] = db (LayerNorm), [2] = d scale1p, [3] = d shift  for the (batch, group) the block works on
+// (block blk handles batch blk / (2 P), group (blk / P) % 2; the caller reduces over the P blocks of a (batch, group)).
+__global__ void adaln_bwd_kernel(AdaLNBwdArgs a) {
+    __shared__ float sh[16];
+    const int D = a.D, nw = blockDim.x >> 6, L = a.Lt + a.Lv;
+    const int o8 = threadIdx.x * 8;
+    const bool act = o8 < D;
+    const int P = a.P;
+    const int b = blockIdx.x / (2 * P), g = (blockIdx.x / P) % 2, pi = blockIdx.x % P;
+    const int n_tok = g == 0 ? a.Lt : a.Lv, t0 = g == 0 ? 0 : a.Lt;
+    float w8[8], b8[8], sc[8], dw[8], db[8], dsc[8], dsh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { w8[j] = 0.f; b8[j] = 0.f; sc[j] = 0.f; dw[j] = 0.f; db[j] = 0.f; dsc[j] = 0.f; dsh[j] = 0.f; }
+    if (act) { ldf8(a.w + o8, w8); ldf8(a.b + o8, b8); ldf8(a.scale1p + ((size_t)b * 2 + g) * D + o8, sc); }
+    for (int tt = pi; tt < n_tok; tt += P) {
+        const __bf16* src = g == 0 ? a.text + ((size_t)b * a.Lt + tt) * D : a.vid + ((size_t)b * a.Lv + tt) * D;
+        __bf16* dst = g == 0 ? a.dtext + ((size_t)b * a.Lt + tt) * D : a.dvid + ((size_t)b * a.Lv + tt) * D;
+        float x[8], gy[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { x[j] = 0.f; gy[j] = 0.f; }
+        if (act) { ld8(src + o8, x); ld8(a.dout + ((size_t)b * L + t0 + tt) * D + o8, gy); }
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += x[j];
+        const float mean = block_sum(s, sh, nw) / D;
+        float vs = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { x[j] = act ? x[j] - mean : 0.f; vs += x[j] * x[j]; }
+        const float rstd = 1.0f / sqrtf(block_sum(vs, sh, nw) / D + a.eps);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            x[j] *= rstd;                                                // x_hat
+            dsh[j] += gy[j];
+            dsc[j] += gy[j] * bf16_round(x[j] * w8[j] + b8[j]);          // d(scale1p): dOut * LN output
+            gy[j] *= sc[j];                                              // gradient w.r.t. the LN output
+            dw[j] += gy[j] * x[j];
+            db[j] += gy[j];
+            gy[j] *= w8[j];
+            s1 += gy[j];
+            s2 += gy[j] * x[j];
+        }
+        s1 = block_sum(s1, sh, nw) / D;
+        s2 = block_sum(s2, sh, nw) / D;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gy[j] = (gy[j] - s1 - x[j] * s2) * rstd;
+        if (act) st8(dst + o8, gy);
+    }
+    if (act) {
+        float* pr = a.part + (size_t)blockIdx.x * 4 * D + o8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { pr[j] = dw[j]; pr[D + j] = db[j]; pr[2 * D + j] = dsc[j]; pr[3 * D + j] = dsh[j]; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ gated residual (TransformerLayer glue)
+// new_vid = vid + g_v * y[:, Lt:], new_text = text + g_t * y[:, :Lt]  (cogvideo/dit.py:358-359, 372-373); y is [text | video].
+__global__ __launch_bounds__(256) void resgate_fwd_kernel(ResGateArgs a) {
+    const int D8 = a.D / 8, L = a.Lt + a.Lv;
+    const long total = (long)a.B * L * D8;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = idx % D8;
+        const int t = (idx / D8) % L;
+        const int b = idx / ((long)D8 * L);
+        const int g = t < a.Lt ? 0 : 1;
+        const size_t ro = g == 0 ? ((size_t)b * a.Lt + t) * a.D + 8 * c : ((size_t)b * a.Lv + (t - a.Lt)) * a.D + 8 * c;
+        float r[8], y[8], gt[8];
+        ld8((g == 0 ? a.text : a.vid) + ro, r);
+        ld8(a.y + idx * 8, y);
+        ldf8(a.gate + ((size_t)b * 2 + g) * a.D + 8 * c, gt);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] += bf16_round(gt[j] * y[j]);
+        st8((g == 0 ? a.otext : a.ovid) + ro, r);
+    }
+}
+
+// backward: dy = gate * d_out (written as one [text | video] tensor), d gate partials [P][B][2][D]; the residual gradients are
+// d_out itself (returned by the caller as-is).  Threads are persistent over tokens with a fixed feature octet.
+__global__ __launch_bounds__(256) void resgate_bwd_kernel(ResGateBwdArgs a) {
+    const int D8 = a.D / 8, L = a.Lt + a.Lv;
+    const long tid0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long nthreads = (long)gridDim.x * blockDim.x;     // multiple of D8
+    const int c = tid0 % D8;
+    const long prow = tid0 / D8, nrows = nthreads / D8;
+    for (int b = 0; b < a.B; ++b) {
+        float gt[2][8], acc[2][8];
+        ldf8(a.gate + ((size_t)b * 2 + 0) * a.D + 8 * c, gt[0]);
+        ldf8(a.gate + ((size_t)b * 2 + 1) * a.D + 8 * c, gt[1]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { acc[0][j] = 0.f; acc[1][j] = 0.f; }
+        for (long t = prow; t < L; t += nrows) {
+            const int g = t < a.Lt ? 0 : 1;
+            const size_t ro = g == 0 ? ((size_t)b * a.Lt + t) * a.D + 8 * c : ((size_t)b * a.Lv + (t - a.Lt)) * a.D + 8 * c;
+            const size_t yo = ((size_t)b * L + t) * a.D + 8 * c;
+            float d[8], y[8];
+            ld8((g == 0 ? a.dtext : a.dvid) + ro, d);
+            ld8(a.y + yo, y);
+            if (g == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { acc[0][j] += d[j] * y[j]; d[j] *= gt[0][j]; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { acc[1][j] += d[j] * y[j]; d[j] *= gt[1][j]; }
+            }
+            st8(a.dy + yo, d);
+        }
+        float* p0 = a.dgate_part + (((size_t)prow * a.B + b) * 2 + 0) * a.D + 8 * c;
+        float* p1 = a.dgate_part + (((size_t)prow * a.B + b) * 2 + 1) * a.D + 8 * c;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { p0[j] = acc[0][j]; p1[j] = acc[1][j]; }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
 static int grid_for(long total_threads, int block, int cap_blocks) {
     long g = (total_threads + block - 1) / block;
@@ -404,6 +559,32 @@ void gate_backward(const GateBwdArgs& a, hipStream_t s) {
     int blocks = 2048;
     while ((long)blocks * 256 % per) --blocks;
     hipLaunchKernelGGL(gate_bwd_kernel, dim3(blocks), dim3(256), 0, s, a);
+}
+
+
+int adaln_blocks(int B, int Lt, int Lv) {
+    const long n = (long)B * (Lt + Lv);
+    return (int)(n < 2048 ? n : 2048);
+}
+void adaln_forward(const AdaLNArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(adaln_fwd_kernel, dim3(adaln_blocks(a.B, a.Lt, a.Lv)), dim3((a.D / 8 + 63) / 64 * 64), 0, s, a);
+}
+int adaln_backward_partials() { return 256; }          // P blocks per (batch, group)
+void adaln_backward(const AdaLNBwdArgs& a0, hipStream_t s) {
+    AdaLNBwdArgs a = a0;
+    a.P = adaln_backward_partials();
+    hipLaunchKernelGGL(adaln_bwd_kernel, dim3(a.B * 2 * a.P), dim3((a.D / 8 + 63) / 64 * 64), 0, s, a);
+}
+void resgate_forward(const ResGateArgs& a, hipStream_t s) {
+    const long total = (long)a.B * (a.Lt + a.Lv) * (a.D / 8);
+    hipLaunchKernelGGL(resgate_fwd_kernel, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, a);
+}
+int resgate_backward_partials(int D) { return gate_backward_partials(D); }
+void resgate_backward(const ResGateBwdArgs& a, hipStream_t s) {
+    const int per = a.D / 8;
+    int blocks = 2048;
+    while ((long)blocks * 256 % per) --blocks;
+    hipLaunchKernelGGL(resgate_bwd_kernel, dim3(blocks), dim3(256), 0, s, a);
 }
 
 }  // namespace prepost

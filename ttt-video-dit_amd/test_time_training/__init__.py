@@ -72,6 +72,8 @@ EXPORTED_SYMBOLS = (
     "ttt_hip_post_forward", "ttt_hip_post_backward", "ttt_hip_gate_forward", "ttt_hip_gate_backward_partials",
     "ttt_hip_gate_backward", "ttt_hip_attn_forward", "ttt_hip_attn_backward",
     "ttt_hip_attn_pre_forward", "ttt_hip_attn_pre_partials", "ttt_hip_attn_pre_backward",
+    "ttt_hip_adaln_forward", "ttt_hip_adaln_backward_partials", "ttt_hip_adaln_backward",
+    "ttt_hip_resgate_forward", "ttt_hip_resgate_backward_partials", "ttt_hip_resgate_backward",
 )
 
 _lib: Optional[ctypes.CDLL] = None
@@ -485,3 +487,57 @@ def attn_pre_backward(q_raw, k_raw, dq, dk, wq, wk, cos, sin, dq_raw, dk_raw, pa
     tq, tk = _attn_tensor(dq, "dq", (B, NH, S, 64)), _attn_tensor(dk, "dk", (B, NH, S, 64))
     _call("ttt_hip_attn_pre_backward", B, S, NH, int(n_text), ctypes.c_float(eps), _p(q_raw), _p(k_raw), ctypes.byref(tq), ctypes.byref(tk),
           _p(wq), _p(wk), _p(cos), _p(sin), _p(dq_raw), _p(dk_raw), _p(part), device=q_raw.device)
+
+
+# ------------------------------------------------------------------------------------------------
+# TransformerLayer glue (include/ttt_hip.h, "TransformerLayer glue"): bf16 activations, fp32 parameter vectors.
+def adaln_forward(vid, text, w, b, shift, scale1p, out, eps):
+    B, Lv, D = vid.shape
+    Lt = text.shape[1]
+    for t, n in ((vid, "vid"), (text, "text"), (out, "out")):
+        _req(t, n, torch.bfloat16)
+    for t, n in ((w, "w"), (b, "b"), (shift, "shift"), (scale1p, "scale1p")):
+        _req(t, n, torch.float32)
+    if tuple(out.shape) != (B, Lt + Lv, D) or tuple(shift.shape) != (B, 2, D) or tuple(scale1p.shape) != (B, 2, D):
+        raise RuntimeError("adaln_forward: out must be [B, Lt+Lv, D], shift / scale1p [B, 2, D]")
+    _call("ttt_hip_adaln_forward", B, Lt, Lv, D, ctypes.c_float(eps), _p(vid), _p(text), _p(w), _p(b), _p(shift), _p(scale1p), _p(out),
+          device=vid.device)
+
+
+def adaln_backward_partials():
+    return load_library().ttt_hip_adaln_backward_partials()
+
+
+def adaln_backward(vid, text, dout, w, b, scale1p, dvid, dtext, part, eps):
+    B, Lv, D = vid.shape
+    Lt = text.shape[1]
+    for t, n in ((vid, "vid"), (text, "text"), (dout, "dout"), (dvid, "dvid"), (dtext, "dtext")):
+        _req(t, n, torch.bfloat16)
+    for t, n in ((w, "w"), (b, "b"), (scale1p, "scale1p"), (part, "part")):
+        _req(t, n, torch.float32)
+    _call("ttt_hip_adaln_backward", B, Lt, Lv, D, ctypes.c_float(eps), _p(vid), _p(text), _p(dout), _p(w), _p(b), _p(scale1p),
+          _p(dvid), _p(dtext), _p(part), device=vid.device)
+
+
+def resgate_forward(vid, text, y, gate, ovid, otext):
+    B, Lv, D = vid.shape
+    Lt = text.shape[1]
+    for t, n in ((vid, "vid"), (text, "text"), (y, "y"), (ovid, "ovid"), (otext, "otext")):
+        _req(t, n, torch.bfloat16)
+    _req(gate, "gate", torch.float32)
+    if tuple(y.shape) != (B, Lt + Lv, D) or tuple(gate.shape) != (B, 2, D):
+        raise RuntimeError("resgate_forward: y must be [B, Lt+Lv, D], gate [B, 2, D]")
+    _call("ttt_hip_resgate_forward", B, Lt, Lv, D, _p(vid), _p(text), _p(y), _p(gate), _p(ovid), _p(otext), device=vid.device)
+
+
+def resgate_backward_partials(D):
+    return load_library().ttt_hip_resgate_backward_partials(int(D))
+
+
+def resgate_backward(dvid, dtext, y, gate, dy, dgate_part):
+    B, Lv, D = dvid.shape
+    Lt = dtext.shape[1]
+    for t, n in ((dvid, "dvid"), (dtext, "dtext"), (y, "y"), (dy, "dy")):
+        _req(t, n, torch.bfloat16)
+    _req(gate, "gate", torch.float32); _req(dgate_part, "dgate_part", torch.float32)
+    _call("ttt_hip_resgate_backward", B, Lt, Lv, D, _p(dvid), _p(dtext), _p(y), _p(gate), _p(dy), _p(dgate_part), device=dvid.device)

@@ -19,7 +19,7 @@ from ttt_amd.models.cogvideo.attention import FusedSegmentAttention, attn_pre_av
 from ttt_amd.models.cogvideo.utils import (Rotary3DPositionEmbedding, SequenceMetadata, modulate,
                                            timestep_embedding, unpatchify)
 from ttt_amd.models.configs import ModelConfig
-from ttt_amd.models.ssm.fused import FusedGate, fused_available
+from ttt_amd.models.ssm.fused import FusedAdaLN, FusedGate, FusedResGate, fused_available
 from ttt_amd.models.ssm.ttt_layer import TTTWrapper
 
 
@@ -150,12 +150,12 @@ class SeqModelingBlock(nn.Module):
         a = segment_attention(q, k, v)
         return self.o(a.transpose(1, 2).reshape(b, s, -1))
 
-    def _attn_forward(self, vid_emb, text_emb, seq_metadata: SequenceMetadata):
+    def _attn_forward(self, vid_emb, text_emb, seq_metadata: SequenceMetadata, cat=None):
         """Each segment i attends over [text_i, frames 12i .. 12(i+1)] (13 frames, 1 shared with its
         neighbour); the shared frame's outputs are averaged (reference :163-211)."""
         tl, tpf = seq_metadata.text_length, seq_metadata.tokens_per_frame
         if seq_metadata.num_chunks == 1:     # one segment: nothing overlaps, the accumulate / average below is the identity
-            return self._segment(torch.cat((text_emb, vid_emb), dim=1), tl)
+            return self._segment(cat if cat is not None else torch.cat((text_emb, vid_emb), dim=1), tl)
         out_vid = torch.zeros_like(vid_emb)
         out_txt = torch.zeros_like(text_emb)
         count = torch.zeros_like(vid_emb[..., :1])
@@ -186,6 +186,13 @@ class SeqModelingBlock(nn.Module):
         y = rev(emb, seq_metadata, True)
         return self._gate(self.backward_ssm_gating_text, self.backward_ssm_gating_video, emb, y, n_text)
 
+    def forward_cat(self, x, seq_metadata: SequenceMetadata):
+        """Same block on the concatenated ``[text | video]`` sequence, returning it concatenated (the fused TransformerLayer
+        path produces and consumes that layout directly, without the cat / slice pairs around the block)."""
+        n_text = seq_metadata.seq_text_length
+        x = _ckpt(self._attn_forward, self.do_attn_remat)(x[:, n_text:], x[:, :n_text], seq_metadata, x)
+        return self._ssm_forward(x, seq_metadata)
+
     def forward(self, vid_emb, text_emb, seq_metadata: SequenceMetadata):
         x = _ckpt(self._attn_forward, self.do_attn_remat)(vid_emb, text_emb, seq_metadata)
         x = self._ssm_forward(x, seq_metadata)
@@ -202,6 +209,7 @@ class TransformerLayer(nn.Module):
         train = config.adapter_method == "sft"
         self.remat_seq_modeling_block = config.remat_seq_modeling_block
         self.tp_mesh = None
+        self.use_fused_glue = True     # HIP AdaLN / gated-residual kernels when the activations are bf16 on a HIP device
         D = config.model_dim
         self.pre_seq_layernorm = nn.LayerNorm(D, eps=config.layer_norm_eps).requires_grad_(train)
         self.pre_seq_adaLN_modulation = nn.Sequential(nn.SiLU(), nn.Linear(config.time_embed_dim, 6 * D, bias=True).requires_grad_(train))
@@ -210,7 +218,23 @@ class TransformerLayer(nn.Module):
         self.pre_mlp_adaLN_modulation = nn.Sequential(nn.SiLU(), nn.Linear(config.time_embed_dim, 6 * D, bias=True).requires_grad_(train))
         self.mlp = MLP(config)
 
+    def _forward_fused(self, vid_emb, text_emb, seq_metadata: SequenceMetadata):
+        """HIP glue path (bf16 on a HIP device): layernorm + modulate + concat and the gated residuals are one kernel each
+        and the [text | video] sequence stays concatenated through the block and the MLP."""
+        t = seq_metadata.t_emb
+        ln1, ln2 = self.pre_seq_layernorm, self.pre_mlp_layernorm
+        sh_v, sc_v, g_v, sh_t, sc_t, g_t = self.pre_seq_adaLN_modulation(t).chunk(6, dim=1)
+        x = FusedAdaLN.apply(vid_emb, text_emb, ln1.weight, ln1.bias, sh_v, sc_v, sh_t, sc_t, ln1.eps)
+        y = _ckpt(self.seq_modeling_block.forward_cat, self.remat_seq_modeling_block)(x, seq_metadata)
+        vid_emb, text_emb = FusedResGate.apply(vid_emb, text_emb, y, g_v, g_t)
+        sh_v, sc_v, g_v, sh_t, sc_t, g_t = self.pre_mlp_adaLN_modulation(t).chunk(6, dim=1)
+        x = FusedAdaLN.apply(vid_emb, text_emb, ln2.weight, ln2.bias, sh_v, sc_v, sh_t, sc_t, ln2.eps)
+        y = self.mlp(x)
+        return FusedResGate.apply(vid_emb, text_emb, y, g_v, g_t)
+
     def forward(self, vid_emb, text_emb, seq_metadata: SequenceMetadata):
+        if self.use_fused_glue and fused_available(vid_emb, 64) and vid_emb.shape[-1] % 8 == 0 and vid_emb.shape[-1] <= 8192:
+            return self._forward_fused(vid_emb, text_emb, seq_metadata)
         n_text = seq_metadata.seq_text_length
         t = seq_metadata.t_emb
         sh_v, sc_v, g_v, sh_t, sc_t, g_t = self.pre_seq_adaLN_modulation(t).chunk(6, dim=1)

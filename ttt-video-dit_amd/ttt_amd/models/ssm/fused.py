@@ -187,3 +187,71 @@ class FusedPreScanMLP(torch.autograd.Function):
         rows = eta_shape[-2]
         d_eta_full = row if rows == 1 else torch.nn.functional.pad(row, (0, 0, rows - 1, 0))
         return (dq, dk, dv, g_w, g_b, None, None, None, None, *(g.to(st_dt) for g in d_state), d_eta_full.to(eta_dt), None)
+
+
+class FusedAdaLN(torch.autograd.Function):
+    """(vid [B,Lv,D], text [B,Lt,D], LayerNorm weight / bias [D], shift_v, scale_v, shift_t, scale_t [B,D], eps) ->
+    ``cat(modulate(LN(text), shift_t, scale_t), modulate(LN(vid), shift_v, scale_v))`` as one ``[B, Lt+Lv, D]`` tensor:
+    the TransformerLayer's layernorm + modulate + concat (reference ``cogvideo/dit.py:353-357, 366-371``) in one HIP pass
+    per direction; keeps only its inputs for backward."""
+
+    @staticmethod
+    def forward(ctx, vid, text, w, b, shift_v, scale_v, shift_t, scale_t, eps):
+        ext = _ext()
+        v, t = vid.contiguous(), text.contiguous()
+        B, Lv, D = v.shape
+        w32, b32 = w.detach().to(_F32).contiguous(), b.detach().to(_F32).contiguous()
+        # [B, 2, D], group 0 = text, 1 = video; "1 + scale" is formed in the activation dtype like the unfused modulate
+        shift = torch.stack((shift_t, shift_v), dim=1).detach().to(_F32).contiguous()
+        scale1p = torch.stack((1 + scale_t, 1 + scale_v), dim=1).detach().to(_F32).contiguous()
+        out = torch.empty(B, t.shape[1] + Lv, D, device=v.device, dtype=_BF16)
+        ext.adaln_forward(v, t, w32, b32, shift, scale1p, out, float(eps))
+        ctx.save_for_backward(v, t, w32, b32, scale1p)
+        ctx.meta = (float(eps), w.dtype, shift_v.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ext = _ext()
+        v, t, w32, b32, scale1p = ctx.saved_tensors
+        eps, pdt, mdt = ctx.meta
+        B, Lv, D = v.shape
+        P = ext.adaln_backward_partials()
+        dv, dt = torch.empty_like(v), torch.empty_like(t)
+        part = torch.empty(B * 2 * P, 4, D, device=v.device, dtype=_F32)
+        ext.adaln_backward(v, t, g.contiguous(), w32, b32, scale1p, dv, dt, part, eps)
+        part = part.view(B, 2, P, 4, D).sum(2)                     # [B, group, 4, D]
+        dw = part[:, :, 0].sum((0, 1)).to(pdt)
+        db = part[:, :, 1].sum((0, 1)).to(pdt)
+        dsc, dsh = part[:, :, 2].to(mdt), part[:, :, 3].to(mdt)    # [B, group, D]
+        return dv, dt, dw, db, dsh[:, 1], dsc[:, 1], dsh[:, 0], dsc[:, 0], None
+
+
+class FusedResGate(torch.autograd.Function):
+    """(vid [B,Lv,D], text [B,Lt,D], y [B,Lt+Lv,D] = [text | video], gate_v, gate_t [B,D]) ->
+    (vid + gate_v * y[:, Lt:], text + gate_t * y[:, :Lt]): the TransformerLayer's gated residuals
+    (reference ``cogvideo/dit.py:358-359, 372-373``) in one pass; the backward writes dy once instead of two padded slices."""
+
+    @staticmethod
+    def forward(ctx, vid, text, y, gate_v, gate_t):
+        ext = _ext()
+        v, t, yy = vid.contiguous(), text.contiguous(), y.contiguous()
+        gate = torch.stack((gate_t, gate_v), dim=1).detach().to(_F32).contiguous()
+        ov, ot = torch.empty_like(v), torch.empty_like(t)
+        ext.resgate_forward(v, t, yy, gate, ov, ot)
+        ctx.save_for_backward(yy, gate)
+        ctx.gdt = gate_v.dtype
+        return ov, ot
+
+    @staticmethod
+    def backward(ctx, dv, dt):
+        ext = _ext()
+        yy, gate = ctx.saved_tensors
+        dv, dt = dv.contiguous(), dt.contiguous()
+        B, L, D = yy.shape
+        P = ext.resgate_backward_partials(D)
+        dy = torch.empty_like(yy)
+        part = torch.empty(P, B, 2, D, device=yy.device, dtype=_F32)
+        ext.resgate_backward(dv, dt, yy, gate, dy, part)
+        dg = part.sum(0).to(ctx.gdt)                               # [B, 2, D]
+        return dv, dt, dy, dg[:, 1], dg[:, 0]
