@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--fwd-only", action="store_true")
     ap.add_argument("--phases", action="store_true", help="also print per-phase cycle totals of workgroup 0")
     ap.add_argument("--helpers", type=int, default=-1, help="backward sweep prefetch helpers per (b,h); -1 = automatic")
+    ap.add_argument("--lead", type=int, default=1, help="DEBUG A/B: steps the backward's prefetch helpers may run ahead of the scan")
     ap.add_argument("--overlap", action="store_true", help="DEBUG A/B: overlap the next chunk's recompute with the sweep on a side stream")
     ap.add_argument("--sweep-variant", type=int, default=1, help="DEBUG A/B of the backward sweep: 1 = no scheduling fences (default), 0 = fenced")
     ap.add_argument("--variant", type=int, default=2, help="MFMA forward kernel revision (2 = current, 1 = first)")
@@ -44,6 +45,7 @@ def main():
     ext.debug_helpers(a.helpers)
     ext.debug_helpers(-100 - a.sweep_variant)
     ext.debug_helpers(-201 if a.overlap else -200)
+    ext.debug_helpers(-300 - a.lead)
     dev = torch.device("cuda:0")
     B, NH, NC, CS, F, G = a.b, a.nh, a.nc, a.cs, 64, a.g
     H = 4 * F if a.kind == "mlp" else F

@@ -10,6 +10,9 @@
 //   dq     : one workgroup per (batch, head, 256 queries), the forward kernel's structure: keys / values stream
 //            through LDS, scores are computed transposed (rows = key, lane = query) so LSE / Delta are per-lane
 //            scalars, dS^T is re-used in place as the B operand of dQ^T += K^T dS^T.
+// LDS: the Q / dO / K tiles are read both as 16-byte row fragments and through ds_read_b64_tr_b16 from ONE stride-72 image.
+// A second, stride-96 image for the transposed reads (as in the forward kernel's V tile) removes every bank conflict
+// (SQ_LDS_BANK_CONFLICT 23 % -> 0) but measured 1-2.5 % slower here (one more ds_write per tile, larger footprint): not used.
 // No atomics: dQ, dK, dV are each written by exactly one workgroup (deterministic); the price is that S and dP are
 // computed in both kernels (7 GEMM units instead of 5), the usual trade at S ~ 18 k where a dQ atomic stream would be
 // 15+ GB per call.  Math = autograd of the reference's F.scaled_dot_product_attention (cogvideo/dit.py:196-198).
@@ -57,12 +60,7 @@ __device__ __forceinline__ void head_of_block(int b, int nblk, int nbh, int& bh,
 }
 
 // ------------------------------------------------------------------------------------------------------- dK, dV
-// Tiles that are read both ways live twice in LDS: a stride-72 image for the 16-byte row fragments (36 dwords per row:
-// conflict-free ds_read_b128) and a stride-96 image for ds_read_b64_tr_b16 (48 dwords: its 32-lane groups cover 4 rows x 16
-// dwords, which land on disjoint bank quarters; with stride 72 rows r and r+2 overlap - 23 % of the LDS cycles were conflicts).
-constexpr int TS96 = 96;
-constexpr int T72 = ATILE, T96 = 64 * TS96;              // elements
-constexpr int DKV_BUF = (2 * T72 + 2 * T96) * 2 + 2 * 64 * 4;      // Q, dO (both images), lse[64], delta[64]
+constexpr int DKV_BUF = 2 * ATILE * 2 + 2 * 64 * 4;      // Q tile, dO tile, lse[64], delta[64]
 constexpr int LDS_DKV = 2 * DKV_BUF;
 
 struct QStage {
@@ -88,15 +86,11 @@ __device__ __forceinline__ void qstage_issue(QStage& st, const BwdParams& p, con
 }
 __device__ __forceinline__ void qstage_park(const QStage& st, char* buf, int tid) {
     __bf16* Qt = reinterpret_cast<__bf16*>(buf);
-    __bf16* Dt = Qt + T72;
-    __bf16* Qx = Dt + T72;
-    __bf16* Dx = Qx + T96;
-    float* sm = reinterpret_cast<float*>(buf + (2 * T72 + 2 * T96) * 2);
+    __bf16* Dt = Qt + ATILE;
+    float* sm = reinterpret_cast<float*>(buf + 2 * ATILE * 2);
     const int row = tid >> 3, col = (tid & 7) * 8;
     *reinterpret_cast<uint4*>(Qt + row * AS + col) = st.q;
     *reinterpret_cast<uint4*>(Dt + row * AS + col) = st.d;
-    *reinterpret_cast<uint4*>(Qx + row * TS96 + col) = st.q;
-    *reinterpret_cast<uint4*>(Dx + row * TS96 + col) = st.d;
     if (tid < 64) { sm[tid] = st.lse; sm[64 + tid] = st.del; }
 }
 
@@ -141,10 +135,8 @@ __global__ __launch_bounds__(NTB) void attn_dkdv_kernel(BwdParams p) {
     for (int j = 0; j < nt; ++j) {
         const char* buf = smem + (j & 1) * DKV_BUF;
         const __bf16* Qt = reinterpret_cast<const __bf16*>(buf);
-        const __bf16* Dt = Qt + T72;
-        const __bf16* Qx = Dt + T72;
-        const __bf16* Dx = Qx + T96;
-        const float* lseL = reinterpret_cast<const float*>(buf + (2 * T72 + 2 * T96) * 2);
+        const __bf16* Dt = Qt + ATILE;
+        const float* lseL = reinterpret_cast<const float*>(buf + 2 * ATILE * 2);
         const float* delL = lseL + 64;
         const bool more = j + 1 < nt;
         if (more) qstage_issue(st, p, Qp, dOp, lse, del, (j + 1) * 64, tid);
@@ -170,8 +162,8 @@ __global__ __launch_bounds__(NTB) void attn_dkdv_kernel(BwdParams p) {
                 const bf16x8 pf = pack(Sc, s), df = pack(dP, s);
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
-                    dV[db] = mma(pf, tr_frag_pi(Dx, TS96, 32 * qb, s, 32 * db, l), dV[db]);
-                    dK[db] = mma(df, tr_frag_pi(Qx, TS96, 32 * qb, s, 32 * db, l), dK[db]);
+                    dV[db] = mma(pf, tr_frag_pi(Dt, AS, 32 * qb, s, 32 * db, l), dV[db]);
+                    dK[db] = mma(df, tr_frag_pi(Qt, AS, 32 * qb, s, 32 * db, l), dK[db]);
                 }
             }
         }
@@ -195,8 +187,7 @@ __global__ __launch_bounds__(NTB) void attn_dkdv_kernel(BwdParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------------- dQ
-constexpr int DQ_BUF_ELEMS = 2 * T72 + T96;             // K (row image), V (row image), K (transposed-read image)
-constexpr int LDS_DQ = 2 * DQ_BUF_ELEMS * 2;
+constexpr int LDS_DQ = 2 * 2 * ATILE * 2;
 
 struct KVStage2 {
     uint4 k, v;
@@ -212,11 +203,10 @@ __device__ __forceinline__ void kv_issue(KVStage2& st, const __bf16* Kp, const _
         st.v = make_uint4(0, 0, 0, 0);
     }
 }
-__device__ __forceinline__ void kv_park(const KVStage2& st, __bf16* Kt, int tid) {
+__device__ __forceinline__ void kv_park(const KVStage2& st, __bf16* Kt, __bf16* Vt, int tid) {
     const int row = tid >> 3, col = (tid & 7) * 8;
     *reinterpret_cast<uint4*>(Kt + row * AS + col) = st.k;
-    *reinterpret_cast<uint4*>(Kt + T72 + row * AS + col) = st.v;
-    *reinterpret_cast<uint4*>(Kt + 2 * T72 + row * TS96 + col) = st.k;
+    *reinterpret_cast<uint4*>(Vt + row * AS + col) = st.v;
 }
 
 __global__ __launch_bounds__(NTB) void attn_dq_kernel(BwdParams p) {
@@ -255,13 +245,12 @@ __global__ __launch_bounds__(NTB) void attn_dq_kernel(BwdParams p) {
     const int nt = (p.S + 63) / 64;
     KVStage2 st;
     kv_issue(st, Kp, Vp, p.k_ss, p.v_ss, 0, p.S, tid);
-    kv_park(st, lds, tid);
+    kv_park(st, lds, lds + ATILE, tid);
     __syncthreads();
 
     for (int j = 0; j < nt; ++j) {
-        const __bf16* Kt = lds + (j & 1) * DQ_BUF_ELEMS;
-        const __bf16* Vt = Kt + T72;
-        const __bf16* Kx = Kt + 2 * T72;
+        const __bf16* Kt = lds + (j & 1) * 2 * ATILE;
+        const __bf16* Vt = Kt + ATILE;
         const bool more = j + 1 < nt;
         if (more) kv_issue(st, Kp, Vp, p.k_ss, p.v_ss, (j + 1) * 64, p.S, tid);
         const bool ragged = !more && (p.S & 63);
@@ -282,12 +271,13 @@ __global__ __launch_bounds__(NTB) void attn_dq_kernel(BwdParams p) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const bf16x8 df = pack(dP, s);
-                dQ[0] = mma(tr_frag_pi(Kx, TS96, 32 * kb, s, 0, l), df, dQ[0]);
-                dQ[1] = mma(tr_frag_pi(Kx, TS96, 32 * kb, s, 32, l), df, dQ[1]);
+                dQ[0] = mma(tr_frag_pi(Kt, AS, 32 * kb, s, 0, l), df, dQ[0]);
+                dQ[1] = mma(tr_frag_pi(Kt, AS, 32 * kb, s, 32, l), df, dQ[1]);
             }
         }
         if (more) {
-            kv_park(st, lds + ((j + 1) & 1) * DQ_BUF_ELEMS, tid);
+            __bf16* Kn = lds + ((j + 1) & 1) * 2 * ATILE;
+            kv_park(st, Kn, Kn + ATILE, tid);
         }
         __syncthreads();
     }

@@ -53,7 +53,8 @@ void ttt_hip_debug_timing(void* device_buffer) { ttt::mfma::set_debug_timing(dev
 void ttt_hip_debug_groups_per_chunk(int groups) { ttt::mfma::set_debug_groups_per_chunk(groups); }
 void ttt_hip_debug_variant(int v) { ttt::mfma::set_debug_variant(v); }
 void ttt_hip_debug_helpers(int n) {
-    if (n <= -200) ttt::mfma::set_debug_overlap(-200 - n);            // -200: recompute / sweep overlap off, -201: on
+    if (n <= -300) ttt::mfma::set_debug_lead(-300 - n);               // -301, -302, ...: steps the prefetch helpers may run ahead
+    else if (n <= -200) ttt::mfma::set_debug_overlap(-200 - n);       // -200: recompute / sweep overlap off, -201: on
     else if (n <= -100) ttt::mfma::set_debug_sweep_variant(-100 - n); // -100 / -101: sweep scheduling variant
     else ttt::mfma::set_debug_helpers(n);
 }

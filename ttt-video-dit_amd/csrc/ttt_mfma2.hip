@@ -536,6 +536,9 @@ static int g_overlap = 0;      // recompute(next chunk) beside sweep(this chunk)
                                // (the recompute's 2 GB of slot traffic evicts what the prefetch helpers put into L2): off by default
 void set_debug_overlap(int v) { g_overlap = v; }
 int get_debug_overlap() { return g_overlap; }
+static int g_lead = 1;
+void set_debug_lead(int v) { g_lead = v; }
+int get_debug_lead() { return g_lead; }
 static int g_helpers = -1;
 void set_debug_helpers(int n) { g_helpers = n; }
 int get_debug_helpers() { return g_helpers; }

@@ -138,7 +138,8 @@ struct SweepParams2 {
     int NH, NC, chunk_lo, chunk_hi, first, last;
     unsigned long long* dbg;                // optional: per-stage cycle totals of workgroup 0 (entries 16..25)
     int* prog;                              // [B*NH] step the sweep of each (b,h) is working on (read by its prefetch helpers)
-    int nbh, helpers;                       // grid = nbh * (1 + helpers): blocks >= nbh are prefetch helpers of (b,h) = block % nbh
+    int nbh, helpers, lead;                 // grid = nbh * (1 + helpers): blocks >= nbh are prefetch helpers of (b,h) = block % nbh,
+                                            // running at most `lead` steps ahead of the scan
 };
 
 #define TTT_STAMP3(k)                                                        \
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(NT2) void mlp_bwd_sweep8_kernel(SweepParams2 p) {
             int polls = 0;
             while (true) {                                         // stay at most one step ahead of the scan
                 const int cur = __hip_atomic_load(p.prog + bh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (cur <= t + 1 || ++polls > 200000) break;
+                if (cur <= t + p.lead || ++polls > 200000) break;
                 __builtin_amdgcn_s_sleep(8);
             }
             const char* sl = base + (size_t)(t - p.chunk_lo) * SLOT_BYTES;
@@ -917,7 +918,7 @@ void mlp_backward_v2(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hip
         bp.first = (ch == nchunks - 1);
         bp.last = (ch == 0);
         bp.dbg = get_debug_timing();
-        bp.prog = prog; bp.nbh = nbh; bp.helpers = helpers;
+        bp.prog = prog; bp.nbh = nbh; bp.helpers = helpers; bp.lead = get_debug_lead();
         const dim3 grid(nbh * (1 + helpers)), blk(b2::NT2);
         const bool v1 = get_debug_sweep_variant() == 1;     // DEBUG A/B: 1 = no scheduling fences inside the stages
         if (bp.dbg) { if (v1) hipLaunchKernelGGL((b2::mlp_bwd_sweep8_kernel<true, 1>), grid, blk, b2::LDS_SWEEP, s, bp);

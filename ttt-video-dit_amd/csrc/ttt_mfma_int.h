@@ -39,6 +39,8 @@ unsigned long long* get_debug_timing();
 int get_debug_helpers();          // -1 = automatic
 int get_debug_sweep_variant();
 int get_debug_overlap();
+int get_debug_lead();
+void set_debug_lead(int v);
 void set_debug_overlap(int v);
 void set_debug_sweep_variant(int v);
 
