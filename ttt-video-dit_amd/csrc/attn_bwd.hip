@@ -13,10 +13,13 @@
 // LDS: the Q / dO / K tiles are read both as 16-byte row fragments and through ds_read_b64_tr_b16 from ONE stride-72 image.
 // A second, stride-96 image for the transposed reads (as in the forward kernel's V tile) removes every bank conflict
 // (SQ_LDS_BANK_CONFLICT 23 % -> 0) but measured 1-2.5 % slower here (one more ds_write per tile, larger footprint): not used.
+// dk_dv stays at one 8-wave workgroup per CU (189 VGPRs): bounding it to 128 registers or splitting it into 4-wave
+// workgroups (3 per CU) spills inside the loop and was 2.5x slower (measured).
 // No atomics: dQ, dK, dV are each written by exactly one workgroup (deterministic); the price is that S and dP are
 // computed in both kernels (7 GEMM units instead of 5), the usual trade at S ~ 18 k where a dQ atomic stream would be
 // 15+ GB per call.  Math = autograd of the reference's F.scaled_dot_product_attention (cogvideo/dit.py:196-198).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "../../include/ttt_hip.h"
 #include "attn.h"
 #include "attn_dev.h"
@@ -209,7 +212,10 @@ __device__ __forceinline__ void kv_park(const KVStage2& st, __bf16* Kt, __bf16* 
     *reinterpret_cast<uint4*>(Vt + row * AS + col) = st.v;
 }
 
-__global__ __launch_bounds__(NTB) void attn_dq_kernel(BwdParams p) {
+// W = waves per SIMD the register allocation is bounded for: 4 (two workgroups per CU, <= 128 VGPRs, no spills: measured
+// 6.6 vs 7.5 ms at the 3 s segment) or 2 (one workgroup per CU, 166 VGPRs)
+template <int W>
+__global__ __launch_bounds__(NTB, W) void attn_dq_kernel(BwdParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __bf16* lds = reinterpret_cast<__bf16*>(smem);
     const int tid = threadIdx.x;
@@ -299,7 +305,8 @@ void launch_backward(const BwdParams& p, hipStream_t s) {
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)attn_dkdv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DKV);
-        (void)hipFuncSetAttribute((const void*)attn_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DQ);
+        (void)hipFuncSetAttribute((const void*)attn_dq_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DQ);
+        (void)hipFuncSetAttribute((const void*)attn_dq_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DQ);
         attr = true;
     }
     const long rows = (long)p.B * p.NH * p.S;
@@ -307,7 +314,9 @@ void launch_backward(const BwdParams& p, hipStream_t s) {
     hipLaunchKernelGGL(attn_delta_kernel, dim3(dgrid), dim3(256), 0, s, p);
     const int nb = (p.S + 255) / 256;
     hipLaunchKernelGGL(attn_dkdv_kernel, dim3(p.B * p.NH * nb), dim3(NTB), LDS_DKV, s, p);
-    hipLaunchKernelGGL(attn_dq_kernel, dim3(p.B * p.NH * nb), dim3(NTB), LDS_DQ, s, p);
+    static const int dq_occ = getenv("TTT_ATTN_DQ_OCC") ? atoi(getenv("TTT_ATTN_DQ_OCC")) : 4;     // DEBUG A/B knob
+    if (dq_occ == 2) hipLaunchKernelGGL(attn_dq_kernel<2>, dim3(p.B * p.NH * nb), dim3(NTB), LDS_DQ, s, p);
+    else hipLaunchKernelGGL(attn_dq_kernel<4>, dim3(p.B * p.NH * nb), dim3(NTB), LDS_DQ, s, p);
 }
 
 }  // namespace attn
