@@ -42,10 +42,10 @@ def main():
     ext.load_library()
     ext.set_impl(a.impl)
     ext.debug_variant(a.variant)
-    ext.debug_helpers(a.helpers)
-    ext.debug_helpers(-100 - a.sweep_variant)
-    ext.debug_helpers(-201 if a.overlap else -200)
-    ext.debug_helpers(-300 - a.lead)
+    ext.debug_option("helpers", a.helpers)
+    ext.debug_option("sweep_fences", 1 - a.sweep_variant)
+    ext.debug_option("overlap_recompute", int(a.overlap))
+    ext.debug_option("helper_lead", a.lead)
     dev = torch.device("cuda:0")
     B, NH, NC, CS, F, G = a.b, a.nh, a.nc, a.cs, 64, a.g
     H = 4 * F if a.kind == "mlp" else F

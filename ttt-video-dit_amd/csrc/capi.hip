@@ -52,11 +52,17 @@ int ttt_hip_abi_version(void) { return TTT_HIP_ABI_VERSION; }
 void ttt_hip_debug_timing(void* device_buffer) { ttt::mfma::set_debug_timing(device_buffer); }
 void ttt_hip_debug_groups_per_chunk(int groups) { ttt::mfma::set_debug_groups_per_chunk(groups); }
 void ttt_hip_debug_variant(int v) { ttt::mfma::set_debug_variant(v); }
-void ttt_hip_debug_helpers(int n) {
-    if (n <= -300) ttt::mfma::set_debug_lead(-300 - n);               // -301, -302, ...: steps the prefetch helpers may run ahead
-    else if (n <= -200) ttt::mfma::set_debug_overlap(-200 - n);       // -200: recompute / sweep overlap off, -201: on
-    else if (n <= -100) ttt::mfma::set_debug_sweep_variant(-100 - n); // -100 / -101: sweep scheduling variant
-    else ttt::mfma::set_debug_helpers(n);
+void ttt_hip_debug_helpers(int n) { ttt::mfma::set_debug_helpers(n); }
+int ttt_hip_debug_option(const char* name, int value) {
+    if (!name) return -1;
+    if (!strcmp(name, "helpers")) ttt::mfma::set_debug_helpers(value);              // prefetch helpers per (b,h), -1 = automatic
+    else if (!strcmp(name, "helper_lead")) ttt::mfma::set_debug_lead(value);        // steps the helpers may run ahead (default 1)
+    else if (!strcmp(name, "sweep_fences")) ttt::mfma::set_debug_sweep_variant(value ? 0 : 1);   // scheduling fences inside the sweep stages
+    else if (!strcmp(name, "overlap_recompute")) ttt::mfma::set_debug_overlap(value);            // recompute(next chunk) beside sweep(this chunk)
+    else if (!strcmp(name, "variant")) ttt::mfma::set_debug_variant(value);         // kernel revision 2 / 1
+    else if (!strcmp(name, "groups_per_chunk")) ttt::mfma::set_debug_groups_per_chunk(value);
+    else return -1;
+    return 0;
 }
 void ttt_hip_debug_dump(float* buf) { ttt::mfma::set_debug_dump(buf); }
 const char* ttt_hip_last_error(void) { return g_err; }

@@ -67,7 +67,7 @@ EXPORTED_SYMBOLS = (
     "ttt_hip_mlp_forward_workspace", "ttt_hip_mlp_backward_workspace", "ttt_hip_linear_forward_workspace",
     "ttt_hip_linear_backward_workspace", "ttt_hip_mlp_forward", "ttt_hip_mlp_backward", "ttt_hip_linear_forward",
     "ttt_hip_linear_backward", "ttt_hip_resolve_impl", "ttt_hip_abi_version", "ttt_hip_last_error",
-    "ttt_hip_debug_timing", "ttt_hip_debug_groups_per_chunk", "ttt_hip_debug_variant", "ttt_hip_debug_dump", "ttt_hip_debug_helpers",
+    "ttt_hip_debug_timing", "ttt_hip_debug_groups_per_chunk", "ttt_hip_debug_variant", "ttt_hip_debug_dump", "ttt_hip_debug_helpers", "ttt_hip_debug_option",
     "ttt_hip_pre_forward", "ttt_hip_pre_backward_partials", "ttt_hip_pre_backward", "ttt_hip_post_partials",
     "ttt_hip_post_forward", "ttt_hip_post_backward", "ttt_hip_gate_forward", "ttt_hip_gate_backward_partials",
     "ttt_hip_gate_backward", "ttt_hip_attn_forward", "ttt_hip_attn_backward",
@@ -134,6 +134,15 @@ def debug_helpers(n: int) -> None:
     lib = load_library()
     lib.ttt_hip_debug_helpers.argtypes = [ctypes.c_int]
     lib.ttt_hip_debug_helpers(int(n))
+
+
+def debug_option(name: str, value: int) -> None:
+    """DEBUG / A-B knobs of the revision-2 backward by name (see ttt_hip_debug_option in include/ttt_hip.h)."""
+    lib = load_library()
+    lib.ttt_hip_debug_option.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    lib.ttt_hip_debug_option.restype = ctypes.c_int
+    if lib.ttt_hip_debug_option(name.encode(), int(value)) != 0:
+        raise ValueError(f"unknown debug option {name!r}")
 
 
 def debug_dump(buf: Optional[torch.Tensor]) -> None:
