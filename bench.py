@@ -13,8 +13,16 @@ as the reference's apply_fsdp), local batch 1 per GPU (weak scaling), layer-grou
 as in the reference, synthetic latents/text embeddings, random-init weights.  One step = zero_grad,
 loss = CogVideoX(vid, text).mean(), backward, clip_grad_norm, fused AdamW step.
 
+MI355X-first memory policy (same arithmetic as the reference's settings, which remain available as flags):
+  --remat-free-layers auto   leading layers that keep their activations instead of being re-materialised in backward,
+                             sized to the GPU's 288 GB with untimed probe steps (0 = the reference's 80-GB setting)
+  (default)                  FSDP keeps the gathered bf16 parameters resident (--reshard-after-forward = reference)
+  (default)                  committed hipBLASLt / rocBLAS solution selections for this model's GEMM shapes (--no-tuned-gemms)
+
 Rank 0 prints ONE JSON line.  Besides the driver contract it carries
-  roofline     - the dominant hand-written kernel (TTT-MLP scan), algorithmic FLOPs / measured launch time
+  roofline     - the dominant hand-written kernel (TTT-MLP scan), algorithmic FLOPs / measured launch time (HIP events
+                 around every launch on the launch stream); the other hand-written kernels (forward scan, attention
+                 forward / backward) are listed under roofline.other
   cpu_baseline - the CPU port (torch-CPU DiT layer + oracle scan) timed on the host cores, N=1 only
 """
 import argparse
