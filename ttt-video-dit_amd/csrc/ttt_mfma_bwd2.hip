@@ -829,7 +829,8 @@ struct SideStream {
     hipStream_t s2 = nullptr;
     hipEvent_t in = nullptr, rec[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
     bool ok = false;
-    SideStream() {
+    SideStream() {}
+    explicit SideStream(int) {
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
         ok = hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, lo) == hipSuccess;
@@ -839,7 +840,7 @@ struct SideStream {
                  hipEventCreateWithFlags(&done[i], hipEventDisableTiming) == hipSuccess;
     }
 };
-static SideStream& side_stream() { static SideStream ss; return ss; }
+static SideStream& side_stream() { static SideStream ss(1); return ss; }
 
 void mlp_backward_v2(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hipStream_t s) {
     const int nbh = d->B * d->NH, G = d->G, NC = d->NC;
@@ -889,8 +890,9 @@ void mlp_backward_v2(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hip
         attr = true;
     }
     const int nchunks = (K + gpc - 1) / gpc;
-    SideStream& ss = side_stream();
-    const bool overlap = ss.ok && nchunks > 1 && get_debug_overlap() != 0;
+    static SideStream no_side;                                   // handles are only created when the overlap is requested
+    SideStream& ss = get_debug_overlap() != 0 ? side_stream() : no_side;
+    const bool overlap = get_debug_overlap() != 0 && ss.ok && nchunks > 1;
     auto chunk_range = [&](int ch, int& g0, int& ng) { g0 = ch * gpc; ng = (K - g0 < gpc) ? K - g0 : gpc; };
     auto recompute = [&](int ch, hipStream_t st) {
         int g0, ng;
