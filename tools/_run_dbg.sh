@@ -1,14 +1,7 @@
 #!/bin/bash
-# gpurun helper: attention backward timing per kernel (rocprof stats) + tests
-export TMPDIR=/tmp
-R=$PWD
-timeout 200 python -m pytest tests/test_attention_gpu.py -x -q 2>&1 | tail -1
-timeout 200 python tools/attn_bench.py --no-sdpa --iters 9 2>/dev/null | tail -1
-cd /tmp
-timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pa -o a -- python $R/tools/attn_bench.py --iters 5 --no-sdpa > /dev/null 2>&1
-python - <<'PY'
-import csv, glob
-f = glob.glob('/tmp/pa/**/*kernel_stats.csv', recursive=True)[0]
-for r in list(csv.DictReader(open(f)))[:5]:
-    print(r['Name'][:60], r['Calls'], round(float(r['AverageNs'])/1e3,1))
-PY
+# gpurun helper: the bench's reference-settings flags and the 9 s configuration still work
+mkdir -p gpurun_out/dbg
+timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --remat-free-layers 0 --reshard-after-forward --no-tuned-gemms 2> gpurun_out/dbg/ref.err | grep '^{"metric' > gpurun_out/dbg/bench_refsettings.json
+python -c "import json; d=json.loads(open('gpurun_out/dbg/bench_refsettings.json').read()); print('reference settings:', round(d['value'],1), round(d['ms_per_step'],1), d['config']['remat_free_layers'], d['config']['fsdp_reshard_after_forward'], d['config']['tuned_gemm_selections'], round(d['peak_mem_gib'],1), d['loss'])"
+timeout 700 python bench.py --video-length 9sec --steps 1 --warmup 1 --no-cpu-baseline 2> gpurun_out/dbg/b9.err | grep '^{"metric' > gpurun_out/dbg/bench9.json
+python -c "import json; d=json.loads(open('gpurun_out/dbg/bench9.json').read()); print('9 s:', round(d['value'],1), round(d['ms_per_step'],1), d['config']['remat_free_layers'], round(d['peak_mem_gib'],1), d['loss'])"
