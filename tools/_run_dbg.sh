@@ -1,7 +1,8 @@
 #!/bin/bash
-# gpurun helper: the bench's reference-settings flags and the 9 s configuration still work
+# gpurun helper: A/B of the backward sweep variants (same box, interleaved)
 mkdir -p gpurun_out/dbg
-timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --remat-free-layers 0 --reshard-after-forward --no-tuned-gemms 2> gpurun_out/dbg/ref.err | grep '^{"metric' > gpurun_out/dbg/bench_refsettings.json
-python -c "import json; d=json.loads(open('gpurun_out/dbg/bench_refsettings.json').read()); print('reference settings:', round(d['value'],1), round(d['ms_per_step'],1), d['config']['remat_free_layers'], d['config']['fsdp_reshard_after_forward'], d['config']['tuned_gemm_selections'], round(d['peak_mem_gib'],1), d['loss'])"
-timeout 700 python bench.py --video-length 9sec --steps 1 --warmup 1 --no-cpu-baseline 2> gpurun_out/dbg/b9.err | grep '^{"metric' > gpurun_out/dbg/bench9.json
-python -c "import json; d=json.loads(open('gpurun_out/dbg/bench9.json').read()); print('9 s:', round(d['value'],1), round(d['ms_per_step'],1), d['config']['remat_free_layers'], round(d['peak_mem_gib'],1), d['loss'])"
+for v in 1 2 1 2; do
+  timeout 120 python tools/op_bench.py --phases --iters 7 --sweep-variant $v > gpurun_out/dbg/op.json 2>&1
+  tail -1 gpurun_out/dbg/op.json | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('variant $v bwd ms', round(d['bwd']['avg_ms'],3), round(d['bwd']['min_ms'],3), [int(x) for x in d['phase_cycles_per_step'][16:26]])"
+done
+timeout 100 python tools/debug_bwd_v2.py 2>/dev/null | grep -E "dW1 |dXK" | tail -4

@@ -33,7 +33,7 @@ def main():
     ap.add_argument("--helpers", type=int, default=-1, help="backward sweep prefetch helpers per (b,h); -1 = automatic")
     ap.add_argument("--lead", type=int, default=1, help="DEBUG A/B: steps the backward's prefetch helpers may run ahead of the scan")
     ap.add_argument("--overlap", action="store_true", help="DEBUG A/B: overlap the next chunk's recompute with the sweep on a side stream")
-    ap.add_argument("--sweep-variant", type=int, default=1, help="DEBUG A/B of the backward sweep: 1 = no scheduling fences (default), 0 = fenced")
+    ap.add_argument("--sweep-variant", type=int, default=1, help="DEBUG A/B of the backward sweep: 0 = fenced stages, 1 = unfenced, 2 = unfenced + output path before the K/gZ2 barrier")
     ap.add_argument("--variant", type=int, default=2, help="MFMA forward kernel revision (2 = current, 1 = first)")
     a = ap.parse_args()
     import test_time_training as ext
@@ -43,7 +43,7 @@ def main():
     ext.set_impl(a.impl)
     ext.debug_variant(a.variant)
     ext.debug_option("helpers", a.helpers)
-    ext.debug_option("sweep_fences", 1 - a.sweep_variant)
+    ext.debug_option("sweep_variant", a.sweep_variant)
     ext.debug_option("overlap_recompute", int(a.overlap))
     ext.debug_option("helper_lead", a.lead)
     dev = torch.device("cuda:0")

@@ -57,7 +57,7 @@ int ttt_hip_debug_option(const char* name, int value) {
     if (!name) return -1;
     if (!strcmp(name, "helpers")) ttt::mfma::set_debug_helpers(value);              // prefetch helpers per (b,h), -1 = automatic
     else if (!strcmp(name, "helper_lead")) ttt::mfma::set_debug_lead(value);        // steps the helpers may run ahead (default 1)
-    else if (!strcmp(name, "sweep_fences")) ttt::mfma::set_debug_sweep_variant(value ? 0 : 1);   // scheduling fences inside the sweep stages
+    else if (!strcmp(name, "sweep_variant")) ttt::mfma::set_debug_sweep_variant(value);          // 0 fenced stages, 1 unfenced, 2 unfenced + early output path
     else if (!strcmp(name, "overlap_recompute")) ttt::mfma::set_debug_overlap(value);            // recompute(next chunk) beside sweep(this chunk)
     else if (!strcmp(name, "variant")) ttt::mfma::set_debug_variant(value);         // kernel revision 2 / 1
     else if (!strcmp(name, "groups_per_chunk")) ttt::mfma::set_debug_groups_per_chunk(value);

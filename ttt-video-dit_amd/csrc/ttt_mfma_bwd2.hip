@@ -196,6 +196,10 @@ __global__ __launch_bounds__(NT2) void mlp_bwd_sweep8_kernel(SweepParams2 p) {
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int w = wv >> 1, pp = wv & 1;
+    // A/B knob (template variant 2): the output path of step i-1 before barrier Bd instead of after it.  Measured on an
+    // MI355X (3 s shape, 48 heads): 8.32 ms vs 8.26 ms for variant 1 - the work only moves between the two stages
+    // (S4a 10.7k -> 19.1k cycles, S4b 13.2k -> 4.3k), it does not overlap with anything.  Variant 1 stays the default.
+    auto get_move_out = [&]() { return VAR == 2; };
     const int nO = 64 * w + 32 * pp;
     const int fO = 32 * pp, fX = 32 * (1 - pp);
     const int bh = blockIdx.x % p.nbh, head = bh % p.NH;
@@ -651,13 +655,16 @@ __global__ __launch_bounds__(NT2) void mlp_bwd_sweep8_kernel(SweepParams2 p) {
                 if constexpr (VAR == 0) __builtin_amdgcn_sched_barrier(0);
             }
         }
+        // ---- output path of step j (dZ2b_j, Q_j, slot j: nothing of it touches K_i / gZ2_i): before Bd, so that its loads and
+        // MFMAs overlap the tail of S4a instead of waiting behind a barrier
+        if (more && get_move_out()) add_output_path(i - 1);
         TTT_STAMP3(6)
         __syncthreads();                   // Bd: every read of K_i, gZ2_i, dZ2_i, eta_i is done
         TTT_STAMP3(7)
 
-        // ================= S4b : output path of step j, publish, park ====================================================
+        // ================= S4b : (output path of step j,) publish, park ====================================================
         if (more) {
-            add_output_path(i - 1);
+            if (!get_move_out()) add_output_path(i - 1);
             publish_state(i - 1);
             park_kg(st);
         }
@@ -886,6 +893,8 @@ void mlp_backward_v2(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hip
         (void)hipFuncSetAttribute((const void*)b2::mlp_bwd_sweep8_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, b2::LDS_SWEEP);
         (void)hipFuncSetAttribute((const void*)b2::mlp_bwd_sweep8_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, b2::LDS_SWEEP);
         (void)hipFuncSetAttribute((const void*)b2::mlp_bwd_sweep8_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, b2::LDS_SWEEP);
+        (void)hipFuncSetAttribute((const void*)b2::mlp_bwd_sweep8_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, b2::LDS_SWEEP);
+        (void)hipFuncSetAttribute((const void*)b2::mlp_bwd_sweep8_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, b2::LDS_SWEEP);
         (void)hipFuncSetAttribute((const void*)b2::mlp_bwd_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, b2::LDS_TAIL);
         attr = true;
     }
@@ -922,11 +931,16 @@ void mlp_backward_v2(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hip
         bp.dbg = get_debug_timing();
         bp.prog = prog; bp.nbh = nbh; bp.helpers = helpers; bp.lead = get_debug_lead();
         const dim3 grid(nbh * (1 + helpers)), blk(b2::NT2);
-        const bool v1 = get_debug_sweep_variant() == 1;     // DEBUG A/B: 1 = no scheduling fences inside the stages
-        if (bp.dbg) { if (v1) hipLaunchKernelGGL((b2::mlp_bwd_sweep8_kernel<true, 1>), grid, blk, b2::LDS_SWEEP, s, bp);
-                      else hipLaunchKernelGGL((b2::mlp_bwd_sweep8_kernel<true, 0>), grid, blk, b2::LDS_SWEEP, s, bp); }
-        else { if (v1) hipLaunchKernelGGL((b2::mlp_bwd_sweep8_kernel<false, 1>), grid, blk, b2::LDS_SWEEP, s, bp);
-               else hipLaunchKernelGGL((b2::mlp_bwd_sweep8_kernel<false, 0>), grid, blk, b2::LDS_SWEEP, s, bp); }
+        const int sv = get_debug_sweep_variant();   // DEBUG A/B: 0 = scheduling fences inside the stages, 1 = none, 2 = none + output path before Bd
+        if (bp.dbg) {
+            if (sv == 0) hipLaunchKernelGGL((b2::mlp_bwd_sweep8_kernel<true, 0>), grid, blk, b2::LDS_SWEEP, s, bp);
+            else if (sv == 1) hipLaunchKernelGGL((b2::mlp_bwd_sweep8_kernel<true, 1>), grid, blk, b2::LDS_SWEEP, s, bp);
+            else hipLaunchKernelGGL((b2::mlp_bwd_sweep8_kernel<true, 2>), grid, blk, b2::LDS_SWEEP, s, bp);
+        } else {
+            if (sv == 0) hipLaunchKernelGGL((b2::mlp_bwd_sweep8_kernel<false, 0>), grid, blk, b2::LDS_SWEEP, s, bp);
+            else if (sv == 1) hipLaunchKernelGGL((b2::mlp_bwd_sweep8_kernel<false, 1>), grid, blk, b2::LDS_SWEEP, s, bp);
+            else hipLaunchKernelGGL((b2::mlp_bwd_sweep8_kernel<false, 2>), grid, blk, b2::LDS_SWEEP, s, bp);
+        }
         if (overlap && ch > 0) {
             // next chunk's recompute goes to the other buffer, free once the sweep + tail of chunk ch + 1 are done; enqueued
             // AFTER this chunk's sweep so that the sweep's workgroups are dispatched first
