@@ -34,3 +34,13 @@ def max_abs(a, b):
 def tile_states(d, B):
     t = lambda w: torch.tile(w.unsqueeze(0), dims=(B, 1, 1, 1)).contiguous()
     return {k: t(d[k]) for k in ("W1", "b1", "W2", "b2") if k in d}
+
+
+class ToyNet(torch.nn.Module):
+    """Stand-in for the DiT in sampler tests: nonlinear in x, depends on text and timestep, independent per sample."""
+
+    def forward(self, x, text, t):
+        g = torch.tanh(text.float().mean(dim=(1, 2, 3))).view(-1, 1, 1, 1, 1)
+        tt = torch.sin(t.float() / 100).view(-1, 1, 1, 1, 1)
+        xf = x.float()
+        return (0.6 * torch.tanh(xf.roll(1, -1)) + 0.3 * g * xf.roll(1, 1) + 0.1 * tt).to(x.dtype)

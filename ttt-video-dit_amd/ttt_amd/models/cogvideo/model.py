@@ -3,7 +3,7 @@
 
 The zero-terminal-SNR schedule is the training half of the reference's
 ``ZeroSNRDDPMDiscretization`` / ``DiscreteSampler`` (``cogvideo/utils.py``:262-358), rebuilt here as
-a small tensor table; the sampling-time classes of that file are out of scope.
+a small tensor table; the sampling-time classes of that file live in ``sampling.py``.
 Unlike the reference's sampler this one also works without an initialised process group
 (SURVEY.md hazard C8): rank/world default to 0/1.
 """
