@@ -1,8 +1,6 @@
 #!/bin/bash
-# gpurun helper: A/B of the backward sweep variants (same box, interleaved)
+# gpurun helper: CS = 16 MFMA forward scan - parity tests, then timing against the generic kernel
 mkdir -p gpurun_out/dbg
-for v in 1 2 1 2; do
-  timeout 120 python tools/op_bench.py --phases --iters 7 --sweep-variant $v > gpurun_out/dbg/op.json 2>&1
-  tail -1 gpurun_out/dbg/op.json | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('variant $v bwd ms', round(d['bwd']['avg_ms'],3), round(d['bwd']['min_ms'],3), [int(x) for x in d['phase_cycles_per_step'][16:26]])"
-done
-timeout 100 python tools/debug_bwd_v2.py 2>/dev/null | grep -E "dW1 |dXK" | tail -4
+timeout 150 python -m pytest tests/test_kernels_gpu.py -x -q -k "cs16" -s 2>&1 | tail -25 > gpurun_out/dbg/cs16_tests.txt
+cat gpurun_out/dbg/cs16_tests.txt
+timeout 100 python tools/cs16_bench.py --phases 2>&1 | tail -8 | tee gpurun_out/dbg/cs16_bench.txt

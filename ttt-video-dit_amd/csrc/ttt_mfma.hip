@@ -521,8 +521,9 @@ void launch_group_recompute(const ScanParams& p0, int n_bh, hipStream_t s) {
 }
 
 bool supports(const ttt_dims* d, bool mlp, bool backward) {
-    if (!(d->CS == 64 && d->F == 64 && d->act_dtype == TTT_DTYPE_BF16)) return false;
-    return mlp && (!backward || bwd_available());
+    if (!(d->F == 64 && d->act_dtype == TTT_DTYPE_BF16) || !mlp) return false;
+    if (d->CS == 16) return !backward;          // evaluation geometry: forward scan only (ttt_mfma16.hip)
+    return d->CS == 64 && (!backward || bwd_available());
 }
 
 void mlp_forward(const ttt_dims* d, const ttt_mlp_fwd_args* a, void*, hipStream_t s) {
@@ -533,7 +534,8 @@ void mlp_forward(const ttt_dims* d, const ttt_mlp_fwd_args* a, void*, hipStream_
     p.W1c = a->W1_checkpoints; p.b1c = a->b1_checkpoints; p.W2c = a->W2_checkpoints; p.b2c = a->b2_checkpoints;
     p.out = (__bf16*)a->XQW;
     p.NH = d->NH; p.NC = d->NC; p.G = d->G; p.K = (d->NC + d->G - 1) / d->G; p.eps = d->eps;
-    if (get_debug_variant() == 1) launch_scan_forward(p, d->B * d->NH, s);
+    if (d->CS == 16) launch_scan_forward_cs16(p, d->B * d->NH, g_dbg, s);
+    else if (get_debug_variant() == 1) launch_scan_forward(p, d->B * d->NH, s);
     else launch_scan_forward_v2(p, d->B * d->NH, g_dbg, s);
 }
 void linear_forward(const ttt_dims*, const ttt_linear_fwd_args*, void*, hipStream_t) {}

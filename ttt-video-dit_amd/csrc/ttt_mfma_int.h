@@ -33,6 +33,8 @@ size_t workspace_bytes_v2(const ttt_dims* d);
 int groups_per_chunk(const ttt_dims* d);
 // revision-2 forward scan (ttt_mfma2.hip): 8 waves per (b,h), VGPR-form MFMA, LDS transposed reads
 void launch_scan_forward_v2(const ScanParams& p, int n_bh, unsigned long long* dbg, hipStream_t s);
+// mini-batches of 16 tokens, forward only (ttt_mfma16.hip): the evaluation / sampling geometry
+void launch_scan_forward_cs16(const ScanParams& p, int n_bh, unsigned long long* dbg, hipStream_t s);
 void set_debug_dump(float* buf);
 int get_debug_variant();
 unsigned long long* get_debug_timing();
