@@ -19,6 +19,7 @@ ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--phases", action="store_true")
 ap.add_argument("--no-generic", action="store_true")
+ap.add_argument("--linear", action="store_true", help="TTT-Linear instead of TTT-MLP")
 a = ap.parse_args()
 dev = "cuda:0"
 B, NH, NC, CS, F = a.batch, a.nh, a.nc, 16, 64
@@ -32,13 +33,21 @@ lw, lb = torch.ones(1, NH, 1, F, device=dev), torch.zeros(1, NH, 1, F, device=de
 W1, b1 = 0.02 * n(B, NH, F, 4 * F), torch.zeros(B, NH, 1, 4 * F, device=dev)
 W2, b2 = 0.02 * n(B, NH, 4 * F, F), torch.zeros(B, NH, 1, F, device=dev)
 G = NC
+if a.linear:
+    W1l, b1l = 0.02 * n(B, NH, F, F), torch.zeros(B, NH, 1, F, device=dev)
+    lwl, lbl = torch.ones(NH, F, device=dev), torch.zeros(NH, F, device=dev)
+    lel = (1.0 * torch.sigmoid(n(B, NH, NC, CS, 1)) / (F * CS)).bfloat16()
+    ckl = (torch.empty(B, NH, 1, F, F, device=dev), torch.empty(B, NH, 1, 1, F, device=dev))
 cks = (torch.empty(B, NH, 1, F, 4 * F, device=dev), torch.empty(B, NH, 1, 1, 4 * F, device=dev),
        torch.empty(B, NH, 1, 4 * F, F, device=dev), torch.empty(B, NH, 1, 1, F, device=dev))
 outs = {}
 for impl in (("mfma",) if a.no_generic else ("mfma", "generic")):
     e.set_impl(impl)
     out = torch.empty_like(XQ)
-    run = lambda: e.ttt_forward(XQ, XK, XV, le, lw, lb, W1, b1, W2, b2, *cks, out, G)
+    if a.linear:
+        run = lambda: e.ttt_linear_forward(XQ, XK, XV, lel, lwl, lbl, W1l, b1l, *ckl, out, G)
+    else:
+        run = lambda: e.ttt_forward(XQ, XK, XV, le, lw, lb, W1, b1, W2, b2, *cks, out, G)
     run()
     torch.cuda.synchronize()
     t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -49,12 +58,12 @@ for impl in (("mfma",) if a.no_generic else ("mfma", "generic")):
     torch.cuda.synchronize()
     ms = t0.elapsed_time(t1) / a.iters
     outs[impl] = out.float()
-    flops = B * NH * NC * 7 * 2 * CS * F * 4 * F
-    print(f"{impl:8s} fwd {ms:8.3f} ms  {ms * 1e3 / NC:6.2f} us/step  {flops / ms / 1e9:7.2f} TFLOP/s (7 GEMMs/step)")
+    flops = B * NH * NC * (3 * 2 * CS * F * F if a.linear else 7 * 2 * CS * F * 4 * F)
+    print(f"{'linear ' if a.linear else ''}{impl:8s} fwd {ms:8.3f} ms  {ms * 1e3 / NC:6.2f} us/step  {flops / ms / 1e9:7.2f} TFLOP/s ({3 if a.linear else 7} GEMMs/step)")
 if not a.no_generic:
   d = (outs["mfma"] - outs["generic"]).flatten(2).norm(dim=2) / outs["generic"].flatten(2).norm(dim=2)
   print("per-head rel-L2 mfma vs generic: median %.3e max %.3e" % (d.median().item(), d.max().item()))
-if a.phases:
+if a.phases and not a.linear:
     e.set_impl("mfma")
     buf = torch.zeros(16, dtype=torch.int64, device=dev)
     e.debug_timing(buf)

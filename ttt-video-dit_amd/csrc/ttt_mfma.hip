@@ -521,8 +521,9 @@ void launch_group_recompute(const ScanParams& p0, int n_bh, hipStream_t s) {
 }
 
 bool supports(const ttt_dims* d, bool mlp, bool backward) {
-    if (!(d->F == 64 && d->act_dtype == TTT_DTYPE_BF16) || !mlp) return false;
-    if (d->CS == 16) return !backward;          // evaluation geometry: forward scan only (ttt_mfma16.hip)
+    if (!(d->F == 64 && d->act_dtype == TTT_DTYPE_BF16)) return false;
+    if (d->CS == 16) return !backward;          // mini-batches of 16: forward scans only (ttt_mfma16.hip), MLP and Linear
+    if (!mlp) return false;
     return d->CS == 64 && (!backward || bwd_available());
 }
 
@@ -538,7 +539,16 @@ void mlp_forward(const ttt_dims* d, const ttt_mlp_fwd_args* a, void*, hipStream_
     else if (get_debug_variant() == 1) launch_scan_forward(p, d->B * d->NH, s);
     else launch_scan_forward_v2(p, d->B * d->NH, g_dbg, s);
 }
-void linear_forward(const ttt_dims*, const ttt_linear_fwd_args*, void*, hipStream_t) {}
+void linear_forward(const ttt_dims* d, const ttt_linear_fwd_args* a, void*, hipStream_t s) {
+    ScanParams p = {};
+    p.XQ = (const __bf16*)a->XQ; p.XK = (const __bf16*)a->XK; p.XV = (const __bf16*)a->XV; p.eta = (const __bf16*)a->last_eta;
+    p.ln_w = a->ttt_norm_weight; p.ln_b = a->ttt_norm_bias;
+    p.W1 = a->W1_init; p.b1 = a->b1_init;
+    p.W1c = a->W1_checkpoints; p.b1c = a->b1_checkpoints;
+    p.out = (__bf16*)a->XQW;
+    p.NH = d->NH; p.NC = d->NC; p.G = d->G; p.K = (d->NC + d->G - 1) / d->G; p.eps = d->eps;
+    launch_linear_forward_cs16(p, d->B * d->NH, s);
+}
 void linear_backward(const ttt_dims*, const ttt_linear_bwd_args*, void*, hipStream_t) {}
 
 }  // namespace mfma

@@ -35,6 +35,7 @@ int groups_per_chunk(const ttt_dims* d);
 void launch_scan_forward_v2(const ScanParams& p, int n_bh, unsigned long long* dbg, hipStream_t s);
 // mini-batches of 16 tokens, forward only (ttt_mfma16.hip): the evaluation / sampling geometry
 void launch_scan_forward_cs16(const ScanParams& p, int n_bh, unsigned long long* dbg, hipStream_t s);
+void launch_linear_forward_cs16(const ScanParams& p, int n_bh, hipStream_t s);   // TTT-Linear, one wave per (b,h)
 void set_debug_dump(float* buf);
 int get_debug_variant();
 unsigned long long* get_debug_timing();
