@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--layers", type=int, default=None)
     ap.add_argument("--sequential", action="store_true", help="evaluate the guidance pair one sample at a time")
     ap.add_argument("--impl", default="auto", choices=["auto", "generic", "mfma"])
+    ap.add_argument("--no-warmup", action="store_true", help="skip the untimed step (long videos: the timed steps then include one-time costs)")
     a = ap.parse_args()
 
     import test_time_training as ext
@@ -80,7 +81,8 @@ def main():
         torch.cuda.synchronize()
         return out
 
-    run(1)                                                   # warm-up: GEMM selection, allocator
+    if not a.no_warmup:
+        run(1)                                               # warm-up: GEMM selection, allocator
     t0 = time.perf_counter()
     out = run(a.steps)
     dt = (time.perf_counter() - t0) / a.steps
@@ -89,7 +91,7 @@ def main():
                       "latent_frames_per_s": round(frames / dt, 2), "projected_50_step_video_s": round(50 * dt, 1),
                       "config": {"workload": f"CogVideoX-5B+TTT-MLP sampling, {a.video_length}, CS=16, CFG pair "
                                              + ("sequential" if a.sequential else "batched"),
-                                 "layers": cfg.num_layers, "tokens": L, "mini_batches": NC, "scan_impl": impl},
+                                 "layers": cfg.num_layers, "timed_steps": a.steps, "warmup": not a.no_warmup, "tokens": L, "mini_batches": NC, "scan_impl": impl},
                       "dtype": "bf16", "data": "synthetic", "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}))
 
 
