@@ -1,0 +1,112 @@
+// Host-side emulation of ONE gfx950 wavefront for the wave-level kernel bodies of csrc/ttt_lin16_body.h (TEST
+// INFRASTRUCTURE: lets the CPU test-suite execute the very same kernel body, lane by lane, and compare it with the oracle
+// when no GPU is at hand).  64 host threads play the 64 lanes; every cross-lane primitive (MFMA, transposed LDS read, DPP
+// row reduction) is a rendezvous: deposit operands, barrier, compute this lane's share of the result from everybody's
+// operands, barrier.  Lane / register layouts are those of the hardware instructions:
+//   v_mfma_f32_16x16x32_bf16 : A lane (g,i) = A[i][8g+e], B lane (g,i) = B[8g+e][i], D lane (g,i) = D[4g+r][i]
+//   v_mfma_f32_16x16x16_bf16 : A lane (g,i) = A[i][4g+e], B lane (g,i) = B[4g+e][i], D as above
+//   ds_read_b64_tr_b16       : within a 16-lane group, lane i receives element (i & 3) of the 8-byte chunks addressed by
+//                              lanes 4e + (i >> 2), e = 0..3   (probe: tools/probe_tr.hip)
+#pragma once
+#include <barrier>
+#include <cmath>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "ttt_wave_types.h"
+
+namespace ttt {
+namespace emul {
+using namespace ttt::wv;
+
+struct WaveShared {
+    std::barrier<> bar{64};
+    alignas(16) char lds[65536];
+    bf16x8 a8[64], b8[64];
+    bf16x4 a4[64], b4[64];
+    float f[64];
+};
+
+struct EmulWave {
+    WaveShared* sh;
+    int l;
+
+    int lane() const { return l; }
+    int opaque(int v) const { return v; }
+    void sync() { sh->bar.arrive_and_wait(); }
+    void lds_fence() { sync(); }                       // same-wave LDS write -> read ordering point (free on the device)
+    template <class T> T& lds(int byte_off) { return *reinterpret_cast<T*>(sh->lds + byte_off); }
+    char* lds_ptr(int byte_off) { return sh->lds + byte_off; }
+    float rsq(float x) const { return 1.0f / std::sqrt(x); }
+
+    f32x4 mma32(bf16x8 a, bf16x8 b, f32x4 c) {
+        sh->a8[l] = a; sh->b8[l] = b;
+        sync();
+        const int g = l >> 4, i = l & 15;
+        for (int r = 0; r < 4; ++r) {
+            float acc = 0.f;
+            for (int gk = 0; gk < 4; ++gk)
+                for (int e = 0; e < 8; ++e) acc += (float)sh->a8[16 * gk + 4 * g + r][e] * (float)sh->b8[16 * gk + i][e];
+            c[r] += acc;
+        }
+        sync();
+        return c;
+    }
+    f32x4 mma16(bf16x4 a, bf16x4 b, f32x4 c) {
+        sh->a4[l] = a; sh->b4[l] = b;
+        sync();
+        const int g = l >> 4, i = l & 15;
+        for (int r = 0; r < 4; ++r) {
+            float acc = 0.f;
+            for (int gk = 0; gk < 4; ++gk)
+                for (int e = 0; e < 4; ++e) acc += (float)sh->a4[16 * gk + 4 * g + r][e] * (float)sh->b4[16 * gk + i][e];
+            c[r] += acc;
+        }
+        sync();
+        return c;
+    }
+    // ds_read_b64_tr_b16 with this lane's byte address into LDS
+    bf16x4 tr_read(int byte_addr) {
+        sync();                                          // earlier LDS writes of every lane have landed
+        sh->a4[l] = *reinterpret_cast<const bf16x4*>(sh->lds + byte_addr);
+        sync();
+        const int base = l & ~15, i = l & 15;
+        bf16x4 r;
+        for (int e = 0; e < 4; ++e) r[e] = sh->a4[base + 4 * e + (i >> 2)][i & 3];
+        sync();
+        return r;
+    }
+    float sum16(float v) {                               // sum over the 16 lanes of this lane's DPP row
+        sh->f[l] = v;
+        sync();
+        float s = 0.f;
+        for (int j = 0; j < 16; ++j) s += sh->f[(l & ~15) + j];
+        sync();
+        return s;
+    }
+    float xor_add(float v, int mask) {                   // v + v of lane (l ^ mask)
+        sh->f[l] = v;
+        sync();
+        const float s = v + sh->f[l ^ mask];
+        sync();
+        return s;
+    }
+};
+
+// run `body(EmulWave&)` on 64 lanes
+template <class F>
+void run_wave(F body) {
+    WaveShared* sh = new WaveShared();
+    std::vector<std::thread> th;
+    for (int l = 0; l < 64; ++l)
+        th.emplace_back([sh, l, &body] {
+            EmulWave w{sh, l};
+            body(w);
+        });
+    for (auto& t : th) t.join();
+    delete sh;
+}
+
+}  // namespace emul
+}  // namespace ttt

@@ -1,0 +1,129 @@
+"""The wave-level kernel bodies of csrc/ttt_lin16_body.h (TTT-Linear, mini-batches of 16) executed on the CPU by the
+lane-level wave emulator of tests/emul (64 host threads = 64 lanes; MFMA / transposed-LDS-read / DPP semantics of gfx950),
+against the fp64 oracle.  The same template bodies are instantiated with the device backend in csrc/ttt_mfma16.hip, so this
+checks the kernels' index algebra and arithmetic without a GPU (tolerances as for the GPU parity tests: SURVEY.md 8c)."""
+import ctypes
+import os
+import shutil
+import subprocess
+
+import pytest
+import torch
+
+from helpers import rel_l2, tile_states
+from oracle import ttt_oracle as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CLANG = "/opt/rocm/lib/llvm/bin/amdclang++"
+
+
+class Params(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in
+                ("XQ", "XK", "XV", "eta", "ln_w", "ln_b", "W1", "b1", "W1c", "b1c", "out", "dOut", "dW1_last", "db1_last",
+                 "scratch_w", "scratch_b", "dln_w", "dln_b", "dW1", "db1", "deta", "dXQ", "dXK", "dXV")] + \
+               [(n, ctypes.c_int) for n in ("NH", "NC", "G", "K")] + [("eps", ctypes.c_float)]
+
+
+@pytest.fixture(scope="module")
+def emul():
+    if not os.path.exists(CLANG):
+        pytest.skip("host clang of the ROCm toolchain not available")
+    build = os.path.join(HERE, "emul", "_build")
+    os.makedirs(build, exist_ok=True)
+    so = os.path.join(build, "liblin16_emul.so")
+    srcs = [os.path.join(HERE, "emul", f) for f in ("lin16_emul.cpp", "wave_emul.h")] + \
+           [os.path.join(ROOT, "ttt-video-dit_amd", "csrc", f) for f in ("ttt_lin16_body.h", "ttt_wave_types.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call([CLANG, "-std=c++20", "-O1", "-pthread", "-shared", "-fPIC", "-Wno-unknown-pragmas",
+                               "-I", os.path.join(ROOT, "ttt-video-dit_amd", "csrc"), "-I", os.path.join(HERE, "emul"),
+                               srcs[0], "-o", so])
+    lib = ctypes.CDLL(so)
+    assert lib.emul_lin16_params_size() == ctypes.sizeof(Params)
+    return lib
+
+
+def _inputs(B, NH, NC, seed):
+    d = O.make_inputs("linear", B, NH, NC, 16, 64, seed=seed)
+    for k in ("XQ", "XK", "XV", "eta", "dOut"):
+        d[k] = d[k].to(torch.bfloat16).to(torch.float32)            # the kernels see bf16 activations
+    return d
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _forward(lib, d, G):
+    B, NH, NC = d["XQ"].shape[:3]
+    K = -(-NC // G)
+    bf = lambda t: t.to(torch.bfloat16).contiguous()
+    XQ, XK, XV = bf(d["XQ"]), bf(d["XK"]), bf(d["XV"])
+    eta = bf(d["eta"][:, :, :, -1, :, None])
+    st = tile_states(d, B)
+    W1, b1 = st["W1"].float().contiguous(), st["b1"].float().contiguous()
+    lw, lb = d["ln_w"].float().contiguous(), d["ln_b"].float().contiguous()
+    W1c, b1c = torch.full((B, NH, K, 64, 64), float("nan")), torch.full((B, NH, K, 1, 64), float("nan"))
+    out = torch.full((B, NH, NC, 16, 64), float("nan"), dtype=torch.bfloat16)
+    p = Params()
+    for n, t in dict(XQ=XQ, XK=XK, XV=XV, eta=eta, ln_w=lw, ln_b=lb, W1=W1, b1=b1, W1c=W1c, b1c=b1c, out=out).items():
+        setattr(p, n, t.data_ptr())
+    p.NH, p.NC, p.G, p.K, p.eps = NH, NC, G, K, 1e-8
+    lib.emul_lin16_forward(ctypes.byref(p), B * NH)
+    keep = (XQ, XK, XV, eta, lw, lb, W1, b1)
+    return out, (W1c, b1c), keep
+
+
+def _oracle(d, G):
+    d64 = {k: v.double() for k, v in d.items()}
+    st = tile_states(d64, d64["XQ"].shape[0])
+    le = d64["eta"][:, :, :, -1, :, None]
+    out, cks, _ = O.linear_forward(d64["XQ"], d64["XK"], d64["XV"], le, d64["ln_w"], d64["ln_b"], st["W1"], st["b1"], G)
+    g = O.linear_backward(d64["XQ"], d64["XK"], d64["XV"], le, d64["ln_w"], d64["ln_b"], cks, G, d64["dOut"])
+    return out, cks, g
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1, 1), (1, 2, 5, 2), (2, 1, 6, 4)])
+def test_emulated_linear_forward_vs_oracle(emul, shape):
+    B, NH, NC, G = shape
+    d = _inputs(B, NH, NC, seed=17 + NC)
+    out, cks, _ = _forward(emul, d, G)
+    ro, rc, _ = _oracle(d, G)
+    assert rel_l2(out, ro) < 1e-2
+    assert rel_l2(cks[0], rc[0]) < 1e-2 and rel_l2(cks[1], rc[1]) < 1e-2
+
+
+def _backward(lib, d, G, fwd):
+    out, (W1c, b1c), (XQ, XK, XV, eta, lw, lb, W1, b1) = fwd
+    B, NH, NC = XQ.shape[:3]
+    K = -(-NC // G)
+    dOut = d["dOut"].to(torch.bfloat16).contiguous()
+    z = lambda *s: torch.zeros(*s)
+    nan = lambda *s, dt=torch.float32: torch.full(s, float("nan"), dtype=dt)
+    g = dict(dln_w=nan(B, NH, 1, 64), dln_b=nan(B, NH, 1, 64), dW1=nan(B, NH, 64, 64), db1=nan(B, NH, 1, 64),
+             dlast_eta=nan(B, NH, NC, 16, 1, dt=torch.bfloat16), dXQ=nan(B, NH, NC, 16, 64, dt=torch.bfloat16),
+             dXK=nan(B, NH, NC, 16, 64, dt=torch.bfloat16), dXV=nan(B, NH, NC, 16, 64, dt=torch.bfloat16))
+    dWl, dbl = z(B, NH, 64, 64), z(B, NH, 1, 64)
+    scr_w, scr_b = torch.zeros(B * NH * G * 16 * 1024, dtype=torch.uint8), nan(B, NH, G, 1, 64)
+    p = Params()
+    for n, t in dict(XQ=XQ, XK=XK, XV=XV, eta=eta, ln_w=lw, ln_b=lb, W1c=W1c, b1c=b1c, dOut=dOut, dW1_last=dWl, db1_last=dbl,
+                     scratch_w=scr_w, scratch_b=scr_b, dln_w=g["dln_w"], dln_b=g["dln_b"], dW1=g["dW1"], db1=g["db1"],
+                     deta=g["dlast_eta"], dXQ=g["dXQ"], dXK=g["dXK"], dXV=g["dXV"]).items():
+        setattr(p, n, t.data_ptr())
+    p.NH, p.NC, p.G, p.K, p.eps = NH, NC, G, K, 1e-8
+    lib.emul_lin16_backward(ctypes.byref(p), B * NH)
+    return g
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1, 1), (1, 2, 5, 2), (2, 1, 6, 4), (1, 1, 7, 3)])
+def test_emulated_linear_backward_vs_oracle(emul, shape):
+    """Reverse sweep of the TTT-Linear scan (mini-batch 16) on the wave emulator vs fp64 autograd-equivalent oracle:
+    single step, even / odd group sizes, ragged last group."""
+    B, NH, NC, G = shape
+    d = _inputs(B, NH, NC, seed=29 + NC)
+    fwd = _forward(emul, d, G)
+    g = _backward(emul, d, G, fwd)
+    _, _, rg = _oracle(d, G)
+    errs = {k: rel_l2(g[k], rg[k].reshape(g[k].shape) if k in ("dln_w", "dln_b") else rg[k]) for k in g}
+    print("emulated linear backward errors", shape, {k: round(v, 5) for k, v in errs.items()})
+    assert all(v < 3e-2 for v in errs.values()), errs

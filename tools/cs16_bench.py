@@ -63,6 +63,32 @@ for impl in (("mfma",) if a.no_generic else ("mfma", "generic")):
 if not a.no_generic:
   d = (outs["mfma"] - outs["generic"]).flatten(2).norm(dim=2) / outs["generic"].flatten(2).norm(dim=2)
   print("per-head rel-L2 mfma vs generic: median %.3e max %.3e" % (d.median().item(), d.max().item()))
+if a.linear:
+    # backward (training geometry of TTT-Linear: G = 4, configs/train/ttt-linear/3s.toml)
+    Gb = 4
+    Kb = -(-NC // Gb)
+    ckb = (torch.empty(B, NH, Kb, F, F, device=dev), torch.empty(B, NH, Kb, 1, F, device=dev))
+    dOut = n(B, NH, NC, CS, F).bfloat16()
+    z = lambda *s: torch.zeros(*s, device=dev)
+    scr = (torch.empty(B, NH, Gb, F, F, device=dev), torch.empty(B, NH, Gb, 1, F, device=dev))
+    grads = (torch.empty(B, NH, 1, F, device=dev), torch.empty(B, NH, 1, F, device=dev), torch.empty(B, NH, F, F, device=dev),
+             torch.empty(B, NH, 1, F, device=dev), torch.empty(B, NH, NC, CS, 1, device=dev, dtype=torch.bfloat16),
+             torch.empty_like(XQ), torch.empty_like(XQ), torch.empty_like(XQ))
+    for impl in (("mfma",) if a.no_generic else ("mfma", "generic")):
+        e.set_impl(impl)
+        out = torch.empty_like(XQ)
+        e.ttt_linear_forward(XQ, XK, XV, lel, lwl, lbl, W1l, b1l, *ckb, out, Gb)
+        run = lambda: e.ttt_linear_backward(XQ, XK, XV, lel, lwl, lbl, *ckb, z(B, NH, F, F), z(B, NH, 1, F), dOut, *scr, *grads, Gb)
+        run()
+        torch.cuda.synchronize()
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0.record()
+        for _ in range(a.iters):
+            run()
+        t1.record()
+        torch.cuda.synchronize()
+        ms = t0.elapsed_time(t1) / a.iters
+        print(f"linear {impl:8s} bwd {ms:8.3f} ms  {ms * 1e3 / NC:6.2f} us/step (G = {Gb}, incl. the group recompute)")
 if a.phases and not a.linear:
     e.set_impl("mfma")
     buf = torch.zeros(16, dtype=torch.int64, device=dev)

@@ -522,7 +522,7 @@ void launch_group_recompute(const ScanParams& p0, int n_bh, hipStream_t s) {
 
 bool supports(const ttt_dims* d, bool mlp, bool backward) {
     if (!(d->F == 64 && d->act_dtype == TTT_DTYPE_BF16)) return false;
-    if (d->CS == 16) return !backward;          // mini-batches of 16: forward scans only (ttt_mfma16.hip), MLP and Linear
+    if (d->CS == 16) return !backward || !mlp;  // mini-batches of 16 (ttt_mfma16.hip): MLP forward, Linear forward + backward
     if (!mlp) return false;
     return d->CS == 64 && (!backward || bwd_available());
 }
@@ -540,7 +540,7 @@ void mlp_forward(const ttt_dims* d, const ttt_mlp_fwd_args* a, void*, hipStream_
     else launch_scan_forward_v2(p, d->B * d->NH, g_dbg, s);
 }
 void linear_forward(const ttt_dims* d, const ttt_linear_fwd_args* a, void*, hipStream_t s) {
-    ScanParams p = {};
+    wv::Lin16Params p = {};
     p.XQ = (const __bf16*)a->XQ; p.XK = (const __bf16*)a->XK; p.XV = (const __bf16*)a->XV; p.eta = (const __bf16*)a->last_eta;
     p.ln_w = a->ttt_norm_weight; p.ln_b = a->ttt_norm_bias;
     p.W1 = a->W1_init; p.b1 = a->b1_init;
@@ -549,7 +549,20 @@ void linear_forward(const ttt_dims* d, const ttt_linear_fwd_args* a, void*, hipS
     p.NH = d->NH; p.NC = d->NC; p.G = d->G; p.K = (d->NC + d->G - 1) / d->G; p.eps = d->eps;
     launch_linear_forward_cs16(p, d->B * d->NH, s);
 }
-void linear_backward(const ttt_dims*, const ttt_linear_bwd_args*, void*, hipStream_t) {}
+void linear_backward(const ttt_dims* d, const ttt_linear_bwd_args* a, void*, hipStream_t s) {
+    wv::Lin16Params p = {};
+    p.XQ = (const __bf16*)a->XQ; p.XK = (const __bf16*)a->XK; p.XV = (const __bf16*)a->XV; p.eta = (const __bf16*)a->last_eta;
+    p.ln_w = a->ttt_norm_weight; p.ln_b = a->ttt_norm_bias;
+    p.W1c = const_cast<float*>(a->W1_checkpoints); p.b1c = const_cast<float*>(a->b1_checkpoints);      // read only here
+    p.dOut = (const __bf16*)a->grad_L_XQW;
+    p.dW1_last = a->grad_L_W1_last; p.db1_last = a->grad_L_b1_last;
+    p.scratch_w = (char*)a->W1_init_group; p.scratch_b = a->b1_init_group;      // G x 16 KiB and G x 64 floats per (b,h)
+    p.dln_w = a->grad_L_ttt_norm_weight; p.dln_b = a->grad_L_ttt_norm_bias;
+    p.dW1 = a->grad_L_W1_init; p.db1 = a->grad_L_b1_init;
+    p.deta = (__bf16*)a->grad_L_last_eta; p.dXQ = (__bf16*)a->grad_L_XQ; p.dXK = (__bf16*)a->grad_L_XK; p.dXV = (__bf16*)a->grad_L_XV;
+    p.NH = d->NH; p.NC = d->NC; p.G = d->G; p.K = (d->NC + d->G - 1) / d->G; p.eps = d->eps;
+    launch_linear_backward_cs16(p, d->B * d->NH, s);
+}
 
 }  // namespace mfma
 }  // namespace ttt

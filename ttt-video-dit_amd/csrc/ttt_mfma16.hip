@@ -35,6 +35,8 @@
 #include "ttt_mfma.h"
 #include "ttt_mfma_dev.h"
 #include "ttt_mfma_int.h"
+#define TTT_WV_FN __device__ __forceinline__
+#include "ttt_lin16_body.h"
 
 namespace ttt {
 namespace mfma {
@@ -419,212 +421,48 @@ __global__ __launch_bounds__(NT16) void mlp_scan16_kernel(ScanParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// TTT-Linear forward scan, mini-batches of 16 tokens (the reference trains and evaluates TTT-Linear at mini_batch_size 16:
-// configs/train/ttt-linear/*.toml; replaces the Triton launch linear_triton.py:98-129, math ops/ttt_linear.py:8-54).
-//
-// The whole state of a head (W1 [64 x 64] fp32 = 16 accumulator tiles, b1) fits one wave, so a (b, h) scan is ONE wave and
-// a step has no barrier at all: Z1 = K W1 + b1 (rows = t, lane = f; mma32 with W1 in place as B operand), the fused
-// LayerNorm / L2 backward entirely in that layout (a token's 64 features sit in 16 lanes x 4 tiles: in-lane adds + one
-// 16-lane DPP reduction), W1 += K^T Gs (mma16, Gs in place), Z1b = Q W1' + b1', LayerNorm, + Q.  Values that are needed in
-// the accumulator layout but arrive as bf16 tiles (the target V - K, the residual Q) are brought there EXACTLY by MFMAs
-// against +-identity fragments (bf16 x 1.0 accumulated in fp32), reading the transposed fragments the update needs anyway.
-// The output goes through a [f][t] LDS image (8-byte stores) and transposed reads, so every lane stores 4 consecutive
-// features of one token.  Inputs are prefetched one step ahead into registers and parked in the wave's double-buffered LDS
-// tiles; 4 waves (4 heads) share a workgroup only to fill the CU's four SIMDs.
-constexpr int LIN_WAVES = 4;
-constexpr int LIN_TILES = 6 * TILE16 * 2;             // K, V, Q x 2 buffers, bytes
-constexpr int LIN_OIMG = 64 * IS * 2;                 // out^T image [64 f][IS]
-constexpr int LIN_WAVE_BYTES = LIN_TILES + LIN_OIMG + 2 * 16 * 4;
-constexpr int LDS_LIN = LIN_WAVES * LIN_WAVE_BYTES;
-static_assert(LIN_WAVE_BYTES % 16 == 0, "alignment");
+// TTT-Linear at mini-batches of 16 tokens (the reference trains and evaluates TTT-Linear at mini_batch_size 16:
+// configs/train/ttt-linear/*.toml; replaces the Triton launches linear_triton.py:98-129, :203-246).  The kernel bodies live
+// in ttt_lin16_body.h, written against a wave backend so that the CPU test-suite can execute the same code on a lane-level
+// emulator (tests/emul); here is the device backend: the gfx950 instructions behind those primitives.  One wave per (b, h),
+// 4 waves (4 heads) per workgroup only to fill the CU's four SIMDs; no workgroup barriers.
+struct DeviceWave {
+    char* base;                                                       // this wave's private LDS region
+    __device__ __forceinline__ int lane() const { return threadIdx.x & 63; }
+    __device__ __forceinline__ int opaque(int v) const { asm volatile("" : "+v"(v)); return v; }
+    __device__ __forceinline__ void lds_fence() const { asm volatile("" ::: "memory"); }    // LDS is in order within a wave
+    template <class T> __device__ __forceinline__ T& lds(int byte_off) const { return *reinterpret_cast<T*>(base + byte_off); }
+    __device__ __forceinline__ char* lds_ptr(int byte_off) const { return base + byte_off; }
+    __device__ __forceinline__ float rsq(float x) const { return __builtin_amdgcn_rsqf(x); }
+    __device__ __forceinline__ f32x4 mma32(bf16x8 a, bf16x8 b, f32x4 c) const { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+    __device__ __forceinline__ f32x4 mma16(bf16x4 a, bf16x4 b, f32x4 c) const {
+        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+    }
+    __device__ __forceinline__ bf16x4 tr_read(int byte_addr) const {
+        typedef __attribute__((address_space(3))) bf16x4 lds_b4;
+        return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(base + byte_addr));
+    }
+    __device__ __forceinline__ float sum16(float v) const { return v16::sum16(v); }
+    __device__ __forceinline__ float xor_add(float v, int mask) const { return v + __shfl_xor(v, mask, 64); }
+};
 
-// per-token-row reduction over the 64 features: in-lane over the 4 feature tiles, then over the 16 lanes of the DPP row
-__device__ __forceinline__ f32x4 rowsum64(const f32x4 (&v)[4]) {
-    f32x4 s = v[0] + v[1] + v[2] + v[3];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) s[r] = sum16(s[r]);
-    return s;
+constexpr int LIN_WAVES = 4;
+constexpr int LDS_LIN = LIN_WAVES * lin16::WAVE_LDS;
+
+__global__ __launch_bounds__(64 * LIN_WAVES) void linear_scan16_kernel(wv::Lin16Params p, int n_bh) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int bh = blockIdx.x * LIN_WAVES + w;
+    if (bh >= n_bh) return;                                          // whole wave; no barriers in this kernel
+    DeviceWave bk{smem + w * lin16::WAVE_LDS};
+    lin16::forward(bk, p, bh);
 }
 
-__global__ __launch_bounds__(64 * LIN_WAVES) void linear_scan16_kernel(ScanParams p, int n_bh) {
+// backward: one wave per workgroup (48 .. 96 scans on 256 CUs: a CU of its own per scan; up to 512 registers per lane)
+__global__ __launch_bounds__(64) void linear_bwd16_kernel(wv::Lin16Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int bh = blockIdx.x * LIN_WAVES + wv;
-    if (bh >= n_bh) return;                                          // whole wave; no barriers in this kernel
-    char* base = smem + wv * LIN_WAVE_BYTES;
-    __bf16* Kb = reinterpret_cast<__bf16*>(base);
-    __bf16* Vb = Kb + 2 * TILE16;
-    __bf16* Qb = Vb + 2 * TILE16;
-    __bf16* oimg = reinterpret_cast<__bf16*>(base + LIN_TILES);
-    float* etaL = reinterpret_cast<float*>(base + LIN_TILES + LIN_OIMG);        // [2][16]
-    const int l0 = threadIdx.x & 63;
-    const int NC = p.NC, G = p.G, head = bh % p.NH;
-
-    f32x4 W1t[4][4];     // [fa][fb]  W1[16fa + 4g + r][16fb + i]     (rows = f_in, lane = f_out)
-    float b1v[4], gam[4], bet[4];
-    {
-        const int g = l0 >> 4, i = l0 & 15;
-        const float* W1g = p.W1 + (size_t)bh * 64 * 64;
-#pragma unroll
-        for (int fa = 0; fa < 4; ++fa)
-#pragma unroll
-            for (int fb = 0; fb < 4; ++fb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) W1t[fa][fb][r] = W1g[(size_t)(16 * fa + 4 * g + r) * 64 + 16 * fb + i];
-#pragma unroll
-        for (int fb = 0; fb < 4; ++fb) {
-            b1v[fb] = p.b1[(size_t)bh * 64 + 16 * fb + i];
-            gam[fb] = p.ln_w[(size_t)head * 64 + 16 * fb + i];
-            bet[fb] = p.ln_b[(size_t)head * 64 + 16 * fb + i];
-        }
-    }
-    bf16x4 ONES = {(__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f};
-    // +-identity fragments for mma16 (A operand: lane = t = i, k-slot e = token 4g + e)
-    bf16x4 IDP, IDN;
-    {
-        const int g = l0 >> 4, i = l0 & 15;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            IDP[e] = (__bf16)((4 * g + e) == i ? 1.0f : 0.0f);
-            IDN[e] = (__bf16)((4 * g + e) == i ? -1.0f : 0.0f);
-        }
-    }
-    bf16x8 W1F[2][4];    // [ks][fb] packed entering state, carried across steps
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int fb = 0; fb < 4; ++fb) W1F[ks][fb] = stack(W1t[2 * ks][fb], W1t[2 * ks + 1][fb]);
-
-    // staging: a tile is 2 KiB = 2 x 16 bytes per lane (rows 0..7 and 8..15)
-    const size_t tile0 = (size_t)bh * NC;
-    const int srow = l0 >> 3, scol = (l0 & 7) * 8;
-    const size_t gofs = (size_t)srow * 64 + scol;
-    const int lofs = srow * TS + scol;
-    uint4 pk0, pk1, pv0, pv1, pq0, pq1;
-    unsigned short pe;
-#define LIN_REQUEST(t)                                                                                                     \
-    {                                                                                                                       \
-        const size_t _o = (size_t)(t) * 1024 + gofs;                                                                        \
-        pk0 = *reinterpret_cast<const uint4*>(p.XK + _o); pk1 = *reinterpret_cast<const uint4*>(p.XK + _o + 512);          \
-        pv0 = *reinterpret_cast<const uint4*>(p.XV + _o); pv1 = *reinterpret_cast<const uint4*>(p.XV + _o + 512);          \
-        pq0 = *reinterpret_cast<const uint4*>(p.XQ + _o); pq1 = *reinterpret_cast<const uint4*>(p.XQ + _o + 512);          \
-        pe = *reinterpret_cast<const unsigned short*>(p.eta + (size_t)(t) * 16 + (l0 & 15));                               \
-    }
-#define LIN_PARK(b)                                                                                                         \
-    {                                                                                                                       \
-        *reinterpret_cast<uint4*>(Kb + (b) * TILE16 + lofs) = pk0; *reinterpret_cast<uint4*>(Kb + (b) * TILE16 + lofs + 8 * TS) = pk1; \
-        *reinterpret_cast<uint4*>(Vb + (b) * TILE16 + lofs) = pv0; *reinterpret_cast<uint4*>(Vb + (b) * TILE16 + lofs + 8 * TS) = pv1; \
-        *reinterpret_cast<uint4*>(Qb + (b) * TILE16 + lofs) = pq0; *reinterpret_cast<uint4*>(Qb + (b) * TILE16 + lofs + 8 * TS) = pq1; \
-        if (l0 < 16) etaL[(b) * 16 + l0] = (float)__builtin_bit_cast(__bf16, pe);                                           \
-    }
-    LIN_REQUEST(tile0)
-    LIN_PARK(0)
-
-    for (int it = 0; it < NC; ++it) {
-        const size_t tile = tile0 + it;
-        const int buf = it & 1;
-        int l_op = l0;
-        asm volatile("" : "+v"(l_op));
-        const int l = l_op, g = l >> 4, i = l & 15;
-        const __bf16* Kt = Kb + buf * TILE16;
-        const __bf16* Vt = Vb + buf * TILE16;
-        const __bf16* Qt = Qb + buf * TILE16;
-        LIN_REQUEST(tile0 + (it + 1 < NC ? it + 1 : it))          // next step's inputs, parked at the end of this step
-
-        if (it % G == 0) {      // checkpoint: state entering step `it` (linear_triton.py:84-97)
-            const size_t ck = (size_t)bh * p.K + it / G;
-            float* W1g = p.W1c + ck * 64 * 64;
-#pragma unroll
-            for (int fa = 0; fa < 4; ++fa)
-#pragma unroll
-                for (int fb = 0; fb < 4; ++fb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) W1g[(size_t)(16 * fa + 4 * g + r) * 64 + 16 * fb + i] = W1t[fa][fb][r];
-            if (g == 0) {
-#pragma unroll
-                for (int fb = 0; fb < 4; ++fb) p.b1c[ck * 64 + 16 * fb + i] = b1v[fb];
-            }
-        }
-        // ---- Z1 = K W1 + b1 ; target = V - K, both (rows = t, lane = f) -----------------------------------------------
-        const bf16x8 kA0 = rho_read(Kt + i * TS, 0, g), kA1 = rho_read(Kt + i * TS, 32, g);
-        const f32x4 eta4 = *reinterpret_cast<const f32x4*>(etaL + buf * 16 + 4 * g);          // eta of token rows 4g .. 4g+3
-        bf16x4 kT[4];
-        f32x4 z[4], tg[4];
-#pragma unroll
-        for (int fb = 0; fb < 4; ++fb) {
-            kT[fb] = tr4(Kt, TS, 0, 16 * fb, l);                                             // lane = f, k = t
-            f32x4 a = zero4();
-            a = mma32(kA0, W1F[0][fb], a);
-            a = mma32(kA1, W1F[1][fb], a);
-            z[fb] = a + b1v[fb];
-            tg[fb] = mma16(IDN, kT[fb], mma16(IDP, tr4(Vt, TS, 0, 16 * fb, l), zero4()));     // exact V - K
-        }
-        // ---- fused LayerNorm + L2 backward per token row ; Gs = -eta gZ1 ------------------------------------------------
-        bf16x4 gzp[4];
-        {
-            const f32x4 mu = rowsum64(z) * (1.0f / 64.0f);
-            f32x4 d2[4];
-#pragma unroll
-            for (int fb = 0; fb < 4; ++fb) { z[fb] -= mu; d2[fb] = z[fb] * z[fb]; }
-            const f32x4 var = rowsum64(d2) * (1.0f / 64.0f);
-            f32x4 rstd;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) rstd[r] = __builtin_amdgcn_rsqf(var[r] + p.eps);
-            f32x4 gx[4], gxx[4];
-#pragma unroll
-            for (int fb = 0; fb < 4; ++fb) {
-                z[fb] *= rstd;                                                               // x_hat
-                gx[fb] = (gam[fb] * z[fb] + bet[fb] - tg[fb]) * gam[fb];
-                gxx[fb] = gx[fb] * z[fb];
-            }
-            const f32x4 s1 = rowsum64(gx), s2 = rowsum64(gxx);
-            const f32x4 sc = eta4 * rstd * (-1.0f / 64.0f);
-#pragma unroll
-            for (int fb = 0; fb < 4; ++fb) gzp[fb] = pack4((64.0f * gx[fb] - s1 - z[fb] * s2) * sc);   // lane = f, k = t
-        }
-        // ---- W1 += K^T Gs ; b1 += colsum Gs ; repack -----------------------------------------------------------------------
-#pragma unroll
-        for (int fb = 0; fb < 4; ++fb) {
-            b1v[fb] += mma16(ONES, gzp[fb], zero4())[0];
-#pragma unroll
-            for (int fa = 0; fa < 4; ++fa) W1t[fa][fb] = mma16(kT[fa], gzp[fb], W1t[fa][fb]);
-        }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int fb = 0; fb < 4; ++fb) W1F[ks][fb] = stack(W1t[2 * ks][fb], W1t[2 * ks + 1][fb]);
-        // ---- Z1b = Q W1' + b1' ; LayerNorm ; + Q -> out^T image ----------------------------------------------------------------
-        {
-            const bf16x8 qA0 = rho_read(Qt + i * TS, 0, g), qA1 = rho_read(Qt + i * TS, 32, g);
-            f32x4 y[4], qc[4];
-#pragma unroll
-            for (int fb = 0; fb < 4; ++fb) {
-                f32x4 a = zero4();
-                a = mma32(qA0, W1F[0][fb], a);
-                a = mma32(qA1, W1F[1][fb], a);
-                y[fb] = a + b1v[fb];
-                qc[fb] = mma16(IDP, tr4(Qt, TS, 0, 16 * fb, l), zero4());                     // exact Q in the accumulator layout
-            }
-            const f32x4 mu = rowsum64(y) * (1.0f / 64.0f);
-            f32x4 d2[4];
-#pragma unroll
-            for (int fb = 0; fb < 4; ++fb) { y[fb] -= mu; d2[fb] = y[fb] * y[fb]; }
-            const f32x4 var = rowsum64(d2) * (1.0f / 64.0f);
-            f32x4 rstd;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) rstd[r] = __builtin_amdgcn_rsqf(var[r] + p.eps);
-#pragma unroll
-            for (int fb = 0; fb < 4; ++fb)
-                *reinterpret_cast<bf16x4*>(oimg + (16 * fb + i) * IS + 4 * g) = pack4(qc[fb] + gam[fb] * (y[fb] * rstd) + bet[fb]);
-        }
-        // out^T image [f][t] -> lane (g, i) stores features 16fb + 4g .. +3 of token i
-#pragma unroll
-        for (int fb = 0; fb < 4; ++fb)
-            *reinterpret_cast<bf16x4*>(p.out + tile * 1024 + (size_t)i * 64 + 16 * fb + 4 * g) = tr4(oimg, IS, 16 * fb, 0, l);
-        LIN_PARK(buf ^ 1)
-    }
-#undef LIN_REQUEST
-#undef LIN_PARK
+    DeviceWave bk{smem};
+    lin16::backward(bk, p, blockIdx.x);
 }
 
 static void set_attr_once() {
@@ -638,14 +476,22 @@ static void set_attr_once() {
 
 }  // namespace v16
 
-void launch_linear_forward_cs16(const ScanParams& p, int n_bh, hipStream_t s) {
+static void lin_attr_once() {
     static bool done = false;
     if (!done) {
         (void)hipFuncSetAttribute((const void*)v16::linear_scan16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, v16::LDS_LIN);
+        (void)hipFuncSetAttribute((const void*)v16::linear_bwd16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lin16::WAVE_LDS_BWD);
         done = true;
     }
+}
+void launch_linear_forward_cs16(const wv::Lin16Params& p, int n_bh, hipStream_t s) {
+    lin_attr_once();
     const int blocks = (n_bh + v16::LIN_WAVES - 1) / v16::LIN_WAVES;
     hipLaunchKernelGGL(v16::linear_scan16_kernel, dim3(blocks), dim3(64 * v16::LIN_WAVES), v16::LDS_LIN, s, p, n_bh);
+}
+void launch_linear_backward_cs16(const wv::Lin16Params& p, int n_bh, hipStream_t s) {
+    lin_attr_once();
+    hipLaunchKernelGGL(v16::linear_bwd16_kernel, dim3(n_bh), dim3(64), lin16::WAVE_LDS_BWD, s, p);
 }
 
 void launch_scan_forward_cs16(const ScanParams& p0, int n_bh, unsigned long long* dbg, hipStream_t s) {

@@ -1,5 +1,6 @@
 // Internal interface between the MFMA translation units (scan/recompute kernel and reverse sweep).
 #pragma once
+#include "ttt_wave_types.h"
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include "../../include/ttt_hip.h"
@@ -35,7 +36,8 @@ int groups_per_chunk(const ttt_dims* d);
 void launch_scan_forward_v2(const ScanParams& p, int n_bh, unsigned long long* dbg, hipStream_t s);
 // mini-batches of 16 tokens, forward only (ttt_mfma16.hip): the evaluation / sampling geometry
 void launch_scan_forward_cs16(const ScanParams& p, int n_bh, unsigned long long* dbg, hipStream_t s);
-void launch_linear_forward_cs16(const ScanParams& p, int n_bh, hipStream_t s);   // TTT-Linear, one wave per (b,h)
+void launch_linear_forward_cs16(const wv::Lin16Params& p, int n_bh, hipStream_t s);   // TTT-Linear, one wave per (b,h)
+void launch_linear_backward_cs16(const wv::Lin16Params& p, int n_bh, hipStream_t s);
 void set_debug_dump(float* buf);
 int get_debug_variant();
 unsigned long long* get_debug_timing();
