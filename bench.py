@@ -196,6 +196,8 @@ def main():
     over = {}
     if args.layers is not None:
         over["num_layers"] = args.layers
+    if args.ssm_layer == "ttt_linear":      # the reference trains TTT-Linear with these (configs/train/ttt-linear/3s.toml:9,32)
+        over.update(mini_batch_size=16, scan_checkpoint_group_size=4)
     cfg = ModelConfig.get_preset("5B", args.video_length, ssm_layer=args.ssm_layer, adapter_method="sft", **over)
     frames, text_len = cfg.compressed_num_frames, TEXT_LEN[args.video_length]
     scenes = max((frames - 1) // 12, 1)
