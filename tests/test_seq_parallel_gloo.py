@@ -1,0 +1,95 @@
+"""Sequence-parallel inference (ttt_amd/infra/sequence_parallel.py) on CPU over gloo: T ranks, each holding 1/T of the tokens
+for the token-wise work and 1/T of the heads for attention / the TTT scan, must reproduce the single-process forward of the
+same DiT.  World sizes 2 and 3 (3 = token shards that need padding), single- and multi-scene, TTT-MLP and TTT-Linear, the
+dual-form PyTorch scan and the kernel plumbing (HIP extension replaced by the oracle-backed stand-in, as in
+test_fsdp_gloo.py)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CASES = {
+    # name: (world, num_heads, ssm_layer, frames, scenes, use_kernel)
+    "mlp_3scene_w2": (2, 2, "ttt_mlp", 7, 3, False),
+    "mlp_3scene_w3_padded": (3, 3, "ttt_mlp", 7, 3, False),
+    "linear_1scene_w2_kernel": (2, 2, "ttt_linear", 3, 1, True),
+    "linear_2scene_w2_kernel": (2, 4, "ttt_linear", 5, 2, True),     # (the TTT-MLP kernel boundary is bf16-only, as in the reference)
+}
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _build(case):
+    from ttt_amd.models.cogvideo.dit import DiffusionTransformer
+    from ttt_amd.models.configs import ModelConfig
+    world, nh, ssm, frames, scenes, use_kernel = CASES[case]
+    torch.manual_seed(7)
+    cfg = ModelConfig(model_dim=64 * nh, num_heads=nh, num_layers=2, mini_batch_size=16, latent_height=8, latent_width=8,
+                      compressed_num_frames=frames, ssm_layer=ssm, text_dim=32, time_embed_dim=64, attn_length=2,
+                      prefix_temporal_length=1, adapter_method="sft", scan_checkpoint_group_size=2)
+    m = DiffusionTransformer(cfg)
+    with torch.no_grad():
+        for _, p in m.named_parameters():
+            if p.ndim >= 2:
+                p.normal_(0, 0.05)
+            elif p.ndim == 1:
+                p.add_(0.05 * torch.randn_like(p))
+    for layer in m.layers:
+        layer.seq_modeling_block.ssm.ttt.use_kernel = use_kernel
+    g = torch.Generator().manual_seed(11)
+    inputs = (torch.randn(2, frames, 16, 8, 8, generator=g), torch.randn(2, scenes, 16, 32, generator=g), torch.tensor([300, 650]))
+    return m.eval(), inputs
+
+
+def _worker(rank, world, port, case, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "ttt-video-dit_amd")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    from oracle import cpu_ext
+    from ttt_amd.infra.sequence_parallel import SeqParallel
+    if CASES[case][5]:
+        cpu_ext.install()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m, inputs = _build(case)
+    m.sequence_parallel = SeqParallel()
+    with torch.no_grad():
+        out = m(*inputs)
+    torch.save(out, os.path.join(out_dir, f"sp_{rank}.pt"))
+    with pytest.raises(RuntimeError):          # inference mode only
+        m(*inputs)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_sequence_parallel_forward_equals_single_process(case, tmp_path):
+    world = CASES[case][0]
+    mp.spawn(_worker, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)
+    for p in (ROOT, os.path.join(ROOT, "ttt-video-dit_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from oracle import cpu_ext
+    if CASES[case][5]:
+        cpu_ext.install()
+    try:
+        m, inputs = _build(case)
+        with torch.no_grad():
+            ref = m(*inputs)
+    finally:
+        if CASES[case][5]:
+            cpu_ext.uninstall()
+    outs = [torch.load(os.path.join(str(tmp_path), f"sp_{r}.pt")) for r in range(world)]
+    for o in outs:
+        err = float((o - ref).norm() / ref.norm())
+        assert err < 1e-5, (case, err)
+    assert torch.equal(outs[0], outs[-1])      # every rank ends with the same full output

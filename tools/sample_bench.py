@@ -30,6 +30,9 @@ def main():
     ap.add_argument("--layers", type=int, default=None)
     ap.add_argument("--sequential", action="store_true", help="evaluate the guidance pair one sample at a time")
     ap.add_argument("--impl", default="auto", choices=["auto", "generic", "mfma"])
+    ap.add_argument("--sequence-parallel", action="store_true",
+                    help="launched with torch.distributed.run on N GPUs: one video sampled by N ranks (token shards for the "
+                         "token-wise work, head shards for attention / the TTT scan; ttt_amd/infra/sequence_parallel.py)")
     ap.add_argument("--no-warmup", action="store_true", help="skip the untimed step (long videos: the timed steps then include one-time costs)")
     a = ap.parse_args()
 
@@ -39,8 +42,16 @@ def main():
     from ttt_amd.models.cogvideo.sampling import DiscreteDenoiser, VPSDEDPMPP2MSampler
     from ttt_amd.models.configs import ModelConfig
 
-    dev = torch.device("cuda:0")
-    torch.cuda.set_device(dev)
+    rank = 0
+    if a.sequence_parallel:
+        import torch.distributed as dist
+        rank = int(os.environ.get("RANK", "0"))
+        dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl")                     # RCCL over xGMI
+    else:
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
     ext.load_library()
     ext.set_impl(a.impl)
     enable_tuned_gemms()
@@ -59,6 +70,9 @@ def main():
             layer.seq_modeling_block.rotary.init_freqs()
             layer.seq_modeling_block.ssm.init_freqs()
     net = net.to(torch.bfloat16).eval()
+    if a.sequence_parallel:
+        from ttt_amd.infra.sequence_parallel import SeqParallel
+        net.sequence_parallel = SeqParallel()               # same weights (same seed) and same inputs on every rank
     for layer in net.layers:                                # rotary tables stay fp32 (reference cast_rotary_freqs)
         layer.seq_modeling_block.rotary.init_freqs()
         layer.seq_modeling_block.ssm.init_freqs()
@@ -72,6 +86,7 @@ def main():
             denoiser=DiscreteDenoiser(net, num_idx=1000, quantize_c_noise=False, dtype=torch.bfloat16, batch_samples=not a.sequential),
             discretization_config={"shift_scale": 1.0}, guider_config={"scale": 6, "exp": 5, "num_steps": n_steps},
             device=dev, num_steps=n_steps)
+        torch.manual_seed(99)                                # the sampler's noise draws must agree across ranks
         g = torch.Generator(device=dev).manual_seed(7)
         noise = torch.randn(1, frames, 16, 60, 90, device=dev, generator=g)
         text = torch.randn(1, scenes, text_len, cfg.text_dim, device=dev, generator=g).bfloat16()
@@ -87,10 +102,13 @@ def main():
     out = run(a.steps)
     dt = (time.perf_counter() - t0) / a.steps
     assert torch.isfinite(out).all()
+    if rank != 0:
+        return
     print(json.dumps({"metric": "sampling_denoising_step_seconds", "value": round(dt, 4), "unit": "s/step (cond+uncond)",
                       "latent_frames_per_s": round(frames / dt, 2), "projected_50_step_video_s": round(50 * dt, 1),
                       "config": {"workload": f"CogVideoX-5B+TTT-MLP sampling, {a.video_length}, CS=16, CFG pair "
-                                             + ("sequential" if a.sequential else "batched"),
+                                             + ("sequential" if a.sequential else "batched")
+                                             + (f", sequence-parallel over {int(os.environ.get('WORLD_SIZE', '1'))} ranks" if a.sequence_parallel else ""),
                                  "layers": cfg.num_layers, "timed_steps": a.steps, "warmup": not a.no_warmup, "tokens": L, "mini_batches": NC, "scan_impl": impl},
                       "dtype": "bf16", "data": "synthetic", "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}))
 

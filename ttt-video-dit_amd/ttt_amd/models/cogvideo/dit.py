@@ -186,6 +186,64 @@ class SeqModelingBlock(nn.Module):
         y = rev(emb, seq_metadata, True)
         return self._gate(self.backward_ssm_gating_text, self.backward_ssm_gating_video, emb, y, n_text)
 
+    # -- sequence-parallel inference (ttt_amd/infra/sequence_parallel.py) ------------------------------------------------
+    def _segment_heads(self, emb, n_text, h0, h1):
+        """``_segment`` for heads [h0, h1) only and without the output projection: [b, s, D] -> [b, s, (h1-h0)*F]."""
+        b, s, _ = emb.shape
+        nh, Fh = h1 - h0, self.head_dim
+        sl = slice(h0 * Fh, h1 * Fh)
+        lin = lambda m: F.linear(emb, m.weight[sl], m.bias[sl])
+        heads = lambda t: t.view(b, s, nh, Fh).transpose(1, 2)
+        if attn_pre_available(emb, Fh):
+            cos, sin = self.rotary.tables_f32()
+            a = FusedSegmentAttention.apply(lin(self.q), lin(self.k), heads(lin(self.v)), self.q_norm.weight, self.q_norm.bias,
+                                            self.k_norm.weight, self.k_norm.bias, cos, sin, nh, n_text, self.q_norm.eps)
+        else:
+            q, k, v = heads(lin(self.q)), heads(lin(self.k)), heads(lin(self.v))
+            q, k = self.q_norm(q), self.k_norm(k)
+            q = torch.cat((q[:, :, :n_text], self.rotary(q[:, :, n_text:])), dim=2)
+            k = torch.cat((k[:, :, :n_text], self.rotary(k[:, :, n_text:])), dim=2)
+            a = segment_attention(q, k, v)
+        return a.transpose(1, 2).reshape(b, s, -1)
+
+    def _attn_heads(self, vid_emb, text_emb, seq_metadata: SequenceMetadata, h0, h1):
+        """``_attn_forward`` for heads [h0, h1) before the output projection (which is linear, so it commutes with the
+        averaging of the shared frames and is applied afterwards on the token shards)."""
+        tl, tpf = seq_metadata.text_length, seq_metadata.tokens_per_frame
+        if seq_metadata.num_chunks == 1:
+            return self._segment_heads(torch.cat((text_emb, vid_emb), dim=1), tl, h0, h1)
+        d = (h1 - h0) * self.head_dim
+        out_vid = vid_emb.new_zeros(*vid_emb.shape[:2], d)
+        out_txt = text_emb.new_zeros(*text_emb.shape[:2], d)
+        count = torch.zeros_like(vid_emb[..., :1])
+        for i in range(seq_metadata.num_chunks):
+            lo = i * self.attn_length * tpf
+            hi = (self.prefix_temporal_length + (i + 1) * self.attn_length) * tpf
+            o = self._segment_heads(torch.cat((text_emb[:, i * tl:(i + 1) * tl], vid_emb[:, lo:hi]), dim=1), tl, h0, h1)
+            out_txt[:, i * tl:(i + 1) * tl] = o[:, :tl]
+            out_vid[:, lo:hi] += o[:, tl:]
+            count[:, lo:hi] += 1
+        return torch.cat((out_txt, out_vid / count), dim=1)
+
+    @torch.no_grad()
+    def forward_sp(self, vid_loc, text_loc, seq_metadata: SequenceMetadata, sp):
+        """The block on token shards ``vid_loc [B, ceil(Lv/T), D]``, ``text_loc [B, ceil(Lt/T), D]``: sequence-mixing parts on
+        this rank's heads over the gathered sequence, token-wise parts (o, post_norm, wo, gates) on the shard."""
+        n_text = seq_metadata.seq_text_length
+        n_vid = seq_metadata.num_frames * seq_metadata.tokens_per_frame
+        h0, h1 = sp.head_range(self.num_heads)
+        a = self._attn_heads(sp.gather_tokens(vid_loc, n_vid), sp.gather_tokens(text_loc, n_text), seq_metadata, h0, h1)
+        text_loc, vid_loc = self.o(sp.heads_to_tokens(a[:, :n_text])), self.o(sp.heads_to_tokens(a[:, n_text:]))
+        ttt = self.ssm.ttt
+        for g_text, g_vid, reverse in ((self.forward_ssm_gating_text, self.forward_ssm_gating_video, False),
+                                       (self.backward_ssm_gating_text, self.backward_ssm_gating_video, True)):
+            full = torch.cat((sp.gather_tokens(text_loc, n_text), sp.gather_tokens(vid_loc, n_vid)), dim=1)
+            y = self.ssm.forward_heads(full, seq_metadata, reverse, h0, h1)                       # [B, L, (h1-h0)*F], token order
+            y_text = ttt.wo(ttt.post_norm(sp.heads_to_tokens(y[:, :n_text])))
+            y_vid = ttt.wo(ttt.post_norm(sp.heads_to_tokens(y[:, n_text:])))
+            text_loc, vid_loc = text_loc + g_text(y_text), vid_loc + g_vid(y_vid)
+        return vid_loc, text_loc
+
     def forward_cat(self, x, seq_metadata: SequenceMetadata):
         """Same block on the concatenated ``[text | video]`` sequence, returning it concatenated (the fused TransformerLayer
         path produces and consumes that layout directly, without the cat / slice pairs around the block)."""
@@ -231,6 +289,20 @@ class TransformerLayer(nn.Module):
         x = FusedAdaLN.apply(vid_emb, text_emb, ln2.weight, ln2.bias, sh_v, sc_v, sh_t, sc_t, ln2.eps)
         y = self.mlp(x)
         return FusedResGate.apply(vid_emb, text_emb, y, g_v, g_t)
+
+    @torch.no_grad()
+    def forward_sp(self, vid_emb, text_emb, seq_metadata: SequenceMetadata, sp):
+        """``forward`` on token shards (sequence-parallel inference): AdaLN, residual gates and the MLP are token-wise."""
+        t = seq_metadata.t_emb
+        sh_v, sc_v, g_v, sh_t, sc_t, g_t = self.pre_seq_adaLN_modulation(t).chunk(6, dim=1)
+        v_out, t_out = self.seq_modeling_block.forward_sp(modulate(self.pre_seq_layernorm(vid_emb), sh_v, sc_v),
+                                                          modulate(self.pre_seq_layernorm(text_emb), sh_t, sc_t), seq_metadata, sp)
+        vid_emb = vid_emb + g_v.unsqueeze(1) * v_out
+        text_emb = text_emb + g_t.unsqueeze(1) * t_out
+        sh_v, sc_v, g_v, sh_t, sc_t, g_t = self.pre_mlp_adaLN_modulation(t).chunk(6, dim=1)
+        vid_emb = vid_emb + g_v.unsqueeze(1) * self.mlp(modulate(self.pre_mlp_layernorm(vid_emb), sh_v, sc_v))
+        text_emb = text_emb + g_t.unsqueeze(1) * self.mlp(modulate(self.pre_mlp_layernorm(text_emb), sh_t, sc_t))
+        return vid_emb, text_emb
 
     def forward(self, vid_emb, text_emb, seq_metadata: SequenceMetadata):
         if self.use_fused_glue and fused_available(vid_emb, 64) and vid_emb.shape[-1] % 8 == 0 and vid_emb.shape[-1] <= 8192:
@@ -294,6 +366,7 @@ class DiffusionTransformer(nn.Module):
         self.layers = nn.ModuleList([TransformerLayer(config) for _ in range(config.num_layers)])
         self.transformer_norm = nn.LayerNorm(config.model_dim, eps=config.layer_norm_eps).requires_grad_(train)
         self.final_layer = FinalLayer(config)
+        self.sequence_parallel = None      # a ttt_amd.infra.sequence_parallel.SeqParallel: inference over the ranks of its group
 
     def _run_group(self, start, vid_emb, text_emb, seq_metadata):
         for layer in self.layers[start:start + self.remat_transformer_layer_group_size]:
@@ -311,6 +384,16 @@ class DiffusionTransformer(nn.Module):
         if meta.is_multiscene:
             meta.init_multiscene_offsets()
         text_emb = text_emb.flatten(1, 2)
+        if self.sequence_parallel is not None:        # every rank got the same inputs; each keeps 1/T of the tokens
+            if torch.is_grad_enabled():
+                raise RuntimeError("sequence parallelism is an inference mode: call under torch.no_grad()")
+            sp = self.sequence_parallel
+            n_vid = vid_emb.shape[1]
+            vid_emb, text_emb = sp.shard_tokens(vid_emb), sp.shard_tokens(text_emb)
+            for layer in self.layers:
+                vid_emb, text_emb = layer.forward_sp(vid_emb, text_emb, meta, sp)
+            vid_emb = sp.gather_tokens(vid_emb, n_vid)
+            return self.final_layer(self.transformer_norm(vid_emb), meta)
         for i in range(0, len(self.layers), self.remat_transformer_layer_group_size):
             if torch.is_grad_enabled() and i >= self.remat_free_layers:
                 vid_emb, text_emb = checkpoint(self._run_group, i, vid_emb, text_emb, meta, use_reentrant=False)

@@ -71,6 +71,9 @@ class TTTWrapper(nn.Module):
         call; here the fused pre/post kernels absorb the flips into their token maps)."""
         return self.ttt(x, self.freqs_cis, seq_metadata, reverse)
 
+    def forward_heads(self, x: torch.Tensor, seq_metadata: SequenceMetadata, reverse: bool, h0: int, h1: int):
+        return self.ttt.forward_heads(x, self.freqs_cis, seq_metadata, reverse, h0, h1)
+
 
 def scene_permutation(meta: SequenceMetadata, seq_len: int) -> torch.Tensor:
     """Index ``p`` with ``interleaved = tokens[p]``: [text_0..text_n, video] -> [text_0 video_0 text_1
@@ -152,8 +155,9 @@ class TTTBase(nn.Module):
         nn.init.zeros_(self.learnable_ttt_lr_bias)
 
     def init_device_mesh(self, tp_mesh):
-        raise NotImplementedError("head-sharded tensor parallelism is a next-row item (SURVEY.md 8f #2); "
-                                  "the MI355X target runs FSDP-only (288 GB HBM per GPU)")
+        raise NotImplementedError("DTensor tensor parallelism is not mirrored: training on MI355X runs FSDP-only (288 GB HBM "
+                                  "per GPU); the head-sharded / sequence-parallel layout exists for inference with explicit "
+                                  "collectives (forward_heads, ttt_amd/infra/sequence_parallel.py)")
 
     # -- pieces of process_input ------------------------------------------------------------------
     def get_qkv_projections(self, hidden_states):
@@ -246,17 +250,44 @@ class TTTBase(nn.Module):
     def ttt(self, inputs):
         raise NotImplementedError("ttt method must be implemented in TTTBase subclasses.")
 
-    def forward(self, hidden_states: torch.Tensor, freqs_cis: torch.Tensor, seq_metadata: SequenceMetadata, reverse: bool = False):
+    def forward(self, hidden_states: torch.Tensor, freqs_cis: torch.Tensor, seq_metadata: SequenceMetadata, reverse: bool = False,
+                heads_only: bool = False):
+        """``heads_only=True`` stops before ``post_norm`` / ``wo`` and returns the scan output ``[B, L, NH*F]`` in the
+        original token order: the head-sharded half of the layer under sequence parallelism (see ``forward_heads``)."""
         assert hidden_states.size(1) % self.config.mini_batch_size == 0, "Sequence len must be multiple of mini batch size."
         if self.use_kernel and self.use_fused and fused_available(hidden_states, self.head_dim) and not freqs_cis.is_complex():
-            return self._forward_fused(hidden_states, freqs_cis, seq_metadata, reverse)
+            return self._forward_fused(hidden_states, freqs_cis, seq_metadata, reverse, heads_only)
         if reverse:
             hidden_states = flip_sequence(hidden_states, seq_metadata)
         y = self.ttt(self.process_input(hidden_states, freqs_cis, seq_metadata))
-        y = self.wo(self.post_norm(y))
+        if not heads_only:
+            y = self.wo(self.post_norm(y))
         if seq_metadata.is_multiscene:
             y = self.undo_interleave(y, seq_metadata)
         return flip_sequence(y, seq_metadata) if reverse else y
+
+    _HEAD_SLICED = ("wq.weight", "wq.bias", "wk.weight", "wk.bias", "wv.weight", "wv.bias", "learnable_ttt_lr_weight",
+                    "learnable_ttt_lr_bias", "ttt_norm_weight", "ttt_norm_bias", "W1", "b1", "W2", "b2")
+
+    @torch.no_grad()
+    def forward_heads(self, hidden_states, freqs_cis, seq_metadata: SequenceMetadata, reverse: bool, h0: int, h1: int):
+        """The layer restricted to heads ``[h0, h1)`` up to (not including) ``post_norm``: ``[B, L, D] -> [B, L, (h1-h0)*F]``.
+        Every per-head parameter is sliced along its head dimension and the unchanged module code runs on the slice
+        (inference only: sequence-parallel sampling, ``ttt_amd/infra/sequence_parallel.py``).  The reference gets the same
+        head-locality from DTensor placements (``ttt_layer.py``:114-131, ``mlp_tk.py``:297-343)."""
+        Fh = self.head_dim
+        params = dict(self.named_parameters())
+        sliced = {}
+        for name in self._HEAD_SLICED:
+            if name in params:
+                p = params[name]
+                sliced[name] = p[h0 * Fh:h1 * Fh] if name.startswith(("wq.", "wk.", "wv.")) else p[h0:h1]
+        nh = self.num_heads
+        self.num_heads = h1 - h0
+        try:
+            return torch.func.functional_call(self, sliced, (hidden_states, freqs_cis, seq_metadata, reverse), {"heads_only": True})
+        finally:
+            self.num_heads = nh
 
     # -- fused path: HIP pre/post kernels around the scan (bf16 on a HIP device) ------------------------------
     def _token_maps(self, meta: SequenceMetadata, L: int, device, reverse: bool):
@@ -275,7 +306,7 @@ class TTTBase(nn.Module):
             self._perm_cache[key] = hit
         return hit
 
-    def _forward_fused(self, x, freqs_cis, meta: SequenceMetadata, reverse: bool):
+    def _forward_fused(self, x, freqs_cis, meta: SequenceMetadata, reverse: bool, heads_only: bool = False):
         B, L, _ = x.shape
         NH, Fh, CS = self.num_heads, self.head_dim, self.mini_batch_size
         NC = L // CS
@@ -300,6 +331,10 @@ class TTTBase(nn.Module):
         else:
             XQ, XK, XV = FusedPre.apply(XQr, XKr, XVr, self.ttt_norm_weight, self.ttt_norm_bias, rope, src, pos, NH)
             Y = self.ttt_raw({"XQ": mb(XQ), "XK": mb(XK), "XV": mb(XV), "eta": eta})                              # [B,NH,NC,CS,F]
+        if heads_only:     # scan position t holds token src[t]: back to the original order, [B, L, NH*F]
+            out = torch.empty(B, L, NH, Fh, device=Y.device, dtype=Y.dtype)
+            out.index_copy_(1, src.long(), Y.reshape(B, NH, L, Fh).transpose(1, 2))
+            return out.view(B, L, NH * Fh)
         y = FusedPost.apply(Y.reshape(B, NH, L, Fh), self.post_norm.weight, self.post_norm.bias, src, self.post_norm.eps)
         return self.wo(y)
 
@@ -341,7 +376,7 @@ class TTTLinear(TTTBase):
         else:
             out = ttt_linear(inputs["XK"], inputs["XQ"], inputs["XV"], inputs["eta"], self.ttt_norm_weight,
                              self.ttt_norm_bias, W1, b1, G)
-        return out.reshape(B, NC * CS, self.width)
+        return out.reshape(B, NC * CS, -1)          # all heads of this module (a head shard under sequence parallelism)
 
 
 class TTTMLP(TTTBase):
@@ -379,4 +414,4 @@ class TTTMLP(TTTBase):
         else:
             out = ttt_mlp(inputs["XK"], inputs["XQ"], inputs["XV"], inputs["eta"], self.ttt_norm_weight,
                           self.ttt_norm_bias, *st, G)
-        return out.reshape(B, NC * CS, self.width)
+        return out.reshape(B, NC * CS, -1)          # all heads of this module (a head shard under sequence parallelism)
