@@ -38,8 +38,9 @@ extern "C" {
 #define TTT_HIP_ABI_VERSION 1
 
 enum { TTT_DTYPE_BF16 = 0, TTT_DTYPE_F32 = 1 };
-/* implementation selector: AUTO picks the MFMA kernels when the geometry is supported
- * (bf16, CS=64, F=64) and the generic fp32-arithmetic kernels otherwise. */
+/* implementation selector: AUTO picks the MFMA kernels when the geometry is supported - bf16, F=64 and
+ * TTT-MLP forward/backward at CS=64, TTT-MLP forward at CS=16, TTT-Linear forward/backward at CS=16 -
+ * and the generic fp32-arithmetic kernels otherwise; TTT_IMPL_MFMA makes an unsupported geometry an error. */
 enum { TTT_IMPL_AUTO = 0, TTT_IMPL_GENERIC = 1, TTT_IMPL_MFMA = 2 };
 
 typedef struct ttt_dims {
@@ -120,8 +121,8 @@ typedef struct ttt_linear_bwd_args {
     const float* W1_checkpoints; const float* b1_checkpoints;
     const float* grad_L_W1_last; const float* grad_L_b1_last;
     const void*  grad_L_XQW;
-    float* W1_init_group;        /* [B,NH,G,F,F] scratch (linear_triton.py:172) */
-    float* b1_init_group;        /* [B,NH,G,1,F] scratch                          */
+    float* W1_init_group;        /* [B,NH,G,F,F] scratch (linear_triton.py:172); opaque: the MFMA kernel parks packed */
+    float* b1_init_group;        /* [B,NH,G,1,F] scratch    per-step states there, not the fp32 states of the Triton kernel */
     float* grad_L_ttt_norm_weight; float* grad_L_ttt_norm_bias;  /* [B,NH,1,F] */
     float* grad_L_W1_init; float* grad_L_b1_init;
     void*  grad_L_last_eta;      /* [B,NH,NC,CS,1] act */
