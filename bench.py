@@ -64,6 +64,9 @@ def parse():
     ap.add_argument("--reshard-after-forward", action="store_true",
                     help="FSDP: free the gathered bf16 parameters after each layer's forward and all-gather them again in "
                          "backward (the reference's 80-GB setting); default: keep them resident (14.5 GB of 288)")
+    ap.add_argument("--local-batch", type=int, default=1,
+                    help="samples per GPU (default 1 = the reference's training setting).  The TTT scans of a second sample run "
+                         "beside the first at no extra wall time (one workgroup per head, 48 of 256 CUs at batch 1)")
     ap.add_argument("--layers", type=int, default=None, help="DEBUG: fewer layers (result flagged invalid)")
     return ap.parse_args()
 
@@ -216,8 +219,9 @@ def main():
     opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-5, weight_decay=1e-4, fused=True)
 
     g = torch.Generator(device=dev).manual_seed(100 + rank)
-    vid = torch.randn(1, frames, 16, 60, 90, device=dev, generator=g)
-    text = torch.randn(1, scenes, text_len, cfg.text_dim, device=dev, generator=g)
+    LB = args.local_batch
+    vid = torch.randn(LB, frames, 16, 60, 90, device=dev, generator=g)
+    text = torch.randn(LB, scenes, text_len, cfg.text_dim, device=dev, generator=g)
 
     timer = KernelTimer(ext)
     timer.install()
@@ -314,11 +318,11 @@ def main():
 
     if rank == 0:
         ms_per_step = 1e3 * dt / args.steps
-        video_tokens = world * 1 * frames * TOKENS_PER_FRAME
+        video_tokens = world * LB * frames * TOKENS_PER_FRAME
         value = video_tokens / (dt / args.steps)
         ks = timer.summary()
         # ---- roofline of the dominant hand-written kernel ---------------------------------
-        B, NH, NC, CS, F = 1, cfg.num_heads, L // cfg.mini_batch_size, cfg.mini_batch_size, cfg.head_dim
+        B, NH, NC, CS, F = LB, cfg.num_heads, L // cfg.mini_batch_size, cfg.mini_batch_size, cfg.head_dim
         if args.ssm_layer == "ttt_mlp":
             gemm = 2.0 * CS * F * 4 * F
             flops = {"fwd": 7 * gemm, "bwd": 14 * gemm}         # algorithmic; the in-kernel recompute (7g) is excluded
@@ -327,7 +331,7 @@ def main():
             flops = {"fwd": 3 * gemm, "bwd": 6 * gemm}
         # local attention (hand-written MFMA kernels too): algorithmic 4 S^2 D NH forward, 2.5x that backward
         seg_S = 13 * TOKENS_PER_FRAME + text_len
-        a_flops = 4.0 * seg_S * seg_S * cfg.head_dim * cfg.num_heads
+        a_flops = 4.0 * LB * seg_S * seg_S * cfg.head_dim * cfg.num_heads
         flops["attn_fwd"], flops["attn_bwd"] = a_flops / (B * NH * NC), 2.5 * a_flops / (B * NH * NC)     # per (b,h,step) units like the scan
         scan_keys = [k for k in ks if k in ("fwd", "bwd")]
         dom = max(scan_keys, key=lambda k: ks[k]["total_ms"]) if scan_keys else None
@@ -351,7 +355,7 @@ def main():
                 "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                 "config": {"workload": f"CogVideoX-5B+{args.ssm_layer} {args.video_length} training step (fwd+bwd+AdamW), "
                                        f"{cfg.num_layers} layers, L={L} tokens/sample, adapter=sft",
-                           "global_batch": world, "seq_len": L, "parallelism": f"fsdp{world}", "ttt_impl": args.impl,
+                           "global_batch": world * LB, "seq_len": L, "parallelism": f"fsdp{world}", "ttt_impl": args.impl,
                            "remat_free_layers": n_free, "fsdp_reshard_after_forward": bool(args.reshard_after_forward), "tuned_gemm_selections": bool(tuned),
                            "valid": args.layers is None},
                 "roofline": roof, "loss": loss_val, "peak_mem_gib": peak_mem, "total_tokens_per_s": world * L / (dt / args.steps)}
