@@ -115,10 +115,10 @@ def _backward(lib, d, G, fwd):
     return g
 
 
-@pytest.mark.parametrize("shape", [(1, 1, 1, 1), (1, 2, 5, 2), (2, 1, 6, 4), (1, 1, 7, 3)])
+@pytest.mark.parametrize("shape", [(1, 1, 1, 1), (1, 2, 5, 2), (2, 1, 6, 4), (1, 1, 7, 3), (1, 1, 4, 1), (1, 1, 3, 3)])
 def test_emulated_linear_backward_vs_oracle(emul, shape):
     """Reverse sweep of the TTT-Linear scan (mini-batch 16) on the wave emulator vs fp64 autograd-equivalent oracle:
-    single step, even / odd group sizes, ragged last group."""
+    single step, even / odd group sizes, ragged last group, one step per group, one group for the whole sequence."""
     B, NH, NC, G = shape
     d = _inputs(B, NH, NC, seed=29 + NC)
     fwd = _forward(emul, d, G)
