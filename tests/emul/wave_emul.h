@@ -22,7 +22,7 @@ using namespace ttt::wv;
 
 struct WaveShared {
     std::barrier<> bar{64};
-    alignas(16) char lds[65536];
+    alignas(16) char lds[160 * 1024];
     bf16x8 a8[64], b8[64];
     bf16x4 a4[64], b4[64];
     float f[64];

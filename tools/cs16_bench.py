@@ -20,6 +20,7 @@ ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--phases", action="store_true")
 ap.add_argument("--no-generic", action="store_true")
 ap.add_argument("--linear", action="store_true", help="TTT-Linear instead of TTT-MLP")
+ap.add_argument("--lds-slots", type=int, default=0, help="TTT-Linear backward: per-step state slots kept in LDS (A/B knob, 0..6)")
 a = ap.parse_args()
 dev = "cuda:0"
 B, NH, NC, CS, F = a.batch, a.nh, a.nc, 16, 64
@@ -74,6 +75,7 @@ if a.linear:
     grads = (torch.empty(B, NH, 1, F, device=dev), torch.empty(B, NH, 1, F, device=dev), torch.empty(B, NH, F, F, device=dev),
              torch.empty(B, NH, 1, F, device=dev), torch.empty(B, NH, NC, CS, 1, device=dev, dtype=torch.bfloat16),
              torch.empty_like(XQ), torch.empty_like(XQ), torch.empty_like(XQ))
+    e.debug_option("linear_bwd_lds_slots", a.lds_slots)
     for impl in (("mfma",) if a.no_generic else ("mfma", "generic")):
         e.set_impl(impl)
         out = torch.empty_like(XQ)

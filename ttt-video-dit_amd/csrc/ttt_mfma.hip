@@ -561,6 +561,7 @@ void linear_backward(const ttt_dims* d, const ttt_linear_bwd_args* a, void*, hip
     p.dW1 = a->grad_L_W1_init; p.db1 = a->grad_L_b1_init;
     p.deta = (__bf16*)a->grad_L_last_eta; p.dXQ = (__bf16*)a->grad_L_XQ; p.dXK = (__bf16*)a->grad_L_XK; p.dXV = (__bf16*)a->grad_L_XV;
     p.NH = d->NH; p.NC = d->NC; p.G = d->G; p.K = (d->NC + d->G - 1) / d->G; p.eps = d->eps;
+    p.lds_slots = get_debug_lin_lds_slots();
     launch_linear_backward_cs16(p, d->B * d->NH, s);
 }
 

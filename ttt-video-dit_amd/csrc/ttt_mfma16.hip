@@ -459,10 +459,11 @@ __global__ __launch_bounds__(64 * LIN_WAVES) void linear_scan16_kernel(wv::Lin16
 }
 
 // backward: one wave per workgroup (48 .. 96 scans on 256 CUs: a CU of its own per scan; up to 512 registers per lane)
+template <bool LDS_SLOTS>
 __global__ __launch_bounds__(64) void linear_bwd16_kernel(wv::Lin16Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     DeviceWave bk{smem};
-    lin16::backward(bk, p, blockIdx.x);
+    lin16::backward<LDS_SLOTS>(bk, p, blockIdx.x);
 }
 
 static void set_attr_once() {
@@ -480,7 +481,8 @@ static void lin_attr_once() {
     static bool done = false;
     if (!done) {
         (void)hipFuncSetAttribute((const void*)v16::linear_scan16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, v16::LDS_LIN);
-        (void)hipFuncSetAttribute((const void*)v16::linear_bwd16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lin16::WAVE_LDS_BWD);
+        (void)hipFuncSetAttribute((const void*)v16::linear_bwd16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lin16::WAVE_LDS_BWD);
+        (void)hipFuncSetAttribute((const void*)v16::linear_bwd16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lin16::WAVE_LDS_BWD);
         done = true;
     }
 }
@@ -491,7 +493,10 @@ void launch_linear_forward_cs16(const wv::Lin16Params& p, int n_bh, hipStream_t 
 }
 void launch_linear_backward_cs16(const wv::Lin16Params& p, int n_bh, hipStream_t s) {
     lin_attr_once();
-    hipLaunchKernelGGL(v16::linear_bwd16_kernel, dim3(n_bh), dim3(64), lin16::WAVE_LDS_BWD, s, p);
+    // LDS: the fixed regions + the state slots kept in LDS (debug option "linear_bwd_lds_slots", default 0 = all in scratch)
+    const int n_lds = p.lds_slots < lin16::MAX_LDS_SLOTS ? (p.lds_slots > 0 ? p.lds_slots : 0) : lin16::MAX_LDS_SLOTS;
+    if (n_lds > 0) hipLaunchKernelGGL(v16::linear_bwd16_kernel<true>, dim3(n_bh), dim3(64), lin16::L_SLOTS + n_lds * lin16::SLOT_BYTES, s, p);
+    else hipLaunchKernelGGL(v16::linear_bwd16_kernel<false>, dim3(n_bh), dim3(64), lin16::L_SLOTS, s, p);
 }
 
 void launch_scan_forward_cs16(const ScanParams& p0, int n_bh, unsigned long long* dbg, hipStream_t s) {

@@ -539,6 +539,9 @@ int get_debug_overlap() { return g_overlap; }
 static int g_lead = 1;
 void set_debug_lead(int v) { g_lead = v; }
 int get_debug_lead() { return g_lead; }
+static int g_lin_lds_slots = 0;       // TTT-Linear backward (CS = 16): per-step state slots kept in LDS; unmeasured -> off
+void set_debug_lin_lds_slots(int n) { g_lin_lds_slots = n; }
+int get_debug_lin_lds_slots() { return g_lin_lds_slots; }
 static int g_helpers = -1;
 void set_debug_helpers(int n) { g_helpers = n; }
 int get_debug_helpers() { return g_helpers; }

@@ -38,6 +38,8 @@ void launch_scan_forward_v2(const ScanParams& p, int n_bh, unsigned long long* d
 void launch_scan_forward_cs16(const ScanParams& p, int n_bh, unsigned long long* dbg, hipStream_t s);
 void launch_linear_forward_cs16(const wv::Lin16Params& p, int n_bh, hipStream_t s);   // TTT-Linear, one wave per (b,h)
 void launch_linear_backward_cs16(const wv::Lin16Params& p, int n_bh, hipStream_t s);
+void set_debug_lin_lds_slots(int n);
+int get_debug_lin_lds_slots();
 void set_debug_dump(float* buf);
 int get_debug_variant();
 unsigned long long* get_debug_timing();

@@ -29,6 +29,7 @@ struct Lin16Params {
     __bf16 *deta, *dXQ, *dXK, *dXV;
     int NH, NC, G, K;
     float eps;
+    int lds_slots;                          // backward: how many of a group's per-step state slots live in LDS instead of scratch_w
 };
 
 }  // namespace wv
