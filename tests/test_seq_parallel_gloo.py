@@ -1,6 +1,6 @@
-"""Sequence-parallel inference (ttt_amd/infra/sequence_parallel.py) on CPU over gloo: T ranks, each holding 1/T of the tokens
+"""Sequence parallelism (ttt_amd/infra/sequence_parallel.py) on CPU over gloo: T ranks, each holding 1/T of the tokens
 for the token-wise work and 1/T of the heads for attention / the TTT scan, must reproduce the single-process forward of the
-same DiT.  World sizes 2 and 3 (3 = token shards that need padding), single- and multi-scene, TTT-MLP and TTT-Linear, the
+same DiT and, through the differentiable collectives + ``sum_gradients``, its loss and every parameter gradient.  World sizes 2 and 3 (3 = token shards that need padding), single- and multi-scene, TTT-MLP and TTT-Linear, the
 dual-form PyTorch scan and the kernel plumbing (HIP extension replaced by the oracle-backed stand-in, as in
 test_fsdp_gloo.py)."""
 import os
@@ -51,6 +51,10 @@ def _build(case):
     return m.eval(), inputs
 
 
+def _loss(out):
+    return (out * torch.linspace(-1, 1, out.numel()).view_as(out)).sum() / out.numel() + out.square().mean()
+
+
 def _worker(rank, world, port, case, out_dir):
     for p in (ROOT, os.path.join(ROOT, "ttt-video-dit_amd")):
         sys.path.insert(0, p)
@@ -62,12 +66,18 @@ def _worker(rank, world, port, case, out_dir):
         cpu_ext.install()
     dist.init_process_group("gloo", rank=rank, world_size=world)
     m, inputs = _build(case)
-    m.sequence_parallel = SeqParallel()
+    sp = m.sequence_parallel = SeqParallel()
     with torch.no_grad():
         out = m(*inputs)
     torch.save(out, os.path.join(out_dir, f"sp_{rank}.pt"))
-    with pytest.raises(RuntimeError):          # inference mode only
-        m(*inputs)
+    # training through the same layout: every rank evaluates the loss on the gathered output, parameter gradients are
+    # partial per rank (its tokens / its heads) and summed over the group
+    loss = _loss(m(*inputs))
+    loss.backward()
+    sp.sum_gradients(m)
+    if rank == 0:
+        torch.save({"loss": loss.detach(), "grads": {n: p.grad for n, p in m.named_parameters() if p.grad is not None}},
+                   os.path.join(out_dir, "sp_train.pt"))
     dist.destroy_process_group()
 
 
@@ -85,6 +95,9 @@ def test_sequence_parallel_forward_equals_single_process(case, tmp_path):
         m, inputs = _build(case)
         with torch.no_grad():
             ref = m(*inputs)
+        ref_loss = _loss(m(*inputs))
+        ref_loss.backward()
+        ref_grads = {n: p.grad for n, p in m.named_parameters() if p.grad is not None}
     finally:
         if CASES[case][5]:
             cpu_ext.uninstall()
@@ -93,3 +106,17 @@ def test_sequence_parallel_forward_equals_single_process(case, tmp_path):
         err = float((o - ref).norm() / ref.norm())
         assert err < 1e-5, (case, err)
     assert torch.equal(outs[0], outs[-1])      # every rank ends with the same full output
+    tr = torch.load(os.path.join(str(tmp_path), "sp_train.pt"))
+    assert abs(float(tr["loss"]) - float(ref_loss.detach())) < 1e-5 * max(1.0, abs(float(ref_loss.detach())))
+    # (a parameter that cannot influence the loss - the text gates of the last layer - has an all-zero gradient in one
+    # graph and none in the other)
+    zero = torch.zeros(())
+    errs = []
+    for n, g in ref_grads.items():
+        got = tr["grads"].get(n)
+        if got is None:
+            assert float(g.abs().max()) == 0.0, n
+            continue
+        errs.append((float((got - g).norm() / g.norm().clamp_min(1e-12)) if float(g.norm()) > 0 else float(got.abs().max()), n))
+    assert set(tr["grads"]) <= set(ref_grads)
+    assert max(errs)[0] < 2e-4, max(errs)

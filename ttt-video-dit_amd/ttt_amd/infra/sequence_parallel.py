@@ -12,8 +12,11 @@ used here for a different reason, latency, and with explicit RCCL collectives in
 
 Per sequence-mixing op: one all-gather of the token shards (its input is needed for every head) and one all-to-all back
 (heads -> tokens).  Token shards are padded to equal size (63 s: 341 550 video tokens are not a multiple of 8); pad rows
-are carried through the token-wise ops and dropped at every gather.  Inference only (no autograd through the
-collectives); weights are replicated (14.5 GB in bf16).  ``nccl`` = RCCL on ROCm; the CPU tests run it over ``gloo``.
+are carried through the token-wise ops and dropped at every gather.  Weights are replicated (14.5 GB in bf16 for
+sampling).  The collectives are autograd functions (all-gather <-> reduce-scatter, all-to-all <-> all-to-all), so the same
+layout also trains: every rank then holds partial parameter gradients (its tokens' share of the token-wise parameters,
+its heads' slices of the per-head ones) and ``sum_gradients`` adds them up over the group.  ``nccl`` = RCCL on ROCm; the
+CPU tests run it over ``gloo``.
 """
 from __future__ import annotations
 
@@ -48,22 +51,92 @@ class SeqParallel:
         return torch.cat((x, x.new_zeros(shape)), dim=dim)
 
     def shard_tokens(self, x: torch.Tensor) -> torch.Tensor:
-        """[B, L, ...] (identical on every rank) -> this rank's [B, ceil(L/T), ...] shard (zero rows pad the last one)."""
+        """[B, L, ...] (identical on every rank) -> this rank's [B, ceil(L/T), ...] shard (zero rows pad the last one).
+        A slice: under autograd the gradient lands in this rank's rows of ``x`` (see ``sum_gradients``)."""
         n = self.shard_len(x.shape[1])
         return self._pad(x)[:, self.rank * n:(self.rank + 1) * n].contiguous()
 
-    # ---- collectives ---------------------------------------------------------------------------------------------------
-    def gather_tokens(self, x_loc: torch.Tensor, length: int) -> torch.Tensor:
-        """token shards [B, n, D] -> the full [B, length, D] on every rank."""
+    # ---- collectives (raw) -----------------------------------------------------------------------------------------------
+    def _all_gather(self, x_loc: torch.Tensor) -> torch.Tensor:          # [B, n, D] -> [B, T*n, D]
         parts = [torch.empty_like(x_loc) for _ in range(self.size)]
         dist.all_gather(parts, x_loc.contiguous(), group=self.group)
-        return torch.cat(parts, dim=1)[:, :length]
+        return torch.cat(parts, dim=1)
 
-    def heads_to_tokens(self, x: torch.Tensor) -> torch.Tensor:
-        """head shard over the full sequence [B, L, (NH/T)*F] -> token shard with every head [B, ceil(L/T), NH*F]."""
-        B, L, d = x.shape
-        n = self.shard_len(L)
-        send = self._pad(x).view(B, self.size, n, d).transpose(0, 1).contiguous()          # [T, B, n, d]: chunk j -> rank j
+    def _reduce_scatter(self, g: torch.Tensor) -> torch.Tensor:          # [B, T*n, D] (differs per rank) -> sum, my [B, n, D]
+        n = g.shape[1] // self.size
+        if dist.get_backend(self.group) == "gloo":          # no reduce_scatter in gloo (CPU tests): all-reduce and slice
+            g = g.clone()
+            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+            return g[:, self.rank * n:(self.rank + 1) * n].contiguous()
+        parts = [p.contiguous() for p in g.split(n, dim=1)]
+        out = torch.empty_like(parts[0])
+        dist.reduce_scatter(out, parts, op=dist.ReduceOp.SUM, group=self.group)
+        return out
+
+    def _a2a_heads_to_tokens(self, x: torch.Tensor) -> torch.Tensor:     # [B, T*n, d] -> [B, n, T*d]
+        B, Lp, d = x.shape
+        n = Lp // self.size
+        send = x.reshape(B, self.size, n, d).transpose(0, 1).contiguous()                    # [T, B, n, d]: chunk j -> rank j
         recv = torch.empty_like(send)
         dist.all_to_all_single(recv, send, group=self.group)                                # recv[r] = rank r's heads, my tokens
         return recv.permute(1, 2, 0, 3).reshape(B, n, self.size * d)                        # heads in rank order = global order
+
+    def _a2a_tokens_to_heads(self, y: torch.Tensor) -> torch.Tensor:     # [B, n, T*d] -> [B, T*n, d]   (inverse of the above)
+        B, n, D = y.shape
+        d = D // self.size
+        send = y.reshape(B, n, self.size, d).permute(2, 0, 1, 3).contiguous()               # [T, B, n, d]: head block r -> rank r
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send, group=self.group)                                # recv[j] = token chunk j, my heads
+        return recv.transpose(0, 1).reshape(B, self.size * n, d)
+
+    # ---- collectives (differentiable) -------------------------------------------------------------------------------------
+    def gather_tokens(self, x_loc: torch.Tensor, length: int, replicated_consumer: bool = False) -> torch.Tensor:
+        """token shards [B, n, D] -> the full [B, length, D] on every rank.  Backward: the consumers on different ranks (head
+        shards) each produce a gradient for the full tensor -> reduce-scatter; with ``replicated_consumer=True`` every rank
+        runs the SAME computation on the result (the final layer / loss), so its own rows of its own gradient are the
+        answer."""
+        return _Gather.apply(x_loc, self, length, replicated_consumer)
+
+    def heads_to_tokens(self, x: torch.Tensor) -> torch.Tensor:
+        """head shard over the full sequence [B, L, (NH/T)*F] -> token shard with every head [B, ceil(L/T), NH*F]."""
+        return _HeadsToTokens.apply(x, self)
+
+    def sum_gradients(self, module: torch.nn.Module) -> None:
+        """After backward: add up the partial parameter gradients of the ranks (one flat all-reduce)."""
+        grads = [p.grad for p in module.parameters() if p.grad is not None]
+        if not grads:
+            return
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        o = 0
+        for g in grads:
+            g.copy_(flat[o:o + g.numel()].view_as(g))
+            o += g.numel()
+
+
+class _Gather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_loc, sp, length, replicated_consumer):
+        ctx.sp, ctx.n, ctx.length, ctx.rep = sp, x_loc.shape[1], length, replicated_consumer
+        return sp._all_gather(x_loc)[:, :length]
+
+    @staticmethod
+    def backward(ctx, g):
+        sp, n = ctx.sp, ctx.n
+        pad = sp.size * n - ctx.length
+        if pad:
+            g = torch.cat((g, g.new_zeros(g.shape[0], pad, *g.shape[2:])), dim=1)
+        if ctx.rep:
+            return g[:, sp.rank * n:(sp.rank + 1) * n].contiguous(), None, None, None
+        return sp._reduce_scatter(g.contiguous()), None, None, None
+
+
+class _HeadsToTokens(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, sp):
+        ctx.sp, ctx.length = sp, x.shape[1]
+        return sp._a2a_heads_to_tokens(sp._pad(x))
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.sp._a2a_tokens_to_heads(g.contiguous())[:, :ctx.length], None

@@ -225,7 +225,6 @@ class SeqModelingBlock(nn.Module):
             count[:, lo:hi] += 1
         return torch.cat((out_txt, out_vid / count), dim=1)
 
-    @torch.no_grad()
     def forward_sp(self, vid_loc, text_loc, seq_metadata: SequenceMetadata, sp):
         """The block on token shards ``vid_loc [B, ceil(Lv/T), D]``, ``text_loc [B, ceil(Lt/T), D]``: sequence-mixing parts on
         this rank's heads over the gathered sequence, token-wise parts (o, post_norm, wo, gates) on the shard."""
@@ -290,9 +289,8 @@ class TransformerLayer(nn.Module):
         y = self.mlp(x)
         return FusedResGate.apply(vid_emb, text_emb, y, g_v, g_t)
 
-    @torch.no_grad()
     def forward_sp(self, vid_emb, text_emb, seq_metadata: SequenceMetadata, sp):
-        """``forward`` on token shards (sequence-parallel inference): AdaLN, residual gates and the MLP are token-wise."""
+        """``forward`` on token shards (sequence parallelism): AdaLN, residual gates and the MLP are token-wise."""
         t = seq_metadata.t_emb
         sh_v, sc_v, g_v, sh_t, sc_t, g_t = self.pre_seq_adaLN_modulation(t).chunk(6, dim=1)
         v_out, t_out = self.seq_modeling_block.forward_sp(modulate(self.pre_seq_layernorm(vid_emb), sh_v, sc_v),
@@ -366,7 +364,7 @@ class DiffusionTransformer(nn.Module):
         self.layers = nn.ModuleList([TransformerLayer(config) for _ in range(config.num_layers)])
         self.transformer_norm = nn.LayerNorm(config.model_dim, eps=config.layer_norm_eps).requires_grad_(train)
         self.final_layer = FinalLayer(config)
-        self.sequence_parallel = None      # a ttt_amd.infra.sequence_parallel.SeqParallel: inference over the ranks of its group
+        self.sequence_parallel = None      # a ttt_amd.infra.sequence_parallel.SeqParallel: one sample over the ranks of its group
 
     def _run_group(self, start, vid_emb, text_emb, seq_metadata):
         for layer in self.layers[start:start + self.remat_transformer_layer_group_size]:
@@ -385,15 +383,18 @@ class DiffusionTransformer(nn.Module):
             meta.init_multiscene_offsets()
         text_emb = text_emb.flatten(1, 2)
         if self.sequence_parallel is not None:        # every rank got the same inputs; each keeps 1/T of the tokens
-            if torch.is_grad_enabled():
-                raise RuntimeError("sequence parallelism is an inference mode: call under torch.no_grad()")
             sp = self.sequence_parallel
             n_vid = vid_emb.shape[1]
             vid_emb, text_emb = sp.shard_tokens(vid_emb), sp.shard_tokens(text_emb)
             for layer in self.layers:
                 vid_emb, text_emb = layer.forward_sp(vid_emb, text_emb, meta, sp)
-            vid_emb = sp.gather_tokens(vid_emb, n_vid)
-            return self.final_layer(self.transformer_norm(vid_emb), meta)
+            # final norm / AdaLN / projection are token-wise too; only the unpatchify reshape needs the whole sequence.  Every
+            # rank then evaluates the same loss on the gathered output, hence replicated_consumer.
+            fl = self.final_layer
+            shift, scale = fl.adaLN_modulation(t_emb).chunk(2, dim=1)
+            y = fl.linear(modulate(fl.norm(self.transformer_norm(vid_emb)), shift, scale))
+            y = sp.gather_tokens(y, n_vid, replicated_consumer=True)
+            return unpatchify(y, c=fl.out_channels, p=fl.patch_size, w=width // fl.patch_size, h=height // fl.patch_size)
         for i in range(0, len(self.layers), self.remat_transformer_layer_group_size):
             if torch.is_grad_enabled() and i >= self.remat_free_layers:
                 vid_emb, text_emb = checkpoint(self._run_group, i, vid_emb, text_emb, meta, use_reentrant=False)

@@ -269,7 +269,6 @@ class TTTBase(nn.Module):
     _HEAD_SLICED = ("wq.weight", "wq.bias", "wk.weight", "wk.bias", "wv.weight", "wv.bias", "learnable_ttt_lr_weight",
                     "learnable_ttt_lr_bias", "ttt_norm_weight", "ttt_norm_bias", "W1", "b1", "W2", "b2")
 
-    @torch.no_grad()
     def forward_heads(self, hidden_states, freqs_cis, seq_metadata: SequenceMetadata, reverse: bool, h0: int, h1: int):
         """The layer restricted to heads ``[h0, h1)`` up to (not including) ``post_norm``: ``[B, L, D] -> [B, L, (h1-h0)*F]``.
         Every per-head parameter is sliced along its head dimension and the unchanged module code runs on the slice
