@@ -3,6 +3,7 @@
 #include "wave_emul.h"
 
 #include "ttt_lin16_body.h"
+#include "ttt_mlp16_body.h"
 
 using namespace ttt;
 
@@ -20,4 +21,10 @@ void emul_lin16_backward(const wv::Lin16Params* p, int n_bh) {
 }
 
 int emul_lin16_params_size() { return (int)sizeof(wv::Lin16Params); }
+
+// TTT-MLP forward scan (mini-batch 16): one emulated 8-wave workgroup per (b, h)
+void emul_mlp16_forward(const wv::Mlp16Params* p, int n_bh) {
+    for (int bh = 0; bh < n_bh; ++bh) emul::run_group(8, [&](emul::EmulWave& w) { mlp16::forward(w, *p, bh); });
+}
+int emul_mlp16_params_size() { return (int)sizeof(wv::Mlp16Params); }
 }

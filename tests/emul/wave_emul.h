@@ -1,4 +1,4 @@
-// Host-side emulation of ONE gfx950 wavefront for the wave-level kernel bodies of csrc/ttt_lin16_body.h (TEST
+// Host-side emulation of gfx950 wavefronts / workgroups for the kernel bodies of csrc/ttt_lin16_body.h, ttt_mlp16_body.h (TEST
 // INFRASTRUCTURE: lets the CPU test-suite execute the very same kernel body, lane by lane, and compare it with the oracle
 // when no GPU is at hand).  64 host threads play the 64 lanes; every cross-lane primitive (MFMA, transposed LDS read, DPP
 // row reduction) is a rendezvous: deposit operands, barrier, compute this lane's share of the result from everybody's
@@ -11,6 +11,7 @@
 #include <barrier>
 #include <cmath>
 #include <cstring>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -20,25 +21,39 @@ namespace ttt {
 namespace emul {
 using namespace ttt::wv;
 
-struct WaveShared {
+struct WaveShared {                                    // rendezvous state of one wave
     std::barrier<> bar{64};
-    alignas(16) char lds[160 * 1024];
     bf16x8 a8[64], b8[64];
     bf16x4 a4[64], b4[64];
     float f[64];
 };
 
+struct GroupShared {                                   // one workgroup: LDS + a barrier over all of its threads
+    alignas(16) char lds[160 * 1024];
+    std::barrier<> bar;
+    std::vector<std::unique_ptr<WaveShared>> waves;
+    explicit GroupShared(int n_waves) : bar(64 * n_waves) {
+        for (int w = 0; w < n_waves; ++w) waves.emplace_back(new WaveShared());
+    }
+};
+
 struct EmulWave {
+    GroupShared* grp;
     WaveShared* sh;
-    int l;
+    int l, w;
 
     int lane() const { return l; }
+    int wave() const { return w; }
+    int thread() const { return 64 * w + l; }
     int opaque(int v) const { return v; }
     void sync() { sh->bar.arrive_and_wait(); }
+    void barrier() { grp->bar.arrive_and_wait(); }     // __syncthreads()
     void lds_fence() { sync(); }                       // same-wave LDS write -> read ordering point (free on the device)
-    template <class T> T& lds(int byte_off) { return *reinterpret_cast<T*>(sh->lds + byte_off); }
-    char* lds_ptr(int byte_off) { return sh->lds + byte_off; }
+    template <class T> T& lds(int byte_off) { return *reinterpret_cast<T*>(grp->lds + byte_off); }
+    char* lds_ptr(int byte_off) { return grp->lds + byte_off; }
     float rsq(float x) const { return 1.0f / std::sqrt(x); }
+    float exp2(float x) const { return std::exp2(x); }
+    float rcp(float x) const { return 1.0f / x; }
 
     f32x4 mma32(bf16x8 a, bf16x8 b, f32x4 c) {
         sh->a8[l] = a; sh->b8[l] = b;
@@ -68,8 +83,8 @@ struct EmulWave {
     }
     // ds_read_b64_tr_b16 with this lane's byte address into LDS
     bf16x4 tr_read(int byte_addr) {
-        sync();                                          // earlier LDS writes of every lane have landed
-        sh->a4[l] = *reinterpret_cast<const bf16x4*>(sh->lds + byte_addr);
+        sync();                                          // earlier LDS writes of every lane of the wave have landed
+        sh->a4[l] = *reinterpret_cast<const bf16x4*>(grp->lds + byte_addr);
         sync();
         const int base = l & ~15, i = l & 15;
         bf16x4 r;
@@ -94,19 +109,22 @@ struct EmulWave {
     }
 };
 
-// run `body(EmulWave&)` on 64 lanes
+// run `body(EmulWave&)` on the 64 * n_waves threads of one workgroup
 template <class F>
-void run_wave(F body) {
-    WaveShared* sh = new WaveShared();
+void run_group(int n_waves, F body) {
+    GroupShared* grp = new GroupShared(n_waves);
     std::vector<std::thread> th;
-    for (int l = 0; l < 64; ++l)
-        th.emplace_back([sh, l, &body] {
-            EmulWave w{sh, l};
-            body(w);
-        });
+    for (int w = 0; w < n_waves; ++w)
+        for (int l = 0; l < 64; ++l)
+            th.emplace_back([grp, w, l, &body] {
+                EmulWave bk{grp, grp->waves[w].get(), l, w};
+                body(bk);
+            });
     for (auto& t : th) t.join();
-    delete sh;
+    delete grp;
 }
+template <class F>
+void run_wave(F body) { run_group(1, body); }
 
 }  // namespace emul
 }  // namespace ttt

@@ -33,7 +33,7 @@ def emul():
     os.makedirs(build, exist_ok=True)
     so = os.path.join(build, "liblin16_emul.so")
     srcs = [os.path.join(HERE, "emul", f) for f in ("lin16_emul.cpp", "wave_emul.h")] + \
-           [os.path.join(ROOT, "ttt-video-dit_amd", "csrc", f) for f in ("ttt_lin16_body.h", "ttt_wave_types.h")]
+           [os.path.join(ROOT, "ttt-video-dit_amd", "csrc", f) for f in ("ttt_lin16_body.h", "ttt_mlp16_body.h", "ttt_wave_types.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call([CLANG, "-std=c++20", "-O1", "-pthread", "-shared", "-fPIC", "-Wno-unknown-pragmas",
                                "-I", os.path.join(ROOT, "ttt-video-dit_amd", "csrc"), "-I", os.path.join(HERE, "emul"),
@@ -128,3 +128,43 @@ def test_emulated_linear_backward_vs_oracle(emul, shape, lds_slots):
     errs = {k: rel_l2(g[k], rg[k].reshape(g[k].shape) if k in ("dln_w", "dln_b") else rg[k]) for k in g}
     print("emulated linear backward errors", shape, {k: round(v, 5) for k, v in errs.items()})
     assert all(v < 3e-2 for v in errs.values()), errs
+
+
+# ---------------------------------------------------------------------------------------------- TTT-MLP, mini-batch 16
+class MlpParams(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in
+                ("XQ", "XK", "XV", "eta", "ln_w", "ln_b", "W1", "b1", "W2", "b2", "W1c", "b1c", "W2c", "b2c", "out")] + \
+               [(n, ctypes.c_int) for n in ("NH", "NC", "G", "K")] + [("eps", ctypes.c_float)]
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1, 1), (1, 2, 5, 2), (2, 1, 4, 4)])
+def test_emulated_mlp_scan16_forward_vs_oracle(emul, shape):
+    """The 8-wave / two-barriers-per-step TTT-MLP forward scan body (csrc/ttt_mlp16_body.h) on the multi-wave emulator (512
+    host threads) vs the fp64 oracle: output, checkpoints."""
+    assert emul.emul_mlp16_params_size() == ctypes.sizeof(MlpParams)
+    B, NH, NC, G = shape
+    d = O.make_inputs("mlp", B, NH, NC, 16, 64, seed=41 + NC)
+    for k in ("XQ", "XK", "XV", "eta", "dOut"):
+        d[k] = d[k].to(torch.bfloat16).to(torch.float32)
+    K = -(-NC // G)
+    bf = lambda t: t.to(torch.bfloat16).contiguous()
+    XQ, XK, XV = bf(d["XQ"]), bf(d["XK"]), bf(d["XV"])
+    eta = bf(d["eta"][:, :, :, -1, :, None])
+    st = {k: v.float().contiguous() for k, v in tile_states(d, B).items()}
+    lw, lb = d["ln_w"].float().contiguous(), d["ln_b"].float().contiguous()
+    nan = lambda *s: torch.full(s, float("nan"))
+    cks = (nan(B, NH, K, 64, 256), nan(B, NH, K, 1, 256), nan(B, NH, K, 256, 64), nan(B, NH, K, 1, 64))
+    out = torch.full((B, NH, NC, 16, 64), float("nan"), dtype=torch.bfloat16)
+    p = MlpParams()
+    for n, t in dict(XQ=XQ, XK=XK, XV=XV, eta=eta, ln_w=lw, ln_b=lb, W1=st["W1"], b1=st["b1"], W2=st["W2"], b2=st["b2"],
+                     W1c=cks[0], b1c=cks[1], W2c=cks[2], b2c=cks[3], out=out).items():
+        setattr(p, n, t.data_ptr())
+    p.NH, p.NC, p.G, p.K, p.eps = NH, NC, G, K, 1e-8
+    emul.emul_mlp16_forward(ctypes.byref(p), B * NH)
+    d64 = {k: v.double() for k, v in d.items()}
+    s64 = tile_states(d64, B)
+    ro, rc, _ = O.mlp_forward(d64["XQ"], d64["XK"], d64["XV"], d64["eta"][:, :, :, -1, :, None], d64["ln_w"], d64["ln_b"],
+                              s64["W1"], s64["b1"], s64["W2"], s64["b2"], G)
+    assert rel_l2(out, ro) < 1e-2
+    for c, r in zip(cks, rc):
+        assert rel_l2(c, r) < 1e-2

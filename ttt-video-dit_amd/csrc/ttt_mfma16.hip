@@ -37,6 +37,7 @@
 #include "ttt_mfma_int.h"
 #define TTT_WV_FN __device__ __forceinline__
 #include "ttt_lin16_body.h"
+#include "ttt_mlp16_body.h"
 
 namespace ttt {
 namespace mfma {
@@ -429,6 +430,11 @@ __global__ __launch_bounds__(NT16) void mlp_scan16_kernel(ScanParams p) {
 struct DeviceWave {
     char* base;                                                       // this wave's private LDS region
     __device__ __forceinline__ int lane() const { return threadIdx.x & 63; }
+    __device__ __forceinline__ int wave() const { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
+    __device__ __forceinline__ int thread() const { return threadIdx.x; }
+    __device__ __forceinline__ void barrier() const { __syncthreads(); }
+    __device__ __forceinline__ float exp2(float x) const { return __builtin_amdgcn_exp2f(x); }
+    __device__ __forceinline__ float rcp(float x) const { return __builtin_amdgcn_rcpf(x); }
     __device__ __forceinline__ int opaque(int v) const { asm volatile("" : "+v"(v)); return v; }
     __device__ __forceinline__ void lds_fence() const { asm volatile("" ::: "memory"); }    // LDS is in order within a wave
     template <class T> __device__ __forceinline__ T& lds(int byte_off) const { return *reinterpret_cast<T*>(base + byte_off); }
@@ -456,6 +462,14 @@ __global__ __launch_bounds__(64 * LIN_WAVES) void linear_scan16_kernel(wv::Lin16
     if (bh >= n_bh) return;                                          // whole wave; no barriers in this kernel
     DeviceWave bk{smem + w * lin16::WAVE_LDS};
     lin16::forward(bk, p, bh);
+}
+
+// TTT-MLP forward scan as the backend-templated workgroup body (ttt_mlp16_body.h): opt-in variant of mlp_scan16_kernel
+// (debug option "scan16_body") until it has been timed against it on an MI355X
+__global__ __launch_bounds__(NT16) void mlp_scan16_body_kernel(wv::Mlp16Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    DeviceWave bk{smem};
+    mlp16::forward(bk, p, blockIdx.x);
 }
 
 // backward: one wave per workgroup (48 .. 96 scans on 256 CUs: a CU of its own per scan; up to 512 registers per lane)
@@ -503,6 +517,19 @@ void launch_scan_forward_cs16(const ScanParams& p0, int n_bh, unsigned long long
     ScanParams p = p0;
     p.dbg = dbg;
     v16::set_attr_once();
+    if (get_debug_scan16_body()) {
+        static bool done = false;
+        if (!done) {
+            (void)hipFuncSetAttribute((const void*)v16::mlp_scan16_body_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, mlp16::GROUP_LDS);
+            done = true;
+        }
+        wv::Mlp16Params q = {};
+        q.XQ = p.XQ; q.XK = p.XK; q.XV = p.XV; q.eta = p.eta; q.ln_w = p.ln_w; q.ln_b = p.ln_b;
+        q.W1 = p.W1; q.b1 = p.b1; q.W2 = p.W2; q.b2 = p.b2; q.W1c = p.W1c; q.b1c = p.b1c; q.W2c = p.W2c; q.b2c = p.b2c;
+        q.out = p.out; q.NH = p.NH; q.NC = p.NC; q.G = p.G; q.K = p.K; q.eps = p.eps;
+        hipLaunchKernelGGL(v16::mlp_scan16_body_kernel, dim3(n_bh), dim3(v16::NT16), mlp16::GROUP_LDS, s, q);
+        return;
+    }
     if (p.dbg) hipLaunchKernelGGL(v16::mlp_scan16_kernel<true>, dim3(n_bh), dim3(v16::NT16), v16::LDS_V16, s, p);
     else hipLaunchKernelGGL(v16::mlp_scan16_kernel<false>, dim3(n_bh), dim3(v16::NT16), v16::LDS_V16, s, p);
 }

@@ -542,6 +542,9 @@ int get_debug_lead() { return g_lead; }
 static int g_lin_lds_slots = 0;       // TTT-Linear backward (CS = 16): per-step state slots kept in LDS; unmeasured -> off
 void set_debug_lin_lds_slots(int n) { g_lin_lds_slots = n; }
 int get_debug_lin_lds_slots() { return g_lin_lds_slots; }
+static int g_scan16_body = 0;         // CS = 16 TTT-MLP forward: the backend-templated body instead of the hand-placed kernel
+void set_debug_scan16_body(int v) { g_scan16_body = v; }
+int get_debug_scan16_body() { return g_scan16_body; }
 static int g_helpers = -1;
 void set_debug_helpers(int n) { g_helpers = n; }
 int get_debug_helpers() { return g_helpers; }

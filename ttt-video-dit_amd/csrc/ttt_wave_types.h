@@ -32,5 +32,16 @@ struct Lin16Params {
     int lds_slots;                          // backward: how many of a group's per-step state slots live in LDS instead of scratch_w
 };
 
+// arguments of the TTT-MLP forward scan at mini-batches of 16 tokens (F = 64, hidden 256)
+struct Mlp16Params {
+    const __bf16 *XQ, *XK, *XV, *eta;
+    const float *ln_w, *ln_b;               // [NH,64] (also addressed as [1,NH,1,64])
+    const float *W1, *b1, *W2, *b2;         // initial state [B,NH,64,256], [B,NH,1,256], [B,NH,256,64], [B,NH,1,64]
+    float *W1c, *b1c, *W2c, *b2c;           // checkpoints [B,NH,K,...]
+    __bf16* out;
+    int NH, NC, G, K;
+    float eps;
+};
+
 }  // namespace wv
 }  // namespace ttt
