@@ -101,17 +101,34 @@ class SeqParallel:
         """head shard over the full sequence [B, L, (NH/T)*F] -> token shard with every head [B, ceil(L/T), NH*F]."""
         return _HeadsToTokens.apply(x, self)
 
-    def sum_gradients(self, module: torch.nn.Module) -> None:
-        """After backward: add up the partial parameter gradients of the ranks (one flat all-reduce)."""
-        grads = [p.grad for p in module.parameters() if p.grad is not None]
-        if not grads:
-            return
-        flat = torch.cat([g.reshape(-1) for g in grads])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-        o = 0
-        for g in grads:
-            g.copy_(flat[o:o + g.numel()].view_as(g))
-            o += g.numel()
+    def sum_gradients(self, module: torch.nn.Module, bucket_bytes: int = 512 << 20) -> None:
+        """After backward: add up the partial parameter gradients of the ranks, in flat buckets of ``bucket_bytes`` (few,
+        large all-reduces: the xGMI links are point-to-point, a ring all-reduce is per-link bound)."""
+        bucket, size = [], 0
+
+        def flush():
+            nonlocal bucket, size
+            if not bucket:
+                return
+            flat = torch.cat([g.reshape(-1) for g in bucket])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            o = 0
+            for g in bucket:
+                g.copy_(flat[o:o + g.numel()].view_as(g))
+                o += g.numel()
+            bucket, size = [], 0
+
+        by_dtype = {}
+        for p in module.parameters():
+            if p.grad is not None:
+                by_dtype.setdefault(p.grad.dtype, []).append(p.grad)
+        for grads in by_dtype.values():
+            for g in grads:
+                bucket.append(g)
+                size += g.numel() * g.element_size()
+                if size >= bucket_bytes:
+                    flush()
+            flush()
 
 
 class _Gather(torch.autograd.Function):
