@@ -74,7 +74,7 @@ def _worker(rank, world, port, case, out_dir):
     # partial per rank (its tokens / its heads) and summed over the group
     loss = _loss(m(*inputs))
     loss.backward()
-    sp.sum_gradients(m)
+    sp.sum_gradients(m, bucket_bytes=1 << 14)          # several buckets
     if rank == 0:
         torch.save({"loss": loss.detach(), "grads": {n: p.grad for n, p in m.named_parameters() if p.grad is not None}},
                    os.path.join(out_dir, "sp_train.pt"))
