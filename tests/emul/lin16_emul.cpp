@@ -27,4 +27,34 @@ void emul_mlp16_forward(const wv::Mlp16Params* p, int n_bh) {
     for (int bh = 0; bh < n_bh; ++bh) emul::run_group(8, [&](emul::EmulWave& w) { mlp16::forward(w, *p, bh); });
 }
 int emul_mlp16_params_size() { return (int)sizeof(wv::Mlp16Params); }
+
+// self-test of the emulated MFMA shapes: D = A B for A [M x K], B [K x N] given row-major in fp32 (rounded to bf16 inside)
+void emul_mfma_selftest(int shape, const float* A, const float* B, float* D) {
+    emul::run_wave([&](emul::EmulWave& w) {
+        const int l = w.lane();
+        if (shape == 0) {            // 16x16x32
+            const int g = l >> 4, i = l & 15;
+            wv::bf16x8 a, b;
+            for (int e = 0; e < 8; ++e) { a[e] = (__bf16)A[i * 32 + 8 * g + e]; b[e] = (__bf16)B[(8 * g + e) * 16 + i]; }
+            wv::f32x4 c = {0.f, 0.f, 0.f, 0.f};
+            c = w.mma32(a, b, c);
+            for (int r = 0; r < 4; ++r) D[(4 * g + r) * 16 + i] = c[r];
+        } else if (shape == 1) {     // 16x16x16
+            const int g = l >> 4, i = l & 15;
+            wv::bf16x4 a, b;
+            for (int e = 0; e < 4; ++e) { a[e] = (__bf16)A[i * 16 + 4 * g + e]; b[e] = (__bf16)B[(4 * g + e) * 16 + i]; }
+            wv::f32x4 c = {0.f, 0.f, 0.f, 0.f};
+            c = w.mma16(a, b, c);
+            for (int r = 0; r < 4; ++r) D[(4 * g + r) * 16 + i] = c[r];
+        } else {                     // 32x32x16
+            const int h = l >> 5, c0 = l & 31;
+            wv::bf16x8 a, b;
+            for (int e = 0; e < 8; ++e) { a[e] = (__bf16)A[c0 * 16 + 8 * h + e]; b[e] = (__bf16)B[(8 * h + e) * 32 + c0]; }
+            wv::f32x16 c;
+            for (int r = 0; r < 16; ++r) c[r] = 0.f;
+            c = w.mma3216(a, b, c);
+            for (int r = 0; r < 16; ++r) D[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + c0] = c[r];
+        }
+    });
+}
 }

@@ -5,6 +5,7 @@
 // operands, barrier.  Lane / register layouts are those of the hardware instructions:
 //   v_mfma_f32_16x16x32_bf16 : A lane (g,i) = A[i][8g+e], B lane (g,i) = B[8g+e][i], D lane (g,i) = D[4g+r][i]
 //   v_mfma_f32_16x16x16_bf16 : A lane (g,i) = A[i][4g+e], B lane (g,i) = B[4g+e][i], D as above
+//   v_mfma_f32_32x32x16_bf16 : A lane (h,c) = A[c][8h+e], B lane (h,c) = B[8h+e][c], D lane (h,c) = D[(r&3)+8(r>>2)+4h][c], r < 16
 //   ds_read_b64_tr_b16       : within a 16-lane group, lane i receives element (i & 3) of the 8-byte chunks addressed by
 //                              lanes 4e + (i >> 2), e = 0..3   (probe: tools/probe_tr.hip)
 #pragma once
@@ -80,6 +81,29 @@ struct EmulWave {
         }
         sync();
         return c;
+    }
+    // v_mfma_f32_32x32x16_bf16 (the CS = 64 kernels' shape; lane (h, c) = (l >> 5, l & 31))
+    f32x16 mma3216(bf16x8 a, bf16x8 b, f32x16 c) {
+        sh->a8[l] = a; sh->b8[l] = b;
+        sync();
+        const int h = l >> 5, col = l & 31;
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            float acc = 0.f;
+            for (int hk = 0; hk < 2; ++hk)
+                for (int e = 0; e < 8; ++e) acc += (float)sh->a8[32 * hk + row][e] * (float)sh->b8[32 * hk + col][e];
+            c[r] += acc;
+        }
+        sync();
+        return c;
+    }
+    float sum8(float v) {                                // sum over the aligned group of 8 lanes (quad_perm x2 + row_half_mirror)
+        sh->f[l] = v;
+        sync();
+        float s = 0.f;
+        for (int j = 0; j < 8; ++j) s += sh->f[(l & ~7) + j];
+        sync();
+        return s;
     }
     // ds_read_b64_tr_b16 with this lane's byte address into LDS
     bf16x4 tr_read(int byte_addr) {

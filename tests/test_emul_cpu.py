@@ -168,3 +168,15 @@ def test_emulated_mlp_scan16_forward_vs_oracle(emul, shape):
     assert rel_l2(out, ro) < 1e-2
     for c, r in zip(cks, rc):
         assert rel_l2(c, r) < 1e-2
+
+
+@pytest.mark.parametrize("shape,M,N,K", [(0, 16, 16, 32), (1, 16, 16, 16), (2, 32, 32, 16)])
+def test_emulated_mfma_shapes_are_matmuls(emul, shape, M, N, K):
+    """The emulator's MFMA fragment layouts (the same lane / register maps the kernels are written against) really compute
+    D = A B: 16x16x32, 16x16x16 and the 32x32x16 shape of the CS = 64 kernels."""
+    g = torch.Generator().manual_seed(shape)
+    A, B = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g)
+    D = torch.full((M, N), float("nan"))
+    emul.emul_mfma_selftest(shape, ctypes.c_void_p(A.data_ptr()), ctypes.c_void_p(B.data_ptr()), ctypes.c_void_p(D.data_ptr()))
+    ref = A.bfloat16().float() @ B.bfloat16().float()
+    assert torch.allclose(D, ref, atol=1e-5, rtol=1e-5)
