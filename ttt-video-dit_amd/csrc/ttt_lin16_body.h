@@ -339,14 +339,12 @@ TTT_WV_FN void backward(BK& bk, const Lin16Params& p, int bh) {
     const size_t tile0 = (size_t)bh * NC;
     char* scr_w = p.scratch_w + (size_t)bh * G * SLOT_BYTES;
     float* scr_b = p.scratch_b + (size_t)bh * G * 64;
-    // state slot j of the group: the caller's scratch (L2-resident), or - LDS_SLOTS variant, unmeasured so far and therefore
-    // opt-in (debug option "linear_bwd_lds_slots") - LDS for the first p.lds_slots of them
-    const int n_lds = LDS_SLOTS ? (p.lds_slots < MAX_LDS_SLOTS ? p.lds_slots : MAX_LDS_SLOTS) : 0;
-    auto slot_ptr = [&](int j) -> char* {
-        if constexpr (LDS_SLOTS) {
-            if (j < n_lds) return bk.lds_ptr(L_SLOTS + j * SLOT_BYTES);
-        }
-        return scr_w + (size_t)j * SLOT_BYTES;
+    // state slot j of the group: the caller's scratch (L2-resident) or - LDS_SLOTS variant, unmeasured so far and therefore
+    // opt-in (debug option "linear_bwd_lds_slots") - LDS for the first p.lds_slots of them.  The default instantiation is kept
+    // textually identical to the code that was validated on the hardware.
+    [[maybe_unused]] const int n_lds = LDS_SLOTS ? (p.lds_slots < MAX_LDS_SLOTS ? p.lds_slots : MAX_LDS_SLOTS) : 0;
+    [[maybe_unused]] auto slot_ptr = [&](int j) -> char* {
+        return j < n_lds ? bk.lds_ptr(L_SLOTS + j * SLOT_BYTES) : scr_w + (size_t)j * SLOT_BYTES;
     };
 
     float gam[4], bet[4];
@@ -418,7 +416,9 @@ TTT_WV_FN void backward(BK& bk, const Lin16Params& p, int bh) {
                 const bool fin = (it == hi), last = (it + 1 == hi);
                 bf16x8 WF[2][4];
                 {
-                    char* slot = fin ? bk.lds_ptr(L_WHI) : slot_ptr(it - lo);
+                    char* slot;
+                    if constexpr (LDS_SLOTS) slot = fin ? bk.lds_ptr(L_WHI) : slot_ptr(it - lo);
+                    else slot = fin ? bk.lds_ptr(L_WHI) : scr_w + (size_t)(it - lo) * SLOT_BYTES;
                     bf16x8 WT[2][4];
                     transposed_packs(bk, W1t, WT);
 #pragma unroll
@@ -503,8 +503,14 @@ TTT_WV_FN void backward(BK& bk, const Lin16Params& p, int bh) {
                     stage_request(bk, sd, p.dOut + (tile0 + nxt) * 1024);
                 }
             }
-            const char* slot = slot_ptr(it - lo);                                                         // state entering the step
-            const char* slot_n = (it + 1 < hi) ? slot_ptr(it + 1 - lo) : bk.lds_ptr(L_WHI);              // state after the step
+            const char *slot, *slot_n;                                                                    // state entering / after the step
+            if constexpr (LDS_SLOTS) {
+                slot = slot_ptr(it - lo);
+                slot_n = (it + 1 < hi) ? slot_ptr(it + 1 - lo) : bk.lds_ptr(L_WHI);
+            } else {
+                slot = scr_w + (size_t)(it - lo) * SLOT_BYTES;
+                slot_n = (it + 1 < hi) ? slot + SLOT_BYTES : bk.lds_ptr(L_WHI);
+            }
             const f32x4 eta4 = bk.template lds<f32x4>(L_ETA + (buf * 16 + 4 * g) * 4);
             float b1v[4], b1n[4];
 #pragma unroll
