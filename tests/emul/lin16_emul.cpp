@@ -1,5 +1,7 @@
 // Host build of the TTT-Linear (mini-batch 16) wave-level kernel bodies on the wave emulator: TEST INFRASTRUCTURE, compiled
 // on the fly by tests/test_emul_cpu.py with the host clang of the ROCm toolchain.  Every (b, h) scan is one emulated wave.
+#include <cstdio>
+
 #include "wave_emul.h"
 
 #include "ttt_lin16_body.h"
@@ -23,8 +25,33 @@ void emul_lin16_backward(const wv::Lin16Params* p, int n_bh) {
 int emul_lin16_params_size() { return (int)sizeof(wv::Lin16Params); }
 
 // TTT-MLP forward scan (mini-batch 16): one emulated 8-wave workgroup per (b, h)
-void emul_mlp16_forward(const wv::Mlp16Params* p, int n_bh) {
-    for (int bh = 0; bh < n_bh; ++bh) emul::run_group(8, [&](emul::EmulWave& w) { mlp16::forward(w, *p, bh); });
+// returns the number of LDS races the detector saw (0 expected); the first one is described in `msg`
+int emul_mlp16_forward(const wv::Mlp16Params* p, int n_bh, char* msg, int msg_len) {
+    int races = 0;
+    for (int bh = 0; bh < n_bh; ++bh) {
+        const emul::RaceReport r = emul::run_group(8, [&](emul::EmulWave& w) { mlp16::forward(w, *p, bh); });
+        if (r.races && !races && msg) snprintf(msg, msg_len, "%s", r.first.c_str());
+        races += r.races;
+    }
+    return races;
+}
+
+// a deliberately broken exchange between two waves: mode 0 = correct (barrier between write and read), 1 = the barrier is
+// missing (read-after-write race), 2 = both waves write the same words in one epoch, 3 = the buffer is rewritten while the
+// other wave may still be reading it (write-after-read: a missing second barrier)
+int emul_race_selftest(int mode, char* msg, int msg_len) {
+    const emul::RaceReport r = emul::run_group(2, [&](emul::EmulWave& w) {
+        const int other = 1 - w.wave();
+        w.lds_store<float>((64 * (mode == 2 ? 0 : w.wave()) + w.lane()) * 4, 1.0f);
+        if (mode != 1) w.barrier();
+        volatile float x = w.lds_load<float>((64 * other + w.lane()) * 4);
+        (void)x;
+        if (mode != 3) w.barrier();
+        w.lds_store<float>((64 * w.wave() + w.lane()) * 4, 2.0f);
+        w.barrier();
+    });
+    if (r.races && msg) snprintf(msg, msg_len, "%s", r.first.c_str());
+    return r.races;
 }
 int emul_mlp16_params_size() { return (int)sizeof(wv::Mlp16Params); }
 

@@ -13,6 +13,8 @@
 #include <cmath>
 #include <cstring>
 #include <memory>
+#include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -29,12 +31,44 @@ struct WaveShared {                                    // rendezvous state of on
     float f[64];
 };
 
+// LDS race detector: every 4-byte word remembers its last tracked write and read as (barrier epoch, wave).  Two accesses
+// of DIFFERENT waves to a word within the SAME epoch (no workgroup barrier between them), at least one of them a write,
+// are a race on the hardware however the host threads happened to interleave here.  Accesses of one wave are ordered
+// (LDS is in order within a wave).  Tracked: lds_load / lds_store / tr_read; untracked: lds<T>() references and lds_ptr().
+struct Shadow {
+    int w_epoch = -1, w_wave = -1, r_epoch = -1, r_wave = -1;      // r_wave = -2: several waves read it in r_epoch
+};
 struct GroupShared {                                   // one workgroup: LDS + a barrier over all of its threads
     alignas(16) char lds[160 * 1024];
     std::barrier<> bar;
     std::vector<std::unique_ptr<WaveShared>> waves;
-    explicit GroupShared(int n_waves) : bar(64 * n_waves) {
+    std::vector<Shadow> shadow;
+    std::mutex shadow_mu[256];
+    std::mutex report_mu;
+    std::string first_race;
+    int races = 0;
+    explicit GroupShared(int n_waves) : bar(64 * n_waves), shadow(sizeof(lds) / 4) {
         for (int w = 0; w < n_waves; ++w) waves.emplace_back(new WaveShared());
+    }
+    void report(const char* what, int word, int epoch, int wave, int other) {
+        std::lock_guard<std::mutex> g(report_mu);
+        if (races++ == 0)
+            first_race = std::string(what) + " at LDS byte " + std::to_string(4 * word) + ", epoch " + std::to_string(epoch) + ": wave " +
+                         std::to_string(wave) + " vs wave " + std::to_string(other);
+    }
+    void track(int byte_off, int bytes, bool write, int epoch, int wave) {
+        for (int word = byte_off / 4; word <= (byte_off + bytes - 1) / 4; ++word) {
+            std::lock_guard<std::mutex> g(shadow_mu[word & 255]);
+            Shadow& s = shadow[word];
+            if (s.w_epoch == epoch && s.w_wave != wave) report(write ? "write after write" : "read after write", word, epoch, wave, s.w_wave);
+            if (write) {
+                if (s.r_epoch == epoch && s.r_wave != wave) report("write after read", word, epoch, wave, s.r_wave);
+                s.w_epoch = epoch; s.w_wave = wave;
+            } else {
+                if (s.r_epoch == epoch) { if (s.r_wave != wave) s.r_wave = -2; }
+                else { s.r_epoch = epoch; s.r_wave = wave; }
+            }
+        }
     }
 };
 
@@ -42,16 +76,25 @@ struct EmulWave {
     GroupShared* grp;
     WaveShared* sh;
     int l, w;
+    int epoch = 0;                                     // workgroup barriers passed so far
 
     int lane() const { return l; }
     int wave() const { return w; }
     int thread() const { return 64 * w + l; }
     int opaque(int v) const { return v; }
     void sync() { sh->bar.arrive_and_wait(); }
-    void barrier() { grp->bar.arrive_and_wait(); }     // __syncthreads()
+    void barrier() { grp->bar.arrive_and_wait(); ++epoch; }     // __syncthreads()
     void lds_fence() { sync(); }                       // same-wave LDS write -> read ordering point (free on the device)
     template <class T> T& lds(int byte_off) { return *reinterpret_cast<T*>(grp->lds + byte_off); }
     char* lds_ptr(int byte_off) { return grp->lds + byte_off; }
+    template <class T> T lds_load(int byte_off) {      // tracked by the race detector
+        grp->track(byte_off, (int)sizeof(T), false, epoch, w);
+        return *reinterpret_cast<const T*>(grp->lds + byte_off);
+    }
+    template <class T> void lds_store(int byte_off, T v) {
+        grp->track(byte_off, (int)sizeof(T), true, epoch, w);
+        *reinterpret_cast<T*>(grp->lds + byte_off) = v;
+    }
     float rsq(float x) const { return 1.0f / std::sqrt(x); }
     float exp2(float x) const { return std::exp2(x); }
     float rcp(float x) const { return 1.0f / x; }
@@ -108,6 +151,7 @@ struct EmulWave {
     // ds_read_b64_tr_b16 with this lane's byte address into LDS
     bf16x4 tr_read(int byte_addr) {
         sync();                                          // earlier LDS writes of every lane of the wave have landed
+        grp->track(byte_addr, 8, false, epoch, w);
         sh->a4[l] = *reinterpret_cast<const bf16x4*>(grp->lds + byte_addr);
         sync();
         const int base = l & ~15, i = l & 15;
@@ -134,8 +178,12 @@ struct EmulWave {
 };
 
 // run `body(EmulWave&)` on the 64 * n_waves threads of one workgroup
+struct RaceReport {
+    int races = 0;
+    std::string first;
+};
 template <class F>
-void run_group(int n_waves, F body) {
+RaceReport run_group(int n_waves, F body) {
     GroupShared* grp = new GroupShared(n_waves);
     std::vector<std::thread> th;
     for (int w = 0; w < n_waves; ++w)
@@ -145,7 +193,9 @@ void run_group(int n_waves, F body) {
                 body(bk);
             });
     for (auto& t : th) t.join();
+    RaceReport r{grp->races, grp->first_race};
     delete grp;
+    return r;
 }
 template <class F>
 void run_wave(F body) { run_group(1, body); }

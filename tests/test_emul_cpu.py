@@ -35,7 +35,7 @@ def emul():
     srcs = [os.path.join(HERE, "emul", f) for f in ("lin16_emul.cpp", "wave_emul.h")] + \
            [os.path.join(ROOT, "ttt-video-dit_amd", "csrc", f) for f in ("ttt_lin16_body.h", "ttt_mlp16_body.h", "ttt_wave_types.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        subprocess.check_call([CLANG, "-std=c++20", "-O1", "-pthread", "-shared", "-fPIC", "-Wno-unknown-pragmas",
+        subprocess.check_call([CLANG, "-std=c++20", "-O1", "-pthread", "-shared", "-fPIC", "-Wno-unknown-pragmas", "-Wno-psabi",
                                "-I", os.path.join(ROOT, "ttt-video-dit_amd", "csrc"), "-I", os.path.join(HERE, "emul"),
                                srcs[0], "-o", so])
     lib = ctypes.CDLL(so)
@@ -160,7 +160,9 @@ def test_emulated_mlp_scan16_forward_vs_oracle(emul, shape):
                      W1c=cks[0], b1c=cks[1], W2c=cks[2], b2c=cks[3], out=out).items():
         setattr(p, n, t.data_ptr())
     p.NH, p.NC, p.G, p.K, p.eps = NH, NC, G, K, 1e-8
-    emul.emul_mlp16_forward(ctypes.byref(p), B * NH)
+    msg = ctypes.create_string_buffer(256)
+    races = emul.emul_mlp16_forward(ctypes.byref(p), B * NH, msg, 256)
+    assert races == 0, f"LDS race between waves (hazard analysis of the two-barrier schedule violated): {msg.value.decode()}"
     d64 = {k: v.double() for k, v in d.items()}
     s64 = tile_states(d64, B)
     ro, rc, _ = O.mlp_forward(d64["XQ"], d64["XK"], d64["XV"], d64["eta"][:, :, :, -1, :, None], d64["ln_w"], d64["ln_b"],
@@ -180,3 +182,16 @@ def test_emulated_mfma_shapes_are_matmuls(emul, shape, M, N, K):
     emul.emul_mfma_selftest(shape, ctypes.c_void_p(A.data_ptr()), ctypes.c_void_p(B.data_ptr()), ctypes.c_void_p(D.data_ptr()))
     ref = A.bfloat16().float() @ B.bfloat16().float()
     assert torch.allclose(D, ref, atol=1e-5, rtol=1e-5)
+
+
+def test_race_detector_flags_missing_barriers(emul):
+    """The emulator's LDS race detector on a two-wave exchange: clean with both barriers, and every way of breaking it
+    (missing barrier before the read, two writers in one epoch, rewrite before the readers are done) is reported."""
+    msg = ctypes.create_string_buffer(256)
+    assert emul.emul_race_selftest(0, msg, 256) == 0
+    # (which of the two racing accesses the host threads perform first decides whether a read/write race is reported as
+    # "read after write" or "write after read" - it is the same race)
+    for mode, kinds in ((1, ("read after write", "write after read")), (2, ("write after write",)),
+                        (3, ("write after read", "read after write"))):
+        assert emul.emul_race_selftest(mode, msg, 256) > 0
+        assert any(k in msg.value.decode() for k in kinds), (mode, msg.value.decode())

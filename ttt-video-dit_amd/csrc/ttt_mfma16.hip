@@ -439,6 +439,8 @@ struct DeviceWave {
     __device__ __forceinline__ void lds_fence() const { asm volatile("" ::: "memory"); }    // LDS is in order within a wave
     template <class T> __device__ __forceinline__ T& lds(int byte_off) const { return *reinterpret_cast<T*>(base + byte_off); }
     __device__ __forceinline__ char* lds_ptr(int byte_off) const { return base + byte_off; }
+    template <class T> __device__ __forceinline__ T lds_load(int byte_off) const { return *reinterpret_cast<const T*>(base + byte_off); }
+    template <class T> __device__ __forceinline__ void lds_store(int byte_off, T v) const { *reinterpret_cast<T*>(base + byte_off) = v; }
     __device__ __forceinline__ float rsq(float x) const { return __builtin_amdgcn_rsqf(x); }
     __device__ __forceinline__ f32x4 mma32(bf16x8 a, bf16x8 b, f32x4 c) const { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
     __device__ __forceinline__ f32x4 mma16(bf16x4 a, bf16x4 b, f32x4 c) const {

@@ -2,7 +2,8 @@
 // backend idea): 8 waves per (b, h), two barriers per step.  It restates the schedule of mlp_scan16_kernel (ttt_mfma16.hip,
 // where the step structure and the hazard analysis are documented) against the backend primitives plus
 //   bk.wave()  wave index in the workgroup,  bk.thread() = 64 wave + lane,  bk.barrier()  workgroup barrier,
-//   bk.exp2(x), bk.rcp(x)
+//   bk.exp2(x), bk.rcp(x),  bk.lds_load<T>(off) / bk.lds_store<T>(off, v)  (plain LDS accesses on the device; on the emulator
+//   they feed its LDS race detector: two waves touching a word without a workgroup barrier in between is reported)
 // so that the CPU suite can execute it on the multi-wave emulator (tests/emul).  STATUS: emulator-verified against the
 // oracle; on the device it is the opt-in variant `scan16_body` of ttt_hip_debug_option until it has been timed against the
 // hand-placed kernel on an MI355X.
@@ -14,7 +15,6 @@ namespace mlp16 {
 using namespace ttt::wv;
 using ttt::lin16::cat;
 using ttt::lin16::pack4;
-using ttt::lin16::rho_read;
 using ttt::lin16::stack;
 using ttt::lin16::tr4;
 using ttt::lin16::zero4;
@@ -27,6 +27,14 @@ constexpr int L_REDA = L_IMG + 8 * IMG_BYTES, RED_BYTES = 8 * CS * PS * 4, L_RED
 constexpr int L_ETA = L_REDB + RED_BYTES, L_B2 = L_ETA + 32 * 4, L_GAM = L_B2 + 64 * 4, L_BET = L_GAM + 64 * 4;
 constexpr int GROUP_LDS = L_BET + 64 * 4;
 static_assert(GROUP_LDS <= 160 * 1024 && L_IMG % 16 == 0 && L_REDA % 16 == 0 && L_ETA % 16 == 0, "LDS map");
+
+// rho-order operand from this lane's row of a row-major [16][TS] tile (tracked LDS loads: the race detector sees them)
+template <class BK>
+TTT_WV_FN bf16x8 rho_read(BK& bk, int tile_off, int c0) {
+    const int g = bk.lane() >> 4, i = bk.lane() & 15;
+    const int o = tile_off + (i * TS + c0 + 4 * g) * 2;
+    return cat(bk.template lds_load<bf16x4>(o), bk.template lds_load<bf16x4>(o + 32));
+}
 
 constexpr float GELU_A = 0.79788456f, GELU_C = 0.044715f, GELU_3AC = 0.1070322243f;
 constexpr float GELU_K0 = -2.0f * GELU_A * 1.4426950408889634f, GELU_K1 = GELU_K0 * GELU_C;
@@ -44,9 +52,9 @@ TTT_WV_FN float gelu_fwd(BK& bk, float x) { return x * bk.rcp(1.0f + bk.exp2(x *
 // owner thread (token ot, features of0 .. of0 + 3): bias + sum of the 8 waves' partials, then LayerNorm statistics
 template <class BK>
 TTT_WV_FN f32x4 gather8(BK& bk, int red_off, int ot, int of0) {
-    f32x4 z = bk.template lds<f32x4>(L_B2 + of0 * 4);
+    f32x4 z = bk.template lds_load<f32x4>(L_B2 + of0 * 4);
 #pragma unroll
-    for (int ww = 0; ww < 8; ++ww) z += bk.template lds<f32x4>(red_off + ((ww * CS + ot) * PS + of0) * 4);
+    for (int ww = 0; ww < 8; ++ww) z += bk.template lds_load<f32x4>(red_off + ((ww * CS + ot) * PS + of0) * 4);
     return z;
 }
 template <class BK>
@@ -86,9 +94,9 @@ TTT_WV_FN void forward(BK& bk, const Mlp16Params& p, int bh) {
 #pragma unroll
         for (int fb = 0; fb < 4; ++fb) b2v[fb] = p.b2[(size_t)bh * 64 + 16 * fb + i];
         if (tid0 < 64) {
-            bk.template lds<float>(L_B2 + tid0 * 4) = p.b2[(size_t)bh * 64 + tid0];
-            bk.template lds<float>(L_GAM + tid0 * 4) = p.ln_w[(size_t)head * 64 + tid0];
-            bk.template lds<float>(L_BET + tid0 * 4) = p.ln_b[(size_t)head * 64 + tid0];
+            bk.template lds_store<float>(L_B2 + tid0 * 4, p.b2[(size_t)bh * 64 + tid0]);
+            bk.template lds_store<float>(L_GAM + tid0 * 4, p.ln_w[(size_t)head * 64 + tid0]);
+            bk.template lds_store<float>(L_BET + tid0 * 4, p.ln_b[(size_t)head * 64 + tid0]);
         }
     }
     const bf16x4 ONES = {(__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f};
@@ -112,8 +120,8 @@ TTT_WV_FN void forward(BK& bk, const Mlp16Params& p, int bh) {
     unsigned short pfEO;
     {
         const u32x4 t0 = *reinterpret_cast<const u32x4*>(src + tile0 * 1024 + gofs);
-        if (which < 3) bk.template lds<u32x4>(dstb + lofs) = t0;
-        if (tid0 < 16) bk.template lds<float>(L_ETA + tid0 * 4) = (float)p.eta[tile0 * 16 + tid0];
+        if (which < 3) bk.template lds_store<u32x4>(dstb + lofs, t0);
+        if (tid0 < 16) bk.template lds_store<float>(L_ETA + tid0 * 4, (float)p.eta[tile0 * 16 + tid0]);
         const size_t t1 = tile0 + (NC > 1 ? 1 : 0);
         pfO = *reinterpret_cast<const u32x4*>(src + t1 * 1024 + gofs);
         pfEO = *reinterpret_cast<const unsigned short*>(p.eta + t1 * 16 + (tid0 & 15));
@@ -172,14 +180,14 @@ TTT_WV_FN void forward(BK& bk, const Mlp16Params& p, int bh) {
                     D1[nb][r] = dy;
                 }
                 X2p[nb] = pack4(Z);
-                bk.template lds<bf16x4>(img + ((16 * nb + i) * IS + 4 * g) * 2) = X2p[nb];
+                bk.template lds_store<bf16x4>(img + ((16 * nb + i) * IS + 4 * g) * 2, X2p[nb]);
             }
             bk.lds_fence();
             // A2: partial Z2^T[f, t] over this wave's hidden slice
             const bf16x8 xB = cat(tr4(bk, img, IS, 0, 0), tr4(bk, img, IS, 16, 0));           // lane = t, k = n (rho)
 #pragma unroll
             for (int fb = 0; fb < 4; ++fb)
-                bk.template lds<f32x4>(L_REDA + ((wv * CS + i) * PS + 4 * g + 16 * fb) * 4) = bk.mma32(W2F[fb], xB, zero4());
+                bk.template lds_store<f32x4>(L_REDA + ((wv * CS + i) * PS + 4 * g + 16 * fb) * 4, bk.mma32(W2F[fb], xB, zero4()));
         }
         bk.barrier();                 // B1
 
@@ -188,9 +196,9 @@ TTT_WV_FN void forward(BK& bk, const Mlp16Params& p, int bh) {
                 f32x4 z = gather8(bk, L_REDA, ot, of0);
                 float mu, rstd;
                 row_stats(bk, z, p.eps, mu, rstd);
-                const bf16x4 kk = bk.template lds<bf16x4>(Kt + (ot * TS + of0) * 2);
-                const bf16x4 vv = bk.template lds<bf16x4>(Vt + (ot * TS + of0) * 2);
-                const f32x4 gm = bk.template lds<f32x4>(L_GAM + of0 * 4), bt = bk.template lds<f32x4>(L_BET + of0 * 4);
+                const bf16x4 kk = bk.template lds_load<bf16x4>(Kt + (ot * TS + of0) * 2);
+                const bf16x4 vv = bk.template lds_load<bf16x4>(Vt + (ot * TS + of0) * 2);
+                const f32x4 gm = bk.template lds_load<f32x4>(L_GAM + of0 * 4), bt = bk.template lds_load<f32x4>(L_BET + of0 * 4);
                 float s1 = 0.f, s2 = 0.f, gx[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -201,26 +209,26 @@ TTT_WV_FN void forward(BK& bk, const Mlp16Params& p, int bh) {
                 }
                 s1 = bk.sum16(s1);
                 s2 = bk.sum16(s2);
-                const float sc = -bk.template lds<float>(L_ETA + (buf * 16 + ot) * 4) * rstd * (1.0f / 64.0f);
+                const float sc = -bk.template lds_load<float>(L_ETA + (buf * 16 + ot) * 4) * rstd * (1.0f / 64.0f);
                 bf16x4 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = (__bf16)((64.0f * gx[j] - s1 - z[j] * s2) * sc);
-                bk.template lds<bf16x4>(L_G + (ot * TS + of0) * 2) = o;
+                bk.template lds_store<bf16x4>(L_G + (ot * TS + of0) * 2, o);
             }
         } else if (it > 0) {          // P6 (step it-1): owners - reduce, LayerNorm, residual -> XQW
             const f32x4 z = gather8(bk, L_REDB, ot, of0);
             float mu, rstd;
             row_stats(bk, z, p.eps, mu, rstd);
-            const bf16x4 q = bk.template lds<bf16x4>(L_Q + ((it - 1) % 3) * TILE * 2 + (ot * TS + of0) * 2);
-            const f32x4 gm = bk.template lds<f32x4>(L_GAM + of0 * 4), bt = bk.template lds<f32x4>(L_BET + of0 * 4);
+            const bf16x4 q = bk.template lds_load<bf16x4>(L_Q + ((it - 1) % 3) * TILE * 2 + (ot * TS + of0) * 2);
+            const f32x4 gm = bk.template lds_load<f32x4>(L_GAM + of0 * 4), bt = bk.template lds_load<f32x4>(L_BET + of0 * 4);
             bf16x4 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = (__bf16)((float)q[j] + gm[j] * ((z[j] - mu) * rstd) + bt[j]);
             *reinterpret_cast<bf16x4*>(p.out + (tile - 1) * 1024 + (size_t)ot * 64 + of0) = o;
         }
         // park tile it+1 (requested one step ago)
-        if (which < 3) bk.template lds<u32x4>(dstb + ((it + 1) % nbufs) * TILE * 2 + lofs) = pfO;
-        if (tid < 16) bk.template lds<float>(L_ETA + ((buf ^ 1) * 16 + tid) * 4) = (float)*reinterpret_cast<const __bf16*>(&pfEO);
+        if (which < 3) bk.template lds_store<u32x4>(dstb + ((it + 1) % nbufs) * TILE * 2 + lofs, pfO);
+        if (tid < 16) bk.template lds_store<float>(L_ETA + ((buf ^ 1) * 16 + tid) * 4, (float)*reinterpret_cast<const __bf16*>(&pfEO));
         pfO = pfN;
         pfEO = pfEN;
         if (!live) break;
@@ -273,7 +281,7 @@ TTT_WV_FN void forward(BK& bk, const Mlp16Params& p, int bh) {
                 Z = bk.mma32(qA1, W1F[1][nb], Z);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) Z[r] = gelu_fwd(bk, Z[r] + b1v[nb]);
-                bk.template lds<bf16x4>(img + ((16 * nb + i) * IS + 4 * g) * 2) = pack4(Z);
+                bk.template lds_store<bf16x4>(img + ((16 * nb + i) * IS + 4 * g) * 2, pack4(Z));
             }
             bk.lds_fence();
         }
@@ -282,11 +290,11 @@ TTT_WV_FN void forward(BK& bk, const Mlp16Params& p, int bh) {
             const bf16x8 xB = cat(tr4(bk, img, IS, 0, 0), tr4(bk, img, IS, 16, 0));
 #pragma unroll
             for (int fb = 0; fb < 4; ++fb)
-                bk.template lds<f32x4>(L_REDB + ((wv * CS + i) * PS + 4 * g + 16 * fb) * 4) = bk.mma32(W2F[fb], xB, zero4());
+                bk.template lds_store<f32x4>(L_REDB + ((wv * CS + i) * PS + 4 * g + 16 * fb) * 4, bk.mma32(W2F[fb], xB, zero4()));
         }
         if (wv == 0 && g == 0) {
 #pragma unroll
-            for (int fb = 0; fb < 4; ++fb) bk.template lds<float>(L_B2 + (16 * fb + i) * 4) = b2v[fb];
+            for (int fb = 0; fb < 4; ++fb) bk.template lds_store<float>(L_B2 + (16 * fb + i) * 4, b2v[fb]);
         }
     }
 }
