@@ -67,6 +67,9 @@ def parse():
     ap.add_argument("--local-batch", type=int, default=1,
                     help="samples per GPU (default 1 = the reference's training setting).  The TTT scans of a second sample run "
                          "beside the first at no extra wall time (one workgroup per head, 48 of 256 CUs at batch 1)")
+    ap.add_argument("--overlap-wgrad", action="store_true",
+                    help="weight-gradient GEMMs of the projections / MLP on a side stream, beside the backward scans "
+                         "(ttt_amd/infra/wgrad_overlap.py); opt-in until timed")
     ap.add_argument("--layers", type=int, default=None, help="DEBUG: fewer layers (result flagged invalid)")
     return ap.parse_args()
 
@@ -195,6 +198,9 @@ def main():
     ext.set_impl(args.impl)
     init_distributed("nccl")
     tuned = (not args.no_tuned_gemms) and enable_tuned_gemms()
+    if args.overlap_wgrad:
+        from ttt_amd.infra import wgrad_overlap
+        wgrad_overlap.enable(True)
 
     over = {}
     if args.layers is not None:
@@ -356,7 +362,7 @@ def main():
                 "config": {"workload": f"CogVideoX-5B+{args.ssm_layer} {args.video_length} training step (fwd+bwd+AdamW), "
                                        f"{cfg.num_layers} layers, L={L} tokens/sample, adapter=sft",
                            "global_batch": world * LB, "seq_len": L, "parallelism": f"fsdp{world}", "ttt_impl": args.impl,
-                           "remat_free_layers": n_free, "fsdp_reshard_after_forward": bool(args.reshard_after_forward), "tuned_gemm_selections": bool(tuned),
+                           "remat_free_layers": n_free, "fsdp_reshard_after_forward": bool(args.reshard_after_forward), "tuned_gemm_selections": bool(tuned), "overlap_wgrad": bool(args.overlap_wgrad),
                            "valid": args.layers is None},
                 "roofline": roof, "loss": loss_val, "peak_mem_gib": peak_mem, "total_tokens_per_s": world * L / (dt / args.steps)}
         if world == 1 and not args.no_cpu_baseline:

@@ -22,6 +22,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from ttt_amd.infra import wgrad_overlap as wgrad
 from ttt_amd.models.cogvideo.utils import SequenceMetadata
 from ttt_amd.models.configs import ModelConfig
 from ttt_amd.models.ssm.fused import FusedPost, FusedPre, FusedPreScanMLP, fused_available
@@ -161,7 +162,7 @@ class TTTBase(nn.Module):
 
     # -- pieces of process_input ------------------------------------------------------------------
     def get_qkv_projections(self, hidden_states):
-        return self.wq(hidden_states), self.wk(hidden_states), self.wv(hidden_states)
+        return wgrad.linear(self.wq, hidden_states), wgrad.linear(self.wk, hidden_states), wgrad.linear(self.wv, hidden_states)
 
     def get_eta(self, X):
         """Per-token inner-loop learning rate ``base_lr * sigmoid(x.w_h + b_h) / head_dim`` as
@@ -261,7 +262,7 @@ class TTTBase(nn.Module):
             hidden_states = flip_sequence(hidden_states, seq_metadata)
         y = self.ttt(self.process_input(hidden_states, freqs_cis, seq_metadata))
         if not heads_only:
-            y = self.wo(self.post_norm(y))
+            y = wgrad.linear(self.wo, self.post_norm(y))
         if seq_metadata.is_multiscene:
             y = self.undo_interleave(y, seq_metadata)
         return flip_sequence(y, seq_metadata) if reverse else y
@@ -335,7 +336,7 @@ class TTTBase(nn.Module):
             out.index_copy_(1, src.long(), Y.reshape(B, NH, L, Fh).transpose(1, 2))
             return out.view(B, L, NH * Fh)
         y = FusedPost.apply(Y.reshape(B, NH, L, Fh), self.post_norm.weight, self.post_norm.bias, src, self.post_norm.eps)
-        return self.wo(y)
+        return wgrad.linear(self.wo, y)
 
     # helpers shared by the two variants
     def _group_size(self, num_mini_batch: int) -> int:
