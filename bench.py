@@ -67,6 +67,10 @@ def parse():
     ap.add_argument("--local-batch", type=int, default=1,
                     help="samples per GPU (default 1 = the reference's training setting).  The TTT scans of a second sample run "
                          "beside the first at no extra wall time (one workgroup per head, 48 of 256 CUs at batch 1)")
+    ap.add_argument("--no-fsdp", action="store_true",
+                    help="one GPU only: fp32 masters + bf16 compute copies kept by ttt_amd.infra.parallelisms.ReplicaMixedPrecision "
+                         "(three multi-tensor launches per step) instead of FSDP2 over a one-rank mesh (~3000 per-parameter copy "
+                         "kernels per step); same arithmetic, bit-identical updates (tests/test_fsdp_gloo.py); opt-in until timed")
     ap.add_argument("--overlap-wgrad", action="store_true",
                     help="weight-gradient GEMMs of the projections / MLP on a side stream, beside the backward scans "
                          "(ttt_amd/infra/wgrad_overlap.py); opt-in until timed")
@@ -190,7 +194,8 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     import test_time_training as ext
-    from ttt_amd.infra.parallelisms import apply_fsdp, enable_tuned_gemms, get_dp_mesh, init_distributed, init_model_parameters
+    from ttt_amd.infra.parallelisms import (ReplicaMixedPrecision, apply_fsdp, enable_tuned_gemms, get_dp_mesh, init_distributed,
+                                            init_model_parameters)
     from ttt_amd.models.cogvideo.model import CogVideoX
     from ttt_amd.models.configs import ModelConfig
 
@@ -213,16 +218,20 @@ def main():
     L = frames * TOKENS_PER_FRAME + scenes * text_len
     assert L % cfg.mini_batch_size == 0
 
+    assert not (args.no_fsdp and world > 1), "--no-fsdp is the one-GPU replica path"
     with torch.device("meta"):
         model = CogVideoX(cfg, effective_rank=rank, effective_world_size=world)
-    apply_fsdp(model, get_dp_mesh(), reshard_after_forward=args.reshard_after_forward)   # reference parallelisms.py:155-175
+    if not args.no_fsdp:
+        apply_fsdp(model, get_dp_mesh(), reshard_after_forward=args.reshard_after_forward)   # reference parallelisms.py:155-175
     model.to_empty(device=dev)
     torch.manual_seed(1234)                                # same init on every rank, then sharded
     with torch.no_grad():
         init_model_parameters(model)
         model.init_ssm_weights()
     model.setup_generator(seed=rank, device=dev)
-    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-5, weight_decay=1e-4, fused=True)
+    replica = ReplicaMixedPrecision(model.dit) if args.no_fsdp else None
+    train_params = replica.master_parameters() if replica else [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.AdamW(train_params, lr=1e-5, weight_decay=1e-4, fused=True)
 
     g = torch.Generator(device=dev).manual_seed(100 + rank)
     LB = args.local_batch
@@ -236,8 +245,12 @@ def main():
         opt.zero_grad(set_to_none=True)
         loss = model(vid, text).mean()
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        if replica:
+            replica.collect_grads()                 # bf16 gradients -> fp32 gradients of the masters (what FSDP's reduce does)
+        torch.nn.utils.clip_grad_norm_(train_params, 1.0)
         opt.step()
+        if replica:
+            replica.publish()                       # fp32 masters -> bf16 compute copies (what FSDP's all-gather does)
         return loss
 
     # ---- activation re-materialisation sized for this GPU (untimed) -------------------------------------------------------
@@ -304,6 +317,8 @@ def main():
         if ok:
             break
         opt.zero_grad(set_to_none=True)
+        if replica:
+            replica.zero_grad()
         torch.cuda.empty_cache()
         n_free = int(n_free * 0.8)
     dist.barrier(device_ids=[local_rank])
@@ -361,7 +376,7 @@ def main():
                 "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                 "config": {"workload": f"CogVideoX-5B+{args.ssm_layer} {args.video_length} training step (fwd+bwd+AdamW), "
                                        f"{cfg.num_layers} layers, L={L} tokens/sample, adapter=sft",
-                           "global_batch": world * LB, "seq_len": L, "parallelism": f"fsdp{world}", "ttt_impl": args.impl,
+                           "global_batch": world * LB, "seq_len": L, "parallelism": "replica1" if args.no_fsdp else f"fsdp{world}", "ttt_impl": args.impl,
                            "remat_free_layers": n_free, "fsdp_reshard_after_forward": bool(args.reshard_after_forward), "tuned_gemm_selections": bool(tuned), "overlap_wgrad": bool(args.overlap_wgrad),
                            "valid": args.layers is None},
                 "roofline": roof, "loss": loss_val, "peak_mem_gib": peak_mem, "total_tokens_per_s": world * L / (dt / args.steps)}

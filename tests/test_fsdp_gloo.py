@@ -90,3 +90,56 @@ def test_fsdp2_world2_matches_single_process(tmp_path):
     assert set(got) == set(ref_grads)
     for k, v in ref_grads.items():
         assert torch.allclose(got[k], v, rtol=1e-4, atol=1e-7), k
+
+
+def _replica_worker(rank, world, port, out_dir):
+    """FSDP2 over a one-rank mesh vs ReplicaMixedPrecision: three AdamW steps in bf16 compute / fp32 masters."""
+    for p in (ROOT, os.path.join(ROOT, "ttt-video-dit_amd")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    from oracle import cpu_ext
+    from ttt_amd.infra.parallelisms import ReplicaMixedPrecision, apply_fsdp, end_distributed, get_dp_mesh, init_distributed
+    cpu_ext.install()
+    init_distributed("gloo")
+    out = {}
+    for mode in ("fsdp", "replica"):
+        m = _build()
+        if mode == "fsdp":
+            apply_fsdp(m, get_dp_mesh(), reshard_after_forward=False)
+            params, rep = [p for p in m.parameters() if p.requires_grad], None
+        else:
+            rep = ReplicaMixedPrecision(m)
+            params = rep.master_parameters()
+        opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=1e-4)
+        trace = []
+        for _ in range(3):
+            opt.zero_grad(set_to_none=True)
+            loss = _loss(m, 0)
+            loss.backward()
+            if rep:
+                rep.collect_grads()
+            norm = torch.nn.utils.clip_grad_norm_(params, 1.0)
+            opt.step()
+            if rep:
+                rep.publish()
+            trace.append((float(loss.detach()), float(norm.full_tensor() if hasattr(norm, "full_tensor") else norm)))
+        names = [k for k, _ in m.named_parameters()]
+        if rep:
+            assert all(p.dtype == torch.bfloat16 for p in m.parameters())
+            final = dict(zip(names, [x.data.clone() for x in rep._master]))
+        else:
+            final = {k: p.full_tensor().float().clone() for k, p in m.named_parameters()}
+        out[mode] = {"trace": trace, "params": final}
+    torch.save(out, os.path.join(out_dir, "replica.pt"))
+    end_distributed()
+
+
+@pytest.mark.timeout(600)
+def test_replica_mixed_precision_equals_fsdp2_on_one_rank(tmp_path):
+    mp.spawn(_replica_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    out = torch.load(os.path.join(tmp_path, "replica.pt"))
+    assert out["fsdp"]["trace"] == out["replica"]["trace"]
+    assert set(out["fsdp"]["params"]) == set(out["replica"]["params"])
+    for k, v in out["fsdp"]["params"].items():
+        assert torch.equal(out["replica"]["params"][k], v), k

@@ -100,3 +100,74 @@ def init_model_parameters(model, initializer_range: float = 0.02):
                 torch.nn.init.zeros_(p)
             else:
                 torch.nn.init.normal_(p, mean=0.0, std=initializer_range)
+
+
+class ReplicaMixedPrecision:
+    """World-size-1 counterpart of ``apply_fsdp``'s mixed precision: fp32 master parameters, ``param_dtype`` compute
+    copies inside the module, gradients converted to ``reduce_dtype`` for the optimizer - without FSDP2's machinery.
+
+    Why: with one rank there is nothing to shard or gather, yet FSDP2 still walks every parameter of every layer each
+    step (cast into an all-gather input, copy into the all-gather output, chunk-cat + cast of each gradient): about 3000
+    small copy kernels and 190 ms of a 3.26 s step on one MI355X (``profiles/r1f_bench_kernel_stats.csv``:
+    ``__amd_rocclr_copyBuffer`` 80 ms, ``bfloat16_copy`` 60 ms, ``bfloat16tofloat32_copy`` 38 ms, ``chunk_cat`` 11 ms).
+    Here the same conversions are three multi-tensor launches per step.  Arithmetic is the FSDP path's: bf16 parameters
+    and bf16 forward inputs at the root (FSDP2 ``cast_forward_inputs``), bf16 gradients widened to fp32, world-size-1
+    "mean" = identity, fp32 optimizer state.
+
+        rep = ReplicaMixedPrecision(model.dit)            # module parameters become bf16 copies
+        opt = torch.optim.AdamW(rep.master_parameters(), ...)
+        loss.backward(); rep.collect_grads(); clip_grad_norm_(rep.master_parameters(), 1.0); opt.step(); rep.publish()
+    """
+
+    def __init__(self, module: torch.nn.Module, param_dtype=torch.bfloat16, reduce_dtype=torch.float32):
+        self.module, self.param_dtype, self.reduce_dtype = module, param_dtype, reduce_dtype
+        self._compute, self._master = [], []
+        seen = {}
+        for p in module.parameters():
+            if id(p) in seen or not p.is_floating_point():
+                continue
+            seen[id(p)] = True
+            master = torch.nn.Parameter(p.detach().to(torch.float32, copy=True), requires_grad=p.requires_grad)
+            p.data = p.detach().to(param_dtype)
+            self._compute.append(p)
+            self._master.append(master)
+        self._hook = module.register_forward_pre_hook(self._cast_inputs, with_kwargs=True)
+
+    def _cast_inputs(self, module, args, kwargs):
+        cast = lambda t: t.to(self.param_dtype) if isinstance(t, torch.Tensor) and t.is_floating_point() else t
+        return tuple(cast(a) for a in args), {k: cast(v) for k, v in kwargs.items()}
+
+    def master_parameters(self):
+        return [m for m in self._master if m.requires_grad]
+
+    def collect_grads(self):
+        """Gradients of the compute copies -> ``reduce_dtype`` gradients of the masters (accumulating if one is already
+        there), then dropped from the compute copies."""
+        src, dst, acc_src, acc_dst = [], [], [], []
+        for p, m in zip(self._compute, self._master):
+            if p.grad is None:
+                continue
+            if m.grad is None:
+                m.grad = torch.empty_like(m, dtype=self.reduce_dtype)
+                src.append(p.grad)
+                dst.append(m.grad)
+            else:
+                acc_src.append(p.grad)
+                acc_dst.append(m.grad)
+        if src:
+            torch._foreach_copy_(dst, src)
+        if acc_src:
+            torch._foreach_add_(acc_dst, [g.to(self.reduce_dtype) for g in acc_src])
+        for p in self._compute:
+            p.grad = None
+
+    def publish(self):
+        """Masters -> compute copies (after the optimizer step)."""
+        with torch.no_grad():
+            torch._foreach_copy_([p.data for p in self._compute], [m.data for m in self._master])
+
+    def zero_grad(self):
+        for m in self._master:
+            m.grad = None
+        for p in self._compute:
+            p.grad = None
