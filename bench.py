@@ -71,6 +71,8 @@ def parse():
                     help="one GPU only: fp32 masters + bf16 compute copies kept by ttt_amd.infra.parallelisms.ReplicaMixedPrecision "
                          "(three multi-tensor launches per step) instead of FSDP2 over a one-rank mesh (~3000 per-parameter copy "
                          "kernels per step); same arithmetic, bit-identical updates (tests/test_fsdp_gloo.py); opt-in until timed")
+    ap.add_argument("--attn-variant", type=int, default=1, choices=[1, 2],
+                    help="2 = revision 2 of the attention forward / dQ kernels (csrc/attn_v2.hip, emulator-checked); opt-in until timed")
     ap.add_argument("--overlap-wgrad", action="store_true",
                     help="weight-gradient GEMMs of the projections / MLP on a side stream, beside the backward scans "
                          "(ttt_amd/infra/wgrad_overlap.py); opt-in until timed")
@@ -201,6 +203,7 @@ def main():
 
     ext.load_library()
     ext.set_impl(args.impl)
+    ext.debug_option("attn_variant", args.attn_variant)
     init_distributed("nccl")
     tuned = (not args.no_tuned_gemms) and enable_tuned_gemms()
     if args.overlap_wgrad:
@@ -377,7 +380,7 @@ def main():
                 "config": {"workload": f"CogVideoX-5B+{args.ssm_layer} {args.video_length} training step (fwd+bwd+AdamW), "
                                        f"{cfg.num_layers} layers, L={L} tokens/sample, adapter=sft",
                            "global_batch": world * LB, "seq_len": L, "parallelism": "replica1" if args.no_fsdp else f"fsdp{world}", "ttt_impl": args.impl,
-                           "remat_free_layers": n_free, "fsdp_reshard_after_forward": bool(args.reshard_after_forward), "tuned_gemm_selections": bool(tuned), "overlap_wgrad": bool(args.overlap_wgrad),
+                           "remat_free_layers": n_free, "fsdp_reshard_after_forward": bool(args.reshard_after_forward), "tuned_gemm_selections": bool(tuned), "overlap_wgrad": bool(args.overlap_wgrad), "attn_variant": args.attn_variant,
                            "valid": args.layers is None},
                 "roofline": roof, "loss": loss_val, "peak_mem_gib": peak_mem, "total_tokens_per_s": world * L / (dt / args.steps)}
         if world == 1 and not args.no_cpu_baseline:

@@ -1,0 +1,43 @@
+// Host build of the segment-attention workgroup bodies (csrc/attn_body.h) on the wave emulator: TEST INFRASTRUCTURE, compiled on
+// the fly by tests/test_emul_cpu.py with the host clang of the ROCm toolchain.  One emulated 8-wave workgroup per block of
+// 256 query rows, the same (head, block) decomposition as the device launch.
+#include <cstdio>
+
+#include "wave_emul.h"
+
+#include "attn_body.h"
+
+using namespace ttt;
+
+extern "C" {
+
+// returns the number of LDS races the detector saw (0 expected); the first one is described in `msg`
+int emul_attn_forward(const attn::FwdParams* p, char* msg, int msg_len) {
+    const int nqb = (p->S + attnb::QB - 1) / attnb::QB, nbh = p->B * p->NH;
+    int races = 0;
+    for (int b = 0; b < nbh * nqb; ++b) {
+        int bh, qb;
+        attnb::head_of_block(b, nqb, nbh, bh, qb);
+        const emul::RaceReport r = emul::run_group(8, [&](emul::EmulWave& w) { attnb::forward(w, *p, bh, qb); });
+        if (r.races && !races && msg) snprintf(msg, msg_len, "%s", r.first.c_str());
+        races += r.races;
+    }
+    return races;
+}
+
+int emul_attn_dq(const attn::BwdParams* p, char* msg, int msg_len) {
+    const int nqb = (p->S + attnb::QB - 1) / attnb::QB, nbh = p->B * p->NH;
+    int races = 0;
+    for (int b = 0; b < nbh * nqb; ++b) {
+        int bh, qb;
+        attnb::head_of_block(b, nqb, nbh, bh, qb);
+        const emul::RaceReport r = emul::run_group(8, [&](emul::EmulWave& w) { attnb::dq(w, *p, bh, qb); });
+        if (r.races && !races && msg) snprintf(msg, msg_len, "%s", r.first.c_str());
+        races += r.races;
+    }
+    return races;
+}
+
+int emul_attn_fwd_params_size() { return (int)sizeof(attn::FwdParams); }
+int emul_attn_bwd_params_size() { return (int)sizeof(attn::BwdParams); }
+}

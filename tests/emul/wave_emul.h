@@ -95,6 +95,16 @@ struct EmulWave {
         grp->track(byte_off, (int)sizeof(T), true, epoch, w);
         *reinterpret_cast<T*>(grp->lds + byte_off) = v;
     }
+    // element-pointer view of LDS (bf16 elements) used by the attention bodies (csrc/attn_body.h): device = __bf16*
+    struct tile_t {
+        int e;
+        tile_t operator+(int k) const { return tile_t{e + k}; }
+    };
+    tile_t lds_base() const { return tile_t{0}; }
+    template <class T> T ld(tile_t p) { return lds_load<T>(2 * p.e); }
+    template <class T> void st(tile_t p, T v) { lds_store<T>(2 * p.e, v); }
+    bf16x4 tr(tile_t p) { return tr_read(2 * p.e); }
+    float log(float x) const { return std::log(x); }
     float rsq(float x) const { return 1.0f / std::sqrt(x); }
     float exp2(float x) const { return std::exp2(x); }
     float rcp(float x) const { return 1.0f / x; }
@@ -167,6 +177,21 @@ struct EmulWave {
         for (int j = 0; j < 16; ++j) s += sh->f[(l & ~15) + j];
         sync();
         return s;
+    }
+    float xor_read(float v, int mask) {                  // v of lane (l ^ mask)   (__shfl_xor)
+        sh->f[l] = v;
+        sync();
+        const float s = sh->f[l ^ mask];
+        sync();
+        return s;
+    }
+    bool any(bool b) {                                   // wave-wide OR (ballot != 0)
+        sh->f[l] = b ? 1.0f : 0.0f;
+        sync();
+        bool r = false;
+        for (int j = 0; j < 64; ++j) r = r || sh->f[j] != 0.0f;
+        sync();
+        return r;
     }
     float xor_add(float v, int mask) {                   // v + v of lane (l ^ mask)
         sh->f[l] = v;

@@ -174,3 +174,28 @@ def test_fused_attention_node_equals_two_nodes():
         res.append([out.detach()] + [t.grad for t in (qr, kr, vr)] + [t.grad for t in par])
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("B,NH,S,layout", [(2, 3, 300, "bshd"), (1, 8, 1024, "bhsd"), (1, 2, 40, "bshd"), (1, 16, 577, "bshd")])
+def test_attention_v2_equals_v1(B, NH, S, layout):
+    """Revision 2 of the forward and dQ kernels (csrc/attn_v2.hip: the emulator-checked bodies of attn_body.h, debug option
+    attn_variant = 2) against revision 1 on the same tensors: same arithmetic in the same order -> identical bits, and the
+    oracle tolerances on its own."""
+    e = ext()
+    q, k, v, do = make(B, NH, S, 21 + S, layout)
+    from ttt_amd.models.cogvideo.attention import SegmentAttention
+    res = {}
+    try:
+        for variant in (1, 2):
+            e.debug_option("attn_variant", variant)
+            qq, kk, vv = (t.detach().clone().requires_grad_(True) for t in (q, k, v))
+            out = SegmentAttention.apply(qq, kk, vv)
+            out.backward(do)
+            torch.cuda.synchronize()
+            res[variant] = (out.detach(), qq.grad, kk.grad, vv.grad)
+    finally:
+        e.debug_option("attn_variant", 1)
+    ro, rl, rq, rk, rv = oracle_grads(q, k, v, do)
+    assert rel_l2(res[2][0], ro) < 1e-2 and rel_l2(res[2][1], rq) < 2e-2
+    for a, b, name in zip(res[1], res[2], ("out", "dq", "dk", "dv")):
+        assert torch.equal(a, b), name

@@ -1,0 +1,137 @@
+"""The segment-attention workgroup bodies of csrc/attn_body.h (revision 2 of the forward and dQ kernels) executed on the CPU by
+the lane-level wave emulator of tests/emul (8 emulated waves per workgroup, MFMA 32x32x16 / ds_read_b64_tr_b16 / workgroup
+barrier semantics of gfx950, LDS race detector) against the fp64 attention oracle on the same bf16-rounded inputs.  The same
+template bodies are instantiated with the device backend in csrc/attn_v2.hip.  Tolerances as for the GPU parity tests
+(tests/test_attention_gpu.py): outputs rel-L2 <= 1e-2, gradients <= 2e-2."""
+import ctypes
+import math
+import os
+import subprocess
+
+import pytest
+import torch
+
+from helpers import rel_l2
+from oracle import attn_oracle as AO
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CLANG = "/opt/rocm/lib/llvm/bin/amdclang++"
+
+_P, _L, _I, _F = ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_float
+
+
+class FwdParams(ctypes.Structure):
+    _fields_ = [(n, _P) for n in ("Q", "K", "V", "O", "LSE")] + \
+               [(n, _L) for n in ("q_sb", "q_sh", "q_ss", "k_sb", "k_sh", "k_ss", "v_sb", "v_sh", "v_ss", "o_sb", "o_sh", "o_ss")] + \
+               [("B", _I), ("NH", _I), ("S", _I), ("scale", _F)]
+
+
+class BwdParams(ctypes.Structure):
+    _fields_ = [(n, _P) for n in ("Q", "K", "V", "O", "dO", "LSE", "Delta", "dQ", "dK", "dV")] + \
+               [(f"{t}_{s}", _L) for t in ("q", "k", "v", "o", "do", "dq", "dk", "dv") for s in ("sb", "sh", "ss")] + \
+               [("B", _I), ("NH", _I), ("S", _I), ("scale", _F)]
+
+
+@pytest.fixture(scope="module")
+def emul():
+    if not os.path.exists(CLANG):
+        pytest.skip("host clang of the ROCm toolchain not available")
+    build = os.path.join(HERE, "emul", "_build")
+    os.makedirs(build, exist_ok=True)
+    so = os.path.join(build, "libattn_emul.so")
+    csrc = os.path.join(ROOT, "ttt-video-dit_amd", "csrc")
+    srcs = [os.path.join(HERE, "emul", f) for f in ("attn_emul.cpp", "wave_emul.h")] + \
+           [os.path.join(csrc, f) for f in ("attn_body.h", "attn_types.h", "ttt_wave_types.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call([CLANG, "-std=c++20", "-O1", "-pthread", "-shared", "-fPIC", "-Wno-unknown-pragmas", "-Wno-psabi",
+                               "-I", csrc, "-I", os.path.join(HERE, "emul"), srcs[0], "-o", so])
+    lib = ctypes.CDLL(so)
+    assert lib.emul_attn_fwd_params_size() == ctypes.sizeof(FwdParams)
+    assert lib.emul_attn_bwd_params_size() == ctypes.sizeof(BwdParams)
+    return lib
+
+
+def _make(B, NH, S, seed, layout):
+    """bf16 q, k, v, dO as [B, NH, S, 64] views: of [B, S, NH, 64] memory (what the block produces) or contiguous."""
+    g = torch.Generator().manual_seed(seed)
+    mk = lambda s: (torch.randn(B, S, NH, 64, generator=g) * s).bfloat16()
+    q, k, v, do = mk(1.5), mk(1.5), mk(1.0), mk(1.0)
+    f = (lambda t: t.transpose(1, 2)) if layout == "bshd" else (lambda t: t.transpose(1, 2).contiguous())
+    return f(q), f(k), f(v), f(do)
+
+
+def _strides(p, name, t):
+    sb, sh, ss, sd = t.stride()
+    assert sd == 1
+    for s, v in (("sb", sb), ("sh", sh), ("ss", ss)):
+        setattr(p, f"{name}_{s}", v)
+
+
+def _forward(lib, q, k, v):
+    B, NH, S, _ = q.shape
+    out = torch.full((B, S, NH, 64), float("nan"), dtype=torch.bfloat16).transpose(1, 2)
+    lse = torch.full((B, NH, S), float("nan"))
+    p = FwdParams()
+    p.Q, p.K, p.V, p.O, p.LSE = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr()
+    for n, t in (("q", q), ("k", k), ("v", v), ("o", out)):
+        _strides(p, n, t)
+    p.B, p.NH, p.S, p.scale = B, NH, S, 1 / math.sqrt(64)
+    msg = ctypes.create_string_buffer(256)
+    races = lib.emul_attn_forward(ctypes.byref(p), msg, 256)
+    assert races == 0, msg.value.decode()
+    return out, lse
+
+
+def _oracle(q, k, v, do):
+    q64, k64, v64 = (t.double().requires_grad_(True) for t in (q, k, v))
+    out, lse = AO.attention(q64, k64, v64)
+    out.backward(do.double())
+    return out.detach(), lse.detach(), q64.grad, k64.grad, v64.grad
+
+
+# ragged tail inside one tile, ragged over several tiles and blocks (both workgroup->head mappings), exact multiples of 64 / 256
+SHAPES = [(1, 2, 40, "bshd"), (2, 3, 300, "bshd"), (1, 8, 128, "bhsd"), (1, 1, 577, "bshd")]
+
+
+@pytest.mark.parametrize("B,NH,S,layout", SHAPES)
+def test_emulated_attention_forward_vs_oracle(emul, B, NH, S, layout):
+    q, k, v, do = _make(B, NH, S, 7 + S, layout)
+    out, lse = _forward(emul, q, k, v)
+    ro, rl, *_ = _oracle(q, k, v, do)
+    assert not torch.isnan(out.float()).any()
+    assert rel_l2(out, ro) < 1e-2
+    assert (lse.double() - rl).abs().max() < 2e-2
+
+
+def test_emulated_attention_forward_rescale_path(emul):
+    """one key dominates from a late tile on: the running-max rescale of the online softmax (as tests/test_attention_gpu.py)"""
+    B, NH, S = 1, 1, 330
+    q, k, v, do = _make(B, NH, S, 3, "bshd")
+    k = k.clone()
+    k[:, :, 290] = q[:, :, 17] * 6.0
+    out, _ = _forward(emul, q, k, v)
+    ro, _ = AO.attention(q.double(), k.double(), v.double())
+    assert rel_l2(out, ro) < 1e-2
+
+
+@pytest.mark.parametrize("B,NH,S,layout", SHAPES)
+def test_emulated_attention_dq_vs_oracle(emul, B, NH, S, layout):
+    q, k, v, do = _make(B, NH, S, 11 + S, layout)
+    ro, rl, rq, _, _ = _oracle(q, k, v, do)
+    # the kernel's inputs: the forward's bf16 output and fp32 LSE, Delta = rowsum(dO * O) as attn_delta_kernel forms it
+    o = ro.to(torch.bfloat16)
+    lse = rl.float().contiguous()
+    delta = (do.float() * o.float()).sum(-1).contiguous()
+    dq = torch.full((B, S, NH, 64), float("nan"), dtype=torch.bfloat16).transpose(1, 2)
+    p = BwdParams()
+    p.Q, p.K, p.V, p.O, p.dO, p.LSE, p.Delta, p.dQ = (q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(),
+                                                      lse.data_ptr(), delta.data_ptr(), dq.data_ptr())
+    for n, t in (("q", q), ("k", k), ("v", v), ("o", o), ("do", do), ("dq", dq)):
+        _strides(p, n, t)
+    p.B, p.NH, p.S, p.scale = B, NH, S, 1 / math.sqrt(64)
+    msg = ctypes.create_string_buffer(256)
+    races = emul.emul_attn_dq(ctypes.byref(p), msg, 256)
+    assert races == 0, msg.value.decode()
+    assert not torch.isnan(dq.float()).any()
+    assert rel_l2(dq, rq) < 2e-2

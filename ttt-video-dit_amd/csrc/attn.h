@@ -2,29 +2,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "attn_types.h"
 
 namespace ttt {
 namespace attn {
-
-// element (b, h, s, d) of a tensor lives at base + b*sb + h*sh + s*ss + d  (strides in elements, d contiguous)
-struct FwdParams {
-    const __bf16 *Q, *K, *V;
-    __bf16* O;
-    float* LSE;                         // [B, NH, S] natural-log sum-exp of the scaled scores (may be null)
-    long q_sb, q_sh, q_ss, k_sb, k_sh, k_ss, v_sb, v_sh, v_ss, o_sb, o_sh, o_ss;
-    int B, NH, S;
-    float scale;
-};
-struct BwdParams {
-    const __bf16 *Q, *K, *V, *O, *dO;
-    const float* LSE;                   // [B, NH, S]
-    float* Delta;                       // [B, NH, S] workspace: rowsum(dO * O)
-    __bf16 *dQ, *dK, *dV;
-    long q_sb, q_sh, q_ss, k_sb, k_sh, k_ss, v_sb, v_sh, v_ss, o_sb, o_sh, o_ss, do_sb, do_sh, do_ss;
-    long dq_sb, dq_sh, dq_ss, dk_sb, dk_sh, dk_ss, dv_sb, dv_sh, dv_ss;
-    int B, NH, S;
-    float scale;
-};
 
 // fused per-head LayerNorm(64) + RoPE of q and k (attn_pre.hip); q_raw / k_raw / q / k are contiguous [B, S, NH, 64]
 struct PreParams {
@@ -50,6 +31,13 @@ void launch_pre_backward(const PreBwdParams& a, hipStream_t s);
 
 void launch_forward(const FwdParams& p, hipStream_t s);
 void launch_backward(const BwdParams& p, hipStream_t s);
+
+// revision 2 of the forward and dQ kernels (attn_v2.hip, bodies in attn_body.h); debug option "attn_variant": 1 (default) =
+// revision 1 everywhere, 2 = revision 2 for the forward and dQ kernels
+void set_attn_variant(int v);
+int get_attn_variant();
+void launch_forward_v2(const FwdParams& p, hipStream_t s);
+void launch_dq_v2(const BwdParams& p, int occ, hipStream_t s);
 
 }  // namespace attn
 }  // namespace ttt

@@ -1,0 +1,345 @@
+// Segment-attention forward and dQ kernels (revision 2) as workgroup bodies written against a "wave backend", like the
+// TTT bodies of ttt_lin16_body.h / ttt_mlp16_body.h: attn_v2.hip instantiates them with the gfx950 instructions,
+// tests/emul/attn_emul.cpp with the lane-level emulator, so `pytest -m "not gpu"` executes this very code against the fp64
+// attention oracle.
+//
+// Same algorithm, tiling and layout algebra as revision 1 (attn_fwd.hip, attn_bwd.hip: 8 waves x 32 query rows, keys / values
+// streamed through LDS in tiles of 64, scores computed transposed so that a lane owns one query row, probabilities re-used
+// in place as the B operand of the second product).  What changed, and why (static instruction mix of the revision-1 loops,
+// tools/isa_mix.py - they are VALU-issue-bound, 16 / 24 MFMAs against ~270 / ~290 vector instructions per wave and tile):
+//   * the ragged-tail mask (keys >= S exist only in the LAST tile, and only when S % 64 != 0) was if-converted by the
+//     compiler into an index add + compare + select per score in EVERY tile: 97 of the forward loop's 239 VALU instructions
+//     and 130 of the dQ loop's 256.  Here the mask sits behind a wave-uniform branch that is kept a real branch
+//     (TTT_PIN_IN_BRANCH), so full tiles - every tile at the training geometry, S = 18 048 = 282 x 64 - never execute it.
+//     (Peeling the last tile into a second instantiation of the loop body does the same but made the register allocator
+//     spill in the 128-register dQ kernel; this form keeps revision 1's loop shape.)
+// Everything else - the arithmetic, its order, the rounding points - is revision 1's (in the dQ kernel a masked score is set
+// to -1e30 before the exponential instead of zeroing the probability after it: exp2(-1e30 ...) == 0 exactly), so the two
+// revisions agree bit for bit (tests/test_attention_gpu.py::test_attention_v2_equals_v1).
+//
+// Backend contract: lane(), wave(), thread(), barrier(), exp2(), log(); tile_t = element pointer into LDS with lds_base(),
+// ld<T>(ptr), st(ptr, v), tr(ptr) = ds_read_b64_tr_b16; mma3216(a, b, c) = v_mfma_f32_32x32x16_bf16; xor_read(v, mask) = the value
+// of lane l ^ mask; any(bool) = wave-wide OR.  Device: attn_v2.hip (AttnDeviceWave); emulator: tests/emul/attn_emul.cpp.
+#pragma once
+#include <math.h>
+
+#include "attn_types.h"
+#include "ttt_wave_types.h"
+
+#ifndef TTT_BODY_FN
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+#define TTT_BODY_FN __device__ __forceinline__
+#else
+#define TTT_BODY_FN inline
+#endif
+#endif
+
+namespace ttt {
+namespace attnb {
+using namespace ttt::wv;
+using attn::BwdParams;
+using attn::FwdParams;
+
+constexpr int QB = 256, KB = 64;
+constexpr int AS = 72;                  // row stride (elements) of a [64][64] bf16 tile read as 16-byte row fragments
+constexpr int VS = 96;                  // row stride of the forward's V tile, read only through transposed reads (no bank conflicts)
+constexpr int KT_ELEMS = 64 * AS, VT_ELEMS = 64 * VS;
+constexpr int FWD_BUF_ELEMS = KT_ELEMS + VT_ELEMS, LDS_FWD = 2 * FWD_BUF_ELEMS * 2;
+constexpr int DQ_BUF_ELEMS = 2 * KT_ELEMS, LDS_DQ = 2 * DQ_BUF_ELEMS * 2;     // K and V tiles, both stride 72
+constexpr float LOG2E = 1.4426950408889634f;
+
+// Keeps a wave-uniform branch a branch: a value routed through a volatile asm inside it cannot be turned into a select
+// outside it (the compiler does not speculate volatile asm).  No instruction is emitted.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TTT_PIN_IN_BRANCH(x) asm volatile("" : "+v"(x))
+#else
+#define TTT_PIN_IN_BRANCH(x) ((void)0)
+#endif
+
+TTT_BODY_FN int row_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+TTT_BODY_FN f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+TTT_BODY_FN bf16x8 pack(const f32x16& t, int s) {
+    bf16x8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = (__bf16)t[8 * s + e];
+    return r;
+}
+TTT_BODY_FN bf16x8 zero_frag() {
+    bf16x8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = (__bf16)0.0f;
+    return r;
+}
+// LDS tiles are addressed through the backend's element pointer `BK::tile_t` (device: __bf16* into LDS, so that the compiler
+// sees plain pointer arithmetic and folds the constant parts into the ds instructions' offset fields; emulator: an element
+// offset), read with bk.ld<T>(ptr) / bk.tr(ptr) and written with bk.st(ptr, v).
+// operand fragment, outer index = row (lane c reads 8 contiguous elements of row row0 + c), contraction over columns
+template <class BK>
+TTT_BODY_FN bf16x8 row_frag(BK& bk, typename BK::tile_t img, int stride, int row0, int col0, int l) {
+    return bk.template ld<bf16x8>(img + ((row0 + (l & 31)) * stride + col0 + 8 * (l >> 5)));
+}
+// operand fragment through ds_read_b64_tr_b16: outer index = column (32 columns from col0), contraction over the rows
+// r0..r0+3 and r1..r1+3 of the row-major image
+template <class BK>
+TTT_BODY_FN bf16x8 tr_frag(BK& bk, typename BK::tile_t img, int stride, int r0, int r1, int col0, int l) {
+    const int i = l & 15, g1 = (l >> 4) & 1;
+    const int off = (i >> 2) * stride + col0 + 16 * g1 + 4 * (i & 3);
+    const bf16x4 lo = bk.tr(img + (r0 * stride + off));
+    const bf16x4 hi = bk.tr(img + (r1 * stride + off));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+// same, in the k-slot order of in-place fragment s of the 32-row block at row0 (ttt_mfma_dev.h: pi order)
+template <class BK>
+TTT_BODY_FN bf16x8 tr_frag_pi(BK& bk, typename BK::tile_t img, int stride, int row0, int s, int col0, int l) {
+    const int h = l >> 5;
+    return tr_frag(bk, img, stride, row0 + 16 * s + 4 * h, row0 + 16 * s + 8 + 4 * h, col0, l);
+}
+
+struct KVStage {
+    u32x4 k, v;
+};
+TTT_BODY_FN u32x4 zero_u4() {
+    u32x4 z = {0u, 0u, 0u, 0u};
+    return z;
+}
+// this thread's 16 bytes of the next K and V tiles: global -> registers (issued before the tile's MFMAs) ...
+TTT_BODY_FN void kv_issue(KVStage& st, const __bf16* Kp, const __bf16* Vp, long k_ss, long v_ss, int kv0, int S, int tid) {
+    const int row = tid >> 3, col = (tid & 7) * 8;
+    const int key = kv0 + row;
+    if (key < S) {
+        st.k = *reinterpret_cast<const u32x4*>(Kp + (long)key * k_ss + col);
+        st.v = *reinterpret_cast<const u32x4*>(Vp + (long)key * v_ss + col);
+    } else {
+        st.k = zero_u4();
+        st.v = zero_u4();
+    }
+}
+// ... -> LDS (parked after them)
+template <class BK>
+TTT_BODY_FN void kv_park(BK& bk, const KVStage& st, typename BK::tile_t k_img, typename BK::tile_t v_img, int v_stride, int tid) {
+    const int row = tid >> 3, col = (tid & 7) * 8;
+    bk.st(k_img + (row * AS + col), st.k);
+    bk.st(v_img + (row * v_stride + col), st.v);
+}
+
+// workgroup -> (batch*head, block of 256 rows): blocks b, b+8, b+16, ... share an XCD; give each XCD whole heads, so a head's
+// K and V are fetched from HBM once and then served by that XCD's L2
+TTT_BODY_FN void head_of_block(int b, int nblk, int nbh, int& bh, int& blk) {
+    if ((nbh & 7) == 0) {
+        const int xcd = b & 7, idx = b >> 3;
+        bh = xcd + 8 * (idx / nblk);
+        blk = idx % nblk;
+    } else {
+        bh = b / nblk;
+        blk = b % nblk;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- forward
+// O = softmax(Q K^T * scale) V and LSE for the 256 query rows of block qb of head bh (reference dit.py:196-198)
+template <class BK>
+TTT_BODY_FN void forward(BK& bk, const FwdParams& p, int bh, int qb) {
+    const int tid = bk.thread(), wv = bk.wave(), l = bk.lane(), h = l >> 5, c = l & 31;
+    const int bb = bh / p.NH, hh = bh % p.NH;
+    const __bf16* Qp = p.Q + (long)bb * p.q_sb + (long)hh * p.q_sh;
+    const __bf16* Kp = p.K + (long)bb * p.k_sb + (long)hh * p.k_sh;
+    const __bf16* Vp = p.V + (long)bb * p.v_sb + (long)hh * p.v_sh;
+    __bf16* Op = p.O + (long)bb * p.o_sb + (long)hh * p.o_sh;
+
+    const int qrow = qb * QB + 32 * wv + c;    // this lane's query row
+    const bool qvalid = qrow < p.S;
+    bf16x8 Qf[4];                              // B operand: lane = query, 8 contiguous d per k-slice; kept for the whole loop
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+        Qf[kk] = qvalid ? *reinterpret_cast<const bf16x8*>(Qp + (long)qrow * p.q_ss + 16 * kk + 8 * h) : zero_frag();
+
+    f32x16 O[2] = {zero16(), zero16()};        // O^T tiles: rows = d (32 db + row_of(r,h)), lane = query
+    float m = -1e30f, lsum = 0.f;              // running max (raw score units), this half-wave's partial row sum
+    const float sc = p.scale * LOG2E;
+    const int nt = (p.S + KB - 1) / KB;
+    KVStage st;
+
+    const typename BK::tile_t lds = bk.lds_base();
+    kv_issue(st, Kp, Vp, p.k_ss, p.v_ss, 0, p.S, tid);
+    kv_park(bk, st, lds, lds + KT_ELEMS, VS, tid);
+    bk.barrier();
+    for (int j = 0; j < nt; ++j) {
+        const typename BK::tile_t Kt = lds + (j & 1) * FWD_BUF_ELEMS, Vt = Kt + KT_ELEMS;
+        const bool more = j + 1 < nt;
+        if (more) kv_issue(st, Kp, Vp, p.k_ss, p.v_ss, (j + 1) * KB, p.S, tid);
+        // ---- S^T = K Q^T : two key blocks of 32 ----
+        f32x16 Sc[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            f32x16 acc = zero16();
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) acc = bk.mma3216(row_frag(bk, Kt, AS, 32 * kb, 16 * kk, l), Qf[kk], acc);
+            Sc[kb] = acc;
+        }
+        if (!more && (p.S & (KB - 1))) {        // ragged last tile: keys >= S are masked.  Wave-uniform, and kept a real branch
+            const int kv0 = j * KB;             // (if-converted it costs an add + compare + select per score in EVERY tile)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = Sc[kb][r];
+                    if (kv0 + 32 * kb + row_of(r, h) >= p.S) v = -1e30f;
+                    TTT_PIN_IN_BRANCH(v);
+                    Sc[kb][r] = v;
+                }
+        }
+        // ---- online softmax: one query row per lane; the partner half-wave holds the other 32 keys of the tile ----
+        float mt = Sc[0][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mt = fmaxf(mt, Sc[0][r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mt = fmaxf(mt, Sc[1][r]);
+        mt = fmaxf(mt, bk.xor_read(mt, 32));
+        // rescale only when some row of this wave saw a larger maximum (alpha == 1 exactly for every lane otherwise)
+        if (bk.any(mt > m)) {
+            const float mn = fmaxf(m, mt);
+            const float alpha = bk.exp2((m - mn) * sc);
+            m = mn;
+            lsum *= alpha;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) O[db][r] *= alpha;
+        }
+        const float msc = m * sc;
+        float ps = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = bk.exp2(__builtin_fmaf(Sc[kb][r], sc, -msc));
+                Sc[kb][r] = e;
+                ps += e;
+            }
+        lsum += ps;
+        // ---- O^T += V^T P^T ----
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 pf = pack(Sc[kb], s);
+                O[0] = bk.mma3216(tr_frag_pi(bk, Vt, VS, 32 * kb, s, 0, l), pf, O[0]);
+                O[1] = bk.mma3216(tr_frag_pi(bk, Vt, VS, 32 * kb, s, 32, l), pf, O[1]);
+            }
+        if (more) {
+            const typename BK::tile_t Kn = lds + ((j + 1) & 1) * FWD_BUF_ELEMS;
+            kv_park(bk, st, Kn, Kn + KT_ELEMS, VS, tid);
+        }
+        bk.barrier();
+    }
+
+    // ---- epilogue: normalise, store O[q][d] (4 consecutive d per register group) and the log-sum-exp ----
+    const float ltot = lsum + bk.xor_read(lsum, 32);
+    const float inv = 1.0f / ltot;
+    if (qvalid) {
+        __bf16* orow = Op + (long)qrow * p.o_ss;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (__bf16)(O[db][4 * g + e] * inv);
+                *reinterpret_cast<bf16x4*>(orow + 32 * db + 8 * g + 4 * h) = v;
+            }
+        if (h == 0 && p.LSE) p.LSE[(long)bh * p.S + qrow] = m * p.scale + bk.log(ltot);
+    }
+}
+
+// --------------------------------------------------------------------------------------------------------------------- dQ
+// dQ = scale * dS K,  dS = P * (dP - Delta),  P = exp(S*scale - LSE),  dP = dO V^T, for the 256 query rows of block qb
+template <class BK>
+TTT_BODY_FN void dq(BK& bk, const BwdParams& p, int bh, int qb) {
+    const int tid = bk.thread(), wv = bk.wave(), l = bk.lane(), h = l >> 5, c = l & 31;
+    const int bb = bh / p.NH, hh = bh % p.NH;
+    const __bf16* Qp = p.Q + (long)bb * p.q_sb + (long)hh * p.q_sh;
+    const __bf16* Kp = p.K + (long)bb * p.k_sb + (long)hh * p.k_sh;
+    const __bf16* Vp = p.V + (long)bb * p.v_sb + (long)hh * p.v_sh;
+    const __bf16* dOp = p.dO + (long)bb * p.do_sb + (long)hh * p.do_sh;
+
+    const int qrow = qb * QB + 32 * wv + c;
+    const bool qvalid = qrow < p.S;
+    bf16x8 Qf[4], Df[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        Qf[kk] = qvalid ? *reinterpret_cast<const bf16x8*>(Qp + (long)qrow * p.q_ss + 16 * kk + 8 * h) : zero_frag();
+        Df[kk] = qvalid ? *reinterpret_cast<const bf16x8*>(dOp + (long)qrow * p.do_ss + 16 * kk + 8 * h) : zero_frag();
+    }
+    const float lse2 = qvalid ? p.LSE[(long)bh * p.S + qrow] * LOG2E : 1e30f;
+    const float delta = qvalid ? p.Delta[(long)bh * p.S + qrow] : 0.f;
+    const float sc = p.scale * LOG2E;
+    f32x16 dQ[2] = {zero16(), zero16()};       // dQ^T tiles (rows = d, lane = query)
+    const int nt = (p.S + KB - 1) / KB;
+    KVStage st;
+
+    const typename BK::tile_t lds = bk.lds_base();
+    kv_issue(st, Kp, Vp, p.k_ss, p.v_ss, 0, p.S, tid);
+    kv_park(bk, st, lds, lds + KT_ELEMS, AS, tid);
+    bk.barrier();
+    for (int j = 0; j < nt; ++j) {
+        const typename BK::tile_t Kt = lds + (j & 1) * DQ_BUF_ELEMS, Vt = Kt + KT_ELEMS;
+        const bool more = j + 1 < nt;
+        if (more) kv_issue(st, Kp, Vp, p.k_ss, p.v_ss, (j + 1) * KB, p.S, tid);
+        const bool ragged = !more && (p.S & (KB - 1));
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            f32x16 Sc = zero16(), dP = zero16();
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                Sc = bk.mma3216(row_frag(bk, Kt, AS, 32 * kb, 16 * kk, l), Qf[kk], Sc);
+                dP = bk.mma3216(row_frag(bk, Vt, AS, 32 * kb, 16 * kk, l), Df[kk], dP);
+            }
+            if (ragged) {                       // keys >= S (zero-filled rows of the last tile) contribute nothing: P = 0 there.
+#pragma unroll                                  // Wave-uniform and kept a real branch: exp2(-1e30) == 0 exactly
+                for (int r = 0; r < 16; ++r) {
+                    float v = Sc[r];
+                    if (j * KB + 32 * kb + row_of(r, h) >= p.S) v = -1e30f;
+                    TTT_PIN_IN_BRANCH(v);
+                    Sc[r] = v;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pr = bk.exp2(__builtin_fmaf(Sc[r], sc, -lse2));
+                dP[r] = pr * (dP[r] - delta);
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 df = pack(dP, s);
+                dQ[0] = bk.mma3216(tr_frag_pi(bk, Kt, AS, 32 * kb, s, 0, l), df, dQ[0]);
+                dQ[1] = bk.mma3216(tr_frag_pi(bk, Kt, AS, 32 * kb, s, 32, l), df, dQ[1]);
+            }
+        }
+        if (more) {
+            const typename BK::tile_t Kn = lds + ((j + 1) & 1) * DQ_BUF_ELEMS;
+            kv_park(bk, st, Kn, Kn + KT_ELEMS, AS, tid);
+        }
+        bk.barrier();
+    }
+
+    if (qvalid) {
+        __bf16* row = p.dQ + (long)bb * p.dq_sb + (long)hh * p.dq_sh + (long)qrow * p.dq_ss;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (__bf16)(dQ[db][4 * g + e] * p.scale);
+                *reinterpret_cast<bf16x4*>(row + 32 * db + 8 * g + 4 * h) = v;
+            }
+    }
+}
+
+}  // namespace attnb
+}  // namespace ttt

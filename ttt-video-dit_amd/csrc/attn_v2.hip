@@ -1,0 +1,79 @@
+// Segment attention, revision 2 (forward and dQ): the backend-templated workgroup bodies of attn_body.h instantiated with the
+// gfx950 instructions.  Opt-in (debug option "attn_variant" = 2) until it has been timed against revision 1 on an MI355X; the
+// bodies themselves are executed on the CPU by the wave emulator against the fp64 oracle (tests/test_emul_cpu.py), and
+// tests/test_attention_gpu.py compares the two revisions bit for bit on the device.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include "../../include/ttt_hip.h"
+#include "attn.h"
+#include "attn_body.h"
+
+namespace ttt {
+namespace attn {
+
+struct AttnDeviceWave {
+    typedef __bf16* tile_t;                                           // element pointer into the workgroup's LDS
+    typedef __attribute__((address_space(3))) wv::bf16x4 lds_b4;
+    tile_t base;
+    __device__ __forceinline__ int lane() const { return threadIdx.x & 63; }
+    __device__ __forceinline__ int wave() const { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
+    __device__ __forceinline__ int thread() const { return threadIdx.x; }
+    __device__ __forceinline__ void barrier() const { __syncthreads(); }
+    __device__ __forceinline__ float exp2(float x) const { return __builtin_amdgcn_exp2f(x); }
+    __device__ __forceinline__ float log(float x) const { return __logf(x); }
+    __device__ __forceinline__ tile_t lds_base() const { return base; }
+    template <class T> __device__ __forceinline__ T ld(const __bf16* p) const { return *reinterpret_cast<const T*>(p); }
+    template <class T> __device__ __forceinline__ void st(__bf16* p, T v) const { *reinterpret_cast<T*>(p) = v; }
+    __device__ __forceinline__ wv::bf16x4 tr(const __bf16* p) const { return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)p); }
+    __device__ __forceinline__ wv::f32x16 mma3216(wv::bf16x8 a, wv::bf16x8 b, wv::f32x16 c) const {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+    __device__ __forceinline__ float xor_read(float v, int mask) const { return __shfl_xor(v, mask, 64); }
+    __device__ __forceinline__ bool any(bool b) const { return __builtin_amdgcn_ballot_w64(b) != 0; }
+};
+
+__global__ __launch_bounds__(512, 4) void attn_fwd2_kernel(FwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int bh, qb;
+    attnb::head_of_block(blockIdx.x, (p.S + attnb::QB - 1) / attnb::QB, p.B * p.NH, bh, qb);
+    AttnDeviceWave bk{reinterpret_cast<__bf16*>(smem)};
+    attnb::forward(bk, p, bh, qb);
+}
+
+template <int W>
+__global__ __launch_bounds__(512, W) void attn_dq2_kernel(BwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int bh, qb;
+    attnb::head_of_block(blockIdx.x, (p.S + attnb::QB - 1) / attnb::QB, p.B * p.NH, bh, qb);
+    AttnDeviceWave bk{reinterpret_cast<__bf16*>(smem)};
+    attnb::dq(bk, p, bh, qb);
+}
+
+static int g_attn_variant = 1;
+void set_attn_variant(int v) { g_attn_variant = v; }
+int get_attn_variant() { return g_attn_variant; }
+
+void launch_forward_v2(const FwdParams& p, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)attn_fwd2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, attnb::LDS_FWD);
+        attr = true;
+    }
+    const int nqb = (p.S + attnb::QB - 1) / attnb::QB;
+    hipLaunchKernelGGL(attn_fwd2_kernel, dim3(p.B * p.NH * nqb), dim3(512), attnb::LDS_FWD, s, p);
+}
+
+void launch_dq_v2(const BwdParams& p, int occ, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)attn_dq2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, attnb::LDS_DQ);
+        (void)hipFuncSetAttribute((const void*)attn_dq2_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, attnb::LDS_DQ);
+        attr = true;
+    }
+    const int nb = (p.S + attnb::QB - 1) / attnb::QB;
+    if (occ == 2) hipLaunchKernelGGL(attn_dq2_kernel<2>, dim3(p.B * p.NH * nb), dim3(512), attnb::LDS_DQ, s, p);
+    else hipLaunchKernelGGL(attn_dq2_kernel<4>, dim3(p.B * p.NH * nb), dim3(512), attnb::LDS_DQ, s, p);
+}
+
+}  // namespace attn
+}  // namespace ttt
