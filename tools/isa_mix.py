@@ -8,9 +8,14 @@ LDS, VMEM / buffer, scalar, waitcnt, barriers) and a lower bound on the issue ti
 
     cycles >= waves_per_simd * sum(issue cycles of the wave's instructions)   and   >= MFMA pipe cycles,
 
-with the issue costs of MI355X_MICROARCH.md (wave64 VALU 4 cycles, transcendental 16 (quarter rate), 32x32x16 bf16 MFMA 8 passes
-x 4 = 32 cycles of the matrix pipe - 16 for the 16x16x32 shape -, LDS / VMEM / scalar 4 to issue).  It knows nothing about
-latencies or dependencies: it bounds what scheduling can reach and shows whether a loop is MFMA-, VALU- or wait-dominated.
+with the issue costs of MI355X_MICROARCH.md (wave64 VALU 4 cycles, a transcendental ~5/3 of that, 32x32x16 bf16 MFMA 8 passes
+x 4 = 32 cycles of the matrix pipe - 16 for the 16x16x32 shape -, LDS / VMEM 4 to issue).  It knows nothing about latencies
+or dependencies: it bounds what scheduling can reach and shows whether a loop is MFMA-, VALU- or wait-dominated.
+
+CAVEAT: a loop's span contains blocks that the steady state may jump over (a ragged-tail mask behind a uniform branch, a
+checkpoint store every G-th step).  `--blocks` prints the innermost large loop basic block by basic block with the branch
+that ends each block, so that skipped blocks can be told from the hot path (attention forward, revision 1: the 96-VALU
+mask block is skipped by `s_cbranch_vccnz`; its dQ kernel has the mask if-converted INTO the hot block: 243 VALU).
 """
 import os
 import re
@@ -70,7 +75,7 @@ def mfma_cycles(op):
     return 32
 
 
-ISSUE = {"valu": 4, "acc_mov": 4, "trans": 16, "lds": 4, "vmem": 4, "salu": 1, "waitcnt": 1, "barrier": 1, "branch": 1, "nop": 1, "other": 1, "mfma": 4}
+ISSUE = {"valu": 4, "acc_mov": 4, "trans": 7, "lds": 4, "vmem": 4, "salu": 1, "waitcnt": 1, "barrier": 1, "branch": 1, "nop": 1, "other": 1, "mfma": 4}
 
 
 def parse(asm_path):
@@ -122,6 +127,24 @@ def mix(insts):
     return c, mfma_pipe, issue
 
 
+def blocks(insts, a, b, lab):
+    """basic blocks of insts[a..b]: (label, instructions, terminating instruction text)"""
+    out, cur = [], [lab]
+    for x in insts[a:b + 1]:
+        if x[0] == "label":
+            if len(cur) > 1:
+                out.append(cur)
+            cur = [x[1]]
+        else:
+            cur.append(x)
+            if x[1].startswith("s_cbranch") or x[1] == "s_branch":
+                out.append(cur)
+                cur = ["(fallthrough)"]
+    if len(cur) > 1:
+        out.append(cur)
+    return out
+
+
 def demangle(name):
     try:
         return subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", name], capture_output=True, text=True).stdout.strip() or name
@@ -130,8 +153,10 @@ def demangle(name):
 
 
 def main():
-    unit = sys.argv[1]
-    pat = sys.argv[2] if len(sys.argv) > 2 else ""
+    args = [a for a in sys.argv[1:] if a != "--blocks"]
+    show_blocks = "--blocks" in sys.argv
+    unit = args[0]
+    pat = args[1] if len(args) > 1 else ""
     waves_per_simd = int(os.environ.get("WAVES_PER_SIMD", "2"))
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, unit + ".s")
@@ -140,7 +165,7 @@ def main():
         kernels = parse(out)
     for name, insts in kernels.items():
         pretty = demangle(name)
-        if pat and pat not in pretty:
+        if pat and pat not in pretty and pat not in name:
             continue
         c, pipe, issue = mix(insts)
         print(f"\n== {pretty[:150]}\n   whole kernel: {sum(c.values())} instructions  {dict(c)}")
@@ -153,6 +178,15 @@ def main():
             print(f"   loop {lab:>10} [{n:5d} inst]  mfma {c['mfma']:4d} (pipe {pipe:6d} cyc)  valu {c['valu']:5d}  trans {c['trans']:4d}  acc_mov {c['acc_mov']:4d}  "
                   f"lds {c['lds']:4d}  vmem {c['vmem']:4d}  salu {c['salu']:4d}  wait {c['waitcnt']:4d}  barrier {c['barrier']:3d}  "
                   f"| issue/wave {issue:6d} cyc -> SIMD bound at {waves_per_simd} waves: max({waves_per_simd * issue}, {waves_per_simd * pipe}) cyc")
+        big = [l for l in ls if l[1] - l[0] > 100]
+        if show_blocks and big:
+            a, b, lab = big[0] if os.environ.get("ISA_LOOP", "outer") == "outer" else big[-1]
+            print(f"   basic blocks of loop {lab}:")
+            for bl in blocks(insts, a, b, lab):
+                c, pipe, issue = mix(bl[1:])
+                scr = sum(1 for x in bl[1:] if x[1].startswith("scratch"))
+                print(f"      {bl[0]:>14} n={len(bl) - 1:4d} valu={c['valu']:4d} trans={c['trans']:3d} mfma={c['mfma']:3d} lds={c['lds']:3d} "
+                      f"vmem={c['vmem']:3d} (scratch {scr:2d}) wait={c['waitcnt']:3d}   ends: {bl[-1][2]}")
 
 
 if __name__ == "__main__":
