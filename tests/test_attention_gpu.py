@@ -176,6 +176,11 @@ def test_fused_attention_node_equals_two_nodes():
         assert torch.equal(a, b)
 
 
+VARIANTS = pytest.mark.skipif(__import__("os").environ.get("TTT_TEST_VARIANTS") != "1",
+                              reason="opt-in kernel variants (emulator-verified, not yet timed on hardware): TTT_TEST_VARIANTS=1")
+
+
+@VARIANTS
 @pytest.mark.parametrize("B,NH,S,layout", [(2, 3, 300, "bshd"), (1, 8, 1024, "bhsd"), (1, 2, 40, "bshd"), (1, 16, 577, "bshd")])
 def test_attention_v2_equals_v1(B, NH, S, layout):
     """Revision 2 of the forward and dQ kernels (csrc/attn_v2.hip: the emulator-checked bodies of attn_body.h, debug option
