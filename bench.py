@@ -203,7 +203,8 @@ def main():
 
     ext.load_library()
     ext.set_impl(args.impl)
-    ext.debug_option("attn_variant", args.attn_variant)
+    if args.attn_variant != 1:
+        ext.debug_option("attn_variant", args.attn_variant)
     init_distributed("nccl")
     tuned = (not args.no_tuned_gemms) and enable_tuned_gemms()
     if args.overlap_wgrad:
