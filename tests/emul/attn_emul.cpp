@@ -38,6 +38,25 @@ int emul_attn_dq(const attn::BwdParams* p, char* msg, int msg_len) {
     return races;
 }
 
+// variant 2 = <8 waves, revision 1's arithmetic>, 3 = <8, accumulator-initialised row scalars>, 4 = <12, ...> (attn.h)
+int emul_attn_dkdv(const attn::BwdParams* p, int variant, char* msg, int msg_len) {
+    const int nw = variant == 4 ? 12 : 8;
+    const int nkb = (p->S + 32 * nw - 1) / (32 * nw), nbh = p->B * p->NH;
+    int races = 0;
+    for (int b = 0; b < nbh * nkb; ++b) {
+        int bh, kvb;
+        attnb::head_of_block(b, nkb, nbh, bh, kvb);
+        const emul::RaceReport r = emul::run_group(nw, [&](emul::EmulWave& w) {
+            if (variant == 2) attnb::dkdv<8, false>(w, *p, bh, kvb);
+            else if (variant == 3) attnb::dkdv<8, true>(w, *p, bh, kvb);
+            else attnb::dkdv<12, true>(w, *p, bh, kvb);
+        });
+        if (r.races && !races && msg) snprintf(msg, msg_len, "%s", r.first.c_str());
+        races += r.races;
+    }
+    return races;
+}
+
 int emul_attn_fwd_params_size() { return (int)sizeof(attn::FwdParams); }
 int emul_attn_bwd_params_size() { return (int)sizeof(attn::BwdParams); }
 }

@@ -115,23 +115,60 @@ def test_emulated_attention_forward_rescale_path(emul):
     assert rel_l2(out, ro) < 1e-2
 
 
+def _bwd_params(q, k, v, do, ro, rl):
+    """the backward kernels' inputs: the forward's bf16 output and fp32 LSE, Delta = rowsum(dO * O) as attn_delta_kernel forms
+    it; outputs NaN-filled [B, NH, S, 64] views of [B, S, NH, 64] memory"""
+    B, NH, S, _ = q.shape
+    o = ro.to(torch.bfloat16)
+    lse = rl.float().contiguous()
+    delta = (do.float() * o.float()).sum(-1).contiguous()
+    outs = [torch.full((B, S, NH, 64), float("nan"), dtype=torch.bfloat16).transpose(1, 2) for _ in range(3)]
+    p = BwdParams()
+    p.Q, p.K, p.V, p.O, p.dO, p.LSE, p.Delta = (t.data_ptr() for t in (q, k, v, o, do, lse, delta))
+    p.dQ, p.dK, p.dV = (t.data_ptr() for t in outs)
+    for n, t in (("q", q), ("k", k), ("v", v), ("o", o), ("do", do), ("dq", outs[0]), ("dk", outs[1]), ("dv", outs[2])):
+        _strides(p, n, t)
+    p.B, p.NH, p.S, p.scale = B, NH, S, 1 / math.sqrt(64)
+    return p, outs, (o, lse, delta)
+
+
 @pytest.mark.parametrize("B,NH,S,layout", SHAPES)
 def test_emulated_attention_dq_vs_oracle(emul, B, NH, S, layout):
     q, k, v, do = _make(B, NH, S, 11 + S, layout)
     ro, rl, rq, _, _ = _oracle(q, k, v, do)
-    # the kernel's inputs: the forward's bf16 output and fp32 LSE, Delta = rowsum(dO * O) as attn_delta_kernel forms it
-    o = ro.to(torch.bfloat16)
-    lse = rl.float().contiguous()
-    delta = (do.float() * o.float()).sum(-1).contiguous()
-    dq = torch.full((B, S, NH, 64), float("nan"), dtype=torch.bfloat16).transpose(1, 2)
-    p = BwdParams()
-    p.Q, p.K, p.V, p.O, p.dO, p.LSE, p.Delta, p.dQ = (q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(),
-                                                      lse.data_ptr(), delta.data_ptr(), dq.data_ptr())
-    for n, t in (("q", q), ("k", k), ("v", v), ("o", o), ("do", do), ("dq", dq)):
-        _strides(p, n, t)
-    p.B, p.NH, p.S, p.scale = B, NH, S, 1 / math.sqrt(64)
+    p, (dq, _, _), keep = _bwd_params(q, k, v, do, ro, rl)
     msg = ctypes.create_string_buffer(256)
     races = emul.emul_attn_dq(ctypes.byref(p), msg, 256)
     assert races == 0, msg.value.decode()
     assert not torch.isnan(dq.float()).any()
     assert rel_l2(dq, rq) < 2e-2
+
+
+# dK / dV body: 2 = revision 1's arithmetic, 3 = accumulators started from -LSE / scale and -Delta, 4 = the same with 12 waves
+@pytest.mark.parametrize("variant", [2, 3, 4])
+@pytest.mark.parametrize("B,NH,S,layout", [(1, 2, 40, "bshd"), (2, 3, 300, "bshd"), (1, 8, 128, "bhsd"), (1, 1, 800, "bshd")])
+def test_emulated_attention_dkdv_vs_oracle(emul, B, NH, S, layout, variant):
+    q, k, v, do = _make(B, NH, S, 13 + S, layout)
+    ro, rl, _, rk, rv = _oracle(q, k, v, do)
+    p, (_, dk, dv), keep = _bwd_params(q, k, v, do, ro, rl)
+    msg = ctypes.create_string_buffer(256)
+    races = emul.emul_attn_dkdv(ctypes.byref(p), variant, msg, 256)
+    assert races == 0, msg.value.decode()
+    assert not torch.isnan(dk.float()).any() and not torch.isnan(dv.float()).any()
+    errs = (rel_l2(dk, rk), rel_l2(dv, rv))
+    print(variant, (B, NH, S), errs)
+    assert max(errs) < 2e-2, errs
+
+
+def test_emulated_dkdv_variants_agree(emul):
+    """the accumulator-initialised form against revision 1's arithmetic on the same inputs: differences only at the level of
+    the bf16 rounding of P / dS (a few 1e-3 relative), and the 8- and 12-wave decompositions of the SAME arithmetic bit-equal"""
+    q, k, v, do = _make(1, 2, 450, 99, "bshd")
+    ro, rl, *_ = _oracle(q, k, v, do)
+    res = {}
+    for variant in (2, 3, 4):
+        p, (_, dk, dv), keep = _bwd_params(q, k, v, do, ro, rl)
+        assert emul.emul_attn_dkdv(ctypes.byref(p), variant, None, 0) == 0
+        res[variant] = (dk.float().clone(), dv.float().clone())
+    assert torch.equal(res[3][0], res[4][0]) and torch.equal(res[3][1], res[4][1])
+    assert rel_l2(res[3][0], res[2][0]) < 5e-3 and rel_l2(res[3][1], res[2][1]) < 5e-3

@@ -7,12 +7,15 @@ mkdir -p gpurun_out/ab
 O=gpurun_out/ab
 # ---- parity first: kernel variants, attention revision 2 == revision 1, side-stream weight gradients ----------------------
 TTT_TEST_VARIANTS=1 timeout 300 python -m pytest tests/test_kernels_gpu.py -x -q -k "variant or wgrad_overlap" 2>&1 | tail -5 | tee $O/variant_tests.txt
-TTT_TEST_VARIANTS=1 timeout 300 python -m pytest tests/test_attention_gpu.py -x -q -k "v2_equals_v1" 2>&1 | tail -5 | tee -a $O/variant_tests.txt
+TTT_TEST_VARIANTS=1 timeout 400 python -m pytest tests/test_attention_gpu.py -x -q -k "v2_equals_v1 or dkdv_variants" 2>&1 | tail -5 | tee -a $O/variant_tests.txt
 # ---- attention: revision 1 vs revision 2 (forward unchanged in substance, dQ without the per-tile tail mask) ----------------
 for v in 1 2; do
   timeout 120 python tools/attn_bench.py --no-sdpa --iters 10 --variant $v 2>/dev/null | tail -1 | tee -a $O/attn_ab.txt
 done
 TTT_ATTN_DQ_OCC=2 timeout 120 python tools/attn_bench.py --no-sdpa --iters 10 --variant 2 2>/dev/null | tail -1 | tee -a $O/attn_ab.txt
+for d in 2 3 4; do      # dK / dV through the body: same arithmetic / accumulator-initialised row scalars with 8 / 12 waves
+  timeout 120 python tools/attn_bench.py --no-sdpa --iters 10 --variant 2 --dkdv-variant $d 2>/dev/null | tail -1 | tee -a $O/attn_ab.txt
+done
 # ---- CS = 16 kernels ---------------------------------------------------------------------------------------------------
 for body in "" "--body"; do
   timeout 100 python tools/cs16_bench.py --no-generic --batch 2 $body 2>&1 | grep "^mfma" | sed "s/^/mlp16 body='$body' /" | tee -a $O/ab.txt
@@ -27,7 +30,7 @@ if [ "$1" = "bench" ]; then
   timeout 400 $B --attn-variant 2                  2>$O/bench_attn2.err    | tail -1 > $O/bench_attn2.json
   timeout 400 $B --overlap-wgrad                   2>$O/bench_wgrad.err    | tail -1 > $O/bench_wgrad.json
   timeout 400 $B --no-fsdp                         2>$O/bench_nofsdp.err   | tail -1 > $O/bench_nofsdp.json
-  timeout 400 $B --attn-variant 2 --overlap-wgrad --no-fsdp 2>$O/bench_all.err | tail -1 > $O/bench_all.json
+  timeout 400 $B --attn-variant 2 --attn-dkdv-variant 4 --overlap-wgrad --no-fsdp 2>$O/bench_all.err | tail -1 > $O/bench_all.json
   for f in default attn2 wgrad nofsdp all; do
     python - "$O/bench_$f.json" "$f" <<'PY'
 import json, sys

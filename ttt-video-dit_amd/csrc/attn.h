@@ -38,6 +38,11 @@ void set_attn_variant(int v);
 int get_attn_variant();
 void launch_forward_v2(const FwdParams& p, hipStream_t s);
 void launch_dq_v2(const BwdParams& p, int occ, hipStream_t s);
+// dK / dV through the body of attn_body.h; debug option "attn_dkdv_variant": 1 (default) = attn_dkdv_kernel of attn_bwd.hip,
+// 2 = the same arithmetic through the body, 3 = accumulator-initialised row scalars (8 waves), 4 = ... with 12 waves
+void set_dkdv_variant(int v);
+int get_dkdv_variant();
+void launch_dkdv_v2(const BwdParams& p, int variant, hipStream_t s);
 
 }  // namespace attn
 }  // namespace ttt

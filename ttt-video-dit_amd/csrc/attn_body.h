@@ -341,5 +341,173 @@ TTT_BODY_FN void dq(BK& bk, const BwdParams& p, int bh, int qb) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------ dK, dV
+// dV = P^T dO, dK = scale * dS^T Q for the 32 * NW keys of block kvb: each wave keeps 32 key rows of K and V as register-resident
+// B operands and its dK / dV accumulator tiles over the whole loop over query tiles of 64 (Q, dO and the per-query LSE / Delta
+// staged through LDS, double-buffered).  S = Q K^T and dP = dO V^T come out as (rows = query, lane = key) tiles, so P and dS are,
+// in place, the A operands of  dV += P^T dO  and  dK += dS^T Q  (contraction over the tile's row index), with dO / Q fragments
+// from transposed LDS reads.  Revision 1 (attn_bwd.hip) is <8 waves, ACC_INIT = false>.
+//
+// ACC_INIT: in this orientation LSE and Delta are PER-ROW values, i.e. 16 registers each per lane, live next to both
+// accumulators (189 VGPRs in revision 1: one 8-wave workgroup per CU, and the loop is latency-bound at 2.7x its issue
+// bound).  With ACC_INIT the staging code stores -LSE / scale and -Delta, and the two accumulators START from those rows
+// instead of zero:  S' = Q K^T - LSE / scale,  dP' = dO V^T - Delta,  so  P = exp2(S' * scale * log2 e)  and  dS = P * dP'
+// need no row value at all: 32 registers and 32 VALU instructions per tile fewer, which is what lets a workgroup run
+// 12 waves (3 per SIMD, <= 168 registers).  fp32 accumulation of a start value of magnitude ~ |LSE| / scale ~ 1e2 costs
+// ~1e-5 absolute in raw-score units, far below the bf16 rounding of P.
+constexpr int DKV_BUF_ELEMS = 2 * KT_ELEMS + 2 * 64 * 2;       // Q tile, dO tile, lse[64], delta[64] (fp32 = 2 elements each)
+constexpr int LDS_DKV = 2 * DKV_BUF_ELEMS * 2;
+
+struct QStage {
+    u32x4 q, d;
+    float lse, del;
+};
+template <bool ACC_INIT>
+TTT_BODY_FN void qstage_issue(QStage& st, const BwdParams& p, const __bf16* Qp, const __bf16* dOp, const float* lse, const float* del,
+                              float inv_scale, int q0, int tid) {
+    if (tid < 512) {
+        const int row = tid >> 3, col = (tid & 7) * 8;
+        const int q = q0 + row;
+        if (q < p.S) {
+            st.q = *reinterpret_cast<const u32x4*>(Qp + (long)q * p.q_ss + col);
+            st.d = *reinterpret_cast<const u32x4*>(dOp + (long)q * p.do_ss + col);
+        } else {
+            st.q = zero_u4();
+            st.d = zero_u4();
+        }
+    }
+    if (tid < 64) {
+        const int qq = q0 + tid;
+        if (ACC_INIT) {
+            st.lse = qq < p.S ? -lse[qq] * inv_scale : -1e30f;   // invalid rows: P = exp2(-huge) = 0
+            st.del = qq < p.S ? -del[qq] : 0.f;
+        } else {
+            st.lse = qq < p.S ? lse[qq] * LOG2E : 1e30f;
+            st.del = qq < p.S ? del[qq] : 0.f;
+        }
+    }
+}
+template <class BK>
+TTT_BODY_FN void qstage_park(BK& bk, const QStage& st, typename BK::tile_t buf, int tid) {
+    if (tid < 512) {
+        const int row = tid >> 3, col = (tid & 7) * 8;
+        bk.st(buf + (row * AS + col), st.q);
+        bk.st(buf + (KT_ELEMS + row * AS + col), st.d);
+    }
+    if (tid < 64) {
+        bk.st(buf + (2 * KT_ELEMS + 2 * tid), st.lse);
+        bk.st(buf + (2 * KT_ELEMS + 2 * (64 + tid)), st.del);
+    }
+}
+// per-register row values of a (rows = query) tile: o[r] = src[base + row_of(r, h)], src = fp32 array `which` (0 lse, 1 delta)
+template <class BK>
+TTT_BODY_FN f32x16 rows_from_lds(BK& bk, typename BK::tile_t buf, int which, int base, int h) {
+    f32x4 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = bk.template ld<f32x4>(buf + (2 * KT_ELEMS + 2 * (64 * which + base + 8 * q + 4 * h)));
+    typedef float f32x8 __attribute__((ext_vector_type(8)));
+    const f32x8 lo = __builtin_shufflevector(v[0], v[1], 0, 1, 2, 3, 4, 5, 6, 7);
+    const f32x8 hi = __builtin_shufflevector(v[2], v[3], 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+}
+
+template <int NW, bool ACC_INIT, class BK>
+TTT_BODY_FN void dkdv(BK& bk, const BwdParams& p, int bh, int kvb) {
+    const int tid = bk.thread(), wv = bk.wave(), l = bk.lane(), h = l >> 5, c = l & 31;
+    const int bb = bh / p.NH, hh = bh % p.NH;
+    const __bf16* Qp = p.Q + (long)bb * p.q_sb + (long)hh * p.q_sh;
+    const __bf16* Kp = p.K + (long)bb * p.k_sb + (long)hh * p.k_sh;
+    const __bf16* Vp = p.V + (long)bb * p.v_sb + (long)hh * p.v_sh;
+    const __bf16* dOp = p.dO + (long)bb * p.do_sb + (long)hh * p.do_sh;
+    const float* lse = p.LSE + (long)bh * p.S;
+    const float* del = p.Delta + (long)bh * p.S;
+
+    const int key0 = kvb * (32 * NW) + 32 * wv;      // this wave's first key
+    const int krow = key0 + c;
+    bf16x8 Kf[4], Vf[4];                              // B operands: lane = key, 8 contiguous d per k-slice
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        Kf[kk] = krow < p.S ? *reinterpret_cast<const bf16x8*>(Kp + (long)krow * p.k_ss + 16 * kk + 8 * h) : zero_frag();
+        Vf[kk] = krow < p.S ? *reinterpret_cast<const bf16x8*>(Vp + (long)krow * p.v_ss + 16 * kk + 8 * h) : zero_frag();
+    }
+    f32x16 dK[2] = {zero16(), zero16()}, dV[2] = {zero16(), zero16()};   // tiles (rows = key, lane = d in block db)
+    const float sc = p.scale * LOG2E, inv_scale = 1.0f / p.scale;
+
+    const int nt = (p.S + 63) / 64;
+    const typename BK::tile_t lds = bk.lds_base();
+    QStage st;
+    qstage_issue<ACC_INIT>(st, p, Qp, dOp, lse, del, inv_scale, 0, tid);
+    qstage_park(bk, st, lds, tid);
+    bk.barrier();
+
+    for (int j = 0; j < nt; ++j) {
+        const typename BK::tile_t buf = lds + (j & 1) * DKV_BUF_ELEMS;
+        const typename BK::tile_t Qt = buf, Dt = buf + KT_ELEMS;
+        const bool more = j + 1 < nt;
+        if (more) qstage_issue<ACC_INIT>(st, p, Qp, dOp, lse, del, inv_scale, (j + 1) * 64, tid);
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            f32x16 Sc, dP;
+            if (ACC_INIT) {
+                Sc = rows_from_lds(bk, buf, 0, 32 * qb, h);      // -LSE / scale
+                dP = rows_from_lds(bk, buf, 1, 32 * qb, h);      // -Delta
+            } else {
+                Sc = zero16();
+                dP = zero16();
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                Sc = bk.mma3216(row_frag(bk, Qt, AS, 32 * qb, 16 * kk, l), Kf[kk], Sc);
+                dP = bk.mma3216(row_frag(bk, Dt, AS, 32 * qb, 16 * kk, l), Vf[kk], dP);
+            }
+            if (ACC_INIT) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float pr = bk.exp2(Sc[r] * sc);
+                    TTT_PIN_IN_BRANCH(pr);           // opaque to the SLP vectorizer, which otherwise pairs P / dS elements across the
+                    Sc[r] = pr;                      // two tiles and then needs 40 moves / 16-bit shuffles per tile to un-pair them
+                    float ds = pr * dP[r];
+                    TTT_PIN_IN_BRANCH(ds);
+                    dP[r] = ds;
+                }
+            } else {
+                const f32x16 lseR = rows_from_lds(bk, buf, 0, 32 * qb, h);
+                const f32x16 delR = rows_from_lds(bk, buf, 1, 32 * qb, h);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pr = bk.exp2(__builtin_fmaf(Sc[r], sc, -lseR[r]));
+                    Sc[r] = pr;
+                    dP[r] = pr * (dP[r] - delR[r]);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 pf = pack(Sc, s), df = pack(dP, s);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    dV[db] = bk.mma3216(pf, tr_frag_pi(bk, Dt, AS, 32 * qb, s, 32 * db, l), dV[db]);
+                    dK[db] = bk.mma3216(df, tr_frag_pi(bk, Qt, AS, 32 * qb, s, 32 * db, l), dK[db]);
+                }
+            }
+        }
+        if (more) qstage_park(bk, st, lds + ((j + 1) & 1) * DKV_BUF_ELEMS, tid);
+        bk.barrier();
+    }
+
+    // epilogue: lane (c,h) register r of tile db holds element [key = key0 + row_of(r,h)][d = 32 db + c]
+    __bf16* dKp = p.dK + (long)bb * p.dk_sb + (long)hh * p.dk_sh;
+    __bf16* dVp = p.dV + (long)bb * p.dv_sb + (long)hh * p.dv_sh;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = key0 + row_of(r, h);
+            if (key < p.S) {
+                dKp[(long)key * p.dk_ss + 32 * db + c] = (__bf16)(dK[db][r] * p.scale);
+                dVp[(long)key * p.dv_ss + 32 * db + c] = (__bf16)dV[db][r];
+            }
+        }
+}
+
 }  // namespace attnb
 }  // namespace ttt

@@ -313,7 +313,8 @@ void launch_backward(const BwdParams& p, hipStream_t s) {
     const int dgrid = (int)((rows * 8 + 255) / 256 < 65536 ? (rows * 8 + 255) / 256 : 65536);
     hipLaunchKernelGGL(attn_delta_kernel, dim3(dgrid), dim3(256), 0, s, p);
     const int nb = (p.S + 255) / 256;
-    hipLaunchKernelGGL(attn_dkdv_kernel, dim3(p.B * p.NH * nb), dim3(NTB), LDS_DKV, s, p);
+    if (get_dkdv_variant() != 1) launch_dkdv_v2(p, get_dkdv_variant(), s);
+    else hipLaunchKernelGGL(attn_dkdv_kernel, dim3(p.B * p.NH * nb), dim3(NTB), LDS_DKV, s, p);
     static const int dq_occ = getenv("TTT_ATTN_DQ_OCC") ? atoi(getenv("TTT_ATTN_DQ_OCC")) : 4;     // DEBUG A/B knob
     if (get_attn_variant() == 2) return launch_dq_v2(p, dq_occ, s);
     if (dq_occ == 2) hipLaunchKernelGGL(attn_dq_kernel<2>, dim3(p.B * p.NH * nb), dim3(NTB), LDS_DQ, s, p);

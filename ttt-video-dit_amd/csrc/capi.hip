@@ -62,6 +62,7 @@ int ttt_hip_debug_option(const char* name, int value) {
     else if (!strcmp(name, "variant")) ttt::mfma::set_debug_variant(value);         // kernel revision 2 / 1
     else if (!strcmp(name, "groups_per_chunk")) ttt::mfma::set_debug_groups_per_chunk(value);
     else if (!strcmp(name, "scan16_body")) ttt::mfma::set_debug_scan16_body(value);             // 0 (default) / 1
+    else if (!strcmp(name, "attn_dkdv_variant")) ttt::attn::set_dkdv_variant(value);               // 1 (default) .. 4: dK / dV kernel, see attn.h
     else if (!strcmp(name, "attn_variant")) ttt::attn::set_attn_variant(value);                    // 1 (default) / 2: attention forward + dQ revision
     else if (!strcmp(name, "linear_bwd_lds_slots")) ttt::mfma::set_debug_lin_lds_slots(value);    // 0..6, default 0 (unmeasured)
     else return -1;
