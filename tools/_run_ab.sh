@@ -31,7 +31,8 @@ if [ "$1" = "bench" ]; then
   timeout 400 $B --overlap-wgrad                   2>$O/bench_wgrad.err    | tail -1 > $O/bench_wgrad.json
   timeout 400 $B --no-fsdp                         2>$O/bench_nofsdp.err   | tail -1 > $O/bench_nofsdp.json
   timeout 400 $B --attn-variant 2 --attn-dkdv-variant 4 --overlap-wgrad --no-fsdp 2>$O/bench_all.err | tail -1 > $O/bench_all.json
-  for f in default attn2 wgrad nofsdp all; do
+  timeout 600 $B --local-batch 2                   2>$O/bench_lb2.err      | tail -1 > $O/bench_lb2.json
+  for f in default attn2 wgrad nofsdp all lb2; do
     python - "$O/bench_$f.json" "$f" <<'PY'
 import json, sys
 try:
