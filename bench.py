@@ -271,7 +271,9 @@ def main():
     # out-of-memory error on ONE rank cannot be recovered from while the others sit in a collective
     cap = 0.88 if world == 1 else 0.80
     if args.remat_free_layers == "auto":
-        probe = 4 if cfg.num_layers >= 8 else 0
+        # layers in the second probe step: 4 at the 3 s geometry (2.7 GB of activations per layer and sample), 1 for the long
+        # videos, whose layers are 3 - 20 x larger; an out-of-memory error in the probe means "none fit"
+        probe = (4 if frames <= 13 and LB == 1 else 1) if cfg.num_layers >= 8 else 0
         torch.cuda.reset_peak_memory_stats()
         dit.remat_free_layers = 0
         step()
@@ -281,10 +283,19 @@ def main():
         if probe:
             torch.cuda.reset_peak_memory_stats()
             dit.remat_free_layers = probe
-            step()
-            torch.cuda.synchronize()
-            per_layer = max((torch.cuda.max_memory_allocated() - peak0) / probe, 1.0)
-            n_free = int(max(0, min(cfg.num_layers, (cap * total_mem - peak0) // per_layer)))
+            try:
+                step()
+                torch.cuda.synchronize()
+                per_layer = max((torch.cuda.max_memory_allocated() - peak0) / probe, 1.0)
+                n_free = int(max(0, min(cfg.num_layers, (cap * total_mem - peak0) // per_layer)))
+            except torch.cuda.OutOfMemoryError:
+                if world > 1:
+                    raise                  # the other ranks sit in a collective: not recoverable
+                opt.zero_grad(set_to_none=True)
+                if replica:
+                    replica.zero_grad()
+                torch.cuda.empty_cache()
+                n_free = 0
         if world > 1:       # every rank must take the same decision
             t = torch.tensor([n_free], device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
