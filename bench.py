@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--video-length", default="3sec", choices=["3sec", "9sec", "18sec", "30sec", "63sec"])
     ap.add_argument("--ssm-layer", default="ttt_mlp", choices=["ttt_mlp", "ttt_linear"])
     ap.add_argument("--impl", default="auto", choices=["auto", "generic", "mfma"])
+    ap.add_argument("--adapter", default="sft", choices=["sft", "qkvo"],
+                    help="which parameters train: sft = all (the reference's 3 s stage, configs/train/ttt-mlp/3s.toml), qkvo = the attention / "
+                         "TTT projections, TTT inner parameters and gates only (its longer stages, 9s.toml ...)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     # debugging knobs: anything that shrinks the workload marks the result invalid
@@ -220,7 +223,7 @@ def main():
         over["num_layers"] = args.layers
     if args.ssm_layer == "ttt_linear":      # the reference trains TTT-Linear with these (configs/train/ttt-linear/3s.toml:9,32)
         over.update(mini_batch_size=16, scan_checkpoint_group_size=4)
-    cfg = ModelConfig.get_preset("5B", args.video_length, ssm_layer=args.ssm_layer, adapter_method="sft", **over)
+    cfg = ModelConfig.get_preset("5B", args.video_length, ssm_layer=args.ssm_layer, adapter_method=args.adapter, **over)
     frames, text_len = cfg.compressed_num_frames, TEXT_LEN[args.video_length]
     scenes = max((frames - 1) // 12, 1)
     L = frames * TOKENS_PER_FRAME + scenes * text_len
@@ -394,7 +397,7 @@ def main():
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                 "config": {"workload": f"CogVideoX-5B+{args.ssm_layer} {args.video_length} training step (fwd+bwd+AdamW), "
-                                       f"{cfg.num_layers} layers, L={L} tokens/sample, adapter=sft",
+                                       f"{cfg.num_layers} layers, L={L} tokens/sample, adapter={args.adapter}",
                            "global_batch": world * LB, "seq_len": L, "parallelism": "replica1" if args.no_fsdp else f"fsdp{world}", "ttt_impl": args.impl,
                            "remat_free_layers": n_free, "fsdp_reshard_after_forward": bool(args.reshard_after_forward), "tuned_gemm_selections": bool(tuned), "overlap_wgrad": bool(args.overlap_wgrad), "attn_variant": args.attn_variant, "attn_dkdv_variant": args.attn_dkdv_variant,
                            "valid": args.layers is None},
