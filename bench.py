@@ -78,6 +78,8 @@ def parse():
                     help="2 = revision 2 of the attention forward / dQ kernels (csrc/attn_v2.hip, emulator-checked); opt-in until timed")
     ap.add_argument("--attn-dkdv-variant", type=int, default=1, choices=[1, 2, 3, 4],
                     help="dK / dV kernel variant (csrc/attn.h): 3 / 4 = accumulator-initialised row scalars with 8 / 12 waves; opt-in until timed")
+    ap.add_argument("--scan-gelu-pk", action="store_true",
+                    help="TTT-MLP forward scan with the packed-f32 gelu variant (debug option scan8_gelu_pk, same arithmetic); opt-in until timed")
     ap.add_argument("--overlap-wgrad", action="store_true",
                     help="weight-gradient GEMMs of the projections / MLP on a side stream, beside the backward scans "
                          "(ttt_amd/infra/wgrad_overlap.py); opt-in until timed")
@@ -210,6 +212,8 @@ def main():
     ext.set_impl(args.impl)
     if args.attn_variant != 1:
         ext.debug_option("attn_variant", args.attn_variant)
+    if args.scan_gelu_pk:
+        ext.debug_option("scan8_gelu_pk", 1)
     if args.attn_dkdv_variant != 1:
         ext.debug_option("attn_dkdv_variant", args.attn_dkdv_variant)
     init_distributed("nccl")
@@ -399,7 +403,7 @@ def main():
                 "config": {"workload": f"CogVideoX-5B+{args.ssm_layer} {args.video_length} training step (fwd+bwd+AdamW), "
                                        f"{cfg.num_layers} layers, L={L} tokens/sample, adapter={args.adapter}",
                            "global_batch": world * LB, "seq_len": L, "parallelism": "replica1" if args.no_fsdp else f"fsdp{world}", "ttt_impl": args.impl,
-                           "remat_free_layers": n_free, "fsdp_reshard_after_forward": bool(args.reshard_after_forward), "tuned_gemm_selections": bool(tuned), "overlap_wgrad": bool(args.overlap_wgrad), "attn_variant": args.attn_variant, "attn_dkdv_variant": args.attn_dkdv_variant,
+                           "remat_free_layers": n_free, "fsdp_reshard_after_forward": bool(args.reshard_after_forward), "tuned_gemm_selections": bool(tuned), "overlap_wgrad": bool(args.overlap_wgrad), "attn_variant": args.attn_variant, "attn_dkdv_variant": args.attn_dkdv_variant, "scan_gelu_pk": bool(args.scan_gelu_pk),
                            "valid": args.layers is None},
                 "roofline": roof, "loss": loss_val, "peak_mem_gib": peak_mem, "total_tokens_per_s": world * L / (dt / args.steps)}
         if world == 1 and not args.no_cpu_baseline:

@@ -252,7 +252,8 @@ void        ttt_hip_debug_helpers(int helpers);
  * "groups_per_chunk" (revision-2 TTT-MLP backward), "linear_bwd_lds_slots" (TTT-Linear backward at CS=16: per-step
  * state slots kept in LDS, 0..6, default 0), "scan16_body" (TTT-MLP forward at CS=16 through the backend-templated
  * body of ttt_mlp16_body.h, default 0), "attn_variant" (1 = default kernels of attn_fwd.hip / attn_bwd.hip, 2 = revision 2 of
- * the attention forward and dQ kernels: csrc/attn_v2.hip, bodies in attn_body.h), "attn_dkdv_variant" (1 = default dK / dV kernel,
+ * the attention forward and dQ kernels: csrc/attn_v2.hip, bodies in attn_body.h), "scan8_gelu_pk" (0 / 1: CS = 64 TTT-MLP forward scan with the output-path gelu
+ * on aligned packed-f32 register pairs, same arithmetic), "attn_dkdv_variant" (1 = default dK / dV kernel,
  * 2 = the same arithmetic through the body of attn_body.h, 3 / 4 = accumulators started from the per-row -LSE / scale and
  * -Delta with 8 / 12 waves per workgroup).  Returns 0, or -1 for an unknown name. */
 int         ttt_hip_debug_option(const char* name, int value);

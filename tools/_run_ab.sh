@@ -16,6 +16,10 @@ TTT_ATTN_DQ_OCC=2 timeout 120 python tools/attn_bench.py --no-sdpa --iters 10 --
 for d in 2 3 4; do      # dK / dV through the body: same arithmetic / accumulator-initialised row scalars with 8 / 12 waves
   timeout 120 python tools/attn_bench.py --no-sdpa --iters 10 --variant 2 --dkdv-variant $d 2>/dev/null | tail -1 | tee -a $O/attn_ab.txt
 done
+# ---- TTT-MLP forward scan (CS = 64): default vs packed-f32 gelu on aligned register pairs ------------------------------------
+for f in "" "--gelu-pk"; do
+  timeout 120 python tools/op_bench.py --fwd-only --iters 20 $f 2>/dev/null | tail -1 | sed "s/^/scan8 '$f' /" | cut -c1-400 | tee -a $O/ab.txt
+done
 # ---- CS = 16 kernels ---------------------------------------------------------------------------------------------------
 for body in "" "--body"; do
   timeout 100 python tools/cs16_bench.py --no-generic --batch 2 $body 2>&1 | grep "^mfma" | sed "s/^/mlp16 body='$body' /" | tee -a $O/ab.txt
@@ -30,7 +34,7 @@ if [ "$1" = "bench" ]; then
   timeout 400 $B --attn-variant 2                  2>$O/bench_attn2.err    | tail -1 > $O/bench_attn2.json
   timeout 400 $B --overlap-wgrad                   2>$O/bench_wgrad.err    | tail -1 > $O/bench_wgrad.json
   timeout 400 $B --no-fsdp                         2>$O/bench_nofsdp.err   | tail -1 > $O/bench_nofsdp.json
-  timeout 400 $B --attn-variant 2 --attn-dkdv-variant 4 --overlap-wgrad --no-fsdp 2>$O/bench_all.err | tail -1 > $O/bench_all.json
+  timeout 400 $B --attn-variant 2 --attn-dkdv-variant 4 --overlap-wgrad --no-fsdp --scan-gelu-pk 2>$O/bench_all.err | tail -1 > $O/bench_all.json
   timeout 600 $B --local-batch 2                   2>$O/bench_lb2.err      | tail -1 > $O/bench_lb2.json
   for f in default attn2 wgrad nofsdp all lb2; do
     python - "$O/bench_$f.json" "$f" <<'PY'

@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--lead", type=int, default=1, help="DEBUG A/B: steps the backward's prefetch helpers may run ahead of the scan")
     ap.add_argument("--overlap", action="store_true", help="DEBUG A/B: overlap the next chunk's recompute with the sweep on a side stream")
     ap.add_argument("--sweep-variant", type=int, default=1, help="DEBUG A/B of the backward sweep: 0 = fenced stages, 1 = unfenced, 2 = unfenced + output path before the K/gZ2 barrier")
+    ap.add_argument("--gelu-pk", action="store_true", help="DEBUG A/B: forward scan with the output-path gelu / gZ1 product on aligned packed-f32 "
+                    "register pairs (debug option scan8_gelu_pk; same arithmetic, 17 %% fewer VALU instructions per step)")
     ap.add_argument("--variant", type=int, default=2, help="MFMA forward kernel revision (2 = current, 1 = first)")
     a = ap.parse_args()
     import test_time_training as ext
@@ -46,6 +48,7 @@ def main():
     ext.debug_option("sweep_variant", a.sweep_variant)
     ext.debug_option("overlap_recompute", int(a.overlap))
     ext.debug_option("helper_lead", a.lead)
+    ext.debug_option("scan8_gelu_pk", int(a.gelu_pk))
     dev = torch.device("cuda:0")
     B, NH, NC, CS, F, G = a.b, a.nh, a.nc, a.cs, 64, a.g
     H = 4 * F if a.kind == "mlp" else F

@@ -61,6 +61,7 @@ int ttt_hip_debug_option(const char* name, int value) {
     else if (!strcmp(name, "overlap_recompute")) ttt::mfma::set_debug_overlap(value);            // recompute(next chunk) beside sweep(this chunk)
     else if (!strcmp(name, "variant")) ttt::mfma::set_debug_variant(value);         // kernel revision 2 / 1
     else if (!strcmp(name, "groups_per_chunk")) ttt::mfma::set_debug_groups_per_chunk(value);
+    else if (!strcmp(name, "scan8_gelu_pk")) ttt::mfma::set_debug_scan8_gelu_pk(value);         // 0 (default) / 1: packed-f32 gelu of the output path (CS = 64 forward)
     else if (!strcmp(name, "scan16_body")) ttt::mfma::set_debug_scan16_body(value);             // 0 (default) / 1
     else if (!strcmp(name, "attn_dkdv_variant")) ttt::attn::set_dkdv_variant(value);               // 1 (default) .. 4: dK / dV kernel, see attn.h
     else if (!strcmp(name, "attn_variant")) ttt::attn::set_attn_variant(value);                    // 1 (default) / 2: attention forward + dQ revision

@@ -126,7 +126,29 @@ __device__ __forceinline__ void write_partial2(float* redw, const f32x16& P, int
         t_last = _t;                                                         \
     }
 
-template <bool DBG>
+// gelu_tanh over a C tile in place, on ALIGNED register pairs (r, r + 1) with the packed f32 instructions: the same IEEE
+// operations in the same order as gelu_fwd(), two elements per v_pk_mul / v_pk_fma / v_pk_add.  Why (tools/isa_mix.py): left
+// to itself the SLP vectorizer pairs the scalar form's multiplies across MISALIGNED registers of the tile and then spends
+// 24 v_mov + 12 v_alignbit + 4 v_perm per step and wave (in this block and again around the fragment packs) to realign
+// them - 230 VALU for 32 elements where ~120 do.  Opt-in (template parameter PK, debug option "scan8_gelu_pk").
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gelu_fwd_tile_pk(f32x16& z) {
+    const f32x2 k0 = {GELU_K0, GELU_K0}, k1 = {GELU_K1, GELU_K1}, one = {1.0f, 1.0f};
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        f32x2 x = {z[r], z[r + 1]};
+        const f32x2 x2 = x * x;
+        const f32x2 a = x * __builtin_elementwise_fma(x2, k1, k0);
+        const f32x2 e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+        const f32x2 d = one + e;
+        const f32x2 sg = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+        x = x * sg;
+        z[r] = x[0];
+        z[r + 1] = x[1];
+    }
+}
+
+template <bool DBG, bool PK = false>
 __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __bf16* Kt = reinterpret_cast<__bf16*>(smem + L_K);
@@ -389,8 +411,19 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
                     gx = mma(pi_read(Gs + (32 * ti + c) * TS, fO, s, h), W2TF[0][s], gx);
                     gx = mma(pi_read(Gs + (32 * ti + c) * TS, fX, s, h), W2TF[1][s], gx);
                 }
+                if (PK) {         // aligned pairs (see gelu_fwd_tile_pk); products and the order of the bias sum unchanged
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { gx[r] *= D1[ti][r]; sb += gx[r]; }
+                    for (int r = 0; r < 16; r += 2) {
+                        const f32x2 g = f32x2{gx[r], gx[r + 1]} * f32x2{D1[ti][r], D1[ti][r + 1]};
+                        gx[r] = g[0];
+                        gx[r + 1] = g[1];
+                        sb += g[0];
+                        sb += g[1];
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { gx[r] *= D1[ti][r]; sb += gx[r]; }
+                }
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const bf16x8 gz = pack(gx, s);           // (outer=n, k=t)
@@ -431,8 +464,12 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
 #pragma unroll
                     for (int s = 0; s < 2; ++s)
                         zb = mma(W1F[a][s], pi_read(Qt + (32 * ti + c) * TS, 32 * a, s, h), zb);
+                if (PK) {
+                    gelu_fwd_tile_pk(zb);
+                } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) zb[r] = gelu_fwd(zb[r]);
+                    for (int r = 0; r < 16; ++r) zb[r] = gelu_fwd(zb[r]);
+                }
                 if (DBG && p.dump && blockIdx.x == 0 && i == 0)
                     for (int r = 0; r < 16; ++r) p.dump[28992 + (size_t)(nO + row_of(r, h)) * 64 + 32 * ti + c] = zb[r];
                 X2bF[ti][0] = pack(zb, 0);
@@ -518,6 +555,7 @@ static void set_attr_once() {
     if (!done) {
         (void)hipFuncSetAttribute((const void*)mlp_scan8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_V2);
         (void)hipFuncSetAttribute((const void*)mlp_scan8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_V2);
+        (void)hipFuncSetAttribute((const void*)mlp_scan8_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_V2);
         done = true;
     }
 }
@@ -545,6 +583,9 @@ int get_debug_lin_lds_slots() { return g_lin_lds_slots; }
 static int g_scan16_body = 0;         // CS = 16 TTT-MLP forward: the backend-templated body instead of the hand-placed kernel
 void set_debug_scan16_body(int v) { g_scan16_body = v; }
 int get_debug_scan16_body() { return g_scan16_body; }
+static int g_scan8_gelu_pk = 0;       // CS = 64 TTT-MLP forward: gelu of the output path on aligned register pairs (packed f32); unmeasured -> off
+void set_debug_scan8_gelu_pk(int v) { g_scan8_gelu_pk = v; }
+int get_debug_scan8_gelu_pk() { return g_scan8_gelu_pk; }
 static int g_helpers = -1;
 void set_debug_helpers(int n) { g_helpers = n; }
 int get_debug_helpers() { return g_helpers; }
@@ -555,6 +596,7 @@ void launch_scan_forward_v2(const ScanParams& p0, int n_bh, unsigned long long* 
     p.dump = g_dump;
     v2::set_attr_once();
     if (p.dbg || p.dump) hipLaunchKernelGGL(v2::mlp_scan8_kernel<true>, dim3(n_bh), dim3(v2::NT2), v2::LDS_V2, s, p);
+    else if (g_scan8_gelu_pk) hipLaunchKernelGGL((v2::mlp_scan8_kernel<false, true>), dim3(n_bh), dim3(v2::NT2), v2::LDS_V2, s, p);
     else hipLaunchKernelGGL(v2::mlp_scan8_kernel<false>, dim3(n_bh), dim3(v2::NT2), v2::LDS_V2, s, p);
 }
 

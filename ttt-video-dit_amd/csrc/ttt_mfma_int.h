@@ -39,6 +39,8 @@ void launch_scan_forward_cs16(const ScanParams& p, int n_bh, unsigned long long*
 void launch_linear_forward_cs16(const wv::Lin16Params& p, int n_bh, hipStream_t s);   // TTT-Linear, one wave per (b,h)
 void launch_linear_backward_cs16(const wv::Lin16Params& p, int n_bh, hipStream_t s);
 void set_debug_lin_lds_slots(int n);
+void set_debug_scan8_gelu_pk(int v);
+int get_debug_scan8_gelu_pk();
 void set_debug_scan16_body(int v);
 int get_debug_scan16_body();
 int get_debug_lin_lds_slots();
