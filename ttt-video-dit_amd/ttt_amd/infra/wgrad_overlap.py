@@ -87,10 +87,9 @@ class _Queue:
         if not self._grads and not self._pending:
             return
         self.stats["joined"] += 1
-        if self._pending:
-            for idx, side in self._side.items():
-                torch.cuda.current_stream(idx).wait_stream(side)
-            self._pending.clear()
+        for idx, side in self._side.items():       # unconditionally: the buffers below were written on the side stream
+            torch.cuda.current_stream(idx).wait_stream(side)
+        self._pending.clear()
         grads, self._grads = self._grads, {}
         for param, buf in grads.values():
             if param.grad is None:
