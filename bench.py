@@ -8,8 +8,8 @@
 
 Workload (config.workload): BASELINE.json configs[1] - the ("5B", "3sec") preset (42 layers, D=3072,
 48 heads, TTT-MLP with CS=64, 13 latent frames of 30x45 tokens + 498 text tokens = 18 048 tokens),
-adapter "sft" (every parameter trains), bf16 compute with fp32 master weights via FSDP2 (same wrapping
-as the reference's apply_fsdp), local batch 1 per GPU (weak scaling), layer-group re-materialisation
+adapter "sft" (every parameter trains), bf16 compute with fp32 master weights - via FSDP2 on several GPUs (same wrapping
+as the reference's apply_fsdp), via the same arithmetic without FSDP2's per-parameter copies on one (--fsdp) -, local batch 1 per GPU (weak scaling), layer-group re-materialisation
 as in the reference, synthetic latents/text embeddings, random-init weights.  One step = zero_grad,
 loss = CogVideoX(vid, text).mean(), backward, clip_grad_norm, fused AdamW step.
 
@@ -70,10 +70,12 @@ def parse():
     ap.add_argument("--local-batch", type=int, default=1,
                     help="samples per GPU (default 1 = the reference's training setting).  The TTT scans of a second sample run "
                          "beside the first at no extra wall time (one workgroup per head, 48 of 256 CUs at batch 1)")
-    ap.add_argument("--no-fsdp", action="store_true",
-                    help="one GPU only: fp32 masters + bf16 compute copies kept by ttt_amd.infra.parallelisms.ReplicaMixedPrecision "
-                         "(three multi-tensor launches per step) instead of FSDP2 over a one-rank mesh (~3000 per-parameter copy "
-                         "kernels per step); same arithmetic, bit-identical updates (tests/test_fsdp_gloo.py); opt-in until timed")
+    ap.add_argument("--fsdp", default="auto", choices=["auto", "on", "off"],
+                    help="off (one GPU only): fp32 masters + bf16 compute copies kept by ttt_amd.infra.parallelisms.ReplicaMixedPrecision "
+                         "(three multi-tensor launches per step) instead of FSDP2 over a one-rank mesh (~3000 per-parameter cast / copy "
+                         "kernels, 190 ms of a 3.26 s step); same arithmetic, bit-identical updates (tests/test_fsdp_gloo.py).  auto = off "
+                         "on one GPU (falling back to FSDP2 should the replica path fail), FSDP2 on several; on = FSDP2 always")
+    ap.add_argument("--no-fsdp", action="store_true", help="same as --fsdp off")
     ap.add_argument("--attn-variant", type=int, default=1, choices=[1, 2],
                     help="2 = revision 2 of the attention forward / dQ kernels (csrc/attn_v2.hip, emulator-checked); opt-in until timed")
     ap.add_argument("--attn-dkdv-variant", type=int, default=1, choices=[1, 2, 3, 4],
@@ -99,6 +101,9 @@ class KernelTimer:
         self._orig = {}
 
     def install(self):
+        if getattr(self.ext, "_bench_timer", None) is not None:      # a previous run (replica -> FSDP fallback) wrapped it already
+            self.ext._bench_timer.uninstall()
+        self.ext._bench_timer = self
         for name, key in (("ttt_forward", "fwd"), ("ttt_backward", "bwd"), ("ttt_linear_forward", "fwd"), ("ttt_linear_backward", "bwd"),
                           ("attn_forward", "attn_fwd"), ("attn_backward", "attn_bwd")):
             orig = getattr(self.ext, name)
@@ -113,6 +118,12 @@ class KernelTimer:
                 e.record()
                 self.events[_k].append((s, e, tuple(a[0].shape)))
             setattr(self.ext, name, wrapped)
+
+    def uninstall(self):
+        for name, orig in self._orig.items():
+            setattr(self.ext, name, orig)
+        self._orig = {}
+        self.ext._bench_timer = None
 
     def summary(self):
         out = {}
@@ -201,7 +212,28 @@ def main():
     os.environ.setdefault("WORLD_SIZE", "1")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    mode = "off" if args.no_fsdp else args.fsdp
+    assert not (mode == "off" and world > 1), "--fsdp off is the one-GPU replica path"
+    if world == 1 and mode in ("auto", "off"):
+        try:
+            _run(args, world, rank, local_rank, dev, no_fsdp=True)
+            mode = None
+        except Exception as ex:      # an untested corner of the replica path must not cost the measurement
+            if mode == "off":
+                raise
+            print(f"bench.py: replica path failed ({ex!r}); falling back to FSDP2 over a one-rank mesh", file=sys.stderr, flush=True)
+        if mode is not None:
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            _run(args, world, rank, local_rank, dev, no_fsdp=False)
+    else:
+        _run(args, world, rank, local_rank, dev, no_fsdp=False)
+    dist.barrier(device_ids=[local_rank])
+    dist.destroy_process_group()
 
+
+def _run(args, world, rank, local_rank, dev, no_fsdp):
     import test_time_training as ext
     from ttt_amd.infra.parallelisms import (ReplicaMixedPrecision, apply_fsdp, enable_tuned_gemms, get_dp_mesh, init_distributed,
                                             init_model_parameters)
@@ -233,10 +265,9 @@ def main():
     L = frames * TOKENS_PER_FRAME + scenes * text_len
     assert L % cfg.mini_batch_size == 0
 
-    assert not (args.no_fsdp and world > 1), "--no-fsdp is the one-GPU replica path"
     with torch.device("meta"):
         model = CogVideoX(cfg, effective_rank=rank, effective_world_size=world)
-    if not args.no_fsdp:
+    if not no_fsdp:
         apply_fsdp(model, get_dp_mesh(), reshard_after_forward=args.reshard_after_forward)   # reference parallelisms.py:155-175
     model.to_empty(device=dev)
     torch.manual_seed(1234)                                # same init on every rank, then sharded
@@ -244,7 +275,7 @@ def main():
         init_model_parameters(model)
         model.init_ssm_weights()
     model.setup_generator(seed=rank, device=dev)
-    replica = ReplicaMixedPrecision(model.dit) if args.no_fsdp else None
+    replica = ReplicaMixedPrecision(model.dit) if no_fsdp else None
     train_params = replica.master_parameters() if replica else [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.AdamW(train_params, lr=1e-5, weight_decay=1e-4, fused=True)
 
@@ -402,7 +433,7 @@ def main():
                 "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                 "config": {"workload": f"CogVideoX-5B+{args.ssm_layer} {args.video_length} training step (fwd+bwd+AdamW), "
                                        f"{cfg.num_layers} layers, L={L} tokens/sample, adapter={args.adapter}",
-                           "global_batch": world * LB, "seq_len": L, "parallelism": "replica1" if args.no_fsdp else f"fsdp{world}", "ttt_impl": args.impl,
+                           "global_batch": world * LB, "seq_len": L, "parallelism": "replica1" if no_fsdp else f"fsdp{world}", "ttt_impl": args.impl,
                            "remat_free_layers": n_free, "fsdp_reshard_after_forward": bool(args.reshard_after_forward), "tuned_gemm_selections": bool(tuned), "overlap_wgrad": bool(args.overlap_wgrad), "attn_variant": args.attn_variant, "attn_dkdv_variant": args.attn_dkdv_variant, "scan_gelu_pk": bool(args.scan_gelu_pk),
                            "valid": args.layers is None},
                 "roofline": roof, "loss": loss_val, "peak_mem_gib": peak_mem, "total_tokens_per_s": world * L / (dt / args.steps)}
@@ -412,8 +443,6 @@ def main():
             except Exception as ex:  # never lose the GPU measurement because the CPU leg failed
                 line["cpu_baseline"] = {"error": repr(ex)}
         print(json.dumps(line), flush=True)
-    dist.barrier(device_ids=[local_rank])
-    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -33,10 +33,10 @@ if [ "$1" = "bench" ]; then
   timeout 400 $B                                   2>$O/bench_default.err  | tail -1 > $O/bench_default.json
   timeout 400 $B --attn-variant 2                  2>$O/bench_attn2.err    | tail -1 > $O/bench_attn2.json
   timeout 400 $B --overlap-wgrad                   2>$O/bench_wgrad.err    | tail -1 > $O/bench_wgrad.json
-  timeout 400 $B --no-fsdp                         2>$O/bench_nofsdp.err   | tail -1 > $O/bench_nofsdp.json
-  timeout 400 $B --attn-variant 2 --attn-dkdv-variant 4 --overlap-wgrad --no-fsdp --scan-gelu-pk 2>$O/bench_all.err | tail -1 > $O/bench_all.json
+  timeout 400 $B --fsdp on                         2>$O/bench_fsdp1.err    | tail -1 > $O/bench_fsdp1.json     # FSDP2 over a one-rank mesh (the default is the replica path)
+  timeout 400 $B --attn-variant 2 --attn-dkdv-variant 4 --overlap-wgrad --scan-gelu-pk 2>$O/bench_all.err | tail -1 > $O/bench_all.json
   timeout 600 $B --local-batch 2                   2>$O/bench_lb2.err      | tail -1 > $O/bench_lb2.json
-  for f in default attn2 wgrad nofsdp all lb2; do
+  for f in default fsdp1 attn2 wgrad all lb2; do
     python - "$O/bench_$f.json" "$f" <<'PY'
 import json, sys
 try:
