@@ -62,9 +62,19 @@ class PatchEmbedding(nn.Module):
         self.text_proj = nn.Linear(config.text_dim, config.model_dim, bias=True).requires_grad_(train)
 
     def forward(self, video, text_encoding):
-        b, t = video.shape[:2]
-        x = self.vid_proj(video.flatten(0, 1))                       # [(b t), D, h, w]
-        x = x.flatten(2).transpose(1, 2).reshape(b, -1, x.shape[1])  # [b, t*h*w, D]
+        b, t, c, H, W = video.shape
+        conv = self.vid_proj
+        ph, pw = conv.kernel_size
+        if conv.stride == conv.kernel_size and conv.padding == (0, 0) and H % ph == 0 and W % pw == 0:
+            # a stride = kernel convolution is a GEMM over non-overlapping patches: [(b t h w), c*ph*pw] x [c*ph*pw, D] lands in
+            # the [b, t*h*w, D] layout directly (MIOpen's convolution for this shape is a naive kernel, 4.5 ms per call at the
+            # 3 s geometry, and its NCHW output needs a transpose copy)
+            h, w = H // ph, W // pw
+            patches = video.reshape(b * t, c, h, ph, w, pw).permute(0, 2, 4, 1, 3, 5).reshape(b, t * h * w, c * ph * pw)
+            x = F.linear(patches, conv.weight.reshape(conv.out_channels, -1), conv.bias)
+        else:
+            x = conv(video.flatten(0, 1))                                # [(b t), D, h, w]
+            x = x.flatten(2).transpose(1, 2).reshape(b, -1, x.shape[1])  # [b, t*h*w, D]
         return self.text_proj(text_encoding).contiguous(), x.contiguous()
 
 
