@@ -186,6 +186,58 @@ class OverlapGeluLinear(torch.autograd.Function):
         return dz, None, None
 
 
+class Linear3(torch.autograd.Function):
+    """Three projections of the SAME input (q / k / v of the attention block, wq / wk / wv of the TTT layer) as one autograd
+    node: ``(F.linear(x, w0, b0), F.linear(x, w1, b1), F.linear(x, w2, b2))``.  Its backward forms the input gradient as ONE
+    accumulation chain - ``dX = dY0 W0`` then two GEMMs with ``beta = 1`` into the same buffer - instead of three GEMM outputs
+    and the two full-size additions autograd inserts for a tensor with three consumers (2 x 333 MB of traffic per group at
+    the 3 s geometry, 6 such additions per layer; accumulated in the GEMM's fp32 epilogue, so also rounded once instead of
+    three times).  Weight / bias gradients: deferred to the side stream when the queue is armed, inline otherwise."""
+
+    @staticmethod
+    def forward(ctx, x, w0, b0, w1, b1, w2, b2):
+        ctx.save_for_backward(x)
+        ctx.ws, ctx.bs = (w0, w1, w2), (b0, b1, b2)
+        ctx.defer = _Q.enabled and _Q.armed
+        return F.linear(x, w0, b0), F.linear(x, w1, b1), F.linear(x, w2, b2)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        (x,) = ctx.saved_tensors
+        x2 = x.reshape(-1, x.shape[-1])
+        dx2 = None
+        gw, gb = [None] * 3, [None] * 3
+        for i, (dy, w, b) in enumerate(zip(dys, ctx.ws, ctx.bs)):
+            if dy is None:
+                continue
+            dy2 = dy.reshape(-1, dy.shape[-1])
+            if ctx.needs_input_grad[0]:
+                if dx2 is None:
+                    dx2 = dy2.mm(w)
+                else:
+                    dx2.addmm_(dy2, w)
+            if ctx.defer:
+                _defer_weight_grads(w, b, dy2, lambda: x2, (dy2, x2), dy.device)
+            else:
+                if w.requires_grad:
+                    gw[i] = dy2.t().mm(x2)
+                if b is not None and b.requires_grad:
+                    gb[i] = dy2.sum(0)
+        dx = None if dx2 is None else dx2.view(x.shape)
+        return dx, gw[0], gb[0], gw[1], gb[1], gw[2], gb[2]
+
+
+def linear3(m0: torch.nn.Linear, m1: torch.nn.Linear, m2: torch.nn.Linear, x: torch.Tensor):
+    """``(m0(x), m1(x), m2(x))`` through ``Linear3`` when that is an exact substitute (plain-tensor parameters of x's dtype, no
+    autocast, gradients enabled); the three module calls otherwise."""
+    ok = torch.is_grad_enabled() and not torch.is_autocast_enabled(x.device.type) and x.dim() >= 2
+    for m in (m0, m1, m2):
+        ok = ok and _plain(m.weight) and _plain(m.bias) and m.weight.dtype == x.dtype and (m.bias is None or m.bias.dtype == x.dtype)
+    if ok and (x.requires_grad or any(m.weight.requires_grad for m in (m0, m1, m2))):
+        return Linear3.apply(x, m0.weight, m0.bias, m1.weight, m1.bias, m2.weight, m2.bias)
+    return m0(x), m1(x), m2(x)
+
+
 class JoinWgrad(torch.autograd.Function):
     """Identity on a layer's inputs; in backward (= when the layer's input gradients exist) it joins the side stream."""
 

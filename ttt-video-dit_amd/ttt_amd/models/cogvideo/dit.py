@@ -152,12 +152,13 @@ class SeqModelingBlock(nn.Module):
         heads = lambda t: t.view(b, s, self.num_heads, self.head_dim).transpose(1, 2)   # [b, h, s, d]
         if attn_pre_available(emb, self.head_dim):      # HIP: LayerNorm + RoPE fused, layout kept, strided views downstream
             cos, sin = self.rotary.tables_f32()
-            a = FusedSegmentAttention.apply(wgrad.linear(self.q, emb), wgrad.linear(self.k, emb), heads(wgrad.linear(self.v, emb)),
+            q, k, v = wgrad.linear3(self.q, self.k, self.v, emb)
+            a = FusedSegmentAttention.apply(q, k, heads(v),
                                             self.q_norm.weight, self.q_norm.bias, self.k_norm.weight, self.k_norm.bias, cos, sin,
                                             self.num_heads, n_text, self.q_norm.eps)
             return wgrad.linear(self.o, a.transpose(1, 2).reshape(b, s, -1))
         else:
-            q, k, v = heads(wgrad.linear(self.q, emb)), heads(wgrad.linear(self.k, emb)), heads(wgrad.linear(self.v, emb))
+            q, k, v = (heads(t) for t in wgrad.linear3(self.q, self.k, self.v, emb))
             q, k = self.q_norm(q), self.k_norm(k)
             q = torch.cat((q[:, :, :n_text], self.rotary(q[:, :, n_text:])), dim=2)
             k = torch.cat((k[:, :, :n_text], self.rotary(k[:, :, n_text:])), dim=2)

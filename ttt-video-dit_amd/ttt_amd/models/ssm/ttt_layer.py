@@ -162,7 +162,7 @@ class TTTBase(nn.Module):
 
     # -- pieces of process_input ------------------------------------------------------------------
     def get_qkv_projections(self, hidden_states):
-        return wgrad.linear(self.wq, hidden_states), wgrad.linear(self.wk, hidden_states), wgrad.linear(self.wv, hidden_states)
+        return wgrad.linear3(self.wq, self.wk, self.wv, hidden_states)
 
     def get_eta(self, X):
         """Per-token inner-loop learning rate ``base_lr * sigmoid(x.w_h + b_h) / head_dim`` as
