@@ -197,6 +197,7 @@ class Linear3(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w0, b0, w1, b1, w2, b2):
         ctx.save_for_backward(x)
+        ctx.set_materialize_grads(False)             # an unused output arrives as None, not as a tensor of zeros
         ctx.ws, ctx.bs = (w0, w1, w2), (b0, b1, b2)
         ctx.defer = _Q.enabled and _Q.armed
         return F.linear(x, w0, b0), F.linear(x, w1, b1), F.linear(x, w2, b2)
