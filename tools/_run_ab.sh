@@ -6,9 +6,9 @@
 mkdir -p gpurun_out/ab
 O=gpurun_out/ab
 # ---- parity first: kernel variants, attention revision 2 == revision 1, side-stream weight gradients ----------------------
-TTT_TEST_VARIANTS=1 timeout 300 python -m pytest tests/test_kernels_gpu.py -q -k "variant or wgrad_overlap" 2>&1 | tail -5 | tee $O/variant_tests.txt
-TTT_TEST_VARIANTS=1 timeout 400 python -m pytest tests/test_attention_gpu.py -q -k "v2_equals_v1 or dkdv_variants" 2>&1 | tail -5 | tee -a $O/variant_tests.txt
-TTT_TEST_VARIANTS=1 timeout 400 python -m pytest tests/test_zz_replica_gpu.py -q 2>&1 | tail -5 | tee -a $O/variant_tests.txt
+TTT_TEST_VARIANTS=1 timeout 300 python -m pytest tests/test_kernels_gpu.py -q -rf -k "variant or wgrad_overlap" 2>&1 | tail -20 | tee $O/variant_tests.txt
+TTT_TEST_VARIANTS=1 timeout 400 python -m pytest tests/test_attention_gpu.py -q -rf -k "v2_equals_v1 or dkdv_variants" 2>&1 | tail -25 | tee -a $O/variant_tests.txt
+TTT_TEST_VARIANTS=1 timeout 400 python -m pytest tests/test_zz_replica_gpu.py -q -rf 2>&1 | tail -25 | tee -a $O/variant_tests.txt
 # ---- design parameter of the planned multi-CU backward sweep: cost of a workgroup-to-workgroup rendezvous --------------------
 mkdir -p tools/_build
 (/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/probe_rendezvous.hip -o tools/_build/probe_rendezvous 2>/dev/null; timeout 60 tools/_build/probe_rendezvous) 2>&1 | tee $O/rendezvous.txt
