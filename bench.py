@@ -6,12 +6,14 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Workload (config.workload): BASELINE.json configs[1] - the ("5B", "3sec") preset (42 layers, D=3072,
-48 heads, TTT-MLP with CS=64, 13 latent frames of 30x45 tokens + 498 text tokens = 18 048 tokens),
-adapter "sft" (every parameter trains), bf16 compute with fp32 master weights - via FSDP2 on several GPUs (same wrapping
-as the reference's apply_fsdp), via the same arithmetic without FSDP2's per-parameter copies on one (--fsdp) -, local batch 1 per GPU (weak scaling), layer-group re-materialisation
-as in the reference, synthetic latents/text embeddings, random-init weights.  One step = zero_grad,
-loss = CogVideoX(vid, text).mean(), backward, clip_grad_norm, fused AdamW step.
+Workload (config.workload): the configuration BASELINE.json's metric is quoted on - the ("5B", "9sec") preset (42 layers,
+D=3072, 48 heads, TTT-MLP with CS=64, 37 latent frames of 30x45 tokens in 3 interleaved scenes + 3 x 502 text tokens =
+51 456 tokens per sample; it fits one 288-GB MI355X), adapter "qkvo" as in the reference's configs/train/ttt-mlp/9s.toml
+(attention / TTT projections, TTT inner parameters and gates train), bf16 compute with fp32 master weights - via FSDP2 on
+several GPUs (same wrapping as the reference's apply_fsdp), via the same arithmetic without FSDP2's per-parameter copies on
+one (--fsdp) -, local batch 1 per GPU (weak scaling), synthetic latents / text embeddings, random-init weights.  One step =
+zero_grad, loss = CogVideoX(vid, text).mean(), backward, clip_grad_norm, fused AdamW step.  ``--video-length 3sec`` is
+BASELINE configs[1] (adapter "sft", configs/train/ttt-mlp/3s.toml), 30sec / 63sec the later stages.
 
 MI355X-first memory policy (same arithmetic as the reference's settings, which remain available as flags):
   --remat-free-layers auto   leading layers that keep their activations instead of being re-materialised in backward,
@@ -20,10 +22,15 @@ MI355X-first memory policy (same arithmetic as the reference's settings, which r
   (default)                  committed hipBLASLt / rocBLAS solution selections for this model's GEMM shapes (--no-tuned-gemms)
 
 Rank 0 prints ONE JSON line.  Besides the driver contract it carries
-  roofline     - the dominant hand-written kernel (TTT-MLP scan), algorithmic FLOPs / measured launch time (HIP events
-                 around every launch on the launch stream); the other hand-written kernels (forward scan, attention
-                 forward / backward) are listed under roofline.other
-  cpu_baseline - the CPU port (torch-CPU DiT layer + oracle scan) timed on the host cores, N=1 only
+  roofline     - the dominant hand-written kernel (TTT-MLP backward scan), algorithmic FLOPs / measured launch time (HIP
+                 events around every launch on the launch stream); `traffic` = HBM bytes per launch from the committed PMC
+                 passes of the same kernel build at the same scan length (profiles/*pmc_traffic*.json, `traffic_source`), null
+                 when none matches; the other hand-written kernels are listed under roofline.other
+  cpu_baseline - N=1 only: the CPU port of the same layer (fp32, eager; the TTT scan = the oracle's restatement of the
+                 reference ops path, dual form with the reference's checkpoint groups) timed on the host cores on a bounded
+                 sample
+  fsdp1        - N=1 only: the same step through FSDP2 over a one-rank mesh (the code path of N > 1), a few timed steps, so
+                 that a 1 -> 8 curve can be read like for like
 """
 import argparse
 import json
@@ -50,12 +57,18 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--video-length", default="3sec", choices=["3sec", "9sec", "18sec", "30sec", "63sec"])
+    ap.add_argument("--video-length", default="9sec", choices=["3sec", "9sec", "18sec", "30sec", "63sec"],
+                    help="9sec (default) = the configuration BASELINE.json's metric is quoted on; 3sec = BASELINE configs[1]")
     ap.add_argument("--ssm-layer", default="ttt_mlp", choices=["ttt_mlp", "ttt_linear"])
     ap.add_argument("--impl", default="auto", choices=["auto", "generic", "mfma"])
-    ap.add_argument("--adapter", default="sft", choices=["sft", "qkvo"],
+    ap.add_argument("--adapter", default="auto", choices=["auto", "sft", "qkvo"],
                     help="which parameters train: sft = all (the reference's 3 s stage, configs/train/ttt-mlp/3s.toml), qkvo = the attention / "
-                         "TTT projections, TTT inner parameters and gates only (its longer stages, 9s.toml ...)")
+                         "TTT projections, TTT inner parameters and gates only (its longer stages, 9s.toml ...); auto = the reference's "
+                         "setting for the chosen --video-length")
+    ap.add_argument("--no-fsdp1-compare", action="store_true",
+                    help="N=1: skip the extra short run through FSDP2 over a one-rank mesh (reported as `fsdp1`)")
+    ap.add_argument("--fsdp1-steps", type=int, default=3)
+    ap.add_argument("--cpu-baseline-budget", type=float, default=25.0, help="seconds of CPU work the cpu_baseline sample is sized for")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     # debugging knobs: anything that shrinks the workload marks the result invalid
@@ -134,72 +147,93 @@ class KernelTimer:
         return out
 
 
-def pmc_traffic(kernel, video_length):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*pmc_traffic.json: FETCH_SIZE
-    and WRITE_SIZE collected in separate --pmc runs of tools/op_bench.py at the same geometry, FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950).  PMC passes cannot run inside the timed region; None when no summary
-    for this kernel / geometry is committed."""
+def pmc_traffic(kernel, B, NH, NC):
+    """(bytes, source file) - HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
+    (profiles/*pmc_traffic*.json, written by tools/pmc_traffic.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs of
+    tools/op_bench.py, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  Only a summary measured at THIS
+    launch geometry (B, NH, NC) counts; the newest one wins.  PMC passes cannot run inside the timed region, hence a
+    committed measurement of the same kernel build instead of a live one; (None, None) when nothing matches."""
     import glob
-    if video_length != "3sec":
-        return None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), reverse=True):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")), reverse=True):
         try:
-            k = json.load(open(f))["kernels"].get(kernel)
+            d = json.load(open(f))
+            geo = d.get("geometry", {"B": 1, "NH": 48, "NC": 282})
+            k = d["kernels"].get(kernel)
         except Exception:
             continue
-        if k:
-            return k.get("traffic_bytes_per_backward") or (k.get("fetch_bytes", 0) + k.get("write_bytes", 0))
-    return None
+        if k and (geo.get("B"), geo.get("NH"), geo.get("NC")) == (B, NH, NC):
+            return (k.get("traffic_bytes_per_backward") or (k.get("fetch_bytes", 0) + k.get("write_bytes", 0))), os.path.relpath(f, ROOT)
+    return None, None
 
 
-def cpu_baseline(ssm_layer):
-    """CPU port of the same workload on the host cores: ONE 5B-geometry TransformerLayer (torch CPU fp32,
-    TTT scan by the oracle through oracle/cpu_ext.py), fwd+bwd, at a bounded sequence (1 latent frame +
-    58 text tokens = 1408 tokens); scaled to whole-model video-tokens/s by the 42 layers."""
-    from oracle import cpu_ext
+def cpu_baseline(ssm_layer, budget_s=25.0):
+    """CPU port of the same workload on the host cores, fp32, eager: ONE 5B-geometry TransformerLayer (torch CPU; AdaLN, local
+    attention via SDPA, projections, MLP) whose TTT scans run as the ORACLE's restatement of the reference ops path
+    (oracle/ttt_oracle.py:scan_dual = ops/ttt_mlp.py:9-99 statements, dual form on the full eta tile, the reference's
+    checkpoint groups of 16, torch.autograd for the backward) - i.e. what `use_kernel=False` executes in the reference.
+    Forward + backward of the layer at the real per-step shapes (48 heads, mini-batches of 64 tokens, head dim 64) on a
+    BOUNDED sample: one scene of `f` latent frames + its text tokens, f chosen from a 1-frame probe so that the timed pass
+    stays near `budget_s` seconds.  Scaled to whole-model video-tokens/s by the 42 layers (per-token cost of attention
+    grows with the segment length, so a short sample flatters the CPU: the sample is stated)."""
+    from oracle import ttt_oracle as O
+    import ttt_amd.models.ssm.ttt_layer as TL
     from ttt_amd.models.cogvideo.dit import TransformerLayer
     from ttt_amd.models.cogvideo.utils import SequenceMetadata
     from ttt_amd.models.configs import ModelConfig
 
-    real = sys.modules.pop("test_time_training", None)
-    cpu_ext.install()
+    def oracle_scan(kind):
+        def run(XK, XQ, XV, eta, ln_w, ln_b, *states_and_g):
+            *st, G = states_and_g
+            out, _ = O.scan_dual(kind, XQ, XK, XV, eta, ln_w, ln_b, *st, checkpoint_group_size=int(G))
+            return out.permute(0, 2, 3, 1, 4)            # the reference's [B, NC, CS, NH, F] (ops/ttt_mlp.py:99)
+        return run
+
+    saved = (TL.ttt_mlp, TL.ttt_linear)
+    TL.ttt_mlp, TL.ttt_linear = oracle_scan("mlp"), oracle_scan("linear")
     try:
         torch.manual_seed(0)
-        cfg = ModelConfig.get_preset("5B", "3sec", ssm_layer=ssm_layer, adapter_method="sft", compressed_num_frames=1)
-        layer = TransformerLayer(cfg)
-        n_text, n_vid = 58, TOKENS_PER_FRAME
-        meta = SequenceMetadata(text_length=n_text, seq_text_length=n_text, num_frames=1, num_chunks=1,
-                                tokens_per_frame=n_vid, latent_height=60, latent_width=90, t_emb=torch.randn(1, cfg.time_embed_dim))
-        vid = torch.randn(1, n_vid, cfg.model_dim, requires_grad=True)
-        txt = torch.randn(1, n_text, cfg.model_dim, requires_grad=True)
         threads = torch.get_num_threads()
 
-        def step():
-            # TkMLP requires bf16 activations: autocast like the GPU run; GEMMs then run in bf16 on the CPU too
-            with torch.autocast("cpu", dtype=torch.bfloat16):
-                v, t = layer(vid, txt, meta)
-            (v.float().square().mean() + t.float().square().mean()).backward()
+        def timed(frames, n_text):
+            cfg = ModelConfig.get_preset("5B", "3sec", ssm_layer=ssm_layer, adapter_method="sft", compressed_num_frames=frames)
+            layer = TransformerLayer(cfg)
+            for m in layer.modules():
+                if hasattr(m, "use_kernel"):
+                    m.use_kernel = False
+            n_vid = frames * TOKENS_PER_FRAME
+            meta = SequenceMetadata(text_length=n_text, seq_text_length=n_text, num_frames=frames, num_chunks=1,
+                                    tokens_per_frame=TOKENS_PER_FRAME, latent_height=60, latent_width=90,
+                                    t_emb=torch.randn(1, cfg.time_embed_dim))
+            vid = torch.randn(1, n_vid, cfg.model_dim, requires_grad=True)
+            txt = torch.randn(1, n_text, cfg.model_dim, requires_grad=True)
+            t0 = time.perf_counter()
+            v, t = layer(vid, txt, meta)
+            (v.square().mean() + t.square().mean()).backward()
+            return time.perf_counter() - t0, n_vid, n_vid + n_text
 
-        step()                       # warm-up
-        t0 = time.perf_counter()
-        n = 2
-        for _ in range(n):
-            step()
-        dt = (time.perf_counter() - t0) / n
+        # text lengths keep L a multiple of the mini-batch size (64): 1 frame + 58, 2 + 52, 4 + 40, 7 + 22, 13 + 498 (= the 3 s segment)
+        text_for = {1: 58, 2: 52, 4: 40, 7: 22, 13: 498}
+        timed(1, 58)                                      # warm-up (thread pools, oneDNN primitives)
+        t1, _, _ = timed(1, 58)
+        frames = 1
+        for f in (13, 7, 4, 2):
+            if t1 * f * (1.0 + 0.25 * f) <= budget_s:      # linear part + the quadratic attention share, measured at 1 frame
+                frames = f
+                break
+        dt, n_vid, L = (t1, TOKENS_PER_FRAME, TOKENS_PER_FRAME + 58) if frames == 1 else timed(frames, text_for[frames])
     finally:
-        cpu_ext.uninstall()
-        if real is not None:
-            sys.modules["test_time_training"] = real
+        TL.ttt_mlp, TL.ttt_linear = saved
     tok_s = n_vid / (dt * 42)
-    return {"value": tok_s, "unit": "video-tokens/s", "cores": threads, "kind": "port",
-            "sample": f"1 of 42 TransformerLayers (5B geometry, {ssm_layer}) fwd+bwd at 1 latent frame + 58 text tokens "
-                      f"(L=1408), {dt:.2f} s/layer-step on {threads} threads; scaled by 42 layers"}
+    return {"value": tok_s, "unit": "video-tokens/s", "cores": threads, "kind": "port", "dtype": "f32",
+            "sample": f"1 of 42 TransformerLayers (5B geometry, {ssm_layer}) fwd+bwd, fp32 eager, scan = oracle dual form (reference ops "
+                      f"path restated, checkpoint groups of 16), one scene of {frames} latent frame(s) + {L - n_vid} text tokens "
+                      f"(L={L}; the 3 s segment is 13 frames, L=18048): {dt:.2f} s on {threads} threads; scaled by 42 layers"}
 
 
 def main():
     args = parse()
     if args.cpu_baseline_only:
-        print(json.dumps({"cpu_baseline": cpu_baseline(args.ssm_layer)}))
+        print(json.dumps({"cpu_baseline": cpu_baseline(args.ssm_layer, args.cpu_baseline_budget)}))
         return
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -212,28 +246,51 @@ def main():
     os.environ.setdefault("WORLD_SIZE", "1")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if args.adapter == "auto":
+        args.adapter = "sft" if args.video_length == "3sec" else "qkvo"      # configs/train/ttt-mlp/{3s,9s,...}.toml
     mode = "off" if args.no_fsdp else args.fsdp
     assert not (mode == "off" and world > 1), "--fsdp off is the one-GPU replica path"
+    import gc
+    line = None
     if world == 1 and mode in ("auto", "off"):
         try:
-            _run(args, world, rank, local_rank, dev, no_fsdp=True)
-            mode = None
+            line = _run(args, world, rank, local_rank, dev, no_fsdp=True)
         except Exception as ex:      # an untested corner of the replica path must not cost the measurement
             if mode == "off":
                 raise
             print(f"bench.py: replica path failed ({ex!r}); falling back to FSDP2 over a one-rank mesh", file=sys.stderr, flush=True)
-        if mode is not None:
-            import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        if line is None:
+            line = _run(args, world, rank, local_rank, dev, no_fsdp=False)
+        elif not args.no_fsdp1_compare and mode == "auto":
+            # the same step through FSDP2 over a one-rank mesh = the code path of N > 1 (like-for-like point of a 1 -> N curve)
+            try:
+                import copy
+                a2 = copy.copy(args)
+                a2.steps, a2.warmup = max(1, args.fsdp1_steps), 1
+                a2.remat_free_layers = str(line["config"]["remat_free_layers"])
+                f = _run(a2, world, rank, local_rank, dev, no_fsdp=False, quiet=True)
+                line["fsdp1"] = {"value": f["value"], "ms_per_step": f["ms_per_step"], "steps": a2.steps,
+                                 "remat_free_layers": f["config"]["remat_free_layers"], "peak_mem_gib": f["peak_mem_gib"]}
+            except Exception as ex:
+                line["fsdp1"] = {"error": repr(ex)[:300]}
             gc.collect()
             torch.cuda.empty_cache()
-            _run(args, world, rank, local_rank, dev, no_fsdp=False)
     else:
-        _run(args, world, rank, local_rank, dev, no_fsdp=False)
+        line = _run(args, world, rank, local_rank, dev, no_fsdp=False)
+    if rank == 0 and line is not None:
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(args.ssm_layer, args.cpu_baseline_budget)
+            except Exception as ex:  # never lose the GPU measurement because the CPU leg failed
+                line["cpu_baseline"] = {"error": repr(ex)[:300]}
+        print(json.dumps(line), flush=True)
     dist.barrier(device_ids=[local_rank])
     dist.destroy_process_group()
 
 
-def _run(args, world, rank, local_rank, dev, no_fsdp):
+def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False):
     import test_time_training as ext
     from ttt_amd.infra.parallelisms import (ReplicaMixedPrecision, apply_fsdp, enable_tuned_gemms, get_dp_mesh, init_distributed,
                                             init_model_parameters)
@@ -391,7 +448,7 @@ def _run(args, world, rank, local_rank, dev, no_fsdp):
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
-    loss_val = float(loss)
+    loss_val = float(loss.detach())
     peak_mem = torch.cuda.max_memory_allocated() / 2 ** 30
 
     if rank == 0:
@@ -420,8 +477,9 @@ def _run(args, world, rank, local_rank, dev, no_fsdp):
             impl = ext.resolved_impl(B, NH, NC, CS, F, min(cfg.scan_checkpoint_group_size, NC), torch.bfloat16,
                                      mlp=args.ssm_layer == "ttt_mlp", backward=dom == "bwd")
             kname = f"{args.ssm_layer}_{dom}_scan[{impl}]"
+            traffic, traffic_src = pmc_traffic(kname, B, NH, NC)
             roof = {"bound": "mfma", "kernel": kname, "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": pmc_traffic(kname, args.video_length),
+                    "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                     "flops_per_launch": per_launch, "avg_launch_ms": ks[dom]["avg_ms"], "launches_timed": ks[dom]["launches"],
                     "occupied_cu_frac": ach / (MFMA_BF16_PEAK_TFLOPS * min(B * NH, 256) / 256.0),
                     "other": {k: {"avg_ms": v["avg_ms"], "launches": v["launches"],
@@ -437,12 +495,8 @@ def _run(args, world, rank, local_rank, dev, no_fsdp):
                            "remat_free_layers": n_free, "fsdp_reshard_after_forward": bool(args.reshard_after_forward), "tuned_gemm_selections": bool(tuned), "overlap_wgrad": bool(args.overlap_wgrad), "attn_variant": args.attn_variant, "attn_dkdv_variant": args.attn_dkdv_variant, "scan_gelu_pk": bool(args.scan_gelu_pk),
                            "valid": args.layers is None},
                 "roofline": roof, "loss": loss_val, "peak_mem_gib": peak_mem, "total_tokens_per_s": world * L / (dt / args.steps)}
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                line["cpu_baseline"] = cpu_baseline(args.ssm_layer)
-            except Exception as ex:  # never lose the GPU measurement because the CPU leg failed
-                line["cpu_baseline"] = {"error": repr(ex)}
-        print(json.dumps(line), flush=True)
+        return line
+    return None
 
 
 if __name__ == "__main__":

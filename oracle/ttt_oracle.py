@@ -151,21 +151,40 @@ def linear_step_dual(p: Dict[str, torch.Tensor], XQ, XK, XV, eta):
     return dict(p, W1=W1n, b1=b1n), out
 
 
-def scan_dual(kind: str, XQ, XK, XV, eta, ln_w, ln_b, W1, b1, W2=None, b2=None):
+def scan_dual(kind: str, XQ, XK, XV, eta, ln_w, ln_b, W1, b1, W2=None, b2=None, checkpoint_group_size: int = 0):
     """Whole-sequence dual-form scan: ops/ttt_mlp.py:70-99 (resp. ttt_linear.py:57-84) with
-    ssm/utils.py:111-146's loop (checkpointing is a memory device, not arithmetic).
+    ssm/utils.py:111-146's loop.  ``checkpoint_group_size`` > 0 wraps groups of that many steps in
+    ``torch.utils.checkpoint(use_reentrant=False)`` exactly as the reference's scan does (:131-142): a memory
+    device, not arithmetic - used only by bench.py's timed CPU baseline, where autograd runs through the scan.
 
     Inputs [B,NH,NC,CS,F], eta [B,NH,NC,CS,CS]; returns [B,NH,NC,CS,F] (the kernel layout;
     the reference permutes to [B,NC,CS,NH,F] at ops/ttt_mlp.py:99)."""
-    p = {"W1": W1, "b1": b1, "ln_w": ln_w, "ln_b": ln_b}
-    if kind == "mlp":
-        p.update(W2=W2, b2=b2)
+    keys = ("W1", "b1", "W2", "b2") if kind == "mlp" else ("W1", "b1")
+    consts = {"ln_w": ln_w, "ln_b": ln_b}
     step = mlp_step_dual if kind == "mlp" else linear_step_dual
+    NC = XQ.shape[2]
+
+    def run_group(lo, hi, *state):
+        p = dict(consts, **dict(zip(keys, state)))
+        outs = []
+        for i in range(lo, hi):
+            p, o = step(p, XQ[:, :, i], XK[:, :, i], XV[:, :, i], eta[:, :, i])
+            outs.append(o)
+        return (torch.stack(outs, dim=2),) + tuple(p[k] for k in keys)
+
+    state = (W1, b1, W2, b2) if kind == "mlp" else (W1, b1)
+    G = checkpoint_group_size if checkpoint_group_size > 0 else NC
     outs = []
-    for i in range(XQ.shape[2]):
-        p, o = step(p, XQ[:, :, i], XK[:, :, i], XV[:, :, i], eta[:, :, i])
-        outs.append(o)
-    return torch.stack(outs, dim=2), p
+    for lo in range(0, NC, G):
+        hi = min(lo + G, NC)
+        if checkpoint_group_size > 0:
+            from torch.utils.checkpoint import checkpoint
+            res = checkpoint(run_group, lo, hi, *state, use_reentrant=False)
+        else:
+            res = run_group(lo, hi, *state)
+        outs.append(res[0])
+        state = res[1:]
+    return torch.cat(outs, dim=2), dict(consts, **dict(zip(keys, state)))
 
 
 # --------------------------------------------------------------------------- primal form, kernel contract

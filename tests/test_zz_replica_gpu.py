@@ -82,9 +82,7 @@ assert worst < 1e-5, worst
 '''
 
 
-# opt-in like the other not-yet-run-on-hardware checks (tools/_run_ab.sh sets the variable); bench.py itself falls back to FSDP2
-# in-process should the replica path raise
-@pytest.mark.skipif(os.environ.get("TTT_TEST_VARIANTS") != "1", reason="first hardware run pending: TTT_TEST_VARIANTS=1")
+# (first hardware run: round 2, gpurun_out/ab/variant_tests.txt - passed; un-gated since)
 @pytest.mark.timeout(600)
 def test_replica_equals_fsdp2_on_one_gpu(tmp_path):
     script = tmp_path / "replica_vs_fsdp.py"

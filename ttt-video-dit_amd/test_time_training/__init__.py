@@ -362,8 +362,39 @@ def _call(fn, *args, device):
         raise RuntimeError(lib.ttt_hip_last_error().decode())
 
 
+def _req_maps(rope, src, pos, L, F):
+    """Token maps / RoPE table of the fused pre kernels: the kernel indexes ``rope[pos[t]]`` and ``x[src[t]]`` unchecked, so
+    the table must cover every position (the reference's apply_rotary_emb raises a shape error for a video longer than
+    config.compressed_num_frames, ssm/utils.py:82-108) and the maps must be int32 of length L."""
+    for t, n in ((src, "src"), (pos, "pos")):
+        if t is None:
+            continue
+        _req(t, n, torch.int32)
+        if t.numel() != L:
+            raise RuntimeError(f"{n}: expected {L} entries, got {t.numel()}")
+    if rope is None:
+        return
+    _req(rope, "rope", torch.float32)
+    if rope.numel() % F != 0:
+        raise RuntimeError(f"rope: expected [n_pos, {F // 2}, 2] (cos, sin) pairs, got {tuple(rope.shape)}")
+    n_rows = rope.numel() // F
+    n_pos = getattr(pos, "_ttt_max_pos", None)            # cached by the module (host-side, no sync)
+    if n_pos is None and pos is not None:
+        n_pos = int(pos.max().item()) + 1
+        try:
+            pos._ttt_max_pos = n_pos
+        except AttributeError:
+            pass
+    if pos is None:
+        n_pos = L
+    if n_pos > n_rows:
+        raise RuntimeError(f"rope table has {n_rows} positions but the sequence addresses {n_pos} (video longer than "
+                           f"config.compressed_num_frames?)")
+
+
 def pre_forward(XQ_raw, XK_raw, XV_raw, rope, src, pos, ln_w, ln_b, XQ, XK, XV, NH):
     B, L, D = XQ_raw.shape
+    _req_maps(rope, src, pos, L, D // NH)
     for t, n in ((XQ_raw, "XQ_raw"), (XK_raw, "XK_raw"), (XV_raw, "XV_raw"), (XQ, "XQ"), (XK, "XK"), (XV, "XV")):
         _req(t, n, torch.bfloat16)
     for t, n in ((ln_w, "ln_w"), (ln_b, "ln_b")):

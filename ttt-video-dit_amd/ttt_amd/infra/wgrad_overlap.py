@@ -98,14 +98,33 @@ class _Queue:
                 param.grad += buf
 
 
+    def reset(self):
+        """Drop whatever an aborted backward left behind (an exception inside ``backward()`` skips the end-of-backward
+        callback: ``_cb_queued`` would stay set and the half-accumulated buffers would leak into the next step's gradients)."""
+        for idx, side in self._side.items():
+            torch.cuda.current_stream(idx).wait_stream(side)
+        self._pending.clear()
+        self._grads.clear()
+        self._cb_queued = False
+        self.armed = False
+
+
 _Q = _Queue()
 
 
 def enable(on: bool = True):
-    """Switch the deferral on / off (process-wide).  Turning it off joins whatever is outstanding."""
+    """Switch the deferral on / off (process-wide).  Turning it off joins whatever is outstanding; turning it on starts
+    from a clean queue."""
     if not on:
         _Q.join()
+    elif not _Q.enabled:
+        _Q.reset()
     _Q.enabled = bool(on)
+
+
+def reset():
+    """Call after a ``backward()`` that raised (e.g. an out-of-memory probe step) before stepping again."""
+    _Q.reset()
 
 
 def enabled() -> bool:

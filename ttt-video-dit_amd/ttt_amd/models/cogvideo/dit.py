@@ -43,12 +43,17 @@ class GeluLinear(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         z, weight = ctx.saved_tensors
-        h = F.gelu(z, approximate="tanh")
-        dy2, h2 = dy.reshape(-1, dy.shape[-1]), h.reshape(-1, h.shape[-1])
-        dw = dy2.t().mm(h2)
-        db = dy2.sum(0) if ctx.has_bias else None
-        del h, h2
-        dz = torch.ops.aten.gelu_backward(dy.matmul(weight), z, approximate="tanh")
+        need_z, need_w, need_b = ctx.needs_input_grad
+        dw = db = dz = None
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        if need_w:         # frozen MLP weights (adapter_method qkvo / none): no GELU pass, no L x 4D x D GEMM
+            h = F.gelu(z, approximate="tanh")
+            dw = dy2.t().mm(h.reshape(-1, h.shape[-1]))
+            del h
+        if need_b and ctx.has_bias:
+            db = dy2.sum(0)
+        if need_z:
+            dz = torch.ops.aten.gelu_backward(dy.matmul(weight), z, approximate="tanh")
         return dz, dw, db
 
 

@@ -41,7 +41,10 @@ class DiscreteSampler:
 
     def __call__(self, n_samples, rand=None, generator=None, device="cuda"):
         if self.sigmas is None:
-            self.sigmas = zero_snr_alphas_cumprod_sqrt(self.sigma_interval).to(device)
+            # the reference sub-samples the fixed 1000-step schedule and THEN rescales (cogvideo/utils.py:296-298 ->
+            # ZeroSNRDDPMDiscretization()(sigma_interval, flip=True)); identical to a fresh table only at 1000
+            from ttt_amd.models.cogvideo.sampling import ZeroSNRDDPMDiscretization
+            self.sigmas = ZeroSNRDDPMDiscretization()(self.sigma_interval, device=device, flip=True)
         g = self.effective_rank // self.group_width
         lo, hi = g * self.group_sigma_interval, (g + 1) * self.group_sigma_interval
         if rand is None:
@@ -74,11 +77,20 @@ class CogVideoX(nn.Module):
     def get_l2_loss(model_output, target, w):
         return torch.mean((w * (model_output - target) ** 2).reshape(target.shape[0], -1), 1)
 
-    def forward(self, vid, text):
-        """vid [B,T,16,H,W] latent, text [B,n_scenes,S,text_dim] -> per-sample loss [B]."""
-        a, idx = self.sigma_sampler(vid.shape[0], generator=self.noise_generator, device=vid.device)
+    def forward(self, vid, text, *, noise_idx=None, noise=None):
+        """vid [B,T,16,H,W] latent, text [B,n_scenes,S,text_dim] -> per-sample loss [B].
+
+        ``noise_idx`` / ``noise`` (keyword-only, not in the reference's signature) replace the two random draws; parity tests
+        use them to feed a GPU run the draws of a CPU-generated reference fixture."""
+        if noise_idx is None:
+            a, idx = self.sigma_sampler(vid.shape[0], generator=self.noise_generator, device=vid.device)
+        else:
+            a, idx = self.sigma_sampler(vid.shape[0], rand=0, device=vid.device)
+            idx = noise_idx.to(vid.device)
+            a = self.sigma_sampler.sigmas[idx]
         a = a.view(-1, *([1] * (vid.ndim - 1)))
-        noise = torch.randn(vid.shape, dtype=vid.dtype, device=vid.device, generator=self.noise_generator)
+        if noise is None:
+            noise = torch.randn(vid.shape, dtype=vid.dtype, device=vid.device, generator=self.noise_generator)
         noised = vid.float() * a + noise * (1 - a ** 2) ** 0.5
         # v-prediction scaling (VideoScaling, cogvideo/utils.py:252-258): c_skip = a, c_out = -sqrt(1-a^2), c_in = 1
         out = self.dit(noised.to(vid.dtype), text, idx) * (-((1 - a ** 2) ** 0.5)) + noised * a

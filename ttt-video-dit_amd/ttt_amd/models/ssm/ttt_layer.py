@@ -303,6 +303,7 @@ class TTTBase(nn.Module):
             src = rev[seq] if reverse else seq
             to = lambda t: None if t is None else t.to(device=device, dtype=torch.int32).contiguous()
             hit = (to(src), to(pos), None if rev is None else rev.to(device))
+            hit[1]._ttt_max_pos = int(pos.max()) + 1          # read by the binding's RoPE-table bound check (no device sync)
             self._perm_cache[key] = hit
         return hit
 
