@@ -52,6 +52,11 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA, MI355X_MICROARCH.md "Chip
 TOKENS_PER_FRAME = 30 * 45
 
 
+def log(msg):
+    """progress to stderr (the single JSON line owns stdout)"""
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -216,7 +221,8 @@ def cpu_baseline(ssm_layer, budget_s=25.0):
         timed(1, 58)                                      # warm-up (thread pools, oneDNN primitives)
         t1, _, _ = timed(1, 58)
         frames = 1
-        for f in (13, 7, 4, 2):
+        # at most 4 frames (L = 5440): SDPA's math fallback on the CPU would need 4 S^2 bytes per head and direction beyond that
+        for f in (4, 2):
             if t1 * f * (1.0 + 0.25 * f) <= budget_s:      # linear part + the quadratic attention share, measured at 1 frame
                 frames = f
                 break
@@ -254,6 +260,7 @@ def main():
     line = None
     if world == 1 and mode in ("auto", "off"):
         try:
+            log("replica path (one GPU)")
             line = _run(args, world, rank, local_rank, dev, no_fsdp=True)
         except Exception as ex:      # an untested corner of the replica path must not cost the measurement
             if mode == "off":
@@ -266,10 +273,11 @@ def main():
         elif not args.no_fsdp1_compare and mode == "auto":
             # the same step through FSDP2 over a one-rank mesh = the code path of N > 1 (like-for-like point of a 1 -> N curve)
             try:
+                log(f"main line done: {line['value']:.1f} video-tok/s, {line['ms_per_step']:.0f} ms/step; fsdp1 comparison run")
                 import copy
                 a2 = copy.copy(args)
                 a2.steps, a2.warmup = max(1, args.fsdp1_steps), 1
-                a2.remat_free_layers = str(line["config"]["remat_free_layers"])
+                a2.remat_free_layers = str(max(0, line["config"]["remat_free_layers"] - 1))
                 f = _run(a2, world, rank, local_rank, dev, no_fsdp=False, quiet=True)
                 line["fsdp1"] = {"value": f["value"], "ms_per_step": f["ms_per_step"], "steps": a2.steps,
                                  "remat_free_layers": f["config"]["remat_free_layers"], "peak_mem_gib": f["peak_mem_gib"]}
@@ -281,9 +289,16 @@ def main():
         line = _run(args, world, rank, local_rank, dev, no_fsdp=False)
     if rank == 0 and line is not None:
         if world == 1 and not args.no_cpu_baseline:
+            # the CPU leg runs in a child process with a wall-clock limit: whatever happens to it (host out-of-memory kill,
+            # a slow box) the GPU measurement above is still printed
+            log("cpu_baseline leg (child process)")
+            import subprocess
             try:
-                line["cpu_baseline"] = cpu_baseline(args.ssm_layer, args.cpu_baseline_budget)
-            except Exception as ex:  # never lose the GPU measurement because the CPU leg failed
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--ssm-layer", args.ssm_layer,
+                                    "--cpu-baseline-budget", str(args.cpu_baseline_budget)], capture_output=True, text=True,
+                                   timeout=max(240.0, 12 * args.cpu_baseline_budget))
+                line["cpu_baseline"] = json.loads(r.stdout.strip().splitlines()[-1])["cpu_baseline"]
+            except Exception as ex:
                 line["cpu_baseline"] = {"error": repr(ex)[:300]}
         print(json.dumps(line), flush=True)
     dist.barrier(device_ids=[local_rank])
@@ -437,6 +452,8 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False):
         n_free = int(n_free * 0.8)
     dist.barrier(device_ids=[local_rank])
     torch.cuda.synchronize()
+    if rank == 0:
+        log(f"timed region: {args.steps} steps, remat_free_layers={n_free}")
     timer.active = True
     t0 = time.perf_counter()
     for _ in range(args.steps):

@@ -258,6 +258,9 @@ void        ttt_hip_debug_helpers(int helpers);
  * -Delta with 8 / 12 waves per workgroup).  Returns 0, or -1 for an unknown name. */
 int         ttt_hip_debug_option(const char* name, int value);
 /* DEBUG: device buffer (>= 120000 floats) receiving the step-0 intermediates of workgroup 0 (NULL = off). */
+/* TTT-MLP backward, cluster form (four workgroups per (b,h) exchanging partial tiles inside the launch): 0 when no bounded
+ * hand-over poll has ever given up in this process, else 1 + the (b,h) index that did.  Synchronises the device. */
+unsigned    ttt_hip_debug_sweep_error(void);
 void        ttt_hip_debug_dump(float* device_buffer);
 
 int         ttt_hip_abi_version(void);

@@ -183,6 +183,35 @@ def cogvideox_loss_case(seed):
             "grads": {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None and p.numel() <= 20000}}
 
 
+def dit_bf16_yardstick(names):
+    """How far the REFERENCE's own bf16 arithmetic is from its fp32 run, per gradient: the DiT fixtures' models re-run through
+    the reference code under torch.autocast(bfloat16) (GEMMs in bf16, as under FSDP mixed precision).  The GPU test bounds the
+    bf16 HIP path by max(stated tolerance, 2 x this) - small, cancellation-heavy gradients (b1, the learning-rate gate) are
+    ill-conditioned in bf16 for ANY implementation."""
+    from ttt.models.cogvideo.dit import DiffusionTransformer
+    out = {}
+    for name in names:
+        g = torch.load(os.path.join(HERE, name), weights_only=False)
+        m = DiffusionTransformer(ModelConfig(**g["cfg"]))
+        m.load_state_dict(g["state_dict"], strict=True)
+        for mod in m.modules():
+            if hasattr(mod, "use_kernel"):
+                mod.use_kernel = False
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            o = m(g["video"], g["text"], g["timesteps"])
+        o.float().backward(g["dout"])
+        rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+        errs = {"out": rel(o.float(), g["out"])}
+        params = dict(m.named_parameters())
+        for k, r in g["grads"].items():
+            if params[k].grad is not None:
+                errs[k] = rel(params[k].grad, r)
+        out[name] = errs
+        worst = max(errs.items(), key=lambda kv: kv[1])
+        print(name, "reference bf16-autocast vs its fp32 run: out", round(errs["out"], 4), "worst grad", worst[0], round(worst[1], 4))
+    return out
+
+
 def sigma_tables():
     """DiscreteSampler's table for sigma_interval != 1000 (sub-sampled 1000-step schedule, then rescaled)."""
     from ttt.models.cogvideo.utils import ZeroSNRDDPMDiscretization
@@ -199,6 +228,7 @@ def main():
     c["sigma_tables"] = sigma_tables()
     del c["sigma_table_interval_250"]
     save("cogvideox_loss.pt", c)
+    save("dit_bf16_yardstick.pt", dit_bf16_yardstick(["dit_mlp64_1scene.pt", "dit_lin_1scene.pt", "dit_mlp_3scene.pt"]))
 
 
 if __name__ == "__main__":

@@ -209,3 +209,32 @@ def test_cogvideox_forward_on_gpu_vs_reference():
     errs = {k: rel_l2(params[k].grad, r) for k, r in g["grads"].items() if params[k].grad is not None}
     bad = {k: v for k, v in errs.items() if not v < 0.1}
     assert not bad, bad
+
+
+# ---------------------------------------------------------------------------------- 5. backward sweep: cluster form
+@pytest.mark.parametrize("shape", [(1, 2, 11, 2, 0), (1, 8, 40, 16, 5), (2, 3, 7, 3, 0), (1, 4, 33, 16, 1)])
+def test_bwd_cluster_form_vs_single_workgroup_form_and_oracle(shape):
+    """The TTT-MLP backward sweep on a cluster of four workgroups per (b,h) (csrc/ttt_mfma_bwd3.hip: partial d(gZ2) tiles
+    exchanged through global memory inside the launch, Guideline-16 hand-over) against the single-workgroup form
+    (ttt_mfma_bwd2.hip: same products; fp32 accumulations in another order) and against the fp64 oracle, head by head; no
+    hand-over poll may have timed out.  Repeated launches: stale flags / records from the previous call must not matter."""
+    e = ext()
+    B, NH, NC, G, gpc = shape
+    d = round_acts(O.make_inputs("mlp", B, NH, NC, 64, 64, seed=500 + NC), torch.bfloat16)
+    res = {}
+    for mode in (0, -1, -1):
+        e.debug_option("bwd_cluster", mode)
+        e.debug_groups_per_chunk(gpc)
+        try:
+            res[mode] = run_mlp(e, d, G, torch.bfloat16, impl="mfma")
+        finally:
+            e.debug_option("bwd_cluster", -1)
+            e.debug_groups_per_chunk(0)
+    assert e.sweep_error() == 0
+    (o0, _, g0), (o1, _, g1) = res[0], res[-1]
+    assert torch.equal(o0, o1)
+    errs = {k: rel_l2(g1[k], g0[k]) for k in g0}
+    print("cluster vs single-workgroup form:", {k: f"{v:.1e}" for k, v in errs.items()})
+    assert all(v < 5e-3 for v in errs.values()), errs
+    ro, rc, rg = oracle_on(d, G, "mlp")
+    check_per_head(f"cluster backward {shape}", o1, (), g1, ro, (), rg, 1e-2, 3e-2)

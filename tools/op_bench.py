@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--sweep-variant", type=int, default=1, help="DEBUG A/B of the backward sweep: 0 = fenced stages, 1 = unfenced, 2 = unfenced + output path before the K/gZ2 barrier")
     ap.add_argument("--gelu-pk", action="store_true", help="DEBUG A/B: forward scan with the output-path gelu / gZ1 product on aligned packed-f32 "
                     "register pairs (debug option scan8_gelu_pk; same arithmetic, 17 %% fewer VALU instructions per step)")
+    ap.add_argument("--cluster", type=int, default=-1, help="backward sweep on a cluster of 4 workgroups per (b,h): -1 automatic, 0 off")
     ap.add_argument("--variant", type=int, default=2, help="MFMA forward kernel revision (2 = current, 1 = first)")
     a = ap.parse_args()
     import test_time_training as ext
@@ -49,6 +50,7 @@ def main():
     ext.debug_option("overlap_recompute", int(a.overlap))
     ext.debug_option("helper_lead", a.lead)
     ext.debug_option("scan8_gelu_pk", int(a.gelu_pk))
+    ext.debug_option("bwd_cluster", a.cluster)
     dev = torch.device("cuda:0")
     B, NH, NC, CS, F, G = a.b, a.nh, a.nc, a.cs, 64, a.g
     H = 4 * F if a.kind == "mlp" else F

@@ -58,6 +58,7 @@ int ttt_hip_debug_option(const char* name, int value) {
     if (!strcmp(name, "helpers")) ttt::mfma::set_debug_helpers(value);              // prefetch helpers per (b,h), -1 = automatic
     else if (!strcmp(name, "helper_lead")) ttt::mfma::set_debug_lead(value);        // steps the helpers may run ahead (default 1)
     else if (!strcmp(name, "sweep_variant")) ttt::mfma::set_debug_sweep_variant(value);          // 0 fenced stages, 1 unfenced, 2 unfenced + early output path
+    else if (!strcmp(name, "bwd_cluster")) ttt::mfma::set_debug_cluster(value);                  // TTT-MLP backward sweep on 4 workgroups per (b,h): -1 auto (default), 0 off
     else if (!strcmp(name, "overlap_recompute")) ttt::mfma::set_debug_overlap(value);            // recompute(next chunk) beside sweep(this chunk)
     else if (!strcmp(name, "variant")) ttt::mfma::set_debug_variant(value);         // kernel revision 2 / 1
     else if (!strcmp(name, "groups_per_chunk")) ttt::mfma::set_debug_groups_per_chunk(value);
@@ -69,6 +70,7 @@ int ttt_hip_debug_option(const char* name, int value) {
     else return -1;
     return 0;
 }
+unsigned ttt_hip_debug_sweep_error(void) { return ttt::mfma::read_sweep_error(); }
 void ttt_hip_debug_dump(float* buf) { ttt::mfma::set_debug_dump(buf); }
 const char* ttt_hip_last_error(void) { return g_err; }
 

@@ -32,80 +32,13 @@
 #include "ttt_mfma.h"
 #include "ttt_mfma_dev.h"
 #include "ttt_mfma_int.h"
+#include "ttt_mfma_bwd_dev.h"
 
 namespace ttt {
 namespace mfma {
 using namespace ttt::mf;
 
 namespace b2 {
-
-constexpr int NT2 = 512;
-typedef __attribute__((address_space(3))) bf16x4 lds_b4;
-
-// ---- helpers shared with the revision-2 forward (same idioms) --------------------------------------------------------
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float sum8(float v) {
-    v += dpp_f<0xB1>(v);
-    v += dpp_f<0x4E>(v);
-    v += dpp_f<0x141>(v);
-    return v;
-}
-__device__ __forceinline__ bf16x8 tr_frag(const __bf16* img, int stride, int r0, int r1, int col0, int l) {
-    const int i = l & 15, g1 = (l >> 4) & 1;
-    const int off = (i >> 2) * stride + col0 + 16 * g1 + 4 * (i & 3);
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(img + r0 * stride + off));
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(img + r1 * stride + off));
-    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-}
-// operand fragment (outer = column in [col0, col0+32), contraction = rows of the 32-row block at row0, pi slot order s)
-__device__ __forceinline__ bf16x8 tr_pi(const __bf16* img, int row0, int s, int col0, int l) {
-    const int h = l >> 5;
-    return tr_frag(img, TS, row0 + 16 * s + 4 * h, row0 + 16 * s + 8 + 4 * h, col0, l);
-}
-// operand fragment (outer = row 32 ti + c, contraction = columns col0 + pi slots of s)
-__device__ __forceinline__ bf16x8 row_pi(const __bf16* img, int ti, int col0, int s, int l) {
-    return pi_read(img + (32 * ti + (l & 31)) * TS, col0, s, l >> 5);
-}
-__device__ __forceinline__ void load8_bf16(const __bf16* p, float (&o)[8]) {
-    const bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (float)a[j];
-}
-__device__ __forceinline__ void store8_bf16(__bf16* p, const float (&v)[8]) {
-    bf16x8 a;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) a[j] = (__bf16)v[j];
-    *reinterpret_cast<bf16x8*>(p) = a;
-}
-__device__ __forceinline__ void load8_f32(const float* p, float (&o)[8]) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
-    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
-}
-__device__ __forceinline__ void add8_f32(const float* p, float (&o)[8]) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
-    o[0] += a[0]; o[1] += a[1]; o[2] += a[2]; o[3] += a[3]; o[4] += b[0]; o[5] += b[1]; o[6] += b[2]; o[7] += b[3];
-}
-// one wave's partial tile (rows = f in Fp, lane = t of tile ti) -> red[w][t][f]
-__device__ __forceinline__ void write_partial2(float* redw, const f32x16& P, int ti, int p, int h, int c) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        f32x4 v = {P[4 * q], P[4 * q + 1], P[4 * q + 2], P[4 * q + 3]};
-        *reinterpret_cast<f32x4*>(redw + (32 * ti + c) * PS + 32 * p + 8 * q + 4 * h) = v;
-    }
-}
-__device__ __forceinline__ f32x16 ld_tile(const char* wave_base, int arr, int a, int b, int lane) {
-    return unpack2(ld_frag(wave_base, arr, fr_idx(a, b, 0), lane), ld_frag(wave_base, arr, fr_idx(a, b, 1), lane));
-}
-__device__ __forceinline__ float tile_colsum(const f32x16& t) {
-    float s = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s += t[r];
-    return xor_add(s, 32);
-}
-
 // ---- LDS map ------------------------------------------------------------------------------------------------------------
 constexpr int TILE_B = TILE_ELEMS * 2;                    // 9216 bytes
 constexpr int L_K = 0;                                    // K_i          [t][f]
@@ -123,25 +56,6 @@ constexpr int LDS_SWEEP = L_SM + (64 + 256 + 64 + 64 + 8 * 64) * 4;
 static_assert(LDS_SWEEP <= 160 * 1024, "LDS budget");
 static_assert(TILE_B <= XU_BYTES, "dZ2 tile aliases the u exchange");
 
-// carry area per (b,h), floats: natural-layout dW1 [64][256], dW2 [256][64], db1 [256], db2 [64], then per-thread dgamma / dbeta
-constexpr size_t C_DW1 = 0, C_DW2 = 64 * 256, C_DB1 = 2 * 64 * 256, C_DB2 = C_DB1 + 256, C_DG = C_DB2 + 64, C_DBT = C_DG + NT2 * 8,
-                 CARRY_FLOATS2 = C_DBT + NT2 * 8;
-
-struct SweepParams2 {
-    const __bf16 *XQ, *XK, *dOut, *eta;
-    const float* ln_w;
-    const float *uW1, *ub1, *uW2, *ub2;
-    char* slots; size_t slot_stride_bh;
-    float* carry;
-    __bf16 *dXV, *deta;
-    float *dW1, *db1, *dW2, *db2, *dlnw, *dlnb;
-    int NH, NC, chunk_lo, chunk_hi, first, last;
-    unsigned long long* dbg;                // optional: per-stage cycle totals of workgroup 0 (entries 16..25)
-    int* prog;                              // [B*NH] step the sweep of each (b,h) is working on (read by its prefetch helpers)
-    int nbh, helpers, lead;                 // grid = nbh * (1 + helpers): blocks >= nbh are prefetch helpers of (b,h) = block % nbh,
-                                            // running at most `lead` steps ahead of the scan
-};
-
 #define TTT_STAMP3(k)                                                        \
     if (DBG && p.dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {    \
         const unsigned long long _t = __builtin_readcyclecounter();          \
@@ -154,29 +68,8 @@ struct Stage {            // next step's tiles, register-staged: one 16-byte chu
     float eta;
 };
 
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-// Slot / tensor accesses of the sweep go through buffer instructions: wave-uniform base (SRD) + wave-uniform byte offset
-// in an SGPR + ONE per-lane offset register (lane * 16 or thread * 16/32).  With flat addressing hipcc materialises a
-// 64-bit address pair for each of the ~60 distinct slot accesses of a step at the top of the iteration and spills them.
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const void* base, size_t bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(bytes > 0x7fffffffull ? 0x7fffffffull : bytes), 0x00020000);
-}
-__device__ __forceinline__ bf16x8 bld8(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
-}
-__device__ __forceinline__ void bst8(__amdgpu_buffer_rsrc_t r, int voff, int soff, bf16x8 v) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
-}
-__device__ __forceinline__ f32x4 bld4f(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
-}
-__device__ __forceinline__ void bld8f(__amdgpu_buffer_rsrc_t r, int voff, int soff, float (&o)[8]) {
-    const f32x4 a = bld4f(r, voff, soff), b = bld4f(r, voff + 16, soff);
-    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
-}
-constexpr int fro(int arr, int idx) { return (arr * 8 + idx) * (int)FRAG_BYTES; }       // byte offset of a fragment in a wave region
 
-template <bool DBG, int VAR>
+template <bool DBG>
 __global__ __launch_bounds__(NT2) void mlp_bwd_sweep8_kernel(SweepParams2 p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __bf16* Kt = reinterpret_cast<__bf16*>(smem + L_K);
@@ -196,10 +89,6 @@ __global__ __launch_bounds__(NT2) void mlp_bwd_sweep8_kernel(SweepParams2 p) {
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int w = wv >> 1, pp = wv & 1;
-    // A/B knob (template variant 2): the output path of step i-1 before barrier Bd instead of after it.  Measured on an
-    // MI355X (3 s shape, 48 heads): 8.32 ms vs 8.26 ms for variant 1 - the work only moves between the two stages
-    // (S4a 10.7k -> 19.1k cycles, S4b 13.2k -> 4.3k), it does not overlap with anything.  Variant 1 stays the default.
-    auto get_move_out = [&]() { return VAR == 2; };
     const int nO = 64 * w + 32 * pp;
     const int fO = 32 * pp, fX = 32 * (1 - pp);
     const int bh = blockIdx.x % p.nbh, head = bh % p.NH;
@@ -419,8 +308,8 @@ __global__ __launch_bounds__(NT2) void mlp_bwd_sweep8_kernel(SweepParams2 p) {
         // The sweep is bound by per-CU miss parallelism, not by exposed latency: see DESIGN.md 4.)
 
         // ================= S1 : (rows = n, lane = t) products, u^T, d(eta) partial, first half of d(gZ2)^T ==============
-        // Three operand-set blocks, each walking both token tiles, fenced by sched_barriers: hipcc otherwise interleaves
-        // everything for ILP and the live set (state 96 + operands 48 + 6 tiles) no longer fits 256 registers.
+        // Three operand-set blocks, each walking both token tiles.  (Scheduling fences between them, and the output path of step
+        // i - 1 moved before barrier Bd, were A/B-ed in round 1 - 9.6 / 8.32 vs 8.26 ms per backward - and removed in round 2.)
         f32x16 P[2];                       // [ti]  d(gZ2)^T partial (rows = f in Fp, lane = t)
         bf16x8 uN[2][2];                   // [ti][s]  u^T (k = n rows, j = t lane)
         float se2[2];
@@ -451,7 +340,6 @@ __global__ __launch_bounds__(NT2) void mlp_bwd_sweep8_kernel(SweepParams2 p) {
                     *reinterpret_cast<bf16x8*>(exu + ((size_t)(wv * 4 + ti * 2 + s) * 64 + l) * 16) = uf;
                 }
                 se2[ti] = se;
-                if constexpr (VAR == 0) __builtin_amdgcn_sched_barrier(0);
             }
         }
         {
@@ -472,7 +360,6 @@ __global__ __launch_bounds__(NT2) void mlp_bwd_sweep8_kernel(SweepParams2 p) {
                 }
                 se = xor_add(se, 32);
                 if (h == 0) etaP[wv * 64 + 32 * ti + c] = -se;
-                if constexpr (VAR == 0) __builtin_amdgcn_sched_barrier(0);
             }
         }
         {
@@ -490,7 +377,6 @@ __global__ __launch_bounds__(NT2) void mlp_bwd_sweep8_kernel(SweepParams2 p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) pa[r] *= ec;
                 P[ti] = pa;
-                if constexpr (VAR == 0) __builtin_amdgcn_sched_barrier(0);
             }
         }
         TTT_STAMP3(0)
@@ -610,7 +496,6 @@ __global__ __launch_bounds__(NT2) void mlp_bwd_sweep8_kernel(SweepParams2 p) {
                         dz[8 * s + e] = dg * (float)mm[e];
                     }
                 }
-                if constexpr (VAR == 0) __builtin_amdgcn_sched_barrier(0);
                 {
                     f32x16 dx = zero16();
 #pragma unroll
@@ -628,7 +513,6 @@ __global__ __launch_bounds__(NT2) void mlp_bwd_sweep8_kernel(SweepParams2 p) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) dz[r] += dx[r] * (float)d1f[r >> 3][r & 7];     // dZ1
                 }
-                if constexpr (VAR == 0) __builtin_amdgcn_sched_barrier(0);
                 db1v += tile_colsum(dz);
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
@@ -652,19 +536,15 @@ __global__ __launch_bounds__(NT2) void mlp_bwd_sweep8_kernel(SweepParams2 p) {
                         db2v += acc[0];
                     }
                 }
-                if constexpr (VAR == 0) __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // ---- output path of step j (dZ2b_j, Q_j, slot j: nothing of it touches K_i / gZ2_i): before Bd, so that its loads and
-        // MFMAs overlap the tail of S4a instead of waiting behind a barrier
-        if (more && get_move_out()) add_output_path(i - 1);
         TTT_STAMP3(6)
         __syncthreads();                   // Bd: every read of K_i, gZ2_i, dZ2_i, eta_i is done
         TTT_STAMP3(7)
 
         // ================= S4b : (output path of step j,) publish, park ====================================================
         if (more) {
-            if (!get_move_out()) add_output_path(i - 1);
+            add_output_path(i - 1);
             publish_state(i - 1);
             park_kg(st);
         }
@@ -821,11 +701,19 @@ __global__ __launch_bounds__(NT) void mlp_bwd_tail_kernel(TailParams p) {
 }  // namespace b2
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// The sweep of one (b,h) on a cluster of four workgroups (ttt_mfma_bwd3.hip): whenever the four-fold grid fits the chip.
+static int g_cluster = -1;            // -1 = automatic (default), 0 = never (single-workgroup sweep below)
+void set_debug_cluster(int v) { g_cluster = v; }
+static bool use_cluster(int nbh) { return g_cluster != 0 && nbh * 4 <= 256; }
+static size_t align128(size_t v) { return (v + 127) & ~(size_t)127; }
+
 size_t workspace_bytes_v2(const ttt_dims* d) {
     const size_t nbh = (size_t)d->B * d->NH;
     const size_t slots = (size_t)groups_per_chunk(d) * d->G + 1;
     const size_t nbuf = get_debug_overlap() ? 2 : 1;      // a second slot buffer only when recompute and sweep overlap
-    return nbh * (nbuf * slots * SLOT_BYTES + b2::CARRY_FLOATS2 * sizeof(float) + 64);   // slot buffer(s) + carry + progress words
+    // slot buffer(s) + carry + progress words + (cluster form) exchange records and flag lines
+    return nbh * (nbuf * slots * SLOT_BYTES + b2::CARRY_FLOATS2 * sizeof(float)) + align128(nbh * 64) +
+           nbh * (b2::XCH_BH_BYTES + 4 * b2::FLAG_STRIDE * sizeof(unsigned));
 }
 
 // Side stream for the group recompute of the NEXT chunk: it needs only the forward checkpoints, so it runs beside the
@@ -858,11 +746,15 @@ void mlp_backward_v2(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hip
     const size_t buf_bytes = (size_t)nbh * slot_stride;
     float* carry = (float*)(slots0 + (get_debug_overlap() ? 2 : 1) * buf_bytes);
     int* prog = (int*)(carry + (size_t)nbh * b2::CARRY_FLOATS2);
+    char* xch = (char*)prog + align128((size_t)nbh * 64);
+    unsigned* flags = (unsigned*)(xch + (size_t)nbh * b2::XCH_BH_BYTES);
+    const size_t flag_bytes = (size_t)nbh * 4 * b2::FLAG_STRIDE * sizeof(unsigned);
     char* slots = slots0;
-    // prefetch helpers: only when they can share the scans' XCDs (nbh % 8 == 0) and everything is co-resident (1 WG / CU)
+    const bool cluster = use_cluster(nbh);
+    // prefetch helpers (single-workgroup form): only when they can share the scans' XCDs (nbh % 8 == 0) and everything is co-resident
     int helpers = get_debug_helpers();
     if (helpers < 0) helpers = (nbh % 8 == 0 && nbh * 3 <= 256) ? 2 : 0;      // measured: 2 helpers 9.70 ms, 4 helpers 9.97 ms, none 11.68 ms (3 s geometry)
-    if (nbh % 8 != 0 || nbh * (1 + helpers) > 256) helpers = 0;
+    if (cluster || nbh % 8 != 0 || nbh * (1 + helpers) > 256) helpers = 0;
 
     ScanParams sp = {};
     sp.XQ = (const __bf16*)a->XQ; sp.XK = (const __bf16*)a->XK; sp.XV = (const __bf16*)a->XV; sp.eta = (const __bf16*)a->last_eta;
@@ -889,12 +781,8 @@ void mlp_backward_v2(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hip
 
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)b2::mlp_bwd_sweep8_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, b2::LDS_SWEEP);
-        (void)hipFuncSetAttribute((const void*)b2::mlp_bwd_sweep8_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, b2::LDS_SWEEP);
-        (void)hipFuncSetAttribute((const void*)b2::mlp_bwd_sweep8_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, b2::LDS_SWEEP);
-        (void)hipFuncSetAttribute((const void*)b2::mlp_bwd_sweep8_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, b2::LDS_SWEEP);
-        (void)hipFuncSetAttribute((const void*)b2::mlp_bwd_sweep8_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, b2::LDS_SWEEP);
-        (void)hipFuncSetAttribute((const void*)b2::mlp_bwd_sweep8_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, b2::LDS_SWEEP);
+        (void)hipFuncSetAttribute((const void*)b2::mlp_bwd_sweep8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, b2::LDS_SWEEP);
+        (void)hipFuncSetAttribute((const void*)b2::mlp_bwd_sweep8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, b2::LDS_SWEEP);
         (void)hipFuncSetAttribute((const void*)b2::mlp_bwd_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, b2::LDS_TAIL);
         attr = true;
     }
@@ -930,16 +818,14 @@ void mlp_backward_v2(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hip
         bp.last = (ch == 0);
         bp.dbg = get_debug_timing();
         bp.prog = prog; bp.nbh = nbh; bp.helpers = helpers; bp.lead = get_debug_lead();
-        const dim3 grid(nbh * (1 + helpers)), blk(b2::NT2);
-        const int sv = get_debug_sweep_variant();   // DEBUG A/B: 0 = scheduling fences inside the stages, 1 = none, 2 = none + output path before Bd
-        if (bp.dbg) {
-            if (sv == 0) hipLaunchKernelGGL((b2::mlp_bwd_sweep8_kernel<true, 0>), grid, blk, b2::LDS_SWEEP, s, bp);
-            else if (sv == 1) hipLaunchKernelGGL((b2::mlp_bwd_sweep8_kernel<true, 1>), grid, blk, b2::LDS_SWEEP, s, bp);
-            else hipLaunchKernelGGL((b2::mlp_bwd_sweep8_kernel<true, 2>), grid, blk, b2::LDS_SWEEP, s, bp);
+        bp.xch = xch; bp.flags = flags;
+        if (cluster) {
+            (void)hipMemsetAsync(flags, 0, flag_bytes, s);        // hand-over flags restart at 0 for every launch (memset node)
+            launch_sweep_cluster(bp, nbh, s);
         } else {
-            if (sv == 0) hipLaunchKernelGGL((b2::mlp_bwd_sweep8_kernel<false, 0>), grid, blk, b2::LDS_SWEEP, s, bp);
-            else if (sv == 1) hipLaunchKernelGGL((b2::mlp_bwd_sweep8_kernel<false, 1>), grid, blk, b2::LDS_SWEEP, s, bp);
-            else hipLaunchKernelGGL((b2::mlp_bwd_sweep8_kernel<false, 2>), grid, blk, b2::LDS_SWEEP, s, bp);
+            const dim3 grid(nbh * (1 + helpers)), blk(b2::NT2);
+            if (bp.dbg) hipLaunchKernelGGL((b2::mlp_bwd_sweep8_kernel<true>), grid, blk, b2::LDS_SWEEP, s, bp);
+            else hipLaunchKernelGGL((b2::mlp_bwd_sweep8_kernel<false>), grid, blk, b2::LDS_SWEEP, s, bp);
         }
         if (overlap && ch > 0) {
             // next chunk's recompute goes to the other buffer, free once the sweep + tail of chunk ch + 1 are done; enqueued

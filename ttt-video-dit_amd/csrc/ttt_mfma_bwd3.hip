@@ -1,0 +1,684 @@
+// MFMA TTT-MLP backward for gfx950, CLUSTER form of the reverse sweep (round 2): the sweep of one (b,h) runs on FOUR
+// workgroups - four CUs - with role-specialised waves.
+//
+// Why (profiles/r1f, r2a): the single-workgroup sweep (ttt_mfma_bwd2.hip) is bound by what ONE CU can pull from memory - a
+// step reads ~430 KiB of slot data and a CU sustains ~10 bytes / cycle of misses - and by one CU's issue slots; 48 scans
+// occupy 48 of 256 CUs.  Everything the sweep carries or loads is sliced by hidden unit: dW1[:, H], dW2[H, :], db1[H] and the
+// slot fragment arrays of the wave pair w (ttt_mfma_dev.h).  So workgroup cq of a cluster takes the wave pair w = cq of the
+// 8-wave decomposition (64 hidden units: a quarter of the slot bytes, of the state and of the MFMAs per CU).  The ONLY
+// quantity that crosses the slices per step is the partial d(gZ2)^T [64 x 64] fp32 that the single-CU form reduces over w
+// through LDS (+ the per-token d(eta) partials): every workgroup publishes its partial and reads the other three (an
+// all-gather), and all four run the cheap owner stage redundantly with the same summation order, so dZ2 is bit-identical on
+// the four CUs and ONE hand-over per step suffices.
+//
+// Hand-over = the placement-independent recipe of the CDNA4 guide (cdna_hip_programming.md Guideline 16, form R1): payload
+// stored write-through (16-byte sc1 buffer stores), every storing wave drains (s_waitcnt vmcnt(0)), workgroup barrier, ONE
+// lane stores the step number into the workgroup's flag word (relaxed, agent scope); the consumer polls the three partner
+// flags (relaxed, agent scope, one lane each, bounded), then reads the payload with sc1 loads (never served by the reading
+// CU's L1).  Nothing depends on where the four workgroups run (blocks bh + q nbh share an XCD when nbh % 8 == 0: speed only).
+// Records are double-buffered by step parity - a workgroup can be at most one hand-over ahead of its slowest partner -, the
+// flags are zeroed by a memset node ahead of every launch, a poll that gives up reports through g_sweep_err instead of
+// hanging the GPU.  The four workgroups must be co-resident: the host uses this form only when 4 B NH <= 256 CUs.
+//
+// Workgroup = 6 waves:
+//   waves 0, 1  COMPUTE: wave pp owns the 32 hidden units [64 cq + 32 pp, +32): the carried dW1 / dW2 (both orientations) /
+//               db1 tiles and every MFMA of the step (same algebra and products as the 8-wave sweep);
+//   waves 2..5  OWNERS (256 threads = 64 tokens x 4 lanes x 16 features): staging of the next step's K / gZ2 / Q / eta tiles
+//               into LDS (double-buffered), the output-LayerNorm backward of the next step, the hand-over (flag, poll,
+//               partner reads), the fused-LN / L2 backward-of-backward -> dZ2, dV, d(eta), dgamma / dbeta, and - while the
+//               compute waves finish the step - L2 prefetch touches of the slot lines two steps ahead.
+// Per step i (j = i - 1), 4 workgroup barriers:
+//   compute:  S1 (u^T, d(eta) partial, first half of d(gZ2)^T)  |Ba|  S2 (second half -> published record), drain  |Bb|
+//             snapshot of the state operands, OUTPUT PATH OF STEP j (it needs no partner data: it fills the hand-over
+//             latency)  |Bc|  S4a (dZ1, state updates of step i), publish state for step j  |Bd|
+//   owners:   tiles / output-LN of step j, own-array loads of step i  |Ba| |Bb|  flag, poll, partner records, owner math ->
+//             dZ2_i  |Bc|  prefetch touches  |Bd|
+// Math: SURVEY.md Appendix A backward; oracle/ttt_oracle.py:_mlp_step_bwd is the executable spec.
+#include "ttt_mfma.h"
+#include "ttt_mfma_dev.h"
+#include "ttt_mfma_int.h"
+#include "ttt_mfma_bwd_dev.h"
+
+namespace ttt {
+namespace mfma {
+using namespace ttt::mf;
+
+namespace b3 {
+using namespace ttt::mfma::b2;
+
+constexpr int NTC = 384;                                  // 2 compute waves + 4 owner waves
+constexpr int TILE_B = TILE_ELEMS * 2;                    // 9216 bytes: one padded [64][64] bf16 tile
+constexpr int L_K = 0;                                    // K   [2][t][f]  (by step parity)
+constexpr int L_G = L_K + 2 * TILE_B;                     // gZ2 [2][t][f]
+constexpr int L_Q = L_G + 2 * TILE_B;                     // Q_j   [t][f]
+constexpr int L_A = L_Q + TILE_B;                         // dZ2b_j [t][f]
+constexpr int L_B = L_A + TILE_B;                         // dZ2_i  [t][f]
+constexpr int L_XU = L_B + TILE_B;                        // u^T exchange between the two compute waves: 2 x 4 fragments x 1 KiB
+constexpr int L_XD = L_XU + 2 * 4 * 1024;                 // dW2 block exchange: 2 x 2 fragments
+constexpr int L_SM = L_XD + 2 * 2 * 1024;                 // floats: eta[2][64], db1[64], db2[64], gamma[64], sync word
+constexpr int SM_FLOATS = 2 * 64 + 64 + 64 + 64 + 4;
+constexpr int LDS_CL = L_SM + SM_FLOATS * 4;
+static_assert(LDS_CL <= 160 * 1024, "LDS budget");
+static_assert(2 * TILE_B >= 256 * 16 * 4, "the final dgamma / dbeta reduction re-uses the K / gZ2 tiles");
+
+__device__ unsigned g_sweep_err = 0;        // 1 + (b,h) of a cluster workgroup whose bounded hand-over poll gave up (0 = never)
+
+template <int CTRL>
+__device__ __forceinline__ float dppq(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float sum4(float v) {          // over the 4 adjacent lanes that share an owner token
+    v += dppq<0xB1>(v);
+    v += dppq<0x4E>(v);
+    return v;
+}
+__device__ __forceinline__ void ld16f(__amdgpu_buffer_rsrc_t r, int voff, int soff, float (&o)[16]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = bld4f(r, voff + 16 * q, soff);
+        o[4 * q] = v[0]; o[4 * q + 1] = v[1]; o[4 * q + 2] = v[2]; o[4 * q + 3] = v[3];
+    }
+}
+
+#define TTT_STAMP4(k)                                                        \
+    if (DBG && p.dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {    \
+        const unsigned long long _t = __builtin_readcyclecounter();          \
+        p.dbg[16 + (k)] += _t - t_last;                                      \
+        t_last = _t;                                                         \
+    }
+
+template <bool DBG>
+__global__ __launch_bounds__(NTC) void mlp_bwd_cluster_kernel(SweepParams2 p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __bf16* Kt2 = reinterpret_cast<__bf16*>(smem + L_K);
+    __bf16* Gt2 = reinterpret_cast<__bf16*>(smem + L_G);
+    __bf16* Qt = reinterpret_cast<__bf16*>(smem + L_Q);
+    __bf16* At = reinterpret_cast<__bf16*>(smem + L_A);
+    __bf16* Bt = reinterpret_cast<__bf16*>(smem + L_B);
+    char* exu = smem + L_XU;
+    char* exd = smem + L_XD;
+    float* etaL2 = reinterpret_cast<float*>(smem + L_SM);
+    float* db1L = etaL2 + 128;
+    float* db2L = db1L + 64;
+    float* gamL = db2L + 64;
+    unsigned* syncw = reinterpret_cast<unsigned*>(gamL + 64);
+
+    const int tid = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cq = __builtin_amdgcn_readfirstlane((int)(blockIdx.x / p.nbh));     // workgroup of the cluster = wave pair w
+    const int bh = blockIdx.x % p.nbh, head = bh % p.NH;
+    const int NC = p.NC;
+    char* slots = p.slots + (size_t)bh * p.slot_stride_bh;
+    float* carry = p.carry + (size_t)bh * CARRY_FLOATS2;
+    const __amdgpu_buffer_rsrc_t rS = make_srd(slots, p.slot_stride_bh);
+    const size_t act_bytes = (size_t)NC * 4096 * 2;
+    const __amdgpu_buffer_rsrc_t rK = make_srd(p.XK + (size_t)bh * NC * 4096, act_bytes);
+    const __amdgpu_buffer_rsrc_t rQ = make_srd(p.XQ + (size_t)bh * NC * 4096, act_bytes);
+    const __amdgpu_buffer_rsrc_t rO = make_srd(p.dOut + (size_t)bh * NC * 4096, act_bytes);
+    const __amdgpu_buffer_rsrc_t rV = make_srd(p.dXV + (size_t)bh * NC * 4096, act_bytes);
+    const __amdgpu_buffer_rsrc_t rE = make_srd(p.eta + (size_t)bh * NC * 64, (size_t)NC * 64 * 2);
+    const __amdgpu_buffer_rsrc_t rX = make_srd(p.xch + (size_t)bh * XCH_BH_BYTES, XCH_BH_BYTES);
+    const int WREG = cq * (int)SLOT_WAVE_FR;
+    auto slot_off = [&](int step) { return (step - p.chunk_lo) * (int)SLOT_BYTES; };
+    const int i0 = p.chunk_hi - 1;
+    unsigned* const my_flag = p.flags + ((size_t)bh * 4 + cq) * FLAG_STRIDE;
+
+    if (wv < 2) {
+        // =========================================================================================================== COMPUTE
+        const int pp = wv;
+        const int nO = 64 * cq + 32 * pp;                      // first hidden unit of this wave
+        const int fO = 32 * pp, fX = 32 * (1 - pp);
+        f32x16 dW1t[2];      // [a]  dW1[f in 32a.., n in Hp]                                   (rows = f, lane = n)
+        f32x16 dW2t[2];      // [0] dW2[n in Hp, f in Fp], [1] dW2[n in Hp, f in Fx]           (rows = n, lane = f)
+        f32x16 dW2Tt[2];     // same blocks transposed                                          (rows = f, lane = n)
+        float db1v, db2v;    // db1[nO + c] ; db2[fO + c] (every workgroup carries db2: its owners need it)
+        {
+            const int l = tid & 63, h = l >> 5, c = l & 31;
+            const float* g1 = p.first ? p.uW1 + (size_t)bh * 64 * 256 : carry + C_DW1;
+            const float* g2 = p.first ? p.uW2 + (size_t)bh * 256 * 64 : carry + C_DW2;
+            const float* gb1 = p.first ? p.ub1 + (size_t)bh * 256 : carry + C_DB1;
+            const float* gb2 = p.first ? p.ub2 + (size_t)bh * 64 : carry + C_DB2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ro = row_of(r, h);
+                dW1t[0][r] = g1[(size_t)ro * 256 + nO + c];
+                dW1t[1][r] = g1[(size_t)(32 + ro) * 256 + nO + c];
+                dW2t[0][r] = g2[(size_t)(nO + ro) * 64 + fO + c];
+                dW2t[1][r] = g2[(size_t)(nO + ro) * 64 + fX + c];
+                dW2Tt[0][r] = g2[(size_t)(nO + c) * 64 + fO + ro];
+                dW2Tt[1][r] = g2[(size_t)(nO + c) * 64 + fX + ro];
+            }
+            db1v = gb1[nO + c];
+            db2v = gb2[fO + c];
+        }
+        bf16x8 ONES;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ONES[e] = (__bf16)1.0f;
+
+        // output path of step j: W2' = state entering step j + 1 (slot j + 1), X2b / gelu'(Z1b) from slot j, dZ2b_j in At, Q_j in Qt
+        auto add_output_path = [&](int j) {
+            const int l = tid & 63;
+            const int sj = slot_off(j) + WREG, sn = sj + (int)SLOT_BYTES, l16 = l * 16;
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                f32x16 dz = zero16();
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    dz = mma(row_pi(At, ti, fO, s, l), bld8(rS, l16, sn + fro(FR_W2T, fr_idx(pp, pp, s))), dz);
+                    dz = mma(row_pi(At, ti, fX, s, l), bld8(rS, l16, sn + fro(FR_W2T, fr_idx(1 - pp, pp, s))), dz);
+                }
+                const f32x16 d1b = unpack2(bld8(rS, l16, sj + fro(FR_D1B, fr_idx(ti, pp, 0))), bld8(rS, l16, sj + fro(FR_D1B, fr_idx(ti, pp, 1))));
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dz[r] *= d1b[r];
+                db1v += tile_colsum(dz);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const bf16x8 zf = pack(dz, s);                       // dZ1b (k = t rows, j = n lane)
+                    bst8(rS, l16, sj + fro(FR_DZ1B, fr_idx(ti, pp, s)), zf);
+                    dW1t[0] = mma(tr_pi(Qt, 32 * ti, s, 0, l), zf, dW1t[0]);
+                    dW1t[1] = mma(tr_pi(Qt, 32 * ti, s, 32, l), zf, dW1t[1]);
+                    const bf16x8 xb = bld8(rS, l16, sj + fro(FR_X2B, fr_idx(ti, pp, s)));   // X2b (m = n lane, k = t rows)
+                    const bf16x8 aO = tr_pi(At, 32 * ti, s, fO, l), aX = tr_pi(At, 32 * ti, s, fX, l);
+                    dW2t[0] = mma(xb, aO, dW2t[0]);
+                    dW2t[1] = mma(xb, aX, dW2t[1]);
+                    dW2Tt[0] = mma(aO, xb, dW2Tt[0]);
+                    dW2Tt[1] = mma(aX, xb, dW2Tt[1]);
+                    const f32x16 acc = mma(ONES, aO, zero16());          // db2 += column sums of dZ2b
+                    db2v += acc[0];
+                }
+            }
+        };
+        // what the next S1 / the owners / the tail kernel need: complete dW1 (slot j), db1, db2, the dW2 block the partner contracts over
+        auto publish_state = [&](int j) {
+            const int l = tid & 63, h = l >> 5, c = l & 31;
+            const int sj = slot_off(j) + WREG;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) bst8(rS, l * 16, sj + fro(FR_DW1, fr_idx(a, pp, s)), pack(dW1t[a], s));
+#pragma unroll
+            for (int s = 0; s < 2; ++s) *reinterpret_cast<bf16x8*>(exd + ((size_t)(pp * 2 + s) * 64 + l) * 16) = pack(dW2t[1], s);
+            if (h == 0) { db1L[32 * pp + c] = db1v; db2L[fO + c] = db2v; }
+        };
+
+        __syncthreads();                       // P0 (owners: gamma row, sync word)
+        __syncthreads();                       // P1: tiles of step i0, dZ2b_i0 parked by the owners
+        add_output_path(i0);
+        publish_state(i0);
+        __syncthreads();                       // P2
+
+        unsigned long long t_last = __builtin_readcyclecounter();
+        for (int i = i0; i >= p.chunk_lo; --i) {
+            int l_op = tid & 63;
+            asm volatile("" : "+v"(l_op));           // opaque lane id: keeps address arithmetic inside the loop (no hoist + spill)
+            const int l = l_op, h = l >> 5, c = l & 31;
+            const bool more = i > p.chunk_lo;
+            const int cur = (i0 - i) & 1;
+            const __bf16* Kt = Kt2 + cur * TILE_ELEMS;
+            const __bf16* Gt = Gt2 + cur * TILE_ELEMS;
+            const float* etaL = etaL2 + cur * 64;
+            const int sI = slot_off(i), sw = sI + WREG, l16 = l * 16;
+            const unsigned epoch = (unsigned)(i0 - i) + 1;                 // hand-over number of this step, 1-based
+            const int xmine = ((int)(epoch & 1) * 4 + cq) * XCH_REC_BYTES;   // this workgroup's record of this step
+
+            // ================= S1 : (rows = n, lane = t) products, u^T, d(eta) partial, first half of d(gZ2)^T ==============
+            f32x16 P[2];                       // [ti]  d(gZ2)^T partial (rows = f in Fp, lane = t)
+            bf16x8 uN[2][2];                   // [ti][s]  u^T (k = n rows, j = t lane)
+            float se2[2];
+            {
+                const f32x16 db1R = rows_from_lds(db1L + 32 * pp, 0, h);
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti) {
+                    f32x16 e1 = db1R;
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        e1 = mma(pack(dW1t[0], s), row_pi(Kt, ti, 0, s, l), e1);
+                        e1 = mma(pack(dW1t[1], s), row_pi(Kt, ti, 32, s, l), e1);
+                    }
+                    const float ec = -etaL[32 * ti + c];
+                    float se = 0.f;
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const bf16x8 g1 = bld8(rS, l16, sw + fro(FR_GZ1T, fr_idx(pp, ti, s)));
+                        const bf16x8 d1 = bld8(rS, l16, sw + fro(FR_D1N, fr_idx(pp, ti, s)));
+                        bf16x8 uf;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float ev = e1[8 * s + e];
+                            se += (float)g1[e] * ev;
+                            uf[e] = (__bf16)(ec * ev * (float)d1[e]);
+                        }
+                        uN[ti][s] = uf;
+                        *reinterpret_cast<bf16x8*>(exu + ((size_t)(pp * 4 + ti * 2 + s) * 64 + l) * 16) = uf;
+                    }
+                    se2[ti] = se;
+                }
+            }
+            {
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti) {
+                    f32x16 a2 = zero16();
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        a2 = mma(pack(dW2Tt[0], s), row_pi(Gt, ti, fO, s, l), a2);
+                        a2 = mma(pack(dW2Tt[1], s), row_pi(Gt, ti, fX, s, l), a2);
+                    }
+                    float se = se2[ti];
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const bf16x8 x2 = bld8(rS, l16, sw + fro(FR_XT, fr_idx(pp, ti, s)));
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) se += (float)x2[e] * a2[8 * s + e];
+                    }
+                    se = xor_add(se, 32);
+                    if (h == 0) {
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, -se), rX, XCH_PART_BYTES + (pp * 64 + 32 * ti + c) * 4, xmine, 16);
+                    }
+                }
+            }
+            {
+                const bf16x8 D2o0 = pack(dW2t[0], 0), D2o1 = pack(dW2t[0], 1);
+                const bf16x8 D2x0 = *reinterpret_cast<const bf16x8*>(exd + ((size_t)((pp ^ 1) * 2 + 0) * 64 + l) * 16);
+                const bf16x8 D2x1 = *reinterpret_cast<const bf16x8*>(exd + ((size_t)((pp ^ 1) * 2 + 1) * 64 + l) * 16);
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti) {
+                    f32x16 pa = zero16();
+                    pa = mma(D2o0, bld8(rS, l16, sw + fro(FR_XT, fr_idx(pp, ti, 0))), pa);
+                    pa = mma(D2o1, bld8(rS, l16, sw + fro(FR_XT, fr_idx(pp, ti, 1))), pa);
+                    pa = mma(D2x0, bld8(rS, l16, sw + fro(FR_XT, fr_idx(1 - pp, ti, 0))), pa);
+                    pa = mma(D2x1, bld8(rS, l16, sw + fro(FR_XT, fr_idx(1 - pp, ti, 1))), pa);
+                    const float ec = -etaL[32 * ti + c];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) pa[r] *= ec;
+                    P[ti] = pa;
+                }
+            }
+            TTT_STAMP4(0)
+            __syncthreads();                   // Ba: u^T fragments visible
+            TTT_STAMP4(1)
+
+            // ================= S2 : second half of d(gZ2)^T partial -> LDS (own owners) + published record (partners) ======
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const bf16x8 ux = *reinterpret_cast<const bf16x8*>(exu + ((size_t)((pp ^ 1) * 4 + ti * 2 + s) * 64 + l) * 16);
+                    P[ti] = mma(bld8(rS, l16, sw + fro(FR_W2, fr_idx(pp, pp, s))), uN[ti][s], P[ti]);
+                    P[ti] = mma(bld8(rS, l16, sw + fro(FR_W2, fr_idx(1 - pp, pp, s))), ux, P[ti]);
+                }
+                const int vo = ((32 * ti + c) * PS + 32 * pp + 4 * h) * 4;       // [t][f] image (row stride PS), write-through
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const f32x4 v = {P[ti][4 * q4], P[ti][4 * q4 + 1], P[ti][4 * q4 + 2], P[ti][4 * q4 + 3]};
+                    bst4f_sc1(rX, vo + 32 * q4, xmine, v);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0) ; drain: the record is in memory before the flag is stored" ::: "memory");
+            TTT_STAMP4(2)
+            __syncthreads();                   // Bb: this workgroup's record is complete and drained
+            TTT_STAMP4(3)
+
+            // ================= S4a operands of the state ENTERING step i, then the output path of step j =====================
+            // (the output path adds to the carried state; S4a below must contract over the state before those additions)
+            const float db1_old = db1v;
+            bf16x8 D1p[2][2], D2p[2][2];       // [a][s] pack(dW1t[a], s) ; pack(dW2Tt[a], s)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) { D1p[a][s] = pack(dW1t[a], s); D2p[a][s] = pack(dW2Tt[a], s); }
+            if (more) add_output_path(i - 1);
+            TTT_STAMP4(4)
+            __syncthreads();                   // Bc: dZ2_i (Bt) written by the owners
+            TTT_STAMP4(5)
+
+            // ================= S4a : first-layer gradients and this step's state updates ====================================
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                const f32x16 etaR = rows_from_lds(etaL, 32 * ti, h);
+                f32x16 e1 = zero16();
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    e1 = mma(row_pi(Kt, ti, 0, s, l), D1p[0][s], e1);
+                    e1 = mma(row_pi(Kt, ti, 32, s, l), D1p[1][s], e1);
+                }
+                bf16x8 d1f[2], uf[2];                                       // gelu'(Z1) fragments ; u (m = n lane, k = t rows)
+                f32x16 dz;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    d1f[s] = bld8(rS, l16, sw + fro(FR_D1, fr_idx(ti, pp, s)));
+                    const bf16x8 mm = bld8(rS, l16, sw + fro(FR_GX2, fr_idx(ti, pp, s)));
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float dg = -etaR[8 * s + e] * (e1[8 * s + e] + db1_old);      // d(gZ1)
+                        uf[s][e] = (__bf16)(dg * (float)d1f[s][e]);
+                        dz[8 * s + e] = dg * (float)mm[e];
+                    }
+                }
+                {
+                    f32x16 dx = zero16();
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        dx = mma(row_pi(Gt, ti, fO, s, l), D2p[0][s], dx);
+                        dx = mma(row_pi(Gt, ti, fX, s, l), D2p[1][s], dx);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dx[r] *= -etaR[r];          // -eta A2
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        dx = mma(row_pi(Bt, ti, fO, s, l), bld8(rS, l16, sw + fro(FR_W2T, fr_idx(pp, pp, s))), dx);
+                        dx = mma(row_pi(Bt, ti, fX, s, l), bld8(rS, l16, sw + fro(FR_W2T, fr_idx(1 - pp, pp, s))), dx);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dz[r] += dx[r] * (float)d1f[r >> 3][r & 7];     // dZ1
+                }
+                db1v += tile_colsum(dz);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const bf16x8 zf = pack(dz, s);                        // dZ1 (k = t rows, j = n lane)
+                    bst8(rS, l16, sw + fro(FR_DZ1, fr_idx(ti, pp, s)), zf);
+                    dW1t[0] = mma(tr_pi(Kt, 32 * ti, s, 0, l), zf, dW1t[0]);
+                    dW1t[1] = mma(tr_pi(Kt, 32 * ti, s, 32, l), zf, dW1t[1]);
+                    const bf16x8 gO = tr_pi(Gt, 32 * ti, s, fO, l), gX = tr_pi(Gt, 32 * ti, s, fX, l);
+                    dW2t[0] = mma(uf[s], gO, dW2t[0]);
+                    dW2t[1] = mma(uf[s], gX, dW2t[1]);
+                    dW2Tt[0] = mma(gO, uf[s], dW2Tt[0]);
+                    dW2Tt[1] = mma(gX, uf[s], dW2Tt[1]);
+                    const bf16x8 xf = bld8(rS, l16, sw + fro(FR_X2, fr_idx(ti, pp, s)));     // X2 (m = n lane, k = t rows)
+                    const bf16x8 zO = tr_pi(Bt, 32 * ti, s, fO, l), zX = tr_pi(Bt, 32 * ti, s, fX, l);
+                    dW2t[0] = mma(xf, zO, dW2t[0]);
+                    dW2t[1] = mma(xf, zX, dW2t[1]);
+                    dW2Tt[0] = mma(zO, xf, dW2Tt[0]);
+                    dW2Tt[1] = mma(zX, xf, dW2Tt[1]);
+                    const f32x16 acc = mma(ONES, zO, zero16());
+                    db2v += acc[0];
+                }
+            }
+            if (more) publish_state(i - 1);
+            TTT_STAMP4(6)
+            __syncthreads();                   // Bd: every read of K_i, gZ2_i, dZ2_i, dZ2b_j, Q_j is done; state published
+            TTT_STAMP4(7)
+        }
+
+        // ---- hand the state gradient to the next chunk, or emit the final results (this workgroup's slices) -------------------
+        {
+            const int l = tid & 63, h = l >> 5, c = l & 31;
+            float* o1 = p.last ? p.dW1 + (size_t)bh * 64 * 256 : carry + C_DW1;
+            float* o2 = p.last ? p.dW2 + (size_t)bh * 256 * 64 : carry + C_DW2;
+            float* ob1 = p.last ? p.db1 + (size_t)bh * 256 : carry + C_DB1;
+            float* ob2 = p.last ? p.db2 + (size_t)bh * 64 : carry + C_DB2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ro = row_of(r, h);
+                o1[(size_t)ro * 256 + nO + c] = dW1t[0][r];
+                o1[(size_t)(32 + ro) * 256 + nO + c] = dW1t[1][r];
+                o2[(size_t)(nO + ro) * 64 + fO + c] = dW2t[0][r];
+                o2[(size_t)(nO + ro) * 64 + fX + c] = dW2t[1][r];
+            }
+            if (h == 0) ob1[nO + c] = db1v;
+            if (cq == 0 && h == 0) ob2[fO + c] = db2v;
+        }
+        if (p.last) __syncthreads();           // (the owners' final reduction)
+    } else {
+        // =========================================================================================================== OWNERS
+        const int ow = tid - 128;                               // 0 .. 255
+        const int ot = ow >> 2, of0 = 16 * (ow & 3);            // token, first of this thread's 16 features
+        float dgam[16], dbet[16];
+        if (p.first) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { dgam[k] = 0.f; dbet[k] = 0.f; }
+        } else {
+            load16_f32(carry + C_DG + (size_t)ow * 16, dgam);
+            load16_f32(carry + C_DBT + (size_t)ow * 16, dbet);
+        }
+        if (ow < 64) gamL[ow] = p.ln_w[(size_t)head * 64 + ow];
+        if (ow == 0) syncw[0] = 0u;
+
+        // K, gZ2 (slot), eta of `step` -> tile buffers `dst`; Q of `step` -> Qt.  256 threads x 32 bytes per tile.
+        auto stage_tiles = [&](int step, int dst) {
+            const int vo = ow * 32;
+            const uint4 k0 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rK, vo, step * 8192, 0));
+            const uint4 k1 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rK, vo + 16, step * 8192, 0));
+            const int sg = slot_off(step) + (int)(SLOT_FR + SLOT_OWN);
+            const uint4 g0 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rS, vo, sg, 0));
+            const uint4 g1 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rS, vo + 16, sg, 0));
+            const uint4 q0 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rQ, vo, step * 8192, 0));
+            const uint4 q1 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rQ, vo + 16, step * 8192, 0));
+            unsigned short ev = 0;
+            if (ow < 64) ev = __builtin_amdgcn_raw_buffer_load_b16(rE, ow * 2, step * 128, 0);
+            __bf16* kd = Kt2 + dst * TILE_ELEMS + ot * TS + of0;
+            __bf16* gd = Gt2 + dst * TILE_ELEMS + ot * TS + of0;
+            __bf16* qd = Qt + ot * TS + of0;
+            *reinterpret_cast<uint4*>(kd) = k0; *reinterpret_cast<uint4*>(kd + 8) = k1;
+            *reinterpret_cast<uint4*>(gd) = g0; *reinterpret_cast<uint4*>(gd + 8) = g1;
+            *reinterpret_cast<uint4*>(qd) = q0; *reinterpret_cast<uint4*>(qd + 8) = q1;
+            if (ow < 64) etaL2[dst * 64 + ow] = __builtin_bit_cast(float, (unsigned)ev << 16);
+        };
+        // backward of the output LayerNorm of step j -> dZ2b_j tile (At), dgamma / dbeta contributions
+        auto owner_out_ln = [&](int j) {
+            const int so = slot_off(j) + (int)SLOT_FR;
+            float d[16], xl[16], g[16];
+            {
+                const bf16x8 a = bld8(rO, ow * 32, j * 8192), b = bld8(rO, ow * 32 + 16, j * 8192);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { d[k] = (float)a[k]; d[8 + k] = (float)b[k]; }
+            }
+            ld16f(rS, ow * 64, so + 2 * (int)SLOT_OWN_ARR, xl);
+            const float rstdl = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rS, ot * 8 + 4, so + 3 * (int)SLOT_OWN_ARR, 0));
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                dgam[k] += d[k] * xl[k];
+                dbet[k] += d[k];
+                g[k] = d[k] * gamL[of0 + k];
+                s1 += g[k]; s2 += g[k] * xl[k];
+            }
+            s1 = sum4(s1); s2 = sum4(s2);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) g[k] = (64.0f * g[k] - s1 - xl[k] * s2) * rstdl * (1.0f / 64.0f);
+            store16_bf16(At + ot * TS + of0, g);
+        };
+
+        __syncthreads();                       // P0: gamma row, sync word visible to all owner waves
+        stage_tiles(i0, 0);
+        owner_out_ln(i0);
+        __syncthreads();                       // P1
+        __syncthreads();                       // P2
+
+        unsigned tch[4] = {0u, 0u, 0u, 0u};    // in-flight prefetch touches (folded into `sink` one step later)
+        unsigned sink = 0u;
+        for (int i = i0; i >= p.chunk_lo; --i) {
+            const bool more = i > p.chunk_lo;
+            const int cur = (i0 - i) & 1;
+            const int sI = slot_off(i);
+            const unsigned epoch = (unsigned)(i0 - i) + 1;
+            const int xrec = (int)(epoch & 1) * 4 * XCH_REC_BYTES;
+            // ---- O-A: everything of step j that needs no partner data; the step's own-array loads go out early ----------------
+            float xh[16], go[16];
+            const int so = sI + (int)SLOT_FR;
+            ld16f(rS, ow * 64, so, xh);
+            ld16f(rS, ow * 64, so + (int)SLOT_OWN_ARR, go);
+            const float r = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rS, ot * 8, so + 3 * (int)SLOT_OWN_ARR, 0));
+            if (more) {
+                stage_tiles(i - 1, cur ^ 1);
+                owner_out_ln(i - 1);
+            }
+            __syncthreads();                   // Ba
+            __syncthreads();                   // Bb: this workgroup's record is complete and drained
+            // ---- O-C: hand-over ------------------------------------------------------------------------------------------------
+            if (ow == 0) __hip_atomic_store(my_flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (wv == 2) {
+                const int l = tid & 63;
+                if (l < 3) {
+                    const unsigned* f = p.flags + ((size_t)bh * 4 + ((cq + 1 + l) & 3)) * FLAG_STRIDE;
+                    unsigned spins = 0;
+                    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > (1u << 22)) {        // a partner is not running: give up loudly instead of hanging the GPU
+                            __hip_atomic_store(&g_sweep_err, 1u + (unsigned)bh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                    }
+                }
+                // (the wave re-converges here: all three partner records of this step are published)
+                if (l == 0) __hip_atomic_store(syncw, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                unsigned spins = 0;
+                while (__hip_atomic_load(syncw, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < epoch) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1u << 24)) break;
+                }
+            }
+            float G_[16];
+            {
+                // all four records - this workgroup's own included - come back through memory with sc1 loads: no branch on cq,
+                // and the same summation order q = 0..3 on all four workgroups -> bit-identical dZ2 everywhere
+                f32x4 pa[4][4];
+                const int vo = (ot * PS + of0) * 4;
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) pa[qq][u] = bld4f_sc1(rX, vo + 16 * u, xrec + qq * XCH_REC_BYTES);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const f32x4 v = ((pa[0][u] + pa[1][u]) + pa[2][u]) + pa[3][u];
+                    G_[4 * u] = v[0]; G_[4 * u + 1] = v[1]; G_[4 * u + 2] = v[2]; G_[4 * u + 3] = v[3];
+                }
+            }
+            {
+                const float eta_t = etaL2[cur * 64 + ot];
+                float gxh[16], gz[16];
+                float s1g = 0.f, s2g = 0.f;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    gxh[k] = go[k] * gamL[of0 + k];
+                    s1g += gxh[k]; s2g += gxh[k] * xh[k];
+                }
+                s1g = sum4(s1g); s2g = sum4(s2g);
+                float se = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    gz[k] = (64.0f * gxh[k] - s1g - xh[k] * s2g) * r * (1.0f / 64.0f);      // gZ2 (fp32)
+                    const float db2 = db2L[of0 + k];
+                    se += gz[k] * db2;
+                    G_[k] -= eta_t * db2;                                                    // d(gZ2) complete
+                    const float m = -G_[k] * r;
+                    s1 += m; s2 += m * xh[k];
+                }
+                se = sum4(se); s1 = sum4(s1); s2 = sum4(s2);
+                float a1 = 0.f, a2 = 0.f, dxh[16];
+                bf16x8 dv0, dv1;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const float g = gamL[of0 + k];
+                    const float m = -G_[k] * r;
+                    const float dgxh = r * G_[k] + (s1 + xh[k] * s2) * (1.0f / 64.0f);
+                    const float dy = g * dgxh;
+                    dgam[k] += go[k] * dgxh + dy * xh[k];
+                    dbet[k] += dy;
+                    if (k < 8) dv0[k] = (__bf16)(-dy); else dv1[k - 8] = (__bf16)(-dy);     // dt = -dy ; dV = dt
+                    dxh[k] = dy * g + (gxh[k] * s2 + s2g * m) * (1.0f / 64.0f);
+                    const float dstd = -dxh[k] * xh[k] * r - G_[k] * gz[k] * r;
+                    a1 += dxh[k]; a2 += dstd;
+                }
+                a1 = sum4(a1); a2 = sum4(a2);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) G_[k] = dxh[k] * r - a1 * r * (1.0f / 64.0f) + a2 * xh[k] * (1.0f / 64.0f);   // dZ2
+                store16_bf16(Bt + ot * TS + of0, G_);
+                if (cq == 0) {
+                    bst8(rV, ow * 32, i * 8192, dv0);
+                    bst8(rV, ow * 32 + 16, i * 8192, dv1);
+                    if ((ow & 3) == 0) {      // workgroup 0 finishes d(eta): the eight per-wave partials of the four records
+                        float de = -se;
+#pragma unroll
+                        for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+                            for (int u = 0; u < 2; ++u)
+                                de += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, XCH_PART_BYTES + (u * 64 + ot) * 4,
+                                                                                                     xrec + qq * XCH_REC_BYTES, 16));
+                        p.deta[((size_t)bh * NC + i) * 64 + ot] = (__bf16)de;
+                    }
+                }
+            }
+            __syncthreads();                   // Bc: dZ2_i visible to the compute waves
+            // ---- O-D: L2 prefetch touches, two steps ahead (slot lines of this workgroup's wave pair, a quarter of the shared ones)
+            sink ^= tch[0] ^ tch[1] ^ tch[2] ^ tch[3];
+            {
+                const int t = i - 2;
+                if (t >= p.chunk_lo) {
+                    const int st = slot_off(t);
+                    constexpr int FR_LINES = 10 * 64;                               // 10 arrays x 8 fragments x 1 KiB
+                    constexpr int OWN_LINES = (int)((SLOT_OWN + SLOT_G) / 128);
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) {
+                        const int ln = ow + 256 * u;
+                        if (ln < FR_LINES) {
+                            const int ai = ln >> 6, li = ln & 63;
+                            const int arr = ai < 4 ? ai + 1 : ai == 4 ? 6 : ai + 3;      // FR_W2..FR_D1, FR_GX2, FR_GZ1T..FR_D1N
+                            tch[u] = __builtin_amdgcn_raw_buffer_load_b32(rS, li * 128, st + WREG + arr * 8 * (int)FRAG_BYTES, 0);
+                        }
+                    }
+                    {
+                        const int ln = ow * 4 + cq;                                  // shared lines: every workgroup takes a quarter
+                        if (ln < OWN_LINES) tch[3] = __builtin_amdgcn_raw_buffer_load_b32(rS, ln * 128, st + (int)SLOT_FR, 0);
+                        else if (ln < OWN_LINES + 64) tch[3] = __builtin_amdgcn_raw_buffer_load_b32(rK, (ln - OWN_LINES) * 128, t * 8192, 0);
+                        else if (ln < OWN_LINES + 128) tch[3] = __builtin_amdgcn_raw_buffer_load_b32(rQ, (ln - OWN_LINES - 64) * 128, t * 8192, 0);
+                        else if (ln < OWN_LINES + 192) tch[3] = __builtin_amdgcn_raw_buffer_load_b32(rO, (ln - OWN_LINES - 128) * 128, t * 8192, 0);
+                    }
+                }
+            }
+            __syncthreads();                   // Bd
+        }
+        sink ^= tch[0] ^ tch[1] ^ tch[2] ^ tch[3];
+        asm volatile("" :: "v"(sink));
+
+        // ---- dgamma / dbeta: to the next chunk, or reduced over the 64 tokens ----------------------------------------------------
+        if (!p.last) {
+            if (cq == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 a = {dgam[4 * q], dgam[4 * q + 1], dgam[4 * q + 2], dgam[4 * q + 3]};
+                    f32x4 b = {dbet[4 * q], dbet[4 * q + 1], dbet[4 * q + 2], dbet[4 * q + 3]};
+                    *reinterpret_cast<f32x4*>(carry + C_DG + (size_t)ow * 16 + 4 * q) = a;
+                    *reinterpret_cast<f32x4*>(carry + C_DBT + (size_t)ow * 16 + 4 * q) = b;
+                }
+            }
+        } else {
+            float* sg = reinterpret_cast<float*>(smem + L_K);        // [256][16]
+            float* sb = reinterpret_cast<float*>(smem + L_G);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { sg[ow * 16 + k] = dgam[k]; sb[ow * 16 + k] = dbet[k]; }
+            __syncthreads();
+            if (ow < 64 && cq == 0) {
+                const int o = ow >> 4, k = ow & 15;
+                float a = 0.f, b = 0.f;
+                for (int t = 0; t < 64; ++t) { a += sg[(t * 4 + o) * 16 + k]; b += sb[(t * 4 + o) * 16 + k]; }
+                p.dlnw[(size_t)bh * 64 + ow] = a;
+                p.dlnb[(size_t)bh * 64 + ow] = b;
+            }
+        }
+    }
+}
+
+}  // namespace b3
+
+// ---------------------------------------------------------------------------------------------------------------------------
+unsigned read_sweep_error() {
+    unsigned v = 0;
+    (void)hipMemcpyFromSymbol(&v, HIP_SYMBOL(b3::g_sweep_err), sizeof(v));
+    return v;
+}
+
+void launch_sweep_cluster(const b2::SweepParams2& bp, int nbh, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)b3::mlp_bwd_cluster_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, b3::LDS_CL);
+        (void)hipFuncSetAttribute((const void*)b3::mlp_bwd_cluster_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, b3::LDS_CL);
+        attr = true;
+    }
+    const dim3 grid(nbh * 4), blk(b3::NTC);
+    if (bp.dbg) hipLaunchKernelGGL((b3::mlp_bwd_cluster_kernel<true>), grid, blk, b3::LDS_CL, s, bp);
+    else hipLaunchKernelGGL((b3::mlp_bwd_cluster_kernel<false>), grid, blk, b3::LDS_CL, s, bp);
+}
+
+}  // namespace mfma
+}  // namespace ttt

@@ -67,7 +67,7 @@ EXPORTED_SYMBOLS = (
     "ttt_hip_mlp_forward_workspace", "ttt_hip_mlp_backward_workspace", "ttt_hip_linear_forward_workspace",
     "ttt_hip_linear_backward_workspace", "ttt_hip_mlp_forward", "ttt_hip_mlp_backward", "ttt_hip_linear_forward",
     "ttt_hip_linear_backward", "ttt_hip_resolve_impl", "ttt_hip_abi_version", "ttt_hip_last_error",
-    "ttt_hip_debug_timing", "ttt_hip_debug_groups_per_chunk", "ttt_hip_debug_variant", "ttt_hip_debug_dump", "ttt_hip_debug_helpers", "ttt_hip_debug_option",
+    "ttt_hip_debug_timing", "ttt_hip_debug_groups_per_chunk", "ttt_hip_debug_variant", "ttt_hip_debug_dump", "ttt_hip_debug_helpers", "ttt_hip_debug_option", "ttt_hip_debug_sweep_error",
     "ttt_hip_pre_forward", "ttt_hip_pre_backward_partials", "ttt_hip_pre_backward", "ttt_hip_post_partials",
     "ttt_hip_post_forward", "ttt_hip_post_backward", "ttt_hip_gate_forward", "ttt_hip_gate_backward_partials",
     "ttt_hip_gate_backward", "ttt_hip_attn_forward", "ttt_hip_attn_backward",
@@ -143,6 +143,13 @@ def debug_option(name: str, value: int) -> None:
     lib.ttt_hip_debug_option.restype = ctypes.c_int
     if lib.ttt_hip_debug_option(name.encode(), int(value)) != 0:
         raise ValueError(f"unknown debug option {name!r}")
+
+
+def sweep_error() -> int:
+    """0, or 1 + (b,h) of a cluster-form backward workgroup whose hand-over partner never arrived (synchronises)."""
+    lib = load_library()
+    lib.ttt_hip_debug_sweep_error.restype = ctypes.c_uint
+    return int(lib.ttt_hip_debug_sweep_error())
 
 
 def debug_dump(buf: Optional[torch.Tensor]) -> None:
@@ -362,10 +369,12 @@ def _call(fn, *args, device):
         raise RuntimeError(lib.ttt_hip_last_error().decode())
 
 
-def _req_maps(rope, src, pos, L, F):
+def _req_maps(rope, src, pos, L, F, n_pos):
     """Token maps / RoPE table of the fused pre kernels: the kernel indexes ``rope[pos[t]]`` and ``x[src[t]]`` unchecked, so
     the table must cover every position (the reference's apply_rotary_emb raises a shape error for a video longer than
-    config.compressed_num_frames, ssm/utils.py:82-108) and the maps must be int32 of length L."""
+    config.compressed_num_frames, ssm/utils.py:82-108) and the maps must be int32 of length L.  ``n_pos`` = 1 + the largest
+    position the maps address, as a host integer (the module caches it with the maps; no device synchronisation here);
+    None skips the bound check (the backward re-runs with maps its forward has validated)."""
     for t, n in ((src, "src"), (pos, "pos")):
         if t is None:
             continue
@@ -378,23 +387,16 @@ def _req_maps(rope, src, pos, L, F):
     if rope.numel() % F != 0:
         raise RuntimeError(f"rope: expected [n_pos, {F // 2}, 2] (cos, sin) pairs, got {tuple(rope.shape)}")
     n_rows = rope.numel() // F
-    n_pos = getattr(pos, "_ttt_max_pos", None)            # cached by the module (host-side, no sync)
-    if n_pos is None and pos is not None:
-        n_pos = int(pos.max().item()) + 1
-        try:
-            pos._ttt_max_pos = n_pos
-        except AttributeError:
-            pass
-    if pos is None:
+    if n_pos is None and pos is None:
         n_pos = L
-    if n_pos > n_rows:
+    if n_pos is not None and n_pos > n_rows:
         raise RuntimeError(f"rope table has {n_rows} positions but the sequence addresses {n_pos} (video longer than "
                            f"config.compressed_num_frames?)")
 
 
-def pre_forward(XQ_raw, XK_raw, XV_raw, rope, src, pos, ln_w, ln_b, XQ, XK, XV, NH):
+def pre_forward(XQ_raw, XK_raw, XV_raw, rope, src, pos, ln_w, ln_b, XQ, XK, XV, NH, n_pos=None):
     B, L, D = XQ_raw.shape
-    _req_maps(rope, src, pos, L, D // NH)
+    _req_maps(rope, src, pos, L, D // NH, n_pos)
     for t, n in ((XQ_raw, "XQ_raw"), (XK_raw, "XK_raw"), (XV_raw, "XV_raw"), (XQ, "XQ"), (XK, "XK"), (XV, "XV")):
         _req(t, n, torch.bfloat16)
     for t, n in ((ln_w, "ln_w"), (ln_b, "ln_b")):

@@ -31,7 +31,7 @@ class FusedPre(torch.autograd.Function):
         q, k, v = XQ_raw.contiguous(), XK_raw.contiguous(), XV_raw.contiguous()
         w32, b32 = ln_w.detach().to(_F32).contiguous(), ln_b.detach().to(_F32).contiguous()
         outs = [torch.empty(B, NH, L, D // NH, device=q.device, dtype=_BF16) for _ in range(3)]
-        ext.pre_forward(q, k, v, rope, src, pos, w32, b32, *outs, NH)
+        ext.pre_forward(q, k, v, rope, src, pos, w32, b32, *outs, NH, n_pos=getattr(pos, "_ttt_max_pos", None))
         ctx.save_for_backward(q, k, v, w32, rope, src, pos)
         ctx.NH, ctx.param_dtype = NH, ln_w.dtype
         return tuple(outs)
@@ -127,7 +127,7 @@ class FusedPreScanMLP(torch.autograd.Function):
         q, k, v = XQ_raw.contiguous(), XK_raw.contiguous(), XV_raw.contiguous()
         w32, b32 = ln_w.detach().to(_F32).contiguous(), ln_b.detach().to(_F32).contiguous()
         XQ, XK, XV = (torch.empty(B, NH, L, Fh, device=q.device, dtype=_BF16) for _ in range(3))
-        ext.pre_forward(q, k, v, rope, src, pos, w32, b32, XQ, XK, XV, NH)
+        ext.pre_forward(q, k, v, rope, src, pos, w32, b32, XQ, XK, XV, NH, n_pos=getattr(pos, "_ttt_max_pos", None))
         CS = eta.shape[-1]
         NC = L // CS
         K = math.ceil(NC / G)
