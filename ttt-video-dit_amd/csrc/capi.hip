@@ -59,6 +59,7 @@ int ttt_hip_debug_option(const char* name, int value) {
     else if (!strcmp(name, "helper_lead")) ttt::mfma::set_debug_lead(value);        // steps the helpers may run ahead (default 1)
     else if (!strcmp(name, "sweep_variant")) ttt::mfma::set_debug_sweep_variant(value);          // 0 fenced stages, 1 unfenced, 2 unfenced + early output path
     else if (!strcmp(name, "bwd_cluster")) ttt::mfma::set_debug_cluster(value);                  // TTT-MLP backward sweep on 4 workgroups per (b,h): -1 auto (default), 0 off
+    else if (!strcmp(name, "sweep_fast_count")) return -2 - (int)ttt::mfma::read_sweep_fast_count();      // query: returns -2 - count
     else if (!strcmp(name, "overlap_recompute")) ttt::mfma::set_debug_overlap(value);            // recompute(next chunk) beside sweep(this chunk)
     else if (!strcmp(name, "variant")) ttt::mfma::set_debug_variant(value);         // kernel revision 2 / 1
     else if (!strcmp(name, "groups_per_chunk")) ttt::mfma::set_debug_groups_per_chunk(value);

@@ -57,10 +57,23 @@ constexpr int L_XU = L_B + TILE_B;                        // u^T exchange betwee
 constexpr int L_XD = L_XU + 2 * 4 * 1024;                 // dW2 block exchange: 2 x 2 fragments
 constexpr int L_SM = L_XD + 2 * 2 * 1024;                 // floats: eta[2][64], db1[64], db2[64], gamma[64], sync word
 constexpr int SM_FLOATS = 2 * 64 + 64 + 64 + 64 + 4;
-constexpr int LDS_CL = L_SM + SM_FLOATS * 4;
+// Fragment staging regions, filled by the owners' LDS-DMA (global_load_lds_dwordx4: one 1-KiB fragment image per wave
+// instruction, lane-linear = exactly the slot layout) one stage or more ahead of the compute waves, which read every slot
+// operand from here (ds_read_b128 at fragment * 1024 + lane * 16) and never wait for global memory:
+//   R1  S1 operands of the step        GZ1T | D1N | XT           refilled (next step) after Ba
+//   R2  S2 operand                     W2                        refilled after Bb
+//   R3  output-path operands           D1B(j) | X2B(j) | W2T(i)  refilled at the top of the iteration (W2T also feeds S4a)
+//   R4  S4a operands                   D1 | GX2 | X2             refilled at the top of the iteration
+constexpr int FRK = 8 * 1024;                             // one fragment array of a wave pair
+constexpr int L_R1 = (L_SM + SM_FLOATS * 4 + 1023) / 1024 * 1024;
+constexpr int L_R2 = L_R1 + 3 * FRK;
+constexpr int L_R3 = L_R2 + FRK;
+constexpr int L_R4 = L_R3 + 3 * FRK;
+constexpr int LDS_CL = L_R4 + 3 * FRK;
 static_assert(LDS_CL <= 160 * 1024, "LDS budget");
 static_assert(2 * TILE_B >= 256 * 16 * 4, "the final dgamma / dbeta reduction re-uses the K / gZ2 tiles");
 
+__device__ unsigned g_fast_count = 0;       // DEBUG statistic: cluster workgroups that proved same-XCD placement and switched to plain records
 __device__ unsigned g_sweep_err = 0;        // 1 + (b,h) of a cluster workgroup whose bounded hand-over poll gave up (0 = never)
 
 template <int CTRL>
@@ -79,6 +92,15 @@ __device__ __forceinline__ void ld16f(__amdgpu_buffer_rsrc_t r, int voff, int so
         o[4 * q] = v[0]; o[4 * q + 1] = v[1]; o[4 * q + 2] = v[2]; o[4 * q + 3] = v[3];
     }
 }
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) void glb_void;
+// fragment `idx` of a staged array (region byte offset `off`) for lane l
+__device__ __forceinline__ bf16x8 lfr(const char* smem, int off, int idx, int l) {
+    return *reinterpret_cast<const bf16x8*>(smem + off + idx * 1024 + l * 16);
+}
+// owner-wave barrier that leaves LDS-DMA requests in flight (a plain __syncthreads() would drain them: its fence waits vmcnt(0))
+__device__ __forceinline__ void owner_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 #define TTT_STAMP4(k)                                                        \
     if (DBG && p.dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {    \
@@ -101,7 +123,7 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster_kernel(SweepParams2 p) {
     float* db1L = etaL2 + 128;
     float* db2L = db1L + 64;
     float* gamL = db2L + 64;
-    unsigned* syncw = reinterpret_cast<unsigned*>(gamL + 64);
+    unsigned* syncw = reinterpret_cast<unsigned*>(gamL + 64);      // [0] hand-over number the owners have seen complete, [1] fast-path verdict
 
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -158,16 +180,16 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster_kernel(SweepParams2 p) {
         // output path of step j: W2' = state entering step j + 1 (slot j + 1), X2b / gelu'(Z1b) from slot j, dZ2b_j in At, Q_j in Qt
         auto add_output_path = [&](int j) {
             const int l = tid & 63;
-            const int sj = slot_off(j) + WREG, sn = sj + (int)SLOT_BYTES, l16 = l * 16;
+            const int sj = slot_off(j) + WREG, l16 = l * 16;
 #pragma unroll
             for (int ti = 0; ti < 2; ++ti) {
                 f32x16 dz = zero16();
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    dz = mma(row_pi(At, ti, fO, s, l), bld8(rS, l16, sn + fro(FR_W2T, fr_idx(pp, pp, s))), dz);
-                    dz = mma(row_pi(At, ti, fX, s, l), bld8(rS, l16, sn + fro(FR_W2T, fr_idx(1 - pp, pp, s))), dz);
+                    dz = mma(row_pi(At, ti, fO, s, l), lfr(smem, L_R3 + 2 * FRK, fr_idx(pp, pp, s), l), dz);        // W2T of slot j + 1
+                    dz = mma(row_pi(At, ti, fX, s, l), lfr(smem, L_R3 + 2 * FRK, fr_idx(1 - pp, pp, s), l), dz);
                 }
-                const f32x16 d1b = unpack2(bld8(rS, l16, sj + fro(FR_D1B, fr_idx(ti, pp, 0))), bld8(rS, l16, sj + fro(FR_D1B, fr_idx(ti, pp, 1))));
+                const f32x16 d1b = unpack2(lfr(smem, L_R3, fr_idx(ti, pp, 0), l), lfr(smem, L_R3, fr_idx(ti, pp, 1), l));
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dz[r] *= d1b[r];
                 db1v += tile_colsum(dz);
@@ -177,7 +199,7 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster_kernel(SweepParams2 p) {
                     bst8(rS, l16, sj + fro(FR_DZ1B, fr_idx(ti, pp, s)), zf);
                     dW1t[0] = mma(tr_pi(Qt, 32 * ti, s, 0, l), zf, dW1t[0]);
                     dW1t[1] = mma(tr_pi(Qt, 32 * ti, s, 32, l), zf, dW1t[1]);
-                    const bf16x8 xb = bld8(rS, l16, sj + fro(FR_X2B, fr_idx(ti, pp, s)));   // X2b (m = n lane, k = t rows)
+                    const bf16x8 xb = lfr(smem, L_R3 + FRK, fr_idx(ti, pp, s), l);          // X2b (m = n lane, k = t rows)
                     const bf16x8 aO = tr_pi(At, 32 * ti, s, fO, l), aX = tr_pi(At, 32 * ti, s, fX, l);
                     dW2t[0] = mma(xb, aO, dW2t[0]);
                     dW2t[1] = mma(xb, aX, dW2t[1]);
@@ -220,6 +242,10 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster_kernel(SweepParams2 p) {
             const int sI = slot_off(i), sw = sI + WREG, l16 = l * 16;
             const unsigned epoch = (unsigned)(i0 - i) + 1;                 // hand-over number of this step, 1-based
             const int xmine = ((int)(epoch & 1) * 4 + cq) * XCH_REC_BYTES;   // this workgroup's record of this step
+            // Records are published write-through (sc1: placement-independent).  When the first hand-over has PROVEN that the four
+            // workgroups sit on one XCD (they exchanged their HW_REG_XCC_ID), later records are stored plain: the lines stay in
+            // that XCD's L2, where the partners' sc1 loads (L1-bypassing) find them - the same protocol with less latency.
+            const bool fast = epoch > 1 && __hip_atomic_load(syncw + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u;
 
             // ================= S1 : (rows = n, lane = t) products, u^T, d(eta) partial, first half of d(gZ2)^T ==============
             f32x16 P[2];                       // [ti]  d(gZ2)^T partial (rows = f in Fp, lane = t)
@@ -239,8 +265,8 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster_kernel(SweepParams2 p) {
                     float se = 0.f;
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
-                        const bf16x8 g1 = bld8(rS, l16, sw + fro(FR_GZ1T, fr_idx(pp, ti, s)));
-                        const bf16x8 d1 = bld8(rS, l16, sw + fro(FR_D1N, fr_idx(pp, ti, s)));
+                        const bf16x8 g1 = lfr(smem, L_R1, fr_idx(pp, ti, s), l);              // gZ1^T
+                        const bf16x8 d1 = lfr(smem, L_R1 + FRK, fr_idx(pp, ti, s), l);        // gelu'(Z1)^T
                         bf16x8 uf;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
@@ -266,13 +292,14 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster_kernel(SweepParams2 p) {
                     float se = se2[ti];
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
-                        const bf16x8 x2 = bld8(rS, l16, sw + fro(FR_XT, fr_idx(pp, ti, s)));
+                        const bf16x8 x2 = lfr(smem, L_R1 + 2 * FRK, fr_idx(pp, ti, s), l);    // X2^T
 #pragma unroll
                         for (int e = 0; e < 8; ++e) se += (float)x2[e] * a2[8 * s + e];
                     }
                     se = xor_add(se, 32);
                     if (h == 0) {
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, -se), rX, XCH_PART_BYTES + (pp * 64 + 32 * ti + c) * 4, xmine, 16);
+                        if (fast) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, -se), rX, XCH_PART_BYTES + (pp * 64 + 32 * ti + c) * 4, xmine, 0);
+                        else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, -se), rX, XCH_PART_BYTES + (pp * 64 + 32 * ti + c) * 4, xmine, 16);
                     }
                 }
             }
@@ -283,10 +310,10 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster_kernel(SweepParams2 p) {
 #pragma unroll
                 for (int ti = 0; ti < 2; ++ti) {
                     f32x16 pa = zero16();
-                    pa = mma(D2o0, bld8(rS, l16, sw + fro(FR_XT, fr_idx(pp, ti, 0))), pa);
-                    pa = mma(D2o1, bld8(rS, l16, sw + fro(FR_XT, fr_idx(pp, ti, 1))), pa);
-                    pa = mma(D2x0, bld8(rS, l16, sw + fro(FR_XT, fr_idx(1 - pp, ti, 0))), pa);
-                    pa = mma(D2x1, bld8(rS, l16, sw + fro(FR_XT, fr_idx(1 - pp, ti, 1))), pa);
+                    pa = mma(D2o0, lfr(smem, L_R1 + 2 * FRK, fr_idx(pp, ti, 0), l), pa);
+                    pa = mma(D2o1, lfr(smem, L_R1 + 2 * FRK, fr_idx(pp, ti, 1), l), pa);
+                    pa = mma(D2x0, lfr(smem, L_R1 + 2 * FRK, fr_idx(1 - pp, ti, 0), l), pa);
+                    pa = mma(D2x1, lfr(smem, L_R1 + 2 * FRK, fr_idx(1 - pp, ti, 1), l), pa);
                     const float ec = -etaL[32 * ti + c];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) pa[r] *= ec;
@@ -303,14 +330,15 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster_kernel(SweepParams2 p) {
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const bf16x8 ux = *reinterpret_cast<const bf16x8*>(exu + ((size_t)((pp ^ 1) * 4 + ti * 2 + s) * 64 + l) * 16);
-                    P[ti] = mma(bld8(rS, l16, sw + fro(FR_W2, fr_idx(pp, pp, s))), uN[ti][s], P[ti]);
-                    P[ti] = mma(bld8(rS, l16, sw + fro(FR_W2, fr_idx(1 - pp, pp, s))), ux, P[ti]);
+                    P[ti] = mma(lfr(smem, L_R2, fr_idx(pp, pp, s), l), uN[ti][s], P[ti]);
+                    P[ti] = mma(lfr(smem, L_R2, fr_idx(1 - pp, pp, s), l), ux, P[ti]);
                 }
                 const int vo = ((32 * ti + c) * PS + 32 * pp + 4 * h) * 4;       // [t][f] image (row stride PS), write-through
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) {
                     const f32x4 v = {P[ti][4 * q4], P[ti][4 * q4 + 1], P[ti][4 * q4 + 2], P[ti][4 * q4 + 3]};
-                    bst4f_sc1(rX, vo + 32 * q4, xmine, v);
+                    if (fast) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rX, vo + 32 * q4, xmine, 0);
+                    else bst4f_sc1(rX, vo + 32 * q4, xmine, v);
                 }
             }
             asm volatile("s_waitcnt vmcnt(0) ; drain: the record is in memory before the flag is stored" ::: "memory");
@@ -345,8 +373,8 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster_kernel(SweepParams2 p) {
                 f32x16 dz;
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    d1f[s] = bld8(rS, l16, sw + fro(FR_D1, fr_idx(ti, pp, s)));
-                    const bf16x8 mm = bld8(rS, l16, sw + fro(FR_GX2, fr_idx(ti, pp, s)));
+                    d1f[s] = lfr(smem, L_R4, fr_idx(ti, pp, s), l);
+                    const bf16x8 mm = lfr(smem, L_R4 + FRK, fr_idx(ti, pp, s), l);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const float dg = -etaR[8 * s + e] * (e1[8 * s + e] + db1_old);      // d(gZ1)
@@ -365,8 +393,8 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster_kernel(SweepParams2 p) {
                     for (int r = 0; r < 16; ++r) dx[r] *= -etaR[r];          // -eta A2
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
-                        dx = mma(row_pi(Bt, ti, fO, s, l), bld8(rS, l16, sw + fro(FR_W2T, fr_idx(pp, pp, s))), dx);
-                        dx = mma(row_pi(Bt, ti, fX, s, l), bld8(rS, l16, sw + fro(FR_W2T, fr_idx(1 - pp, pp, s))), dx);
+                        dx = mma(row_pi(Bt, ti, fO, s, l), lfr(smem, L_R3 + 2 * FRK, fr_idx(pp, pp, s), l), dx);
+                        dx = mma(row_pi(Bt, ti, fX, s, l), lfr(smem, L_R3 + 2 * FRK, fr_idx(1 - pp, pp, s), l), dx);
                     }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) dz[r] += dx[r] * (float)d1f[r >> 3][r & 7];     // dZ1
@@ -383,7 +411,7 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster_kernel(SweepParams2 p) {
                     dW2t[1] = mma(uf[s], gX, dW2t[1]);
                     dW2Tt[0] = mma(gO, uf[s], dW2Tt[0]);
                     dW2Tt[1] = mma(gX, uf[s], dW2Tt[1]);
-                    const bf16x8 xf = bld8(rS, l16, sw + fro(FR_X2, fr_idx(ti, pp, s)));     // X2 (m = n lane, k = t rows)
+                    const bf16x8 xf = lfr(smem, L_R4 + 2 * FRK, fr_idx(ti, pp, s), l);       // X2 (m = n lane, k = t rows)
                     const bf16x8 zO = tr_pi(Bt, 32 * ti, s, fO, l), zX = tr_pi(Bt, 32 * ti, s, fX, l);
                     dW2t[0] = mma(xf, zO, dW2t[0]);
                     dW2t[1] = mma(xf, zX, dW2t[1]);
@@ -431,79 +459,121 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster_kernel(SweepParams2 p) {
             load16_f32(carry + C_DBT + (size_t)ow * 16, dbet);
         }
         if (ow < 64) gamL[ow] = p.ln_w[(size_t)head * 64 + ow];
-        if (ow == 0) syncw[0] = 0u;
+        float gam[16];
+        load16_f32(p.ln_w + (size_t)head * 64 + of0, gam);
+        const unsigned my_xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));      // HW_REG_XCC_ID[3:0]: the XCD this workgroup runs on
+        if (ow == 0) {
+            syncw[0] = 0u; syncw[1] = 0u;
+            __hip_atomic_store(my_flag + 1, my_xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // drained before P1, i.e. before flag 1
+        }
 
-        // K, gZ2 (slot), eta of `step` -> tile buffers `dst`; Q of `step` -> Qt.  256 threads x 32 bytes per tile.
-        auto stage_tiles = [&](int step, int dst) {
+        // Everything the owners need of a step ahead of its turn - the K / gZ2 / Q / eta tiles (256 threads x 32 bytes per tile)
+        // and the inputs of the output-LayerNorm backward - is REQUESTED at the top of an iteration and CONSUMED after barrier
+        // Ba: the requests fly while the compute waves run S1, and nothing queues in front of the hand-over loads later on.
+        struct StepLoads {
+            uint4 k0, k1, g0, g1, q0, q1;
+            bf16x8 da, db;
+            float xl[16];
+            float rstdl;
+            unsigned short ev;
+        };
+        auto request_step = [&](int step, StepLoads& L) {
             const int vo = ow * 32;
-            const uint4 k0 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rK, vo, step * 8192, 0));
-            const uint4 k1 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rK, vo + 16, step * 8192, 0));
+            L.k0 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rK, vo, step * 8192, 0));
+            L.k1 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rK, vo + 16, step * 8192, 0));
             const int sg = slot_off(step) + (int)(SLOT_FR + SLOT_OWN);
-            const uint4 g0 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rS, vo, sg, 0));
-            const uint4 g1 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rS, vo + 16, sg, 0));
-            const uint4 q0 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rQ, vo, step * 8192, 0));
-            const uint4 q1 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rQ, vo + 16, step * 8192, 0));
-            unsigned short ev = 0;
-            if (ow < 64) ev = __builtin_amdgcn_raw_buffer_load_b16(rE, ow * 2, step * 128, 0);
+            L.g0 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rS, vo, sg, 0));
+            L.g1 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rS, vo + 16, sg, 0));
+            L.q0 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rQ, vo, step * 8192, 0));
+            L.q1 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rQ, vo + 16, step * 8192, 0));
+            L.ev = 0;
+            if (ow < 64) L.ev = __builtin_amdgcn_raw_buffer_load_b16(rE, ow * 2, step * 128, 0);
+            const int so = slot_off(step) + (int)SLOT_FR;
+            L.da = bld8(rO, vo, step * 8192);
+            L.db = bld8(rO, vo + 16, step * 8192);
+            ld16f(rS, ow * 64, so + 2 * (int)SLOT_OWN_ARR, L.xl);
+            L.rstdl = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rS, ot * 8 + 4, so + 3 * (int)SLOT_OWN_ARR, 0));
+        };
+        // tiles -> LDS (K, gZ2, eta into buffer `dst`, Q into Qt); backward of the output LayerNorm -> dZ2b tile (At), dgamma / dbeta
+        auto consume_step = [&](int dst, const StepLoads& L) {
             __bf16* kd = Kt2 + dst * TILE_ELEMS + ot * TS + of0;
             __bf16* gd = Gt2 + dst * TILE_ELEMS + ot * TS + of0;
             __bf16* qd = Qt + ot * TS + of0;
-            *reinterpret_cast<uint4*>(kd) = k0; *reinterpret_cast<uint4*>(kd + 8) = k1;
-            *reinterpret_cast<uint4*>(gd) = g0; *reinterpret_cast<uint4*>(gd + 8) = g1;
-            *reinterpret_cast<uint4*>(qd) = q0; *reinterpret_cast<uint4*>(qd + 8) = q1;
-            if (ow < 64) etaL2[dst * 64 + ow] = __builtin_bit_cast(float, (unsigned)ev << 16);
-        };
-        // backward of the output LayerNorm of step j -> dZ2b_j tile (At), dgamma / dbeta contributions
-        auto owner_out_ln = [&](int j) {
-            const int so = slot_off(j) + (int)SLOT_FR;
-            float d[16], xl[16], g[16];
-            {
-                const bf16x8 a = bld8(rO, ow * 32, j * 8192), b = bld8(rO, ow * 32 + 16, j * 8192);
+            *reinterpret_cast<uint4*>(kd) = L.k0; *reinterpret_cast<uint4*>(kd + 8) = L.k1;
+            *reinterpret_cast<uint4*>(gd) = L.g0; *reinterpret_cast<uint4*>(gd + 8) = L.g1;
+            *reinterpret_cast<uint4*>(qd) = L.q0; *reinterpret_cast<uint4*>(qd + 8) = L.q1;
+            if (ow < 64) etaL2[dst * 64 + ow] = __builtin_bit_cast(float, (unsigned)L.ev << 16);
+            float d[16], g[16];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) { d[k] = (float)a[k]; d[8 + k] = (float)b[k]; }
-            }
-            ld16f(rS, ow * 64, so + 2 * (int)SLOT_OWN_ARR, xl);
-            const float rstdl = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rS, ot * 8 + 4, so + 3 * (int)SLOT_OWN_ARR, 0));
+            for (int k = 0; k < 8; ++k) { d[k] = (float)L.da[k]; d[8 + k] = (float)L.db[k]; }
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
-                dgam[k] += d[k] * xl[k];
+                dgam[k] += d[k] * L.xl[k];
                 dbet[k] += d[k];
-                g[k] = d[k] * gamL[of0 + k];
-                s1 += g[k]; s2 += g[k] * xl[k];
+                g[k] = d[k] * gam[k];
+                s1 += g[k]; s2 += g[k] * L.xl[k];
             }
             s1 = sum4(s1); s2 = sum4(s2);
 #pragma unroll
-            for (int k = 0; k < 16; ++k) g[k] = (64.0f * g[k] - s1 - xl[k] * s2) * rstdl * (1.0f / 64.0f);
+            for (int k = 0; k < 16; ++k) g[k] = (64.0f * g[k] - s1 - L.xl[k] * s2) * L.rstdl * (1.0f / 64.0f);
             store16_bf16(At + ot * TS + of0, g);
+        };
+        // LDS-DMA of one fragment array (8 fragments of this workgroup's wave pair) of slot `step` into a staging region: two
+        // fragments per owner wave, 1 KiB per instruction, destination lane-linear
+        auto dma8 = [&](int lds_off, int arr, int step) {
+            const int l = tid & 63;
+            const char* src = slots + (size_t)slot_off(step) + WREG + (size_t)arr * 8 * FRAG_BYTES + (size_t)l * 16;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int f = 2 * (wv - 2) + u;
+                __builtin_amdgcn_global_load_lds((glb_void*)(src + (size_t)f * FRAG_BYTES), (lds_void*)(smem + lds_off + f * 1024), 16, 0, 0);
+            }
         };
 
         __syncthreads();                       // P0: gamma row, sync word visible to all owner waves
-        stage_tiles(i0, 0);
-        owner_out_ln(i0);
-        __syncthreads();                       // P1
-        __syncthreads();                       // P2
+        dma8(L_R1, FR_GZ1T, i0); dma8(L_R1 + FRK, FR_D1N, i0); dma8(L_R1 + 2 * FRK, FR_XT, i0);
+        dma8(L_R2, FR_W2, i0);
+        dma8(L_R3, FR_D1B, i0); dma8(L_R3 + FRK, FR_X2B, i0); dma8(L_R3 + 2 * FRK, FR_W2T, i0 + 1);
+        {
+            StepLoads L0;
+            request_step(i0, L0);
+            consume_step(0, L0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        owner_barrier();                       // P1
+        owner_barrier();                       // P2
 
-        unsigned tch[4] = {0u, 0u, 0u, 0u};    // in-flight prefetch touches (folded into `sink` one step later)
-        unsigned sink = 0u;
         for (int i = i0; i >= p.chunk_lo; --i) {
             const bool more = i > p.chunk_lo;
             const int cur = (i0 - i) & 1;
             const int sI = slot_off(i);
             const unsigned epoch = (unsigned)(i0 - i) + 1;
             const int xrec = (int)(epoch & 1) * 4 * XCH_REC_BYTES;
-            // ---- O-A: everything of step j that needs no partner data; the step's own-array loads go out early ----------------
+            // ---- requests of this iteration: LDS-DMA staging for its later stages (R3: consumed after Bb, R4: after Bc), the
+            //      owner inputs of step i, the tiles / output-LayerNorm inputs of step j - all in flight across Ba ---------------------
+            if (more) { dma8(L_R3, FR_D1B, i - 1); dma8(L_R3 + FRK, FR_X2B, i - 1); }
+            dma8(L_R3 + 2 * FRK, FR_W2T, i);
+            dma8(L_R4, FR_D1, i); dma8(L_R4 + FRK, FR_GX2, i); dma8(L_R4 + 2 * FRK, FR_X2, i);
             float xh[16], go[16];
             const int so = sI + (int)SLOT_FR;
             ld16f(rS, ow * 64, so, xh);
             ld16f(rS, ow * 64, so + (int)SLOT_OWN_ARR, go);
             const float r = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rS, ot * 8, so + 3 * (int)SLOT_OWN_ARR, 0));
-            if (more) {
-                stage_tiles(i - 1, cur ^ 1);
-                owner_out_ln(i - 1);
+            StepLoads Lj;
+            if (more) request_step(i - 1, Lj);
+            owner_barrier();                   // Ba (nothing of the owners is due yet: they arrive at once)
+            if (more) consume_step(cur ^ 1, Lj);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // R3 / R4 have landed
+            owner_barrier();                   // Bb: this workgroup's record is complete and drained; At / Q_j / R3 visible
+            unsigned long long t_o = 0;
+            if (DBG && p.dbg != nullptr && blockIdx.x == 0 && ow == 0) t_o = __builtin_readcyclecounter();
+#define TTT_OSTAMP(k)                                                            \
+            if (DBG && p.dbg != nullptr && blockIdx.x == 0 && ow == 0) {         \
+                const unsigned long long _t = __builtin_readcyclecounter();      \
+                p.dbg[24 + (k)] += _t - t_o;                                     \
+                t_o = _t;                                                        \
             }
-            __syncthreads();                   // Ba
-            __syncthreads();                   // Bb: this workgroup's record is complete and drained
             // ---- O-C: hand-over ------------------------------------------------------------------------------------------------
             if (ow == 0) __hip_atomic_store(my_flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (wv == 2) {
@@ -520,6 +590,19 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster_kernel(SweepParams2 p) {
                     }
                 }
                 // (the wave re-converges here: all three partner records of this step are published)
+                if (epoch == 1) {              // where do the partners run?  (their XCC words were stored before their first flag)
+                    bool same = true;
+                    if (l < 3) {
+                        const unsigned* f = p.flags + ((size_t)bh * 4 + ((cq + 1 + l) & 3)) * FLAG_STRIDE;
+                        same = __hip_atomic_load(f + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == my_xcc + 1u;
+                    }
+                    const bool all_same = __builtin_amdgcn_ballot_w64(!same) == 0ull;
+                    const bool use_fast = all_same && p.lead != 99;     // (helper_lead = 99: DEBUG switch, write-through records only)
+                    if (l == 0) {
+                        __hip_atomic_store(syncw + 1, use_fast ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (use_fast) atomicAdd(&g_fast_count, 1u);
+                    }
+                }
                 if (l == 0) __hip_atomic_store(syncw, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             } else {
                 unsigned spins = 0;
@@ -528,7 +611,9 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster_kernel(SweepParams2 p) {
                     if (++spins > (1u << 24)) break;
                 }
             }
+            TTT_OSTAMP(0)                      // flag + poll
             float G_[16];
+            float dep[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             {
                 // all four records - this workgroup's own included - come back through memory with sc1 loads: no branch on cq,
                 // and the same summation order q = 0..3 on all four workgroups -> bit-identical dZ2 everywhere
@@ -538,19 +623,28 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster_kernel(SweepParams2 p) {
                 for (int qq = 0; qq < 4; ++qq)
 #pragma unroll
                     for (int u = 0; u < 4; ++u) pa[qq][u] = bld4f_sc1(rX, vo + 16 * u, xrec + qq * XCH_REC_BYTES);
+                if (cq == 0 && (ow & 3) == 0) {            // workgroup 0 finishes d(eta): request the eight per-wave partials now
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+                            dep[2 * qq + u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, XCH_PART_BYTES + (u * 64 + ot) * 4,
+                                                                                                        xrec + qq * XCH_REC_BYTES, 16));
+                }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const f32x4 v = ((pa[0][u] + pa[1][u]) + pa[2][u]) + pa[3][u];
                     G_[4 * u] = v[0]; G_[4 * u + 1] = v[1]; G_[4 * u + 2] = v[2]; G_[4 * u + 3] = v[3];
                 }
             }
+            TTT_OSTAMP(1)                      // the four records have arrived
             {
                 const float eta_t = etaL2[cur * 64 + ot];
                 float gxh[16], gz[16];
                 float s1g = 0.f, s2g = 0.f;
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
-                    gxh[k] = go[k] * gamL[of0 + k];
+                    gxh[k] = go[k] * gam[k];
                     s1g += gxh[k]; s2g += gxh[k] * xh[k];
                 }
                 s1g = sum4(s1g); s2g = sum4(s2g);
@@ -569,7 +663,7 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster_kernel(SweepParams2 p) {
                 bf16x8 dv0, dv1;
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
-                    const float g = gamL[of0 + k];
+                    const float g = gam[k];
                     const float m = -G_[k] * r;
                     const float dgxh = r * G_[k] + (s1 + xh[k] * s2) * (1.0f / 64.0f);
                     const float dy = g * dgxh;
@@ -590,46 +684,23 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster_kernel(SweepParams2 p) {
                     if ((ow & 3) == 0) {      // workgroup 0 finishes d(eta): the eight per-wave partials of the four records
                         float de = -se;
 #pragma unroll
-                        for (int qq = 0; qq < 4; ++qq)
-#pragma unroll
-                            for (int u = 0; u < 2; ++u)
-                                de += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, XCH_PART_BYTES + (u * 64 + ot) * 4,
-                                                                                                     xrec + qq * XCH_REC_BYTES, 16));
+                        for (int u = 0; u < 8; ++u) de += dep[u];
                         p.deta[((size_t)bh * NC + i) * 64 + ot] = (__bf16)de;
                     }
                 }
             }
-            __syncthreads();                   // Bc: dZ2_i visible to the compute waves
-            // ---- O-D: L2 prefetch touches, two steps ahead (slot lines of this workgroup's wave pair, a quarter of the shared ones)
-            sink ^= tch[0] ^ tch[1] ^ tch[2] ^ tch[3];
-            {
-                const int t = i - 2;
-                if (t >= p.chunk_lo) {
-                    const int st = slot_off(t);
-                    constexpr int FR_LINES = 10 * 64;                               // 10 arrays x 8 fragments x 1 KiB
-                    constexpr int OWN_LINES = (int)((SLOT_OWN + SLOT_G) / 128);
-#pragma unroll
-                    for (int u = 0; u < 3; ++u) {
-                        const int ln = ow + 256 * u;
-                        if (ln < FR_LINES) {
-                            const int ai = ln >> 6, li = ln & 63;
-                            const int arr = ai < 4 ? ai + 1 : ai == 4 ? 6 : ai + 3;      // FR_W2..FR_D1, FR_GX2, FR_GZ1T..FR_D1N
-                            tch[u] = __builtin_amdgcn_raw_buffer_load_b32(rS, li * 128, st + WREG + arr * 8 * (int)FRAG_BYTES, 0);
-                        }
-                    }
-                    {
-                        const int ln = ow * 4 + cq;                                  // shared lines: every workgroup takes a quarter
-                        if (ln < OWN_LINES) tch[3] = __builtin_amdgcn_raw_buffer_load_b32(rS, ln * 128, st + (int)SLOT_FR, 0);
-                        else if (ln < OWN_LINES + 64) tch[3] = __builtin_amdgcn_raw_buffer_load_b32(rK, (ln - OWN_LINES) * 128, t * 8192, 0);
-                        else if (ln < OWN_LINES + 128) tch[3] = __builtin_amdgcn_raw_buffer_load_b32(rQ, (ln - OWN_LINES - 64) * 128, t * 8192, 0);
-                        else if (ln < OWN_LINES + 192) tch[3] = __builtin_amdgcn_raw_buffer_load_b32(rO, (ln - OWN_LINES - 128) * 128, t * 8192, 0);
-                    }
-                }
+            // staging of the next step's S1 / S2 operands: requested only after the hand-over (VMEM returns in order, and even the
+            // ISSUE of a request blocks while the CU's queues are full); R1 / R2 were last read before Ba / Bb of this iteration
+            TTT_OSTAMP(2)                      // owner math, dZ2 / dV / d(eta) stores
+            owner_barrier();                   // Bc: dZ2_i visible to the compute waves
+            TTT_OSTAMP(3)                      // wait for the compute waves at Bc
+            if (more) {
+                dma8(L_R1, FR_GZ1T, i - 1); dma8(L_R1 + FRK, FR_D1N, i - 1); dma8(L_R1 + 2 * FRK, FR_XT, i - 1);
+                dma8(L_R2, FR_W2, i - 1);
             }
-            __syncthreads();                   // Bd
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // R1 / R2 of the next step have landed
+            owner_barrier();                   // Bd
         }
-        sink ^= tch[0] ^ tch[1] ^ tch[2] ^ tch[3];
-        asm volatile("" :: "v"(sink));
 
         // ---- dgamma / dbeta: to the next chunk, or reduced over the 64 tokens ----------------------------------------------------
         if (!p.last) {
@@ -665,6 +736,11 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster_kernel(SweepParams2 p) {
 unsigned read_sweep_error() {
     unsigned v = 0;
     (void)hipMemcpyFromSymbol(&v, HIP_SYMBOL(b3::g_sweep_err), sizeof(v));
+    return v;
+}
+unsigned read_sweep_fast_count() {
+    unsigned v = 0;
+    (void)hipMemcpyFromSymbol(&v, HIP_SYMBOL(b3::g_fast_count), sizeof(v));
     return v;
 }
 

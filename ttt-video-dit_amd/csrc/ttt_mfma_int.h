@@ -50,7 +50,8 @@ unsigned long long* get_debug_timing();
 int get_debug_helpers();          // -1 = automatic
 int get_debug_sweep_variant();
 void set_debug_cluster(int v);         // backward sweep over a cluster of 4 workgroups per (b,h): -1 automatic (default), 0 never
-unsigned read_sweep_error();           // 0, or 1 + (b,h) of a cluster workgroup whose partner never arrived (synchronises)
+unsigned read_sweep_error();
+unsigned read_sweep_fast_count();   // DEBUG statistic (synchronises)           // 0, or 1 + (b,h) of a cluster workgroup whose partner never arrived (synchronises)
 int get_debug_overlap();
 int get_debug_lead();
 void set_debug_lead(int v);

@@ -152,6 +152,14 @@ def sweep_error() -> int:
     return int(lib.ttt_hip_debug_sweep_error())
 
 
+def sweep_fast_count() -> int:
+    """DEBUG statistic: cluster workgroup launches that proved same-XCD placement and published plain (L2-resident) records."""
+    lib = load_library()
+    lib.ttt_hip_debug_option.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    lib.ttt_hip_debug_option.restype = ctypes.c_int
+    return -2 - int(lib.ttt_hip_debug_option(b"sweep_fast_count", 0))
+
+
 def debug_dump(buf: Optional[torch.Tensor]) -> None:
     """DEBUG: step-0 intermediates of workgroup 0 of the revision-2 forward go to ``buf`` (>= 120000 fp32 on device)."""
     lib = load_library()
