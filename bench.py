@@ -94,12 +94,6 @@ def parse():
                          "kernels, 190 ms of a 3.26 s step); same arithmetic, bit-identical updates (tests/test_fsdp_gloo.py).  auto = off "
                          "on one GPU (falling back to FSDP2 should the replica path fail), FSDP2 on several; on = FSDP2 always")
     ap.add_argument("--no-fsdp", action="store_true", help="same as --fsdp off")
-    ap.add_argument("--attn-variant", type=int, default=1, choices=[1, 2],
-                    help="2 = revision 2 of the attention forward / dQ kernels (csrc/attn_v2.hip, emulator-checked); opt-in until timed")
-    ap.add_argument("--attn-dkdv-variant", type=int, default=1, choices=[1, 2, 3, 4],
-                    help="dK / dV kernel variant (csrc/attn.h): 3 / 4 = accumulator-initialised row scalars with 8 / 12 waves; opt-in until timed")
-    ap.add_argument("--scan-gelu-pk", action="store_true",
-                    help="TTT-MLP forward scan with the packed-f32 gelu variant (debug option scan8_gelu_pk, same arithmetic); opt-in until timed")
     ap.add_argument("--overlap-wgrad", action="store_true",
                     help="weight-gradient GEMMs of the projections / MLP on a side stream, beside the backward scans "
                          "(ttt_amd/infra/wgrad_overlap.py); opt-in until timed")
@@ -314,12 +308,6 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False):
 
     ext.load_library()
     ext.set_impl(args.impl)
-    if args.attn_variant != 1:
-        ext.debug_option("attn_variant", args.attn_variant)
-    if args.scan_gelu_pk:
-        ext.debug_option("scan8_gelu_pk", 1)
-    if args.attn_dkdv_variant != 1:
-        ext.debug_option("attn_dkdv_variant", args.attn_dkdv_variant)
     init_distributed("nccl")
     tuned = (not args.no_tuned_gemms) and enable_tuned_gemms()
     if args.overlap_wgrad:
@@ -509,7 +497,7 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False):
                 "config": {"workload": f"CogVideoX-5B+{args.ssm_layer} {args.video_length} training step (fwd+bwd+AdamW), "
                                        f"{cfg.num_layers} layers, L={L} tokens/sample, adapter={args.adapter}",
                            "global_batch": world * LB, "seq_len": L, "parallelism": "replica1" if no_fsdp else f"fsdp{world}", "ttt_impl": args.impl,
-                           "remat_free_layers": n_free, "fsdp_reshard_after_forward": bool(args.reshard_after_forward), "tuned_gemm_selections": bool(tuned), "overlap_wgrad": bool(args.overlap_wgrad), "attn_variant": args.attn_variant, "attn_dkdv_variant": args.attn_dkdv_variant, "scan_gelu_pk": bool(args.scan_gelu_pk),
+                           "remat_free_layers": n_free, "fsdp_reshard_after_forward": bool(args.reshard_after_forward), "tuned_gemm_selections": bool(tuned), "overlap_wgrad": bool(args.overlap_wgrad),
                            "valid": args.layers is None},
                 "roofline": roof, "loss": loss_val, "peak_mem_gib": peak_mem, "total_tokens_per_s": world * L / (dt / args.steps)}
         return line

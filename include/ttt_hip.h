@@ -242,20 +242,15 @@ void        ttt_hip_debug_timing(void* device_buffer);
 /* DEBUG: force the number of checkpoint groups the MFMA backward re-materialises per chunk (0 = automatic,
  * sized to cover the 256 CUs); lets tests exercise the chunk-to-chunk gradient hand-over at small sizes. */
 void        ttt_hip_debug_groups_per_chunk(int groups);
-/* DEBUG: select the MFMA forward-scan kernel revision (2 = current 8-wave kernel, 1 = first 4-wave kernel,
- * kept for A/B measurements). */
+/* No-ops since round 2 (one kernel revision per entry point; the backward sweep has no helper workgroups any more):
+ * kept so that binaries built against ABI version 1 keep loading. */
 void        ttt_hip_debug_variant(int revision);
-/* DEBUG: number of L2-prefetch helper workgroups per (batch, head) of the revision-2 backward sweep (-1 = automatic:
- * 4 when B*NH is a multiple of 8 and everything is co-resident, else 0). */
 void        ttt_hip_debug_helpers(int helpers);
-/* DEBUG / A-B knobs by name: "helpers", "helper_lead", "sweep_variant", "overlap_recompute", "variant",
- * "groups_per_chunk" (revision-2 TTT-MLP backward), "linear_bwd_lds_slots" (TTT-Linear backward at CS=16: per-step
- * state slots kept in LDS, 0..6, default 0), "scan16_body" (TTT-MLP forward at CS=16 through the backend-templated
- * body of ttt_mlp16_body.h, default 0), "attn_variant" (1 = default kernels of attn_fwd.hip / attn_bwd.hip, 2 = revision 2 of
- * the attention forward and dQ kernels: csrc/attn_v2.hip, bodies in attn_body.h), "scan8_gelu_pk" (0 / 1: CS = 64 TTT-MLP forward scan with the output-path gelu
- * on aligned packed-f32 register pairs, same arithmetic), "attn_dkdv_variant" (1 = default dK / dV kernel,
- * 2 = the same arithmetic through the body of attn_body.h, 3 / 4 = accumulators started from the per-row -LSE / scale and
- * -Delta with 8 / 12 waves per workgroup).  Returns 0, or -1 for an unknown name. */
+/* DEBUG / A-B knobs by name: "groups_per_chunk" (checkpoint groups per backward chunk, 0 = automatic), "fast_records" (TTT-MLP
+ * backward sweep hand-over: 1 (default) = plain, L2-resident records once the four workgroups of a cluster have proven that they
+ * share an XCD; 0 = write-through records always), "sweep_fast_count" (query: returns -2 - the number of cluster workgroup
+ * launches that took the plain form).  Returns 0, or -1 for an unknown name.  (The round-1 knobs - kernel revisions, prefetch
+ * helpers, attention / scan variants - were A/B-ed on hardware in round 2 and removed together with the losing code.) */
 int         ttt_hip_debug_option(const char* name, int value);
 /* DEBUG: device buffer (>= 120000 floats) receiving the step-0 intermediates of workgroup 0 (NULL = off). */
 /* TTT-MLP backward, cluster form (four workgroups per (b,h) exchanging partial tiles inside the launch): 0 when no bounded

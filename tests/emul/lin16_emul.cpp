@@ -17,8 +17,7 @@ void emul_lin16_forward(const wv::Lin16Params* p, int n_bh) {
 
 void emul_lin16_backward(const wv::Lin16Params* p, int n_bh) {
     for (int bh = 0; bh < n_bh; ++bh) emul::run_wave([&](emul::EmulWave& w) {
-        if (p->lds_slots > 0) lin16::backward<true>(w, *p, bh);
-        else lin16::backward<false>(w, *p, bh);
+        lin16::backward(w, *p, bh);
     });
 }
 

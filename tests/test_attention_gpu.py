@@ -174,61 +174,3 @@ def test_fused_attention_node_equals_two_nodes():
         res.append([out.detach()] + [t.grad for t in (qr, kr, vr)] + [t.grad for t in par])
     for a, b in zip(*res):
         assert torch.equal(a, b)
-
-
-VARIANTS = pytest.mark.skipif(__import__("os").environ.get("TTT_TEST_VARIANTS") != "1",
-                              reason="opt-in kernel variants (emulator-verified, not yet timed on hardware): TTT_TEST_VARIANTS=1")
-
-
-@VARIANTS
-@pytest.mark.parametrize("B,NH,S,layout", [(2, 3, 300, "bshd"), (1, 8, 1024, "bhsd"), (1, 2, 40, "bshd"), (1, 16, 577, "bshd")])
-def test_attention_v2_equals_v1(B, NH, S, layout):
-    """Revision 2 of the forward and dQ kernels (csrc/attn_v2.hip: the emulator-checked bodies of attn_body.h, debug option
-    attn_variant = 2) against revision 1 on the same tensors: same arithmetic in the same order -> identical bits, and the
-    oracle tolerances on its own."""
-    e = ext()
-    q, k, v, do = make(B, NH, S, 21 + S, layout)
-    from ttt_amd.models.cogvideo.attention import SegmentAttention
-    res = {}
-    try:
-        for variant in (1, 2):
-            e.debug_option("attn_variant", variant)
-            qq, kk, vv = (t.detach().clone().requires_grad_(True) for t in (q, k, v))
-            out = SegmentAttention.apply(qq, kk, vv)
-            out.backward(do)
-            torch.cuda.synchronize()
-            res[variant] = (out.detach(), qq.grad, kk.grad, vv.grad)
-    finally:
-        e.debug_option("attn_variant", 1)
-    ro, rl, rq, rk, rv = oracle_grads(q, k, v, do)
-    assert rel_l2(res[2][0], ro) < 1e-2 and rel_l2(res[2][1], rq) < 2e-2
-    for a, b, name in zip(res[1], res[2], ("out", "dq", "dk", "dv")):
-        assert torch.equal(a, b), name
-
-
-@VARIANTS
-@pytest.mark.parametrize("variant", [2, 3, 4])
-@pytest.mark.parametrize("B,NH,S,layout", [(2, 3, 300, "bshd"), (1, 8, 1024, "bhsd"), (1, 2, 40, "bshd"), (1, 16, 577, "bshd")])
-def test_attention_dkdv_variants(B, NH, S, layout, variant):
-    """dK / dV through the emulator-checked body of attn_body.h (debug option attn_dkdv_variant): 2 = revision 1's arithmetic
-    (must reproduce attn_dkdv_kernel bit for bit), 3 / 4 = accumulators started from the per-row -LSE / scale and -Delta with
-    8 / 12 waves (oracle tolerance; bit-equal to each other)."""
-    e = ext()
-    q, k, v, do = make(B, NH, S, 31 + S, layout)
-    from ttt_amd.models.cogvideo.attention import SegmentAttention
-    res = {}
-    try:
-        for var in sorted({1, 3, variant}):
-            e.debug_option("attn_dkdv_variant", var)
-            qq, kk, vv = (t.detach().clone().requires_grad_(True) for t in (q, k, v))
-            SegmentAttention.apply(qq, kk, vv).backward(do)
-            torch.cuda.synchronize()
-            res[var] = (qq.grad, kk.grad, vv.grad)
-    finally:
-        e.debug_option("attn_dkdv_variant", 1)
-    ro, rl, rq, rk, rv = oracle_grads(q, k, v, do)
-    assert rel_l2(res[variant][1], rk) < 2e-2 and rel_l2(res[variant][2], rv) < 2e-2
-    if variant == 2:
-        assert torch.equal(res[2][1], res[1][1]) and torch.equal(res[2][2], res[1][2])
-    if variant == 4:
-        assert torch.equal(res[4][1], res[3][1]) and torch.equal(res[4][2], res[3][2])

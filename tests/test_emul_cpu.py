@@ -22,7 +22,7 @@ class Params(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in
                 ("XQ", "XK", "XV", "eta", "ln_w", "ln_b", "W1", "b1", "W1c", "b1c", "out", "dOut", "dW1_last", "db1_last",
                  "scratch_w", "scratch_b", "dln_w", "dln_b", "dW1", "db1", "deta", "dXQ", "dXK", "dXV")] + \
-               [(n, ctypes.c_int) for n in ("NH", "NC", "G", "K")] + [("eps", ctypes.c_float), ("lds_slots", ctypes.c_int)]
+               [(n, ctypes.c_int) for n in ("NH", "NC", "G", "K")] + [("eps", ctypes.c_float)]
 
 
 @pytest.fixture(scope="module")
@@ -93,7 +93,7 @@ def test_emulated_linear_forward_vs_oracle(emul, shape):
     assert rel_l2(cks[0], rc[0]) < 1e-2 and rel_l2(cks[1], rc[1]) < 1e-2
 
 
-def _backward(lib, d, G, fwd, lds_slots=0):
+def _backward(lib, d, G, fwd):
     out, (W1c, b1c), (XQ, XK, XV, eta, lw, lb, W1, b1) = fwd
     B, NH, NC = XQ.shape[:3]
     K = -(-NC // G)
@@ -110,20 +110,19 @@ def _backward(lib, d, G, fwd, lds_slots=0):
                      scratch_w=scr_w, scratch_b=scr_b, dln_w=g["dln_w"], dln_b=g["dln_b"], dW1=g["dW1"], db1=g["db1"],
                      deta=g["dlast_eta"], dXQ=g["dXQ"], dXK=g["dXK"], dXV=g["dXV"]).items():
         setattr(p, n, t.data_ptr())
-    p.NH, p.NC, p.G, p.K, p.eps, p.lds_slots = NH, NC, G, K, 1e-8, lds_slots
+    p.NH, p.NC, p.G, p.K, p.eps = NH, NC, G, K, 1e-8
     lib.emul_lin16_backward(ctypes.byref(p), B * NH)
     return g
 
 
-@pytest.mark.parametrize("lds_slots", [0, 2, 6])
 @pytest.mark.parametrize("shape", [(1, 1, 1, 1), (1, 2, 5, 2), (2, 1, 6, 4), (1, 1, 7, 3), (1, 1, 4, 1), (1, 1, 3, 3)])
-def test_emulated_linear_backward_vs_oracle(emul, shape, lds_slots):
+def test_emulated_linear_backward_vs_oracle(emul, shape):
     """Reverse sweep of the TTT-Linear scan (mini-batch 16) on the wave emulator vs fp64 autograd-equivalent oracle:
     single step, even / odd group sizes, ragged last group, one step per group, one group for the whole sequence."""
     B, NH, NC, G = shape
     d = _inputs(B, NH, NC, seed=29 + NC)
     fwd = _forward(emul, d, G)
-    g = _backward(emul, d, G, fwd, lds_slots)
+    g = _backward(emul, d, G, fwd)
     _, _, rg = _oracle(d, G)
     errs = {k: rel_l2(g[k], rg[k].reshape(g[k].shape) if k in ("dln_w", "dln_b") else rg[k]) for k in g}
     print("emulated linear backward errors", shape, {k: round(v, 5) for k, v in errs.items()})

@@ -211,31 +211,33 @@ def test_cogvideox_forward_on_gpu_vs_reference():
     assert not bad, bad
 
 
-# ---------------------------------------------------------------------------------- 5. backward sweep: cluster form
-@pytest.mark.parametrize("shape", [(1, 2, 11, 2, 0), (1, 8, 40, 16, 5), (2, 3, 7, 3, 0), (1, 4, 33, 16, 1)])
-def test_bwd_cluster_form_vs_single_workgroup_form_and_oracle(shape):
-    """The TTT-MLP backward sweep on a cluster of four workgroups per (b,h) (csrc/ttt_mfma_bwd3.hip: partial d(gZ2) tiles
-    exchanged through global memory inside the launch, Guideline-16 hand-over) against the single-workgroup form
-    (ttt_mfma_bwd2.hip: same products; fp32 accumulations in another order) and against the fp64 oracle, head by head; no
-    hand-over poll may have timed out.  Repeated launches: stale flags / records from the previous call must not matter."""
+# ---------------------------------------------------------------------------------- 5. backward sweep: cluster hand-over
+@pytest.mark.parametrize("shape", [(1, 2, 11, 2, 0), (1, 8, 40, 16, 5), (2, 3, 7, 3, 0), (1, 4, 33, 16, 1), (2, 40, 9, 4, 0)])
+def test_bwd_cluster_sweep_handover_forms_and_oracle(shape):
+    """The TTT-MLP backward sweep runs on four workgroups per (b,h) that exchange partial d(gZ2) tiles inside the launch
+    (csrc/ttt_mfma_bwd3.hip, Guideline-16 hand-over).  (1) Records published write-through only (placement-independent form)
+    and plain records on a proven common XCD must give IDENTICAL bits - the protocol moves the same values; (2) head by head
+    against the fp64 oracle; (3) no hand-over poll may have timed out; repeated launches: stale flags / records of the previous
+    call must not matter.  Shapes: 2 heads (the four workgroups land on four XCDs), 8 heads (one XCD per cluster, chunked),
+    batch 2, 4 heads (two XCDs per cluster), 80 (b,h) (two sweep launches per chunk: more than 64 clusters do not fit the chip)."""
     e = ext()
     B, NH, NC, G, gpc = shape
     d = round_acts(O.make_inputs("mlp", B, NH, NC, 64, 64, seed=500 + NC), torch.bfloat16)
     res = {}
-    for mode in (0, -1, -1):
-        e.debug_option("bwd_cluster", mode)
+    for mode in (0, 1, 1):
+        e.debug_option("fast_records", mode)
         e.debug_groups_per_chunk(gpc)
         try:
             res[mode] = run_mlp(e, d, G, torch.bfloat16, impl="mfma")
         finally:
-            e.debug_option("bwd_cluster", -1)
+            e.debug_option("fast_records", 1)
             e.debug_groups_per_chunk(0)
     assert e.sweep_error() == 0
     print("cluster workgroup launches that published plain (same-XCD) records so far:", e.sweep_fast_count())
-    (o0, _, g0), (o1, _, g1) = res[0], res[-1]
+    (o0, _, g0), (o1, _, g1) = res[0], res[1]
     assert torch.equal(o0, o1)
-    errs = {k: rel_l2(g1[k], g0[k]) for k in g0}
-    print("cluster vs single-workgroup form:", {k: f"{v:.1e}" for k, v in errs.items()})
-    assert all(v < 1e-2 for v in errs.values()), errs
-    ro, rc, rg = oracle_on(d, G, "mlp")
-    check_per_head(f"cluster backward {shape}", o1, (), g1, ro, (), rg, 1e-2, 3e-2)
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), (k, rel_l2(g1[k], g0[k]))
+    if B * NH <= 16:
+        ro, rc, rg = oracle_on(d, G, "mlp")
+        check_per_head(f"cluster backward {shape}", o1, (), g1, ro, (), rg, 1e-2, 3e-2)

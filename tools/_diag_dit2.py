@@ -53,3 +53,67 @@ for ci, a in enumerate(calls):
         print(f"   {impl:8s}", errs)
     ext.set_impl("auto")
     print("   ref norms", {n: f"{float(ref[n].norm()):.2e}" for n in names})
+
+
+# ---- which property of the captured inputs makes the MFMA backward inaccurate?  variants of call 2 -------------------------
+a = calls[2]
+G = a[-1]
+def run_variant(tag, mod):
+    b = [t.clone() if isinstance(t, torch.Tensor) else t for t in a]
+    mod(b)
+    XQ, XK, XV, le, lnw, lnb = b[:6]
+    # checkpoints must belong to the inputs: re-run the forward (mfma) to regenerate them
+    ext.set_impl("mfma")
+    W1c, b1c, W2c, b2c, XQW = b[6:11]
+    ext.ttt_forward(XQ, XK, XV, le, lnw, lnb, W1c[:, :, 0].contiguous(), b1c[:, :, 0].contiguous(), W2c[:, :, 0].contiguous(), b2c[:, :, 0].contiguous(),
+                    W1c, b1c, W2c, b2c, XQW, G)
+    torch.cuda.synchronize()
+    rest = b[11:-1]
+    ups, gout = rest[16:20], rest[20]
+    f64 = lambda t: t.detach().double().cpu()
+    ref = O.mlp_backward(f64(XQ), f64(XK), f64(XV), f64(le), f64(lnw), f64(lnb), tuple(f64(c) for c in (W1c, b1c, W2c, b2c)), G, f64(gout),
+                         dst_last=tuple(f64(u) for u in ups))
+    outs = [torch.full_like(t, float("nan")) for t in rest[21:]]
+    orig_b(*(list(b[:11]) + [t.clone() for t in rest[:21]] + outs + [G]))
+    torch.cuda.synchronize()
+    errs = {n: round(rel_l2(o, ref[n]), 4) for n, o in zip(names, outs)}
+    print(f"{tag:40s}", {k: errs[k] for k in ("dW1", "db1", "dW2", "dXK", "dXQ", "dlast_eta")}, flush=True)
+    ext.set_impl("auto")
+
+gen = torch.Generator(device=DEV).manual_seed(0)
+rn = lambda t: torch.randn(t.shape, device=DEV, generator=gen)
+run_variant("captured", lambda b: None)
+def m_dout_scale(b): b[11 + 20].mul_(1024.0)
+run_variant("dOut x 1024", m_dout_scale)
+def m_dout_rand(b): b[11 + 20].copy_(rn(b[11 + 20]).bfloat16())
+run_variant("dOut random N(0,1)", m_dout_rand)
+def m_xv_rand(b): b[2].copy_(rn(b[2]).bfloat16())
+run_variant("XV random N(0,1)", m_xv_rand)
+def m_qk_rand(b):
+    b[0].copy_(torch.nn.functional.normalize(rn(b[0]), dim=-1).bfloat16()); b[1].copy_(torch.nn.functional.normalize(rn(b[1]), dim=-1).bfloat16())
+run_variant("XQ, XK random unit", m_qk_rand)
+def m_eta_const(b): b[3].fill_(1.2e-5)
+run_variant("eta constant 1.2e-5", m_eta_const)
+def m_all(b): m_dout_rand(b); m_xv_rand(b); m_qk_rand(b)
+run_variant("dOut, XV, XQ, XK random", m_all)
+
+
+# ---- which kernel family shows it?  single-workgroup sweep (rev 2), cluster sweep, revision-1 backward ----------------------------
+print("--- captured inputs, by backward implementation")
+for tag, setup in (("rev-2 single-workgroup sweep", lambda: ext.debug_option("bwd_cluster", 0)),
+                   ("cluster sweep", lambda: ext.debug_option("bwd_cluster", -1)),
+                   ("revision-1 backward", lambda: ext.debug_variant(1))):
+    setup()
+    run_variant(tag, lambda b: None)
+    ext.debug_option("bwd_cluster", 0); ext.debug_variant(2)
+# and the per-step picture: only the LAST mini-batch has a non-zero dOut (later steps contribute nothing)
+def m_last_only(b): b[11 + 20][:, :, :-1].zero_()
+run_variant("dOut only in the last mini-batch", m_last_only)
+def m_first_only(b): b[11 + 20][:, :, 1:].zero_()
+run_variant("dOut only in the first mini-batch", m_first_only)
+def m_b2_zero(b):
+    b[9][:, :, 0].zero_()     # b2 checkpoint 0 = initial b2 (the forward re-run regenerates the later ones)
+run_variant("initial b2 = 0", m_b2_zero)
+def m_b2_rand_xv(b):
+    m_b2_zero(b)
+run_variant("initial b2 = 0 (again)", m_b2_rand_xv)

@@ -3,7 +3,7 @@
 HIP forward / backward (csrc/attn_*.hip) next to PyTorch's SDPA (aotriton flash) on the same tensors.  Algorithmic
 FLOPs: forward 4*S^2*D*NH, backward 2.5x that.  One JSON line.
 
-    python tools/attn_bench.py [--s 18048] [--nh 48] [--iters 5] [--no-sdpa] [--variant 2]
+    python tools/attn_bench.py [--s 18048] [--nh 48] [--iters 5] [--no-sdpa]
 """
 import argparse
 import json
@@ -34,24 +34,17 @@ def main():
     ap.add_argument("--b", type=int, default=1)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--no-sdpa", action="store_true")
-    ap.add_argument("--variant", type=int, default=1, choices=[1, 2],
-                    help="2 = revision 2 of the forward and dQ kernels (csrc/attn_v2.hip); the dQ occupancy knob is TTT_ATTN_DQ_OCC=2|4")
-    ap.add_argument("--dkdv-variant", type=int, default=1, choices=[1, 2, 3, 4],
-                    help="dK / dV kernel: 1 = attn_dkdv_kernel, 2 = same arithmetic through the body of attn_body.h, 3 = accumulators "
-                         "started from the row scalars (8 waves), 4 = ... with 12 waves per workgroup (3 per SIMD)")
     a = ap.parse_args()
     import test_time_training as ext
     from ttt_amd.models.cogvideo.attention import SegmentAttention
     ext.load_library()
-    ext.debug_option("attn_variant", a.variant)
-    ext.debug_option("attn_dkdv_variant", a.dkdv_variant)
     dev = torch.device("cuda:0")
     B, NH, S = a.b, a.nh, a.s
     g = torch.Generator(device=dev).manual_seed(0)
     mk = lambda: torch.randn(B, S, NH, 64, device=dev, generator=g).bfloat16().transpose(1, 2)
     q, k, v, do = mk(), mk(), mk(), mk()
     flops = 4.0 * S * S * 64 * NH * B
-    res = {"shape": [B, NH, S, 64], "fwd_flops": flops, "attn_variant": a.variant, "dkdv_variant": a.dkdv_variant, "dq_occ": os.environ.get("TTT_ATTN_DQ_OCC", "4")}
+    res = {"shape": [B, NH, S, 64], "fwd_flops": flops}
     out = torch.empty(B, S, NH, 64, device=dev, dtype=torch.bfloat16).transpose(1, 2)
     lse = torch.empty(B, NH, S, device=dev)
     t = timeit(lambda: ext.attn_forward(q, k, v, out, lse, 0.125), a.iters)

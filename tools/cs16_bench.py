@@ -20,8 +20,6 @@ ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--phases", action="store_true")
 ap.add_argument("--no-generic", action="store_true")
 ap.add_argument("--linear", action="store_true", help="TTT-Linear instead of TTT-MLP")
-ap.add_argument("--body", action="store_true", help="TTT-MLP: the backend-templated body (ttt_mlp16_body.h) instead of the hand-placed kernel (A/B knob)")
-ap.add_argument("--lds-slots", type=int, default=0, help="TTT-Linear backward: per-step state slots kept in LDS (A/B knob, 0..6)")
 a = ap.parse_args()
 dev = "cuda:0"
 B, NH, NC, CS, F = a.batch, a.nh, a.nc, 16, 64
@@ -42,7 +40,6 @@ if a.linear:
     ckl = (torch.empty(B, NH, 1, F, F, device=dev), torch.empty(B, NH, 1, 1, F, device=dev))
 cks = (torch.empty(B, NH, 1, F, 4 * F, device=dev), torch.empty(B, NH, 1, 1, 4 * F, device=dev),
        torch.empty(B, NH, 1, 4 * F, F, device=dev), torch.empty(B, NH, 1, 1, F, device=dev))
-e.debug_option("scan16_body", int(a.body))
 outs = {}
 for impl in (("mfma",) if a.no_generic else ("mfma", "generic")):
     e.set_impl(impl)
@@ -77,7 +74,6 @@ if a.linear:
     grads = (torch.empty(B, NH, 1, F, device=dev), torch.empty(B, NH, 1, F, device=dev), torch.empty(B, NH, F, F, device=dev),
              torch.empty(B, NH, 1, F, device=dev), torch.empty(B, NH, NC, CS, 1, device=dev, dtype=torch.bfloat16),
              torch.empty_like(XQ), torch.empty_like(XQ), torch.empty_like(XQ))
-    e.debug_option("linear_bwd_lds_slots", a.lds_slots)
     for impl in (("mfma",) if a.no_generic else ("mfma", "generic")):
         e.set_impl(impl)
         out = torch.empty_like(XQ)

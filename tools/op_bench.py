@@ -29,28 +29,15 @@ def main():
     ap.add_argument("--g", type=int, default=16)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--fwd-only", action="store_true")
+    ap.add_argument("--write-through-records", action="store_true", help="DEBUG A/B: the backward sweep's hand-over records always write-through (sc1), never plain")
     ap.add_argument("--phases", action="store_true", help="also print per-phase cycle totals of workgroup 0")
-    ap.add_argument("--helpers", type=int, default=-1, help="backward sweep prefetch helpers per (b,h); -1 = automatic")
-    ap.add_argument("--lead", type=int, default=1, help="DEBUG A/B: steps the backward's prefetch helpers may run ahead of the scan")
-    ap.add_argument("--overlap", action="store_true", help="DEBUG A/B: overlap the next chunk's recompute with the sweep on a side stream")
-    ap.add_argument("--sweep-variant", type=int, default=1, help="DEBUG A/B of the backward sweep: 0 = fenced stages, 1 = unfenced, 2 = unfenced + output path before the K/gZ2 barrier")
-    ap.add_argument("--gelu-pk", action="store_true", help="DEBUG A/B: forward scan with the output-path gelu / gZ1 product on aligned packed-f32 "
-                    "register pairs (debug option scan8_gelu_pk; same arithmetic, 17 %% fewer VALU instructions per step)")
-    ap.add_argument("--cluster", type=int, default=-1, help="backward sweep on a cluster of 4 workgroups per (b,h): -1 automatic, 0 off")
-    ap.add_argument("--variant", type=int, default=2, help="MFMA forward kernel revision (2 = current, 1 = first)")
     a = ap.parse_args()
     import test_time_training as ext
     from ttt_amd.models.ssm.linear_hip import HipLinear
     from ttt_amd.models.ssm.mlp_tk import TkMLP
     ext.load_library()
     ext.set_impl(a.impl)
-    ext.debug_variant(a.variant)
-    ext.debug_option("helpers", a.helpers)
-    ext.debug_option("sweep_variant", a.sweep_variant)
-    ext.debug_option("overlap_recompute", int(a.overlap))
-    ext.debug_option("helper_lead", a.lead)
-    ext.debug_option("scan8_gelu_pk", int(a.gelu_pk))
-    ext.debug_option("bwd_cluster", a.cluster)
+    ext.debug_option("fast_records", 0 if a.write_through_records else 1)
     dev = torch.device("cuda:0")
     B, NH, NC, CS, F, G = a.b, a.nh, a.nc, a.cs, 64, a.g
     H = 4 * F if a.kind == "mlp" else F
@@ -96,7 +83,7 @@ def main():
     torch.cuda.synchronize()
     g = 2.0 * CS * F * H
     nfl = {"fwd": (7 if a.kind == "mlp" else 3) * g, "bwd": (14 if a.kind == "mlp" else 6) * g}
-    res = {"kind": a.kind, "impl_requested": a.impl, "variant": a.variant, "shape": [B, NH, NC, CS, F], "G": G}
+    res = {"kind": a.kind, "impl_requested": a.impl, "shape": [B, NH, NC, CS, F], "G": G}
     for k, ev in times.items():
         if not ev:
             continue

@@ -32,17 +32,9 @@ void launch_pre_backward(const PreBwdParams& a, hipStream_t s);
 void launch_forward(const FwdParams& p, hipStream_t s);
 void launch_backward(const BwdParams& p, hipStream_t s);
 
-// revision 2 of the forward and dQ kernels (attn_v2.hip, bodies in attn_body.h); debug option "attn_variant": 1 (default) =
-// revision 1 everywhere, 2 = revision 2 for the forward and dQ kernels
-void set_attn_variant(int v);
-int get_attn_variant();
-void launch_forward_v2(const FwdParams& p, hipStream_t s);
-void launch_dq_v2(const BwdParams& p, int occ, hipStream_t s);
-// dK / dV through the body of attn_body.h; debug option "attn_dkdv_variant": 1 (default) = attn_dkdv_kernel of attn_bwd.hip,
-// 2 = the same arithmetic through the body, 3 = accumulator-initialised row scalars (8 waves), 4 = ... with 12 waves
-void set_dkdv_variant(int v);
-int get_dkdv_variant();
-void launch_dkdv_v2(const BwdParams& p, int variant, hipStream_t s);
+// dQ and dK / dV through the workgroup bodies of attn_body.h (attn_v2.hip)
+void launch_dq_v2(const BwdParams& p, hipStream_t s);
+void launch_dkdv_v2(const BwdParams& p, hipStream_t s);
 
 }  // namespace attn
 }  // namespace ttt

@@ -97,228 +97,16 @@ __device__ __forceinline__ void qstage_park(const QStage& st, char* buf, int tid
     if (tid < 64) { sm[tid] = st.lse; sm[64 + tid] = st.del; }
 }
 
-__global__ __launch_bounds__(NTB) void attn_dkdv_kernel(BwdParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l = tid & 63, h = l >> 5, c = l & 31;
-    const int nkb = (p.S + 255) / 256;
-    int bh, kvb;
-    head_of_block(blockIdx.x, nkb, p.B * p.NH, bh, kvb);
-    const int bb = bh / p.NH, hh = bh % p.NH;
-    const __bf16* Qp = p.Q + (long)bb * p.q_sb + (long)hh * p.q_sh;
-    const __bf16* Kp = p.K + (long)bb * p.k_sb + (long)hh * p.k_sh;
-    const __bf16* Vp = p.V + (long)bb * p.v_sb + (long)hh * p.v_sh;
-    const __bf16* dOp = p.dO + (long)bb * p.do_sb + (long)hh * p.do_sh;
-    const float* lse = p.LSE + (long)bh * p.S;
-    const float* del = p.Delta + (long)bh * p.S;
-
-    const int key0 = kvb * 256 + 32 * wv;      // this wave's first key
-    const int krow = key0 + c;
-    bf16x8 Kf[4], Vf[4];                        // B operands: lane = key, 8 contiguous d per k-slice
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-        if (krow < p.S) {
-            Kf[kk] = *reinterpret_cast<const bf16x8*>(Kp + (long)krow * p.k_ss + 16 * kk + 8 * h);
-            Vf[kk] = *reinterpret_cast<const bf16x8*>(Vp + (long)krow * p.v_ss + 16 * kk + 8 * h);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { Kf[kk][e] = (__bf16)0.0f; Vf[kk][e] = (__bf16)0.0f; }
-        }
-    }
-    f32x16 dK[2] = {zero16(), zero16()}, dV[2] = {zero16(), zero16()};   // tiles (rows = key, lane = d in block db)
-    const float sc = p.scale * LOG2E;
-
-    const int nt = (p.S + 63) / 64;
-    QStage st;
-    qstage_issue(st, p, Qp, dOp, lse, del, 0, tid);
-    qstage_park(st, smem, tid);
-    __syncthreads();
-
-    for (int j = 0; j < nt; ++j) {
-        const char* buf = smem + (j & 1) * DKV_BUF;
-        const __bf16* Qt = reinterpret_cast<const __bf16*>(buf);
-        const __bf16* Dt = Qt + ATILE;
-        const float* lseL = reinterpret_cast<const float*>(buf + 2 * ATILE * 2);
-        const float* delL = lseL + 64;
-        const bool more = j + 1 < nt;
-        if (more) qstage_issue(st, p, Qp, dOp, lse, del, (j + 1) * 64, tid);
-
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-            f32x16 Sc = zero16(), dP = zero16();
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                Sc = mma(row_frag(Qt, AS, 32 * qb, 16 * kk, l), Kf[kk], Sc);
-                dP = mma(row_frag(Dt, AS, 32 * qb, 16 * kk, l), Vf[kk], dP);
-            }
-            const f32x16 lseR = rows_from_lds(lseL, 32 * qb, h);
-            const f32x16 delR = rows_from_lds(delL, 32 * qb, h);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(Sc[r], sc, -lseR[r]));
-                Sc[r] = pr;
-                dP[r] = pr * (dP[r] - delR[r]);
-            }
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bf16x8 pf = pack(Sc, s), df = pack(dP, s);
-#pragma unroll
-                for (int db = 0; db < 2; ++db) {
-                    dV[db] = mma(pf, tr_frag_pi(Dt, AS, 32 * qb, s, 32 * db, l), dV[db]);
-                    dK[db] = mma(df, tr_frag_pi(Qt, AS, 32 * qb, s, 32 * db, l), dK[db]);
-                }
-            }
-        }
-        if (more) qstage_park(st, smem + ((j + 1) & 1) * DKV_BUF, tid);
-        __syncthreads();
-    }
-
-    // epilogue: lane (c,h) register r of tile db holds element [key = key0 + row_of(r,h)][d = 32 db + c]
-    __bf16* dKp = p.dK + (long)bb * p.dk_sb + (long)hh * p.dk_sh;
-    __bf16* dVp = p.dV + (long)bb * p.dv_sb + (long)hh * p.dv_sh;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = key0 + row_of(r, h);
-            if (key < p.S) {
-                dKp[(long)key * p.dk_ss + 32 * db + c] = (__bf16)(dK[db][r] * p.scale);
-                dVp[(long)key * p.dv_ss + 32 * db + c] = (__bf16)dV[db][r];
-            }
-        }
-}
-
-// ------------------------------------------------------------------------------------------------------- dQ
-constexpr int LDS_DQ = 2 * 2 * ATILE * 2;
-
-struct KVStage2 {
-    uint4 k, v;
-};
-__device__ __forceinline__ void kv_issue(KVStage2& st, const __bf16* Kp, const __bf16* Vp, long k_ss, long v_ss, int kv0, int S, int tid) {
-    const int row = tid >> 3, col = (tid & 7) * 8;
-    const int key = kv0 + row;
-    if (key < S) {
-        st.k = *reinterpret_cast<const uint4*>(Kp + (long)key * k_ss + col);
-        st.v = *reinterpret_cast<const uint4*>(Vp + (long)key * v_ss + col);
-    } else {
-        st.k = make_uint4(0, 0, 0, 0);
-        st.v = make_uint4(0, 0, 0, 0);
-    }
-}
-__device__ __forceinline__ void kv_park(const KVStage2& st, __bf16* Kt, __bf16* Vt, int tid) {
-    const int row = tid >> 3, col = (tid & 7) * 8;
-    *reinterpret_cast<uint4*>(Kt + row * AS + col) = st.k;
-    *reinterpret_cast<uint4*>(Vt + row * AS + col) = st.v;
-}
-
-// W = waves per SIMD the register allocation is bounded for: 4 (two workgroups per CU, <= 128 VGPRs, no spills: measured
-// 6.6 vs 7.5 ms at the 3 s segment) or 2 (one workgroup per CU, 166 VGPRs)
-template <int W>
-__global__ __launch_bounds__(NTB, W) void attn_dq_kernel(BwdParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    __bf16* lds = reinterpret_cast<__bf16*>(smem);
-    const int tid = threadIdx.x;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l = tid & 63, h = l >> 5, c = l & 31;
-    const int nqb = (p.S + 255) / 256;
-    int bh, qb;
-    head_of_block(blockIdx.x, nqb, p.B * p.NH, bh, qb);
-    const int bb = bh / p.NH, hh = bh % p.NH;
-    const __bf16* Qp = p.Q + (long)bb * p.q_sb + (long)hh * p.q_sh;
-    const __bf16* Kp = p.K + (long)bb * p.k_sb + (long)hh * p.k_sh;
-    const __bf16* Vp = p.V + (long)bb * p.v_sb + (long)hh * p.v_sh;
-    const __bf16* dOp = p.dO + (long)bb * p.do_sb + (long)hh * p.do_sh;
-
-    const int qrow = qb * 256 + 32 * wv + c;
-    const bool qvalid = qrow < p.S;
-    bf16x8 Qf[4], Df[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-        if (qvalid) {
-            Qf[kk] = *reinterpret_cast<const bf16x8*>(Qp + (long)qrow * p.q_ss + 16 * kk + 8 * h);
-            Df[kk] = *reinterpret_cast<const bf16x8*>(dOp + (long)qrow * p.do_ss + 16 * kk + 8 * h);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { Qf[kk][e] = (__bf16)0.0f; Df[kk][e] = (__bf16)0.0f; }
-        }
-    }
-    const float lse2 = qvalid ? p.LSE[(long)bh * p.S + qrow] * LOG2E : 1e30f;
-    const float delta = qvalid ? p.Delta[(long)bh * p.S + qrow] : 0.f;
-    const float sc = p.scale * LOG2E;
-    f32x16 dQ[2] = {zero16(), zero16()};       // dQ^T tiles (rows = d, lane = query)
-
-    const int nt = (p.S + 63) / 64;
-    KVStage2 st;
-    kv_issue(st, Kp, Vp, p.k_ss, p.v_ss, 0, p.S, tid);
-    kv_park(st, lds, lds + ATILE, tid);
-    __syncthreads();
-
-    for (int j = 0; j < nt; ++j) {
-        const __bf16* Kt = lds + (j & 1) * 2 * ATILE;
-        const __bf16* Vt = Kt + ATILE;
-        const bool more = j + 1 < nt;
-        if (more) kv_issue(st, Kp, Vp, p.k_ss, p.v_ss, (j + 1) * 64, p.S, tid);
-        const bool ragged = !more && (p.S & 63);
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            f32x16 Sc = zero16(), dP = zero16();
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                Sc = mma(row_frag(Kt, AS, 32 * kb, 16 * kk, l), Qf[kk], Sc);
-                dP = mma(row_frag(Vt, AS, 32 * kb, 16 * kk, l), Df[kk], dP);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(Sc[r], sc, -lse2));
-                if (ragged && j * 64 + 32 * kb + row_of(r, h) >= p.S) pr = 0.f;
-                dP[r] = pr * (dP[r] - delta);
-            }
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bf16x8 df = pack(dP, s);
-                dQ[0] = mma(tr_frag_pi(Kt, AS, 32 * kb, s, 0, l), df, dQ[0]);
-                dQ[1] = mma(tr_frag_pi(Kt, AS, 32 * kb, s, 32, l), df, dQ[1]);
-            }
-        }
-        if (more) {
-            __bf16* Kn = lds + ((j + 1) & 1) * 2 * ATILE;
-            kv_park(st, Kn, Kn + ATILE, tid);
-        }
-        __syncthreads();
-    }
-    if (qvalid) {
-        __bf16* row = p.dQ + (long)bb * p.dq_sb + (long)hh * p.dq_sh + (long)qrow * p.dq_ss;
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                bf16x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (__bf16)(dQ[db][4 * g + e] * p.scale);
-                *reinterpret_cast<bf16x4*>(row + 32 * db + 8 * g + 4 * h) = v;
-            }
-    }
-}
-
+// dK / dV and dQ: the workgroup bodies of attn_body.h (emulator-checked against the fp64 oracle on the CPU), instantiated in
+// attn_v2.hip.  Round-2 A/B on an MI355X (48 heads, S = 18 048): revision-1 kernels 14.97 ms per backward; dQ through the body
+// (tail mask behind a wave-uniform branch) 14.83; + dK / dV with accumulator-initialised row scalars and 12 waves 14.27.  The
+// revision-1 dK / dV and dQ kernels, and dK / dV variants 2 / 3, were removed.
 void launch_backward(const BwdParams& p, hipStream_t s) {
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)attn_dkdv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DKV);
-        (void)hipFuncSetAttribute((const void*)attn_dq_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DQ);
-        (void)hipFuncSetAttribute((const void*)attn_dq_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DQ);
-        attr = true;
-    }
     const long rows = (long)p.B * p.NH * p.S;
     const int dgrid = (int)((rows * 8 + 255) / 256 < 65536 ? (rows * 8 + 255) / 256 : 65536);
     hipLaunchKernelGGL(attn_delta_kernel, dim3(dgrid), dim3(256), 0, s, p);
-    const int nb = (p.S + 255) / 256;
-    if (get_dkdv_variant() != 1) launch_dkdv_v2(p, get_dkdv_variant(), s);
-    else hipLaunchKernelGGL(attn_dkdv_kernel, dim3(p.B * p.NH * nb), dim3(NTB), LDS_DKV, s, p);
-    static const int dq_occ = getenv("TTT_ATTN_DQ_OCC") ? atoi(getenv("TTT_ATTN_DQ_OCC")) : 4;     // DEBUG A/B knob
-    if (get_attn_variant() == 2) return launch_dq_v2(p, dq_occ, s);
-    if (dq_occ == 2) hipLaunchKernelGGL(attn_dq_kernel<2>, dim3(p.B * p.NH * nb), dim3(NTB), LDS_DQ, s, p);
-    else hipLaunchKernelGGL(attn_dq_kernel<4>, dim3(p.B * p.NH * nb), dim3(NTB), LDS_DQ, s, p);
+    launch_dkdv_v2(p, s);
+    launch_dq_v2(p, s);
 }
 
 }  // namespace attn

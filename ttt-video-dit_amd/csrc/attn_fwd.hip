@@ -196,7 +196,6 @@ __global__ __launch_bounds__(NTF) void attn_fwd_kernel(FwdParams p) {
 }
 
 void launch_forward(const FwdParams& p, hipStream_t s) {
-    if (get_attn_variant() == 2) return launch_forward_v2(p, s);
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FWD);

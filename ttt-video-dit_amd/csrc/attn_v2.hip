@@ -32,14 +32,6 @@ struct AttnDeviceWave {
     __device__ __forceinline__ bool any(bool b) const { return __builtin_amdgcn_ballot_w64(b) != 0; }
 };
 
-__global__ __launch_bounds__(512, 4) void attn_fwd2_kernel(FwdParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    int bh, qb;
-    attnb::head_of_block(blockIdx.x, (p.S + attnb::QB - 1) / attnb::QB, p.B * p.NH, bh, qb);
-    AttnDeviceWave bk{reinterpret_cast<__bf16*>(smem)};
-    attnb::forward(bk, p, bh, qb);
-}
-
 template <int W>
 __global__ __launch_bounds__(512, W) void attn_dq2_kernel(BwdParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -61,48 +53,25 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn_dkdv2_kernel(BwdParams p) 
     attnb::dkdv<NW, ACC_INIT>(bk, p, bh, kvb);
 }
 
-static int g_attn_variant = 1, g_dkdv_variant = 1;
-void set_dkdv_variant(int v) { g_dkdv_variant = v; }
-int get_dkdv_variant() { return g_dkdv_variant; }
-void set_attn_variant(int v) { g_attn_variant = v; }
-int get_attn_variant() { return g_attn_variant; }
-
-void launch_forward_v2(const FwdParams& p, hipStream_t s) {
+void launch_dq_v2(const BwdParams& p, hipStream_t s) {
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)attn_fwd2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, attnb::LDS_FWD);
-        attr = true;
-    }
-    const int nqb = (p.S + attnb::QB - 1) / attnb::QB;
-    hipLaunchKernelGGL(attn_fwd2_kernel, dim3(p.B * p.NH * nqb), dim3(512), attnb::LDS_FWD, s, p);
-}
-
-void launch_dq_v2(const BwdParams& p, int occ, hipStream_t s) {
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)attn_dq2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, attnb::LDS_DQ);
         (void)hipFuncSetAttribute((const void*)attn_dq2_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, attnb::LDS_DQ);
         attr = true;
     }
     const int nb = (p.S + attnb::QB - 1) / attnb::QB;
-    if (occ == 2) hipLaunchKernelGGL(attn_dq2_kernel<2>, dim3(p.B * p.NH * nb), dim3(512), attnb::LDS_DQ, s, p);
-    else hipLaunchKernelGGL(attn_dq2_kernel<4>, dim3(p.B * p.NH * nb), dim3(512), attnb::LDS_DQ, s, p);
+    hipLaunchKernelGGL(attn_dq2_kernel<4>, dim3(p.B * p.NH * nb), dim3(512), attnb::LDS_DQ, s, p);
 }
 
-template <int NW, bool ACC_INIT, int MINW>
-static void launch_dkdv_one(const BwdParams& p, hipStream_t s) {
+void launch_dkdv_v2(const BwdParams& p, hipStream_t s) {       // accumulator-initialised row scalars, 12 waves (3 per SIMD)
+    constexpr int NW = 12;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)attn_dkdv2_kernel<NW, ACC_INIT, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, attnb::LDS_DKV);
+        (void)hipFuncSetAttribute((const void*)attn_dkdv2_kernel<NW, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, attnb::LDS_DKV);
         attr = true;
     }
     const int nb = (p.S + 32 * NW - 1) / (32 * NW);
-    hipLaunchKernelGGL((attn_dkdv2_kernel<NW, ACC_INIT, MINW>), dim3(p.B * p.NH * nb), dim3(64 * NW), attnb::LDS_DKV, s, p);
-}
-void launch_dkdv_v2(const BwdParams& p, int variant, hipStream_t s) {
-    if (variant == 2) launch_dkdv_one<8, false, 1>(p, s);        // revision 1's arithmetic through the body
-    else if (variant == 3) launch_dkdv_one<8, true, 1>(p, s);    // accumulator-initialised row scalars, 8 waves
-    else launch_dkdv_one<12, true, 3>(p, s);                     // ... and 12 waves (3 per SIMD)
+    hipLaunchKernelGGL((attn_dkdv2_kernel<NW, true, 3>), dim3(p.B * p.NH * nb), dim3(64 * NW), attnb::LDS_DKV, s, p);
 }
 
 }  // namespace attn

@@ -51,23 +51,13 @@ extern "C" {
 int ttt_hip_abi_version(void) { return TTT_HIP_ABI_VERSION; }
 void ttt_hip_debug_timing(void* device_buffer) { ttt::mfma::set_debug_timing(device_buffer); }
 void ttt_hip_debug_groups_per_chunk(int groups) { ttt::mfma::set_debug_groups_per_chunk(groups); }
-void ttt_hip_debug_variant(int v) { ttt::mfma::set_debug_variant(v); }
-void ttt_hip_debug_helpers(int n) { ttt::mfma::set_debug_helpers(n); }
+void ttt_hip_debug_variant(int) {}       // (one kernel revision per entry point since round 2: kept for ABI stability)
+void ttt_hip_debug_helpers(int) {}      // (no helpers any more: kept for ABI stability)
 int ttt_hip_debug_option(const char* name, int value) {
     if (!name) return -1;
-    if (!strcmp(name, "helpers")) ttt::mfma::set_debug_helpers(value);              // prefetch helpers per (b,h), -1 = automatic
-    else if (!strcmp(name, "helper_lead")) ttt::mfma::set_debug_lead(value);        // steps the helpers may run ahead (default 1)
-    else if (!strcmp(name, "sweep_variant")) ttt::mfma::set_debug_sweep_variant(value);          // 0 fenced stages, 1 unfenced, 2 unfenced + early output path
-    else if (!strcmp(name, "bwd_cluster")) ttt::mfma::set_debug_cluster(value);                  // TTT-MLP backward sweep on 4 workgroups per (b,h): -1 auto (default), 0 off
+    if (!strcmp(name, "fast_records")) ttt::mfma::set_debug_fast_records(value);              // cluster sweep hand-over: 1 (default) / 0 = write-through records always
     else if (!strcmp(name, "sweep_fast_count")) return -2 - (int)ttt::mfma::read_sweep_fast_count();      // query: returns -2 - count
-    else if (!strcmp(name, "overlap_recompute")) ttt::mfma::set_debug_overlap(value);            // recompute(next chunk) beside sweep(this chunk)
-    else if (!strcmp(name, "variant")) ttt::mfma::set_debug_variant(value);         // kernel revision 2 / 1
     else if (!strcmp(name, "groups_per_chunk")) ttt::mfma::set_debug_groups_per_chunk(value);
-    else if (!strcmp(name, "scan8_gelu_pk")) ttt::mfma::set_debug_scan8_gelu_pk(value);         // 0 (default) / 1: packed-f32 gelu of the output path (CS = 64 forward)
-    else if (!strcmp(name, "scan16_body")) ttt::mfma::set_debug_scan16_body(value);             // 0 (default) / 1
-    else if (!strcmp(name, "attn_dkdv_variant")) ttt::attn::set_dkdv_variant(value);               // 1 (default) .. 4: dK / dV kernel, see attn.h
-    else if (!strcmp(name, "attn_variant")) ttt::attn::set_attn_variant(value);                    // 1 (default) / 2: attention forward + dQ revision
-    else if (!strcmp(name, "linear_bwd_lds_slots")) ttt::mfma::set_debug_lin_lds_slots(value);    // 0..6, default 0 (unmeasured)
     else return -1;
     return 0;
 }

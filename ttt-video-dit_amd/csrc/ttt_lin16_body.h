@@ -41,11 +41,9 @@ constexpr int WAVE_LDS = L_ETA + 2 * 16 * 4;   // what forward() uses
 // ends a checkpoint group (16 operand fragments x 64 lanes x 16 bytes)
 constexpr int TRS = 72;
 constexpr int L_TR = WAVE_LDS, L_WHI = L_TR + 64 * TRS * 2;
-// ... and optionally the first MAX_LDS_SLOTS per-step state slots of the group (Lin16Params::lds_slots; the rest, or all of
-// them, stay in the caller's scratch, i.e. in L2)
-constexpr int MAX_LDS_SLOTS = 6;
-constexpr int L_SLOTS = L_WHI + 16 * 1024;
-constexpr int WAVE_LDS_BWD = L_SLOTS + MAX_LDS_SLOTS * 16 * 1024;
+// (Keeping a group's per-step state slots in LDS instead of the caller's L2-resident scratch was measured in round 2 -
+// 14.7 vs 13.9 ms per backward at the 3 s geometry - and removed.)
+constexpr int WAVE_LDS_BWD = L_WHI + 16 * 1024;
 static_assert(WAVE_LDS_BWD <= 160 * 1024, "LDS budget");
 static_assert(WAVE_LDS % 16 == 0 && L_WHI % 16 == 0, "alignment");
 
@@ -332,20 +330,13 @@ TTT_WV_FN void transposed_packs(BK& bk, const f32x4 (&T)[4][4], bf16x8 (&out)[2]
         for (int fa = 0; fa < 4; ++fa) out[ks][fa] = cat(tr4(bk, L_TR, TRS, 32 * ks, 16 * fa), tr4(bk, L_TR, TRS, 32 * ks + 16, 16 * fa));
 }
 
-template <bool LDS_SLOTS, class BK>
+template <class BK>
 TTT_WV_FN void backward(BK& bk, const Lin16Params& p, int bh) {
     const int l0 = bk.lane();
     const int NC = p.NC, G = p.G, K = p.K, head = bh % p.NH;
     const size_t tile0 = (size_t)bh * NC;
     char* scr_w = p.scratch_w + (size_t)bh * G * SLOT_BYTES;
     float* scr_b = p.scratch_b + (size_t)bh * G * 64;
-    // state slot j of the group: the caller's scratch (L2-resident) or - LDS_SLOTS variant, unmeasured so far and therefore
-    // opt-in (debug option "linear_bwd_lds_slots") - LDS for the first p.lds_slots of them.  The default instantiation is kept
-    // textually identical to the code that was validated on the hardware.
-    [[maybe_unused]] const int n_lds = LDS_SLOTS ? (p.lds_slots < MAX_LDS_SLOTS ? p.lds_slots : MAX_LDS_SLOTS) : 0;
-    [[maybe_unused]] auto slot_ptr = [&](int j) -> char* {
-        return j < n_lds ? bk.lds_ptr(L_SLOTS + j * SLOT_BYTES) : scr_w + (size_t)j * SLOT_BYTES;
-    };
 
     float gam[4], bet[4];
     f32x4 dWt[4][4];      // [fa][fb]  dW1[16fa + 4g + r][16fb + i]    (rows = f_in, lane = f_out)
@@ -416,9 +407,7 @@ TTT_WV_FN void backward(BK& bk, const Lin16Params& p, int bh) {
                 const bool fin = (it == hi), last = (it + 1 == hi);
                 bf16x8 WF[2][4];
                 {
-                    char* slot;
-                    if constexpr (LDS_SLOTS) slot = fin ? bk.lds_ptr(L_WHI) : slot_ptr(it - lo);
-                    else slot = fin ? bk.lds_ptr(L_WHI) : scr_w + (size_t)(it - lo) * SLOT_BYTES;
+                    char* slot = fin ? bk.lds_ptr(L_WHI) : scr_w + (size_t)(it - lo) * SLOT_BYTES;
                     bf16x8 WT[2][4];
                     transposed_packs(bk, W1t, WT);
 #pragma unroll
@@ -503,14 +492,8 @@ TTT_WV_FN void backward(BK& bk, const Lin16Params& p, int bh) {
                     stage_request(bk, sd, p.dOut + (tile0 + nxt) * 1024);
                 }
             }
-            const char *slot, *slot_n;                                                                    // state entering / after the step
-            if constexpr (LDS_SLOTS) {
-                slot = slot_ptr(it - lo);
-                slot_n = (it + 1 < hi) ? slot_ptr(it + 1 - lo) : bk.lds_ptr(L_WHI);
-            } else {
-                slot = scr_w + (size_t)(it - lo) * SLOT_BYTES;
-                slot_n = (it + 1 < hi) ? slot + SLOT_BYTES : bk.lds_ptr(L_WHI);
-            }
+            const char* slot = scr_w + (size_t)(it - lo) * SLOT_BYTES;                                   // state entering / after the step
+            const char* slot_n = (it + 1 < hi) ? slot + SLOT_BYTES : bk.lds_ptr(L_WHI);
             const f32x4 eta4 = bk.template lds<f32x4>(L_ETA + (buf * 16 + 4 * g) * 4);
             float b1v[4], b1n[4];
 #pragma unroll

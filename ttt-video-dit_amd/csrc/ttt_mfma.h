@@ -10,8 +10,6 @@ size_t workspace_bytes(const ttt_dims* d, bool mlp, bool backward);
 void set_debug_timing(void* device_buffer_16_u64);
 void set_debug_groups_per_chunk(int groups);   // 0 = automatic
 void set_debug_dump(float* device_buffer);     // revision-2 forward: intermediates of workgroup 0, step 0 (>= 120000 floats)
-void set_debug_helpers(int n);                  // revision-2 backward: prefetch-helper workgroups per (b,h); -1 = automatic
-void set_debug_variant(int v);                  // forward scan kernel revision: 2 (default) or 1
 void mlp_forward(const ttt_dims* d, const ttt_mlp_fwd_args* a, void* ws, hipStream_t s);
 void mlp_backward(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hipStream_t s);
 void linear_forward(const ttt_dims* d, const ttt_linear_fwd_args* a, void* ws, hipStream_t s);

@@ -221,7 +221,7 @@ __global__ __launch_bounds__(NT, 1) void mlp_scan_kernel(ScanParams p) {
                             st_frag(slot_w, FR_D1, fr_idx(ti, nj, s), pack(D1[ti][nj], s), l);
                             st_frag(slot_w, FR_D2, fr_idx(ti, nj, s), pack(d2, s), l);
                         }
-                        if (p.slot_v2) {      // gelu'(Z1) also in (rows=n, lane=t) orientation for the revision-2 sweep
+                        {                     // gelu'(Z1) also in (rows=n, lane=t) orientation
                             const f32x16 dn = transpose_tile(pack(D1[ti][nj], 0), pack(D1[ti][nj], 1), I0, I1);
                             st_frag(slot_w, FR_D1N, fr_idx(nj, ti, 0), pack(dn, 0), l);
                             st_frag(slot_w, FR_D1N, fr_idx(nj, ti, 1), pack(dn, 1), l);
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(NT, 1) void mlp_scan_kernel(ScanParams p) {
                     const f32x16 wt = transpose_tile(W2F[ni][fj][0], W2F[ni][fj][1], I0, I1);   // (rows=f, lane=n)
                     WTF[fj][ni][0] = pack(wt, 0);
                     WTF[fj][ni][1] = pack(wt, 1);
-                    if (SAVE && p.slot_v2) {
+                    if (SAVE) {
                         st_frag(slot_w, FR_W2T, fr_idx(fj, ni, 0), WTF[fj][ni][0], l);
                         st_frag(slot_w, FR_W2T, fr_idx(fj, ni, 1), WTF[fj][ni][1], l);
                     }
@@ -353,18 +353,13 @@ __global__ __launch_bounds__(NT, 1) void mlp_scan_kernel(ScanParams p) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) g1[r] = gx[r] * D1[ti][nj][r];   // gZ1, unscaled
                     const bf16x8 g1a = pack(g1, 0), g1b = pack(g1, 1);
-                    if (p.slot_v2) {          // revision-2 sweep consumes the product M = gX2 * gelu''(Z1) only
+                    {                         // the sweep consumes the product M = gX2 * gelu''(Z1) only
                         const f32x16 d2 = unpack2(ld_frag(slot_w, FR_D2, fr_idx(ti, nj, 0), l), ld_frag(slot_w, FR_D2, fr_idx(ti, nj, 1), l));
                         f32x16 mm;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) mm[r] = gx[r] * d2[r];
                         st_frag(slot_w, FR_GX2, fr_idx(ti, nj, 0), pack(mm, 0), l);
                         st_frag(slot_w, FR_GX2, fr_idx(ti, nj, 1), pack(mm, 1), l);
-                    } else {
-                        st_frag(slot_w, FR_GX2, fr_idx(ti, nj, 0), pack(gx, 0), l);
-                        st_frag(slot_w, FR_GX2, fr_idx(ti, nj, 1), pack(gx, 1), l);
-                        st_frag(slot_w, FR_GZ1, fr_idx(ti, nj, 0), g1a, l);
-                        st_frag(slot_w, FR_GZ1, fr_idx(ti, nj, 1), g1b, l);
                     }
                     const f32x16 g1t = transpose_tile(g1a, g1b, I0, I1);          // gZ1^T (rows=n, lane=t)
                     st_frag(slot_w, FR_GZ1T, fr_idx(nj, ti, 0), pack(g1t, 0), l);
@@ -483,7 +478,7 @@ __global__ __launch_bounds__(NT, 1) void mlp_scan_kernel(ScanParams p) {
                     st_frag(slot_w, FR_W1, fr_idx(a, b, s), pack(W1t[a][b], s), l);
                     st_frag(slot_w, FR_W2, fr_idx(a, b, s), pack(W2t[a][b], s), l);
                 }
-        if (p.slot_v2) {
+        {
 #pragma unroll
             for (int fj = 0; fj < 2; ++fj)
 #pragma unroll
@@ -500,17 +495,9 @@ __global__ __launch_bounds__(NT, 1) void mlp_scan_kernel(ScanParams p) {
 static void set_lds_attr_once() {
     static bool done = false;
     if (!done) {
-        (void)hipFuncSetAttribute((const void*)mlp_scan_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FWD);
         (void)hipFuncSetAttribute((const void*)mlp_scan_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FWD);
         done = true;
     }
-}
-
-void launch_scan_forward(const ScanParams& p0, int n_bh, hipStream_t s) {
-    ScanParams p = p0;
-    p.dbg = g_dbg;
-    set_lds_attr_once();
-    hipLaunchKernelGGL(mlp_scan_kernel<false>, dim3(n_bh), dim3(NT), LDS_FWD, s, p);
 }
 
 void launch_group_recompute(const ScanParams& p0, int n_bh, hipStream_t s) {
@@ -536,7 +523,6 @@ void mlp_forward(const ttt_dims* d, const ttt_mlp_fwd_args* a, void*, hipStream_
     p.out = (__bf16*)a->XQW;
     p.NH = d->NH; p.NC = d->NC; p.G = d->G; p.K = (d->NC + d->G - 1) / d->G; p.eps = d->eps;
     if (d->CS == 16) launch_scan_forward_cs16(p, d->B * d->NH, g_dbg, s);
-    else if (get_debug_variant() == 1) launch_scan_forward(p, d->B * d->NH, s);
     else launch_scan_forward_v2(p, d->B * d->NH, g_dbg, s);
 }
 void linear_forward(const ttt_dims* d, const ttt_linear_fwd_args* a, void*, hipStream_t s) {
@@ -561,7 +547,6 @@ void linear_backward(const ttt_dims* d, const ttt_linear_bwd_args* a, void*, hip
     p.dW1 = a->grad_L_W1_init; p.db1 = a->grad_L_b1_init;
     p.deta = (__bf16*)a->grad_L_last_eta; p.dXQ = (__bf16*)a->grad_L_XQ; p.dXK = (__bf16*)a->grad_L_XK; p.dXV = (__bf16*)a->grad_L_XV;
     p.NH = d->NH; p.NC = d->NC; p.G = d->G; p.K = (d->NC + d->G - 1) / d->G; p.eps = d->eps;
-    p.lds_slots = get_debug_lin_lds_slots();
     launch_linear_backward_cs16(p, d->B * d->NH, s);
 }
 

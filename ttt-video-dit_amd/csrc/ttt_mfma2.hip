@@ -130,7 +130,9 @@ __device__ __forceinline__ void write_partial2(float* redw, const f32x16& P, int
 // operations in the same order as gelu_fwd(), two elements per v_pk_mul / v_pk_fma / v_pk_add.  Why (tools/isa_mix.py): left
 // to itself the SLP vectorizer pairs the scalar form's multiplies across MISALIGNED registers of the tile and then spends
 // 24 v_mov + 12 v_alignbit + 4 v_perm per step and wave (in this block and again around the fragment packs) to realign
-// them - 230 VALU for 32 elements where ~120 do.  Opt-in (template parameter PK, debug option "scan8_gelu_pk").
+// them - 230 VALU for 32 elements where ~120 do.  Round-2 A/B on an MI355X (NH = 48, NC = 282): 2.368 -> 2.195 ms per scan;
+// the scalar form was removed.  (Not bit-identical to it - the contraction of mul + add into fma differs - but the same
+// distance from the fp64 oracle.)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void gelu_fwd_tile_pk(f32x16& z) {
     const f32x2 k0 = {GELU_K0, GELU_K0}, k1 = {GELU_K1, GELU_K1}, one = {1.0f, 1.0f};
@@ -148,7 +150,7 @@ __device__ __forceinline__ void gelu_fwd_tile_pk(f32x16& z) {
     }
 }
 
-template <bool DBG, bool PK = false>
+template <bool DBG>
 __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __bf16* Kt = reinterpret_cast<__bf16*>(smem + L_K);
@@ -411,18 +413,13 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
                     gx = mma(pi_read(Gs + (32 * ti + c) * TS, fO, s, h), W2TF[0][s], gx);
                     gx = mma(pi_read(Gs + (32 * ti + c) * TS, fX, s, h), W2TF[1][s], gx);
                 }
-                if (PK) {         // aligned pairs (see gelu_fwd_tile_pk); products and the order of the bias sum unchanged
 #pragma unroll
-                    for (int r = 0; r < 16; r += 2) {
-                        const f32x2 g = f32x2{gx[r], gx[r + 1]} * f32x2{D1[ti][r], D1[ti][r + 1]};
-                        gx[r] = g[0];
-                        gx[r + 1] = g[1];
-                        sb += g[0];
-                        sb += g[1];
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) { gx[r] *= D1[ti][r]; sb += gx[r]; }
+                for (int r = 0; r < 16; r += 2) {      // aligned register pairs (see gelu_fwd_tile_pk)
+                    const f32x2 g = f32x2{gx[r], gx[r + 1]} * f32x2{D1[ti][r], D1[ti][r + 1]};
+                    gx[r] = g[0];
+                    gx[r + 1] = g[1];
+                    sb += g[0];
+                    sb += g[1];
                 }
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
@@ -464,12 +461,7 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
 #pragma unroll
                     for (int s = 0; s < 2; ++s)
                         zb = mma(W1F[a][s], pi_read(Qt + (32 * ti + c) * TS, 32 * a, s, h), zb);
-                if (PK) {
-                    gelu_fwd_tile_pk(zb);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) zb[r] = gelu_fwd(zb[r]);
-                }
+                gelu_fwd_tile_pk(zb);
                 if (DBG && p.dump && blockIdx.x == 0 && i == 0)
                     for (int r = 0; r < 16; ++r) p.dump[28992 + (size_t)(nO + row_of(r, h)) * 64 + 32 * ti + c] = zb[r];
                 X2bF[ti][0] = pack(zb, 0);
@@ -555,7 +547,6 @@ static void set_attr_once() {
     if (!done) {
         (void)hipFuncSetAttribute((const void*)mlp_scan8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_V2);
         (void)hipFuncSetAttribute((const void*)mlp_scan8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_V2);
-        (void)hipFuncSetAttribute((const void*)mlp_scan8_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_V2);
         done = true;
     }
 }
@@ -564,39 +555,12 @@ static void set_attr_once() {
 
 static float* g_dump = nullptr;
 void set_debug_dump(float* buf) { g_dump = buf; }
-static int g_variant = 2;
-void set_debug_variant(int v) { g_variant = v; }
-int get_debug_variant() { return g_variant; }
-static int g_sweep_variant = 1;      // 1 (default): no scheduling fences inside the sweep stages (8.8 vs 9.6 ms, 3 s geometry)
-void set_debug_sweep_variant(int v) { g_sweep_variant = v; }
-int get_debug_sweep_variant() { return g_sweep_variant; }
-static int g_overlap = 0;      // recompute(next chunk) beside sweep(this chunk) on a side stream: measured 8.34 -> 8.18 ms only
-                               // (the recompute's 2 GB of slot traffic evicts what the prefetch helpers put into L2): off by default
-void set_debug_overlap(int v) { g_overlap = v; }
-int get_debug_overlap() { return g_overlap; }
-static int g_lead = 1;
-void set_debug_lead(int v) { g_lead = v; }
-int get_debug_lead() { return g_lead; }
-static int g_lin_lds_slots = 0;       // TTT-Linear backward (CS = 16): per-step state slots kept in LDS; unmeasured -> off
-void set_debug_lin_lds_slots(int n) { g_lin_lds_slots = n; }
-int get_debug_lin_lds_slots() { return g_lin_lds_slots; }
-static int g_scan16_body = 0;         // CS = 16 TTT-MLP forward: the backend-templated body instead of the hand-placed kernel
-void set_debug_scan16_body(int v) { g_scan16_body = v; }
-int get_debug_scan16_body() { return g_scan16_body; }
-static int g_scan8_gelu_pk = 0;       // CS = 64 TTT-MLP forward: gelu of the output path on aligned register pairs (packed f32); unmeasured -> off
-void set_debug_scan8_gelu_pk(int v) { g_scan8_gelu_pk = v; }
-int get_debug_scan8_gelu_pk() { return g_scan8_gelu_pk; }
-static int g_helpers = -1;
-void set_debug_helpers(int n) { g_helpers = n; }
-int get_debug_helpers() { return g_helpers; }
-
 void launch_scan_forward_v2(const ScanParams& p0, int n_bh, unsigned long long* dbg, hipStream_t s) {
     ScanParams p = p0;
     p.dbg = dbg;
     p.dump = g_dump;
     v2::set_attr_once();
     if (p.dbg || p.dump) hipLaunchKernelGGL(v2::mlp_scan8_kernel<true>, dim3(n_bh), dim3(v2::NT2), v2::LDS_V2, s, p);
-    else if (g_scan8_gelu_pk) hipLaunchKernelGGL((v2::mlp_scan8_kernel<false, true>), dim3(n_bh), dim3(v2::NT2), v2::LDS_V2, s, p);
     else hipLaunchKernelGGL(v2::mlp_scan8_kernel<false>, dim3(n_bh), dim3(v2::NT2), v2::LDS_V2, s, p);
 }
 

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster_kernel(SweepParams2 p) {
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cq = __builtin_amdgcn_readfirstlane((int)(blockIdx.x / p.nbh));     // workgroup of the cluster = wave pair w
-    const int bh = blockIdx.x % p.nbh, head = bh % p.NH;
+    const int bh = p.bh0 + (int)(blockIdx.x % p.nbh), head = bh % p.NH;
     const int NC = p.NC;
     char* slots = p.slots + (size_t)bh * p.slot_stride_bh;
     float* carry = p.carry + (size_t)bh * CARRY_FLOATS2;
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster_kernel(SweepParams2 p) {
                         same = __hip_atomic_load(f + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == my_xcc + 1u;
                     }
                     const bool all_same = __builtin_amdgcn_ballot_w64(!same) == 0ull;
-                    const bool use_fast = all_same && p.lead != 99;     // (helper_lead = 99: DEBUG switch, write-through records only)
+                    const bool use_fast = all_same && p.fast_records != 0;
                     if (l == 0) {
                         __hip_atomic_store(syncw + 1, use_fast ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         if (use_fast) atomicAdd(&g_fast_count, 1u);

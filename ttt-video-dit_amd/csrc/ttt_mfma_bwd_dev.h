@@ -117,13 +117,13 @@ struct SweepParams2 {
     __bf16 *dXV, *deta;
     float *dW1, *db1, *dW2, *db2, *dlnw, *dlnb;
     int NH, NC, chunk_lo, chunk_hi, first, last;
-    unsigned long long* dbg;                // optional: per-stage cycle totals of workgroup 0 (entries 16..25)
-    int* prog;                              // [B*NH] step the sweep of each (b,h) is working on (read by its prefetch helpers)
-    int nbh, helpers, lead;                 // single-workgroup form: grid = nbh * (1 + helpers), blocks >= nbh are prefetch helpers of (b,h) = block % nbh,
-                                            // running at most `lead` steps ahead of the scan
-    char* xch;                              // cluster form: exchange area, XCH_BH_BYTES per (b,h)
-    unsigned* flags;                        // cluster form: [nbh][4] step flags, one 128-byte line each (zeroed before the launch)
+    unsigned long long* dbg;                // optional: per-stage cycle totals of workgroup 0 (entries 16..27)
+    int bh0, nbh;                           // this launch sweeps (b,h) = bh0 .. bh0 + nbh - 1: grid = 4 nbh workgroups
+    int fast_records;                       // 1: plain (L2-resident) records once same-XCD placement is proven; 0: always write-through
+    char* xch;                              // exchange area, XCH_BH_BYTES per (b,h)
+    unsigned* flags;                        // [B NH][4] hand-over flags, one 128-byte line each (zeroed before every launch)
 };
+
 
 // ---- cluster form: exchange records ------------------------------------------------------------------------------------
 // exchange record of one workgroup and step parity: the partial tile [64][PS] fp32 + the d(eta) partials of its two waves

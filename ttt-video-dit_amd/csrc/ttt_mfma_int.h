@@ -20,17 +20,12 @@ struct ScanParams {
     char* slots;                           // base of the slot area; slot s of (b,h) <-> step chunk_lo + s
     size_t slot_stride_bh;                 // bytes between consecutive (b,h) slot areas
     int chunk_group0, chunk_groups, chunk_lo;
-    int slot_v2;                           // group-recompute: write the revision-2 slot contents (ttt_mfma_dev.h)
     unsigned long long* dbg;               // optional per-phase cycle totals of workgroup 0
     float* dump;                           // DEBUG: intermediates of workgroup 0, step 0 (revision-2 forward)
 };
 
-void launch_scan_forward(const ScanParams& p, int n_bh, hipStream_t s);
 void launch_group_recompute(const ScanParams& p, int n_bh, hipStream_t s);
 bool bwd_available();
-// revision-2 backward (ttt_mfma_bwd2.hip): 8-wave reverse sweep + parallel dK/dQ tail kernel
-void mlp_backward_v2(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hipStream_t s);
-size_t workspace_bytes_v2(const ttt_dims* d);
 int groups_per_chunk(const ttt_dims* d);
 // revision-2 forward scan (ttt_mfma2.hip): 8 waves per (b,h), VGPR-form MFMA, LDS transposed reads
 void launch_scan_forward_v2(const ScanParams& p, int n_bh, unsigned long long* dbg, hipStream_t s);
@@ -38,25 +33,11 @@ void launch_scan_forward_v2(const ScanParams& p, int n_bh, unsigned long long* d
 void launch_scan_forward_cs16(const ScanParams& p, int n_bh, unsigned long long* dbg, hipStream_t s);
 void launch_linear_forward_cs16(const wv::Lin16Params& p, int n_bh, hipStream_t s);   // TTT-Linear, one wave per (b,h)
 void launch_linear_backward_cs16(const wv::Lin16Params& p, int n_bh, hipStream_t s);
-void set_debug_lin_lds_slots(int n);
-void set_debug_scan8_gelu_pk(int v);
-int get_debug_scan8_gelu_pk();
-void set_debug_scan16_body(int v);
-int get_debug_scan16_body();
-int get_debug_lin_lds_slots();
 void set_debug_dump(float* buf);
-int get_debug_variant();
 unsigned long long* get_debug_timing();
-int get_debug_helpers();          // -1 = automatic
-int get_debug_sweep_variant();
-void set_debug_cluster(int v);         // backward sweep over a cluster of 4 workgroups per (b,h): -1 automatic (default), 0 never
+void set_debug_fast_records(int v);   // cluster sweep: 1 (default) plain records on a proven common XCD, 0 write-through always
 unsigned read_sweep_error();
 unsigned read_sweep_fast_count();   // DEBUG statistic (synchronises)           // 0, or 1 + (b,h) of a cluster workgroup whose partner never arrived (synchronises)
-int get_debug_overlap();
-int get_debug_lead();
-void set_debug_lead(int v);
-void set_debug_overlap(int v);
-void set_debug_sweep_variant(int v);
 
 }  // namespace mfma
 }  // namespace ttt

@@ -30,7 +30,6 @@ struct Lin16Params {
     __bf16 *deta, *dXQ, *dXK, *dXV;
     int NH, NC, G, K;
     float eps;
-    int lds_slots;                          // backward: how many of a group's per-step state slots live in LDS instead of scratch_w
 };
 
 // arguments of the TTT-MLP forward scan at mini-batches of 16 tokens (F = 64, hidden 256)

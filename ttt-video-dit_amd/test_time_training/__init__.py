@@ -122,22 +122,8 @@ def debug_groups_per_chunk(groups: int) -> None:
     lib.ttt_hip_debug_groups_per_chunk(int(groups))
 
 
-def debug_variant(revision: int) -> None:
-    """DEBUG: MFMA forward-scan kernel revision (2 = current, 1 = first 4-wave kernel)."""
-    lib = load_library()
-    lib.ttt_hip_debug_variant.argtypes = [ctypes.c_int]
-    lib.ttt_hip_debug_variant(int(revision))
-
-
-def debug_helpers(n: int) -> None:
-    """DEBUG: L2-prefetch helper workgroups per (b, h) of the revision-2 backward sweep (-1 = automatic)."""
-    lib = load_library()
-    lib.ttt_hip_debug_helpers.argtypes = [ctypes.c_int]
-    lib.ttt_hip_debug_helpers(int(n))
-
-
 def debug_option(name: str, value: int) -> None:
-    """DEBUG / A-B knobs of the revision-2 backward by name (see ttt_hip_debug_option in include/ttt_hip.h)."""
+    """DEBUG / A-B knobs by name (see ttt_hip_debug_option in include/ttt_hip.h): ``groups_per_chunk``, ``fast_records``."""
     lib = load_library()
     lib.ttt_hip_debug_option.argtypes = [ctypes.c_char_p, ctypes.c_int]
     lib.ttt_hip_debug_option.restype = ctypes.c_int
