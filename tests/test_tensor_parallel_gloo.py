@@ -1,0 +1,100 @@
+"""Head-sharded tensor parallelism of the TTT layer (``TTTBase.init_device_mesh`` / ``apply_tp``, the reference surface of
+``ttt/models/ssm/ttt_layer.py``:114-131 and ``ttt/infra/parallelisms.py``:106-152) on CPU over gloo: world size 2, a 1-D
+DeviceMesh as the reference passes it.  Every rank runs its heads' scans over the full sequence, head outputs are all-gathered;
+outputs and - after ``tp_sync_gradients`` - every gradient must equal the single-process DiT.  Dual-form scan and kernel plumbing
+(HIP extension replaced by the oracle-backed stand-in), single- and multi-scene."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CASES = {"mlp_dual_3scene": ("ttt_mlp", 4, 7, 3, False), "linear_kernel_1scene": ("ttt_linear", 2, 3, 1, True)}
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _build(case):
+    from ttt_amd.models.cogvideo.dit import DiffusionTransformer
+    from ttt_amd.models.configs import ModelConfig
+    ssm, nh, frames, scenes, use_kernel = CASES[case]
+    torch.manual_seed(5)
+    cfg = ModelConfig(model_dim=64 * nh, num_heads=nh, num_layers=2, mini_batch_size=16, latent_height=8, latent_width=8,
+                      compressed_num_frames=frames, ssm_layer=ssm, text_dim=32, time_embed_dim=64, attn_length=2,
+                      prefix_temporal_length=1, adapter_method="sft", scan_checkpoint_group_size=2)
+    m = DiffusionTransformer(cfg)
+    with torch.no_grad():
+        for _, p in m.named_parameters():
+            if p.ndim >= 2:
+                p.normal_(0, 0.05)
+            elif p.ndim == 1:
+                p.add_(0.05 * torch.randn_like(p))
+    for layer in m.layers:
+        layer.seq_modeling_block.ssm.ttt.use_kernel = use_kernel
+    g = torch.Generator().manual_seed(3)
+    return m, (torch.randn(1, frames, 16, 8, 8, generator=g), torch.randn(1, scenes, 16, 32, generator=g), torch.tensor([412]))
+
+
+def _worker(rank, world, port, case, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "ttt-video-dit_amd")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    from torch.distributed.device_mesh import init_device_mesh
+    from oracle import cpu_ext
+    from ttt_amd.infra.parallelisms import apply_tp, end_distributed, init_distributed, tp_sync_gradients
+    cpu_ext.install()
+    init_distributed("gloo")
+    m, inputs = _build(case)
+    apply_tp(m, init_device_mesh("cpu", (world,), mesh_dim_names=("tp",)))
+    out = m(*inputs)
+    out.square().mean().backward()
+    tp_sync_gradients(m)
+    if rank == 1:     # any rank must hold the complete answer
+        torch.save({"out": out.detach(), "grads": {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}},
+                   os.path.join(out_dir, "tp.pt"))
+    end_distributed()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_head_sharded_tp_matches_single_process(case, tmp_path):
+    mp.spawn(_worker, args=(2, _free_port(), case, str(tmp_path)), nprocs=2, join=True)
+    from oracle import cpu_ext
+    cpu_ext.install()
+    try:
+        m, inputs = _build(case)
+        out = m(*inputs)
+        out.square().mean().backward()
+    finally:
+        cpu_ext.uninstall()
+    got = torch.load(os.path.join(tmp_path, "tp.pt"))
+    rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-30))
+    assert rel(got["out"], out.detach()) < 1e-5
+    ref = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    assert set(got["grads"]) == set(ref)
+    bad = {k: rel(got["grads"][k], v) for k, v in ref.items() if not rel(got["grads"][k], v) < 2e-4}
+    assert not bad, bad
+
+
+def test_init_device_mesh_rejects_indivisible_heads():
+    import torch.distributed as dist
+    from ttt_amd.models.configs import ModelConfig
+    from ttt_amd.models.ssm.ttt_layer import TTTWrapper
+    sys.path.insert(0, os.path.join(ROOT, "ttt-video-dit_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        m = TTTWrapper(ModelConfig(model_dim=128, num_heads=2, num_layers=1, mini_batch_size=16, latent_height=4, latent_width=4,
+                                   compressed_num_frames=2, ssm_layer="ttt_linear"))
+        m.ttt.init_device_mesh(dist.group.WORLD)      # one rank: accepted, forward unchanged
+        assert m.ttt.tp_mesh is not None
+    finally:
+        dist.destroy_process_group()

@@ -63,6 +63,24 @@ def apply_fsdp(model, dp_mesh, param_dtype=torch.bfloat16, reduce_dtype=torch.fl
     return model
 
 
+def apply_tp(model, tp_mesh):
+    """Tensor parallelism over ``tp_mesh`` (reference ``apply_tp`` :106-152, restricted to what it shards by HEAD: the TTT layer's
+    q / k / v projections, RoPE, scan and per-head parameters).  The reference's other placements (sequence-parallel norms and
+    MLP, column-parallel attention projections) exist to fit 30 - 63 s activations into 80-GB GPUs; on 288-GB MI355X they are
+    served by ``ttt_amd.infra.sequence_parallel`` (explicit collectives) when latency, not memory, asks for them.  Call
+    ``tp_sync_gradients(model)`` after backward."""
+    dit = model.dit if hasattr(model, "dit") else model
+    for layer in dit.layers:
+        layer.seq_modeling_block.ssm.ttt.init_device_mesh(tp_mesh)
+    return tp_mesh
+
+
+def tp_sync_gradients(model):
+    dit = model.dit if hasattr(model, "dit") else model
+    for layer in dit.layers:
+        layer.seq_modeling_block.ssm.ttt.tp_sync_gradients()
+
+
 def enable_tuned_gemms(path: str | None = None) -> bool:
     """Plain library GEMMs (projections, MLP) go to hipBLASLt / rocBLAS through PyTorch; this loads a committed
     solution-selection file for the 5B / 3 s GEMM shapes on gfx950 (produced once with PyTorch TunableOp on an MI355X,

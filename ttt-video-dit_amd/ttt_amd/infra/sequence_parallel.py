@@ -157,3 +157,45 @@ class _HeadsToTokens(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         return ctx.sp._a2a_tokens_to_heads(g.contiguous())[:, :ctx.length], None
+
+
+class _GatherFeatures(torch.autograd.Function):
+    """head shards [B, L, d] -> [B, L, T*d] on every rank (feature blocks in rank order = head order).  The consumer is
+    replicated (every rank applies the same post-norm / output projection to the same gathered tensor), so the gradient of a
+    rank's block is that block of its own incoming gradient: no collective in backward."""
+
+    @staticmethod
+    def forward(ctx, x, sp):
+        ctx.sp, ctx.d = sp, x.shape[-1]
+        parts = [torch.empty_like(x) for _ in range(sp.size)]
+        dist.all_gather(parts, x.contiguous(), group=sp.group)
+        return torch.cat(parts, dim=-1)
+
+    @staticmethod
+    def backward(ctx, g):
+        sp, d = ctx.sp, ctx.d
+        return g[..., sp.rank * d:(sp.rank + 1) * d].contiguous(), None
+
+
+def gather_features(x: torch.Tensor, sp: SeqParallel) -> torch.Tensor:
+    return _GatherFeatures.apply(x, sp)
+
+
+class _ReplicatedInput(torch.autograd.Function):
+    """Identity on a tensor that is replicated over the group and consumed by rank-local (head-sharded) work: each rank's
+    backward yields only its heads' share of the input gradient, so the shares are summed (all-reduce) - Megatron's "f"."""
+
+    @staticmethod
+    def forward(ctx, x, sp):
+        ctx.sp = sp
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.sp.group)
+        return g, None
+
+
+def replicated_input(x: torch.Tensor, sp: SeqParallel) -> torch.Tensor:
+    return _ReplicatedInput.apply(x, sp)

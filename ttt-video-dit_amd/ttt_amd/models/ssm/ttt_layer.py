@@ -127,6 +127,7 @@ class TTTBase(nn.Module):
         self.ttt_base_lr = config.ttt_base_lr
         self.scan_checkpoint_group_size = config.scan_checkpoint_group_size
         self.tp_mesh = None
+        self._tp = None
         self.use_kernel = True
         self.use_fused = True          # fused HIP pre/post-processing when the activations are bf16 on a HIP device
 
@@ -156,9 +157,37 @@ class TTTBase(nn.Module):
         nn.init.zeros_(self.learnable_ttt_lr_bias)
 
     def init_device_mesh(self, tp_mesh):
-        raise NotImplementedError("DTensor tensor parallelism is not mirrored: training on MI355X runs FSDP-only (288 GB HBM "
-                                  "per GPU); the head-sharded / sequence-parallel layout exists for inference with explicit "
-                                  "collectives (forward_heads, ttt_amd/infra/sequence_parallel.py)")
+        """Head-sharded tensor parallelism (reference :114-131 + ``mlp_tk.py``:297-343 ``local_map`` over heads +
+        ``parallelisms.py``:106-152): every rank of ``tp_mesh`` runs the projections, RoPE, the scan and its backward for ITS
+        ``NH / T`` heads over the full sequence; the head outputs are all-gathered along the feature dimension before
+        ``post_norm`` / ``wo`` (the reference's one all-gather of ``[B, L, D]``, :329).  MI355X-first form: no DTensor -
+        parameters stay whole on every rank (14.5 GB in bf16 is nothing next to 288 GB), each rank slices its heads' rows
+        (``forward_heads``), the collective is explicit (RCCL all-gather) and differentiable, and ``tp_sync_gradients()``
+        sums the per-head parameter gradients over the group after backward (a rank only produces its own heads' rows).
+        ``tp_mesh``: a 1-D ``DeviceMesh`` (the reference's argument) or a process group."""
+        from ttt_amd.infra.sequence_parallel import SeqParallel
+        group = tp_mesh.get_group() if hasattr(tp_mesh, "get_group") else tp_mesh
+        self._tp = SeqParallel(group)
+        self._tp.head_range(self.num_heads)          # raises if the heads do not divide
+        self.tp_mesh = tp_mesh
+        TkMLP.sharded_mode = HipLinear.sharded_mode = True        # (reference class attributes; informational here)
+
+    def tp_sync_gradients(self):
+        """After backward under ``init_device_mesh``: sum the gradients of the per-head parameters over the tensor-parallel
+        group (every rank holds its own heads' rows, zeros elsewhere); the replicated tail (``post_norm``, ``wo``) sees the
+        same gathered activations on every rank and needs nothing."""
+        import torch.distributed as dist
+        if getattr(self, "_tp", None) is None or self._tp.size == 1:
+            return
+        params = dict(self.named_parameters())
+        grads = [params[n].grad for n in self._HEAD_SLICED if n in params and params[n].grad is not None]
+        if grads:
+            flat = torch.cat([g.reshape(-1).float() for g in grads])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self._tp.group)
+            o = 0
+            for g in grads:
+                g.copy_(flat[o:o + g.numel()].view_as(g))
+                o += g.numel()
 
     # -- pieces of process_input ------------------------------------------------------------------
     def get_qkv_projections(self, hidden_states):
@@ -256,6 +285,13 @@ class TTTBase(nn.Module):
         """``heads_only=True`` stops before ``post_norm`` / ``wo`` and returns the scan output ``[B, L, NH*F]`` in the
         original token order: the head-sharded half of the layer under sequence parallelism (see ``forward_heads``)."""
         assert hidden_states.size(1) % self.config.mini_batch_size == 0, "Sequence len must be multiple of mini batch size."
+        tp = getattr(self, "_tp", None)
+        if tp is not None and tp.size > 1 and not heads_only:
+            from ttt_amd.infra.sequence_parallel import gather_features, replicated_input
+            h0, h1 = tp.head_range(self.num_heads)
+            x = replicated_input(hidden_states, tp)          # backward: the ranks' shares of d(input) are summed
+            y = gather_features(self.forward_heads(x, freqs_cis, seq_metadata, reverse, h0, h1), tp)    # [B, L, NH*F]
+            return wgrad.linear(self.wo, self.post_norm(y))
         if self.use_kernel and self.use_fused and fused_available(hidden_states, self.head_dim) and not freqs_cis.is_complex():
             return self._forward_fused(hidden_states, freqs_cis, seq_metadata, reverse, heads_only)
         if reverse:
