@@ -159,8 +159,15 @@ def test_dit_on_hip_path_vs_reference_golden(name):
     print(name, "bf16 HIP DiT vs reference fp32:", {"out": round(errs["out"], 4), "n_grads": len(errs) - 1, "worst": (worst[0], round(worst[1], 4))})
     multi = g["scenes"] > 1
     assert errs["out"] < (6e-2 if multi else 2e-2), errs
+    # Gradient tolerance 8e-2 (bf16 end to end vs the reference's fp32 run); the reference's own bf16-autocast run of these
+    # models is off by up to 2.3 - 3.0e-2 (tests/golden/dit_bf16_yardstick.pt).  Exception, stated: the two learning-rate-gate
+    # parameters.  Their gradient is the token sum of d(eta), which the kernel contract returns in bf16 (mlp_tk.py:280) and whose
+    # four terms cancel: measured on an MI355X for this fixture 0.12 - 0.15 with the MFMA kernels, 0.02 - 0.03 with the fp32-
+    # arithmetic generic kernels, 0.3 - 1.2 for the reference's ops-path statements evaluated in bf16 (profiles/r2b_dit_gradient_
+    # diagnosis.txt) - so they are bounded by 0.25 here.
     tol = 0.25 if multi else 8e-2
-    bad = {k: v for k, v in errs.items() if k != "out" and not v < tol}
+    lr_gate = ("learnable_ttt_lr_bias", "learnable_ttt_lr_weight")
+    bad = {k: v for k, v in errs.items() if k != "out" and not v < (0.25 if k.endswith(lr_gate) else tol)}
     assert not bad, bad
 
 
