@@ -94,9 +94,6 @@ def parse():
                          "kernels, 190 ms of a 3.26 s step); same arithmetic, bit-identical updates (tests/test_fsdp_gloo.py).  auto = off "
                          "on one GPU (falling back to FSDP2 should the replica path fail), FSDP2 on several; on = FSDP2 always")
     ap.add_argument("--no-fsdp", action="store_true", help="same as --fsdp off")
-    ap.add_argument("--overlap-wgrad", action="store_true",
-                    help="weight-gradient GEMMs of the projections / MLP on a side stream, beside the backward scans "
-                         "(ttt_amd/infra/wgrad_overlap.py); opt-in until timed")
     ap.add_argument("--layers", type=int, default=None, help="DEBUG: fewer layers (result flagged invalid)")
     return ap.parse_args()
 
@@ -310,9 +307,6 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False):
     ext.set_impl(args.impl)
     init_distributed("nccl")
     tuned = (not args.no_tuned_gemms) and enable_tuned_gemms()
-    if args.overlap_wgrad:
-        from ttt_amd.infra import wgrad_overlap
-        wgrad_overlap.enable(True)
 
     over = {}
     if args.layers is not None:
@@ -497,7 +491,7 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False):
                 "config": {"workload": f"CogVideoX-5B+{args.ssm_layer} {args.video_length} training step (fwd+bwd+AdamW), "
                                        f"{cfg.num_layers} layers, L={L} tokens/sample, adapter={args.adapter}",
                            "global_batch": world * LB, "seq_len": L, "parallelism": "replica1" if no_fsdp else f"fsdp{world}", "ttt_impl": args.impl,
-                           "remat_free_layers": n_free, "fsdp_reshard_after_forward": bool(args.reshard_after_forward), "tuned_gemm_selections": bool(tuned), "overlap_wgrad": bool(args.overlap_wgrad),
+                           "remat_free_layers": n_free, "fsdp_reshard_after_forward": bool(args.reshard_after_forward), "tuned_gemm_selections": bool(tuned),
                            "valid": args.layers is None},
                 "roofline": roof, "loss": loss_val, "peak_mem_gib": peak_mem, "total_tokens_per_s": world * L / (dt / args.steps)}
         return line

@@ -15,7 +15,7 @@ import torch.nn.functional as F
 from torch import nn
 from torch.utils.checkpoint import checkpoint
 
-from ttt_amd.infra import wgrad_overlap as wgrad
+from ttt_amd.infra.fused_linear import linear3
 from ttt_amd.models.cogvideo.attention import FusedSegmentAttention, attn_pre_available, segment_attention
 from ttt_amd.models.cogvideo.utils import (Rotary3DPositionEmbedding, SequenceMetadata, modulate,
                                            timestep_embedding, unpatchify)
@@ -96,10 +96,8 @@ class MLP(nn.Module):
         self.tp_mesh = None
 
     def _run(self, x):
-        z = wgrad.linear(self.layer1, x)
+        z = self.layer1(x)
         w2 = self.layer2.weight
-        if wgrad.gelu_linear_usable(z, w2, self.layer2.bias):    # weight gradients on the side stream, under the scans
-            return wgrad.gelu_linear(z, w2, self.layer2.bias)
         if z.is_cuda and type(w2) in (torch.Tensor, nn.Parameter) and torch.is_grad_enabled():
             return GeluLinear.apply(z, w2, self.layer2.bias)     # keeps z only; GELU(z) is re-derived in backward
         return self.layer2(F.gelu(z, approximate="tanh"))
@@ -157,18 +155,18 @@ class SeqModelingBlock(nn.Module):
         heads = lambda t: t.view(b, s, self.num_heads, self.head_dim).transpose(1, 2)   # [b, h, s, d]
         if attn_pre_available(emb, self.head_dim):      # HIP: LayerNorm + RoPE fused, layout kept, strided views downstream
             cos, sin = self.rotary.tables_f32()
-            q, k, v = wgrad.linear3(self.q, self.k, self.v, emb)
+            q, k, v = linear3(self.q, self.k, self.v, emb)
             a = FusedSegmentAttention.apply(q, k, heads(v),
                                             self.q_norm.weight, self.q_norm.bias, self.k_norm.weight, self.k_norm.bias, cos, sin,
                                             self.num_heads, n_text, self.q_norm.eps)
-            return wgrad.linear(self.o, a.transpose(1, 2).reshape(b, s, -1))
+            return self.o(a.transpose(1, 2).reshape(b, s, -1))
         else:
-            q, k, v = (heads(t) for t in wgrad.linear3(self.q, self.k, self.v, emb))
+            q, k, v = (heads(t) for t in linear3(self.q, self.k, self.v, emb))
             q, k = self.q_norm(q), self.k_norm(k)
             q = torch.cat((q[:, :, :n_text], self.rotary(q[:, :, n_text:])), dim=2)
             k = torch.cat((k[:, :, :n_text], self.rotary(k[:, :, n_text:])), dim=2)
         a = segment_attention(q, k, v)
-        return wgrad.linear(self.o, a.transpose(1, 2).reshape(b, s, -1))
+        return self.o(a.transpose(1, 2).reshape(b, s, -1))
 
     def _attn_forward(self, vid_emb, text_emb, seq_metadata: SequenceMetadata, cat=None):
         """Each segment i attends over [text_i, frames 12i .. 12(i+1)] (13 frames, 1 shared with its
@@ -299,7 +297,6 @@ class TransformerLayer(nn.Module):
         """HIP glue path (bf16 on a HIP device): layernorm + modulate + concat and the gated residuals are one kernel each
         and the [text | video] sequence stays concatenated through the block and the MLP."""
         t = seq_metadata.t_emb
-        vid_emb, text_emb = wgrad.layer_entry(vid_emb, text_emb)
         ln1, ln2 = self.pre_seq_layernorm, self.pre_mlp_layernorm
         sh_v, sc_v, g_v, sh_t, sc_t, g_t = self.pre_seq_adaLN_modulation(t).chunk(6, dim=1)
         x = FusedAdaLN.apply(vid_emb, text_emb, ln1.weight, ln1.bias, sh_v, sc_v, sh_t, sc_t, ln1.eps)
@@ -328,7 +325,6 @@ class TransformerLayer(nn.Module):
             return self._forward_fused(vid_emb, text_emb, seq_metadata)
         n_text = seq_metadata.seq_text_length
         t = seq_metadata.t_emb
-        vid_emb, text_emb = wgrad.layer_entry(vid_emb, text_emb)
         sh_v, sc_v, g_v, sh_t, sc_t, g_t = self.pre_seq_adaLN_modulation(t).chunk(6, dim=1)
         block = _ckpt(self.seq_modeling_block, self.remat_seq_modeling_block)
         v_out, t_out = block(modulate(self.pre_seq_layernorm(vid_emb), sh_v, sc_v),

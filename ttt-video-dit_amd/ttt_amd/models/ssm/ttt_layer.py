@@ -22,7 +22,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ttt_amd.infra import wgrad_overlap as wgrad
+from ttt_amd.infra.fused_linear import linear3
 from ttt_amd.models.cogvideo.utils import SequenceMetadata
 from ttt_amd.models.configs import ModelConfig
 from ttt_amd.models.ssm.fused import FusedPost, FusedPre, FusedPreScanMLP, fused_available
@@ -191,7 +191,7 @@ class TTTBase(nn.Module):
 
     # -- pieces of process_input ------------------------------------------------------------------
     def get_qkv_projections(self, hidden_states):
-        return wgrad.linear3(self.wq, self.wk, self.wv, hidden_states)
+        return linear3(self.wq, self.wk, self.wv, hidden_states)
 
     def get_eta(self, X):
         """Per-token inner-loop learning rate ``base_lr * sigmoid(x.w_h + b_h) / head_dim`` as
@@ -291,14 +291,14 @@ class TTTBase(nn.Module):
             h0, h1 = tp.head_range(self.num_heads)
             x = replicated_input(hidden_states, tp)          # backward: the ranks' shares of d(input) are summed
             y = gather_features(self.forward_heads(x, freqs_cis, seq_metadata, reverse, h0, h1), tp)    # [B, L, NH*F]
-            return wgrad.linear(self.wo, self.post_norm(y))
+            return self.wo(self.post_norm(y))
         if self.use_kernel and self.use_fused and fused_available(hidden_states, self.head_dim) and not freqs_cis.is_complex():
             return self._forward_fused(hidden_states, freqs_cis, seq_metadata, reverse, heads_only)
         if reverse:
             hidden_states = flip_sequence(hidden_states, seq_metadata)
         y = self.ttt(self.process_input(hidden_states, freqs_cis, seq_metadata))
         if not heads_only:
-            y = wgrad.linear(self.wo, self.post_norm(y))
+            y = self.wo(self.post_norm(y))
         if seq_metadata.is_multiscene:
             y = self.undo_interleave(y, seq_metadata)
         return flip_sequence(y, seq_metadata) if reverse else y
@@ -373,7 +373,7 @@ class TTTBase(nn.Module):
             out.index_copy_(1, src.long(), Y.reshape(B, NH, L, Fh).transpose(1, 2))
             return out.view(B, L, NH * Fh)
         y = FusedPost.apply(Y.reshape(B, NH, L, Fh), self.post_norm.weight, self.post_norm.bias, src, self.post_norm.eps)
-        return wgrad.linear(self.wo, y)
+        return self.wo(y)
 
     # helpers shared by the two variants
     def _group_size(self, num_mini_batch: int) -> int:
