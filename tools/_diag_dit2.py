@@ -12,8 +12,6 @@ from ttt_amd.models.configs import ModelConfig
 
 DEV = "cuda:0"
 ext.load_library()
-if len(sys.argv) > 1:
-    ext.debug_option("bwd_cluster", int(sys.argv[1]))
 g = load_golden("dit_mlp64_1scene.pt")
 m = DiffusionTransformer(ModelConfig(**g["cfg"]))
 m.load_state_dict(g["state_dict"], strict=True)
@@ -96,24 +94,3 @@ def m_eta_const(b): b[3].fill_(1.2e-5)
 run_variant("eta constant 1.2e-5", m_eta_const)
 def m_all(b): m_dout_rand(b); m_xv_rand(b); m_qk_rand(b)
 run_variant("dOut, XV, XQ, XK random", m_all)
-
-
-# ---- which kernel family shows it?  single-workgroup sweep (rev 2), cluster sweep, revision-1 backward ----------------------------
-print("--- captured inputs, by backward implementation")
-for tag, setup in (("rev-2 single-workgroup sweep", lambda: ext.debug_option("bwd_cluster", 0)),
-                   ("cluster sweep", lambda: ext.debug_option("bwd_cluster", -1)),
-                   ("revision-1 backward", lambda: ext.debug_variant(1))):
-    setup()
-    run_variant(tag, lambda b: None)
-    ext.debug_option("bwd_cluster", 0); ext.debug_variant(2)
-# and the per-step picture: only the LAST mini-batch has a non-zero dOut (later steps contribute nothing)
-def m_last_only(b): b[11 + 20][:, :, :-1].zero_()
-run_variant("dOut only in the last mini-batch", m_last_only)
-def m_first_only(b): b[11 + 20][:, :, 1:].zero_()
-run_variant("dOut only in the first mini-batch", m_first_only)
-def m_b2_zero(b):
-    b[9][:, :, 0].zero_()     # b2 checkpoint 0 = initial b2 (the forward re-run regenerates the later ones)
-run_variant("initial b2 = 0", m_b2_zero)
-def m_b2_rand_xv(b):
-    m_b2_zero(b)
-run_variant("initial b2 = 0 (again)", m_b2_rand_xv)
