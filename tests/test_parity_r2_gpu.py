@@ -130,6 +130,51 @@ def test_fused_module_multiscene_vs_reference_lastrow(name, reverse):
     assert rel_l2(g["dual_form_full_tile_y"], ref["y"]) > 1e-3       # and it is NOT the dual form on the full tiles
 
 
+@pytest.mark.parametrize("reverse", [False, True])
+@pytest.mark.parametrize("name", ["mod_lin_multi_lastrow.pt", "mod_mlp_multi64_lastrow.pt"])
+def test_head_sharded_layer_equals_unsharded_hip_path(name, reverse):
+    """Head sharding on ONE rank (the per-rank work of tensor / sequence parallelism, `forward_heads`): running the layer for
+    heads [0, NH/2) and [NH/2, NH) on the HIP path and concatenating must give the unsharded HIP layer - forward, input
+    gradient and every parameter gradient (a rank produces its own heads' rows; the sum over the shards is what
+    `tp_sync_gradients` forms).  Reference: head-local DTensor placements, ttt_layer.py:114-131, mlp_tk.py:297-343."""
+    from ttt_amd.models.cogvideo.utils import SequenceMetadata
+    from ttt_amd.models.configs import ModelConfig
+    from ttt_amd.models.ssm.ttt_layer import TTTWrapper
+    ext()
+    g = load_golden(name)
+    m = TTTWrapper(ModelConfig(**g["cfg"]))
+    m.load_state_dict(g["state_dict"], strict=True)
+    m = m.to(DEV).to(torch.bfloat16)
+    meta = SequenceMetadata(t_emb=torch.zeros(1, 512, device=DEV), **g["meta"])
+    meta.init_multiscene_offsets()
+    dy = g["dy"].to(DEV, torch.bfloat16)
+    NH = m.ttt.num_heads
+    assert NH % 2 == 0
+
+    def run(sharded):
+        m.zero_grad(set_to_none=True)
+        x = g["x"].to(DEV, torch.bfloat16).requires_grad_(True)
+        if sharded:
+            parts = [m.forward_heads(x, meta, reverse, h0, h0 + NH // 2) for h0 in (0, NH // 2)]
+            y = m.ttt.wo(m.ttt.post_norm(torch.cat(parts, dim=-1)))
+        else:
+            y = m(x, meta, reverse)
+        y.backward(dy)
+        torch.cuda.synchronize()
+        return y.detach(), x.grad, {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    y0, dx0, g0 = run(False)
+    y1, dx1, g1 = run(True)
+    errs = {"y": rel_l2(y1, y0), "dx": rel_l2(dx1, dx0)}
+    assert set(g0) == set(g1), set(g0) ^ set(g1)
+    for k in g0:
+        errs[k] = rel_l2(g1[k], g0[k])
+    print(name, "reverse" if reverse else "forward", "two head shards vs unsharded HIP layer:", {k: round(v, 5) for k, v in errs.items()})
+    # same kernels per head; the projections / the post-norm are GEMMs and reductions of other shapes: bf16 rounding only
+    bad = {k: v for k, v in errs.items() if not v < 2e-2}
+    assert not bad, (bad, errs)
+
+
 # ---------------------------------------------------------------------------------- 3. assembled DiT on the HIP path
 @pytest.mark.parametrize("name", ["dit_mlp64_1scene.pt", "dit_lin_1scene.pt", "dit_mlp_3scene.pt"])
 def test_dit_on_hip_path_vs_reference_golden(name):
@@ -248,3 +293,32 @@ def test_bwd_cluster_sweep_handover_forms_and_oracle(shape):
     if B * NH <= 16:
         ro, rc, rg = oracle_on(d, G, "mlp")
         check_per_head(f"cluster backward {shape}", o1, (), g1, ro, (), rg, 1e-2, 3e-2)
+
+
+@pytest.mark.parametrize("shape", [(1, 8, 40, 16, 1), (2, 3, 23, 3, 2), (1, 48, 96, 16, 0), (2, 40, 9, 2, 1)])
+def test_bwd_recompute_under_sweep_same_bits(shape):
+    """The backward walks the sequence in chunks; the group recompute of the NEXT chunk runs on a side stream underneath the
+    sweep of the current one (two slot buffers, csrc/ttt_mfma_bwd2.hip:mlp_backward).  Same kernels, same order per buffer:
+    the gradients must equal the one-stream schedule bit for bit - also when the call is repeated (the buffers and events
+    are reused) and when other work sits on the stream before and after the call.  2 - 5 chunks each; (1, 48, 96, 16) is
+    the benchmarked head count with the automatic chunking (5 groups per chunk)."""
+    e = ext()
+    B, NH, NC, G, gpc = shape
+    d = round_acts(O.make_inputs("mlp", B, NH, NC, 64, 64, seed=900 + NC), torch.bfloat16)
+    res = {}
+    for mode in (0, 1, 1):
+        e.debug_option("overlap_recompute", mode)
+        e.debug_groups_per_chunk(gpc)
+        try:
+            junk = torch.randn(2048, 2048, device=DEV) @ torch.randn(2048, 2048, device=DEV)      # work queued in front
+            res[mode] = run_mlp(e, d, G, torch.bfloat16, impl="mfma")
+            junk = junk @ junk                                                                     # and behind
+        finally:
+            e.debug_option("overlap_recompute", 1)
+            e.debug_groups_per_chunk(0)
+    torch.cuda.synchronize()
+    assert e.sweep_error() == 0
+    (o0, _, g0), (o1, _, g1) = res[0], res[1]
+    assert torch.equal(o0, o1)
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), (k, rel_l2(g1[k], g0[k]))

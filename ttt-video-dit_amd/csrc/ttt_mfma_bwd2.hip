@@ -5,6 +5,9 @@
 //      its checkpoint and stores every intermediate the reverse sweep needs as MFMA register images ("slots", ttt_mfma_dev.h);
 //   B  reverse sweep (ttt_mfma_bwd3.hip): sequential over the chunk's steps, carrying dW1 / dW2 / db1 / db2 / dgamma / dbeta;
 //      FOUR workgroups per (b, h) with role-specialised waves, at most 64 (b, h) per launch (one workgroup per CU);
+//      Phase A of the NEXT chunk runs on a low-priority side stream underneath phase B of the current one (two slot buffers):
+//      the sweep occupies 4 nbh <= 256 CUs with latency-bound work and leaves the HBM idle, the recompute is bound by its slot
+//      writes and needs no result of the sweep;
 //   C  tail (below): dK and dQ need the carried dW1 and the step's dZ1 but nothing downstream needs them, so the sweep stores
 //      those two (bf16 fragment images) and this fully parallel kernel (one workgroup per step) finishes
 //      dK = -eta (gZ1 dW1'^T) + dZ1 W1^T - dt   and   dQ = dOut + dZ1b W1'^T.
@@ -132,6 +135,8 @@ bool bwd_available() { return true; }
 
 static int g_forced_gpc = 0;
 void set_debug_groups_per_chunk(int g) { g_forced_gpc = g; }
+static int g_overlap = 1;             // phase A of the next chunk underneath phase B of the current one; 0 = one stream (DEBUG, A/B)
+void set_debug_overlap_recompute(int v) { g_overlap = v; }
 static int g_fast_records = 1;        // cluster hand-over: plain (L2-resident) records once same-XCD placement is proven; 0 = always write-through
 void set_debug_fast_records(int v) { g_fast_records = v; }
 
@@ -157,9 +162,34 @@ size_t workspace_bytes(const ttt_dims* d, bool mlp, bool backward) {
     if (!mlp || !backward) return 0;
     const size_t nbh = (size_t)d->B * d->NH;
     const size_t slots = (size_t)groups_per_chunk(d) * d->G + 1;
-    // slot buffer + carried state gradient + exchange records and flag lines of the cluster sweep
-    return nbh * (slots * SLOT_BYTES + b2::CARRY_FLOATS2 * sizeof(float)) + align128(nbh * 64) +
+    // two slot buffers + carried state gradient + exchange records and flag lines of the cluster sweep
+    return nbh * (2 * slots * SLOT_BYTES + b2::CARRY_FLOATS2 * sizeof(float)) + align128(nbh * 64) +
            nbh * (b2::XCH_BH_BYTES + 4 * b2::FLAG_STRIDE * sizeof(unsigned));
+}
+
+// Side stream (lowest priority: the sweep's workgroups are placed first, the recompute fills the CUs they leave) and the
+// events of the two-buffer hand-over, one set per device, created on first use.
+struct OverlapRes {
+    hipStream_t side = nullptr;
+    hipEvent_t start = nullptr, filled[2] = {nullptr, nullptr}, drained[2] = {nullptr, nullptr};
+};
+static OverlapRes* overlap_resources() {
+    static OverlapRes res[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    OverlapRes& r = res[dev];
+    if (!r.side) {
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (hipStreamCreateWithPriority(&r.side, hipStreamNonBlocking, least) != hipSuccess) { r.side = nullptr; return nullptr; }
+        bool ok = hipEventCreateWithFlags(&r.start, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; i < 2; ++i) {
+            ok = ok && hipEventCreateWithFlags(&r.filled[i], hipEventDisableTiming) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&r.drained[i], hipEventDisableTiming) == hipSuccess;
+        }
+        if (!ok) return nullptr;
+    }
+    return &r;
 }
 
 void mlp_backward(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hipStream_t s) {
@@ -167,8 +197,9 @@ void mlp_backward(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hipStr
     const int K = (NC + G - 1) / G;
     const int gpc = groups_per_chunk(d);
     const size_t slot_stride = ((size_t)gpc * G + 1) * SLOT_BYTES;
-    char* slots = (char*)ws;
-    float* carry = (float*)(slots + (size_t)nbh * slot_stride);
+    char* slots = (char*)ws;                                   // two buffers of nbh * slot_stride bytes
+    const size_t slot_buf = (size_t)nbh * slot_stride;
+    float* carry = (float*)(slots + 2 * slot_buf);
     char* xch = (char*)(carry + (size_t)nbh * b2::CARRY_FLOATS2) + align128((size_t)nbh * 64);
     unsigned* flags = (unsigned*)(xch + (size_t)nbh * b2::XCH_BH_BYTES);
     const size_t flag_bytes = (size_t)nbh * 4 * b2::FLAG_STRIDE * sizeof(unsigned);
@@ -179,13 +210,13 @@ void mlp_backward(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hipStr
     sp.W1c = const_cast<float*>(a->W1_checkpoints); sp.b1c = const_cast<float*>(a->b1_checkpoints);
     sp.W2c = const_cast<float*>(a->W2_checkpoints); sp.b2c = const_cast<float*>(a->b2_checkpoints);
     sp.NH = d->NH; sp.NC = NC; sp.G = G; sp.K = K; sp.eps = d->eps;
-    sp.slots = slots; sp.slot_stride_bh = slot_stride;
+    sp.slot_stride_bh = slot_stride;
 
     b2::SweepParams2 bp = {};
     bp.XQ = (const __bf16*)a->XQ; bp.XK = (const __bf16*)a->XK; bp.dOut = (const __bf16*)a->grad_L_XQW; bp.eta = (const __bf16*)a->last_eta;
     bp.ln_w = a->ttt_norm_weight;
     bp.uW1 = a->grad_L_W1_last; bp.ub1 = a->grad_L_b1_last; bp.uW2 = a->grad_L_W2_last; bp.ub2 = a->grad_L_b2_last;
-    bp.slots = slots; bp.slot_stride_bh = slot_stride; bp.carry = carry;
+    bp.slot_stride_bh = slot_stride; bp.carry = carry;
     bp.dXV = (__bf16*)a->grad_L_XV; bp.deta = (__bf16*)a->grad_L_last_eta;
     bp.dW1 = a->grad_L_W1_init; bp.db1 = a->grad_L_b1_init; bp.dW2 = a->grad_L_W2_init; bp.db2 = a->grad_L_b2_init;
     bp.dlnw = a->grad_L_ttt_norm_weight; bp.dlnb = a->grad_L_ttt_norm_bias;
@@ -194,7 +225,7 @@ void mlp_backward(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hipStr
 
     b2::TailParams tp = {};
     tp.dOut = (const __bf16*)a->grad_L_XQW; tp.eta = (const __bf16*)a->last_eta; tp.dXV = (const __bf16*)a->grad_L_XV;
-    tp.slots = slots; tp.slot_stride_bh = slot_stride;
+    tp.slot_stride_bh = slot_stride;
     tp.dXQ = (__bf16*)a->grad_L_XQ; tp.dXK = (__bf16*)a->grad_L_XK; tp.NC = NC;
 
     static bool attr = false;
@@ -203,10 +234,36 @@ void mlp_backward(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hipStr
         attr = true;
     }
     const int nchunks = (K + gpc - 1) / gpc;
-    for (int ch = nchunks - 1; ch >= 0; --ch) {
+    OverlapRes* ov = (g_overlap && nchunks > 1) ? overlap_resources() : nullptr;
+    auto recompute = [&](int ch, hipStream_t st) {
         const int g0 = ch * gpc, ng = (K - g0 < gpc) ? K - g0 : gpc;
         sp.chunk_group0 = g0; sp.chunk_groups = ng; sp.chunk_lo = g0 * G;
-        launch_group_recompute(sp, nbh, s);
+        sp.slots = slots + (size_t)(ch & 1) * slot_buf;
+        launch_group_recompute(sp, nbh, st);
+    };
+    if (ov) {
+        // the side stream joins the caller's stream here; every recompute it runs is waited for by a sweep on `s` below,
+        // so the call leaves nothing behind on the side stream
+        (void)hipEventRecord(ov->start, s);
+        (void)hipStreamWaitEvent(ov->side, ov->start, 0);
+        recompute(nchunks - 1, ov->side);
+        (void)hipEventRecord(ov->filled[(nchunks - 1) & 1], ov->side);
+    }
+    for (int ch = nchunks - 1; ch >= 0; --ch) {
+        const int g0 = ch * gpc, ng = (K - g0 < gpc) ? K - g0 : gpc;
+        const int buf = ch & 1;
+        if (ov) {
+            (void)hipStreamWaitEvent(s, ov->filled[buf], 0);
+            if (ch > 0) {
+                // chunk ch-1 goes into the other buffer: free once the tail of chunk ch+1 has read it
+                if (ch + 1 < nchunks) (void)hipStreamWaitEvent(ov->side, ov->drained[buf ^ 1], 0);
+                recompute(ch - 1, ov->side);
+                (void)hipEventRecord(ov->filled[buf ^ 1], ov->side);
+            }
+        } else {
+            recompute(ch, s);
+        }
+        bp.slots = tp.slots = slots + (size_t)buf * slot_buf;
         bp.chunk_lo = g0 * G;
         bp.chunk_hi = ((g0 + ng) * G < NC) ? (g0 + ng) * G : NC;
         bp.first = (ch == nchunks - 1);
@@ -220,6 +277,7 @@ void mlp_backward(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hipStr
         }
         tp.chunk_lo = bp.chunk_lo; tp.chunk_n = bp.chunk_hi - bp.chunk_lo;
         hipLaunchKernelGGL(b2::mlp_bwd_tail_kernel, dim3(nbh * tp.chunk_n), dim3(NT), b2::LDS_TAIL, s, tp);
+        if (ov) (void)hipEventRecord(ov->drained[buf], s);
     }
 }
 

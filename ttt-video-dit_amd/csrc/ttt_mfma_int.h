@@ -35,6 +35,7 @@ void launch_linear_forward_cs16(const wv::Lin16Params& p, int n_bh, hipStream_t 
 void launch_linear_backward_cs16(const wv::Lin16Params& p, int n_bh, hipStream_t s);
 void set_debug_dump(float* buf);
 unsigned long long* get_debug_timing();
+void set_debug_overlap_recompute(int v);   // backward: 1 (default) next chunk's recompute on a side stream under the sweep, 0 one stream
 void set_debug_fast_records(int v);   // cluster sweep: 1 (default) plain records on a proven common XCD, 0 write-through always
 unsigned read_sweep_error();
 unsigned read_sweep_fast_count();   // DEBUG statistic (synchronises)           // 0, or 1 + (b,h) of a cluster workgroup whose partner never arrived (synchronises)

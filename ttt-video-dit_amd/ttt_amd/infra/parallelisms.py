@@ -83,8 +83,8 @@ def tp_sync_gradients(model):
 
 def enable_tuned_gemms(path: str | None = None) -> bool:
     """Plain library GEMMs (projections, MLP) go to hipBLASLt / rocBLAS through PyTorch; this loads a committed
-    solution-selection file for the 5B / 3 s GEMM shapes on gfx950 (produced once with PyTorch TunableOp on an MI355X,
-    ``tools/_run_dbg.sh`` history: the default heuristic picks 0.39 ms kernels for the 18048x3072x3072 projections where
+    solution-selection file for the 5B GEMM shapes of the 3 s and 9 s configurations on gfx950 (produced with PyTorch
+    TunableOp on an MI355X, ``tools/_run_r2i.sh``: the default heuristic picks 0.39 ms kernels for the 18048x3072x3072 projections where
     0.21 ms ones exist).  No tuning happens at run time; shapes that are not in the file, or a file written for another
     library version (its validator lines are checked by PyTorch), fall back to the default heuristic.  Returns whether
     the selections are active."""
