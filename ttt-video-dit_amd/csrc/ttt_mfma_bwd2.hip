@@ -170,7 +170,7 @@ size_t workspace_bytes(const ttt_dims* d, bool mlp, bool backward) {
 // Side stream (lowest priority: the sweep's workgroups are placed first, the recompute fills the CUs they leave) and the
 // events of the two-buffer hand-over, one set per device, created on first use.
 struct OverlapRes {
-    hipStream_t side = nullptr;
+    hipStream_t side = nullptr, side_low = nullptr, side_norm = nullptr;
     hipEvent_t start = nullptr, filled[2] = {nullptr, nullptr}, drained[2] = {nullptr, nullptr};
 };
 static OverlapRes* overlap_resources() {
@@ -178,10 +178,11 @@ static OverlapRes* overlap_resources() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
     OverlapRes& r = res[dev];
-    if (!r.side) {
+    if (!r.side_low) {
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        if (hipStreamCreateWithPriority(&r.side, hipStreamNonBlocking, least) != hipSuccess) { r.side = nullptr; return nullptr; }
+        if (hipStreamCreateWithPriority(&r.side_low, hipStreamNonBlocking, least) != hipSuccess) { r.side_low = nullptr; return nullptr; }
+        if (hipStreamCreateWithFlags(&r.side_norm, hipStreamNonBlocking) != hipSuccess) return nullptr;      // DEBUG A/B (overlap_recompute = 2)
         bool ok = hipEventCreateWithFlags(&r.start, hipEventDisableTiming) == hipSuccess;
         for (int i = 0; i < 2; ++i) {
             ok = ok && hipEventCreateWithFlags(&r.filled[i], hipEventDisableTiming) == hipSuccess;
@@ -189,6 +190,7 @@ static OverlapRes* overlap_resources() {
         }
         if (!ok) return nullptr;
     }
+    r.side = g_overlap == 2 ? r.side_norm : r.side_low;
     return &r;
 }
 
