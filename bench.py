@@ -365,7 +365,7 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False):
     total_mem = torch.cuda.get_device_properties(dev).total_memory
     # share of the device memory the activations may fill: multi-rank runs stay further from the edge, because an
     # out-of-memory error on ONE rank cannot be recovered from while the others sit in a collective
-    cap = 0.92 if world == 1 else 0.80
+    cap = 0.88 if world == 1 else 0.80
     if args.remat_free_layers == "auto":
         # layers in the second probe step: 4 at the 3 s geometry (2.7 GB of activations per layer and sample), 1 for the long
         # videos, whose layers are 3 - 20 x larger; an out-of-memory error in the probe means "none fit"

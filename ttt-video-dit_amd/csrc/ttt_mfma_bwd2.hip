@@ -5,9 +5,11 @@
 //      its checkpoint and stores every intermediate the reverse sweep needs as MFMA register images ("slots", ttt_mfma_dev.h);
 //   B  reverse sweep (ttt_mfma_bwd3.hip): sequential over the chunk's steps, carrying dW1 / dW2 / db1 / db2 / dgamma / dbeta;
 //      FOUR workgroups per (b, h) with role-specialised waves, at most 64 (b, h) per launch (one workgroup per CU);
-//      Phase A of the NEXT chunk runs on a low-priority side stream underneath phase B of the current one (two slot buffers):
-//      the sweep occupies 4 nbh <= 256 CUs with latency-bound work and leaves the HBM idle, the recompute is bound by its slot
-//      writes and needs no result of the sweep;
+//      Phase A of the NEXT chunk runs on a side stream underneath phase B of the current one (two slot buffers): the sweep
+//      occupies 4 nbh <= 256 CUs with latency-bound work and leaves the HBM idle, the recompute is bound by its slot writes
+//      and needs no result of the sweep.  Both become ready at the same moment (when the tail of the chunk before has read
+//      the buffer), and whichever the dispatcher places first must not starve the other: the recompute goes out in launches of at
+//      most as many workgroups as the sweep leaves CUs free (8 per XCD at 48 heads), one after the other;
 //   C  tail (below): dK and dQ need the carried dW1 and the step's dZ1 but nothing downstream needs them, so the sweep stores
 //      those two (bf16 fragment images) and this fully parallel kernel (one workgroup per step) finishes
 //      dK = -eta (gZ1 dW1'^T) + dZ1 W1^T - dt   and   dQ = dOut + dZ1b W1'^T.
@@ -137,6 +139,8 @@ static int g_forced_gpc = 0;
 void set_debug_groups_per_chunk(int g) { g_forced_gpc = g; }
 static int g_overlap = 1;             // phase A of the next chunk underneath phase B of the current one; 0 = one stream (DEBUG, A/B)
 void set_debug_overlap_recompute(int v) { g_overlap = v; }
+static int g_side_wgs = 0;            // DEBUG A/B: workgroups of the recompute launch that runs beside the sweep (0 = the CUs the sweep leaves free)
+void set_debug_side_workgroups(int v) { g_side_wgs = v; }
 static int g_fast_records = 1;        // cluster hand-over: plain (L2-resident) records once same-XCD placement is proven; 0 = always write-through
 void set_debug_fast_records(int v) { g_fast_records = v; }
 
@@ -171,6 +175,7 @@ size_t workspace_bytes(const ttt_dims* d, bool mlp, bool backward) {
 // events of the two-buffer hand-over, one set per device, created on first use.
 struct OverlapRes {
     hipStream_t side = nullptr, side_low = nullptr, side_norm = nullptr;
+    int n_cu = 0;
     hipEvent_t start = nullptr, filled[2] = {nullptr, nullptr}, drained[2] = {nullptr, nullptr};
 };
 static OverlapRes* overlap_resources() {
@@ -189,6 +194,7 @@ static OverlapRes* overlap_resources() {
             ok = ok && hipEventCreateWithFlags(&r.drained[i], hipEventDisableTiming) == hipSuccess;
         }
         if (!ok) return nullptr;
+        if (hipDeviceGetAttribute(&r.n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) r.n_cu = 0;
     }
     r.side = g_overlap == 2 ? r.side_norm : r.side_low;
     return &r;
@@ -237,33 +243,40 @@ void mlp_backward(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hipStr
     }
     const int nchunks = (K + gpc - 1) / gpc;
     OverlapRes* ov = (g_overlap && nchunks > 1) ? overlap_resources() : nullptr;
-    auto recompute = [&](int ch, hipStream_t st) {
+    // CUs the sweep launch leaves free (one cluster workgroup per CU): the recompute that runs beside it gets that many
+    // workgroups, a multiple of 8 (one share per XCD); too few -> one stream
+    int side_wgs = 0;
+    if (ov) {
+        const int sweep_wgs = 4 * (nbh < SWEEP_BH_PER_LAUNCH ? nbh : SWEEP_BH_PER_LAUNCH);
+        side_wgs = g_side_wgs > 0 ? g_side_wgs : ((ov->n_cu - sweep_wgs) / 8) * 8;
+        if (side_wgs < 32) ov = nullptr;
+    }
+    auto recompute = [&](int ch, hipStream_t st, int max_wgs) {
         const int g0 = ch * gpc, ng = (K - g0 < gpc) ? K - g0 : gpc;
         sp.chunk_group0 = g0; sp.chunk_groups = ng; sp.chunk_lo = g0 * G;
         sp.slots = slots + (size_t)(ch & 1) * slot_buf;
-        launch_group_recompute(sp, nbh, st);
+        launch_group_recompute(sp, nbh, max_wgs, st);
     };
     if (ov) {
         // the side stream joins the caller's stream here; every recompute it runs is waited for by a sweep on `s` below,
-        // so the call leaves nothing behind on the side stream
+        // so the call leaves nothing behind on the side stream.  The first chunk has nothing to hide under: whole grid, on `s`.
         (void)hipEventRecord(ov->start, s);
         (void)hipStreamWaitEvent(ov->side, ov->start, 0);
-        recompute(nchunks - 1, ov->side);
-        (void)hipEventRecord(ov->filled[(nchunks - 1) & 1], ov->side);
+        recompute(nchunks - 1, s, 0);
     }
     for (int ch = nchunks - 1; ch >= 0; --ch) {
         const int g0 = ch * gpc, ng = (K - g0 < gpc) ? K - g0 : gpc;
         const int buf = ch & 1;
         if (ov) {
-            (void)hipStreamWaitEvent(s, ov->filled[buf], 0);
+            if (ch < nchunks - 1) (void)hipStreamWaitEvent(s, ov->filled[buf], 0);
             if (ch > 0) {
                 // chunk ch-1 goes into the other buffer: free once the tail of chunk ch+1 has read it
                 if (ch + 1 < nchunks) (void)hipStreamWaitEvent(ov->side, ov->drained[buf ^ 1], 0);
-                recompute(ch - 1, ov->side);
+                recompute(ch - 1, ov->side, side_wgs);
                 (void)hipEventRecord(ov->filled[buf ^ 1], ov->side);
             }
         } else {
-            recompute(ch, s);
+            recompute(ch, s, 0);
         }
         bp.slots = tp.slots = slots + (size_t)buf * slot_buf;
         bp.chunk_lo = g0 * G;
