@@ -295,30 +295,27 @@ def test_bwd_cluster_sweep_handover_forms_and_oracle(shape):
         check_per_head(f"cluster backward {shape}", o1, (), g1, ro, (), rg, 1e-2, 3e-2)
 
 
-@pytest.mark.parametrize("shape", [(1, 8, 40, 16, 1, 3), (2, 3, 23, 3, 2, 0), (1, 48, 96, 16, 0, 0), (2, 40, 9, 2, 1, 32)])
-def test_bwd_recompute_under_sweep_same_bits(shape):
-    """The backward walks the sequence in chunks; the group recompute of the NEXT chunk runs on a side stream underneath the
-    sweep of the current one (two slot buffers, in launches of at most as many workgroups as the sweep leaves CUs free:
-    csrc/ttt_mfma_bwd2.hip:mlp_backward).  Same kernels, same order per buffer: the gradients must equal the one-stream
-    schedule bit for bit - also when the call is repeated (the buffers and events are reused) and when other work sits on
-    the stream before and after the call.  2 - 5 chunks each; (1, 48, 96, 16) is the benchmarked head count with the
-    automatic chunking (5 groups per chunk, 240 work items in launches of 64); the last entry of a shape forces the launch
-    size (0 = automatic; 80 (b,h) leave no CU free, the automatic choice there is one stream)."""
+@pytest.mark.parametrize("shape", [(1, 8, 40, 16, 1), (2, 3, 23, 3, 2), (1, 48, 96, 16, 0), (1, 48, 130, 16, 2), (2, 40, 9, 2, 1)])
+def test_bwd_tail_under_next_sweep_same_bits(shape):
+    """The backward walks the sequence in chunks (recompute A, sweep B, tail C); the tail of chunk c runs on a side stream
+    underneath the sweep of chunk c-1, in two alternating slot buffers (csrc/ttt_mfma_bwd2.hip:mlp_backward).  Same
+    kernels on the same data: every output must equal the one-stream schedule bit for bit - also when the call is repeated
+    (buffers and events are reused) and when other work sits on the stream before and after the call.  2 - 5 chunks each;
+    (1, 48, ...) is the benchmarked head count (automatic chunking, and 2 groups per chunk = 5 chunks); 80 (b,h) leave no CU
+    free beside the sweep: there the schedule falls back to one stream by itself."""
     e = ext()
-    B, NH, NC, G, gpc, side = shape
+    B, NH, NC, G, gpc = shape
     d = round_acts(O.make_inputs("mlp", B, NH, NC, 64, 64, seed=900 + NC), torch.bfloat16)
     res = {}
     for mode in (0, 1, 1):
-        e.debug_option("overlap_recompute", mode)
-        e.debug_option("side_workgroups", side)
+        e.debug_option("overlap_tail", mode)
         e.debug_groups_per_chunk(gpc)
         try:
             junk = torch.randn(2048, 2048, device=DEV) @ torch.randn(2048, 2048, device=DEV)      # work queued in front
             res[mode] = run_mlp(e, d, G, torch.bfloat16, impl="mfma")
             junk = junk @ junk                                                                     # and behind
         finally:
-            e.debug_option("overlap_recompute", 1)
-            e.debug_option("side_workgroups", 0)
+            e.debug_option("overlap_tail", 1)
             e.debug_groups_per_chunk(0)
     torch.cuda.synchronize()
     assert e.sweep_error() == 0

@@ -29,8 +29,7 @@ def main():
     ap.add_argument("--g", type=int, default=16)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--fwd-only", action="store_true")
-    ap.add_argument("--overlap", type=int, default=1, help="DEBUG A/B: TTT-MLP backward, group recompute of the next chunk 1 = on a low-priority side stream under the sweep (default), 0 = one stream, 2 = side stream of normal priority")
-    ap.add_argument("--side-wgs", type=int, default=0, help="DEBUG A/B: workgroups of the recompute launch that runs beside the sweep (0 = the CUs the sweep leaves free)")
+    ap.add_argument("--overlap", type=int, default=1, help="DEBUG A/B: TTT-MLP backward, tail kernel of a chunk 1 = on a side stream under the next sweep (default), 0 = one stream")
     ap.add_argument("--gpc", type=int, default=0, help="DEBUG A/B: checkpoint groups per backward chunk (0 = automatic)")
     ap.add_argument("--write-through-records", action="store_true", help="DEBUG A/B: the backward sweep's hand-over records always write-through (sc1), never plain")
     ap.add_argument("--phases", action="store_true", help="also print per-phase cycle totals of workgroup 0")
@@ -41,9 +40,8 @@ def main():
     ext.load_library()
     ext.set_impl(a.impl)
     ext.debug_option("fast_records", 0 if a.write_through_records else 1)
-    ext.debug_option("overlap_recompute", a.overlap)
+    ext.debug_option("overlap_tail", a.overlap)
     ext.debug_option("groups_per_chunk", a.gpc)
-    ext.debug_option("side_workgroups", a.side_wgs)
     dev = torch.device("cuda:0")
     B, NH, NC, CS, F, G = a.b, a.nh, a.nc, a.cs, 64, a.g
     H = 4 * F if a.kind == "mlp" else F

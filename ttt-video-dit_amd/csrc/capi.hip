@@ -57,8 +57,7 @@ int ttt_hip_debug_option(const char* name, int value) {
     if (!name) return -1;
     if (!strcmp(name, "fast_records")) ttt::mfma::set_debug_fast_records(value);              // cluster sweep hand-over: 1 (default) / 0 = write-through records always
     else if (!strcmp(name, "sweep_fast_count")) return -2 - (int)ttt::mfma::read_sweep_fast_count();      // query: returns -2 - count
-    else if (!strcmp(name, "overlap_recompute")) ttt::mfma::set_debug_overlap_recompute(value);  // backward: 1 (default) / 0 = recompute and sweep on one stream
-    else if (!strcmp(name, "side_workgroups")) ttt::mfma::set_debug_side_workgroups(value);
+    else if (!strcmp(name, "overlap_tail")) ttt::mfma::set_debug_overlap_tail(value);            // backward: 1 (default) / 0 = tail kernel on the caller's stream
     else if (!strcmp(name, "groups_per_chunk")) ttt::mfma::set_debug_groups_per_chunk(value);
     else return -1;
     return 0;

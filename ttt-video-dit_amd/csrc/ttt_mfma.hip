@@ -91,11 +91,9 @@ __global__ __launch_bounds__(NT, 1) void mlp_scan_kernel(ScanParams p) {
 
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63, h = l >> 5, c = l & 31;
     const int NC = p.NC, G = p.G;
-    // forward: one workgroup per (b,h), all steps.  SAVE: one workgroup per work item (b,h,group of the chunk); a chunk may be
-    // spread over several launches (item0 = first item of this one).
-    const int item = SAVE ? p.item0 + (int)blockIdx.x : (int)blockIdx.x;
-    const int bh = SAVE ? item / p.chunk_groups : item;
-    const int grp = SAVE ? p.chunk_group0 + item % p.chunk_groups : 0;
+    // forward: one workgroup per (b,h), all steps.  SAVE: one workgroup per (b,h,group of the chunk).
+    const int bh = SAVE ? blockIdx.x / p.chunk_groups : blockIdx.x;
+    const int grp = SAVE ? p.chunk_group0 + blockIdx.x % p.chunk_groups : 0;
     const int i_lo = SAVE ? grp * G : 0;
     const int i_hi = SAVE ? min(i_lo + G, NC) : NC;
     const int head = bh % p.NH;
@@ -502,18 +500,11 @@ static void set_lds_attr_once() {
     }
 }
 
-// max_workgroups > 0: the chunk's work items go out as consecutive launches of at most that many workgroups (the launches
-// that run beside the reverse sweep are limited to the CUs the sweep leaves free; same stream, so they follow one another)
-void launch_group_recompute(const ScanParams& p0, int n_bh, int max_workgroups, hipStream_t s) {
+void launch_group_recompute(const ScanParams& p0, int n_bh, hipStream_t s) {
     ScanParams p = p0;
     p.dbg = nullptr;
     set_lds_attr_once();
-    const int n_items = n_bh * p.chunk_groups;
-    const int per = (max_workgroups > 0 && max_workgroups < n_items) ? max_workgroups : n_items;
-    for (int i0 = 0; i0 < n_items; i0 += per) {
-        p.item0 = i0;
-        hipLaunchKernelGGL(mlp_scan_kernel<true>, dim3(n_items - i0 < per ? n_items - i0 : per), dim3(NT), LDS_FWD, s, p);
-    }
+    hipLaunchKernelGGL(mlp_scan_kernel<true>, dim3(n_bh * p.chunk_groups), dim3(NT), LDS_FWD, s, p);
 }
 
 bool supports(const ttt_dims* d, bool mlp, bool backward) {

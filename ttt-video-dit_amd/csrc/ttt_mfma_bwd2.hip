@@ -5,14 +5,14 @@
 //      its checkpoint and stores every intermediate the reverse sweep needs as MFMA register images ("slots", ttt_mfma_dev.h);
 //   B  reverse sweep (ttt_mfma_bwd3.hip): sequential over the chunk's steps, carrying dW1 / dW2 / db1 / db2 / dgamma / dbeta;
 //      FOUR workgroups per (b, h) with role-specialised waves, at most 64 (b, h) per launch (one workgroup per CU);
-//      Phase A of the NEXT chunk runs on a side stream underneath phase B of the current one (two slot buffers): the sweep
-//      occupies 4 nbh <= 256 CUs with latency-bound work and leaves the HBM idle, the recompute is bound by its slot writes
-//      and needs no result of the sweep.  Both become ready at the same moment (when the tail of the chunk before has read
-//      the buffer), and whichever the dispatcher places first must not starve the other: the recompute goes out in launches of at
-//      most as many workgroups as the sweep leaves CUs free (8 per XCD at 48 heads), one after the other;
 //   C  tail (below): dK and dQ need the carried dW1 and the step's dZ1 but nothing downstream needs them, so the sweep stores
 //      those two (bf16 fragment images) and this fully parallel kernel (one workgroup per step) finishes
 //      dK = -eta (gZ1 dW1'^T) + dZ1 W1^T - dt   and   dQ = dOut + dZ1b W1'^T.
+//      The tail of chunk c runs on a side stream UNDER the sweep of chunk c-1 (two slot buffers): the sweep is latency-bound on
+//      4 nbh <= 256 CUs, the tail's small workgroups fill the CUs it leaves free.  (The other pairing - the recompute of the
+//      next chunk under the sweep - was measured and removed: each recompute workgroup is bound by its own CU's store path,
+//      ~0.5 ms for 16 steps however many run, so on the 64 free CUs the chunk takes 1.9 ms, longer than the sweep it would
+//      hide under, and without a limit its 240 workgroups win the dispatch race and the sweep waits: profiles/r2k_*, r2l_*.)
 // History: revision 1 (4-wave sweep, 17.3 ms per backward at the 3 s geometry), revision 2 (8-wave single-workgroup sweep with
 // prefetch-helper workgroups, 8.4 ms) were removed in round 2; revision 2's sweep was found to be inaccurate on model-like inputs
 // (output bias dominating Z2: dW1 / dW2 / dK off by 20 - 50 % although every random-input oracle test passed; found by the
@@ -137,10 +137,8 @@ bool bwd_available() { return true; }
 
 static int g_forced_gpc = 0;
 void set_debug_groups_per_chunk(int g) { g_forced_gpc = g; }
-static int g_overlap = 1;             // phase A of the next chunk underneath phase B of the current one; 0 = one stream (DEBUG, A/B)
-void set_debug_overlap_recompute(int v) { g_overlap = v; }
-static int g_side_wgs = 0;            // DEBUG A/B: workgroups of the recompute launch that runs beside the sweep (0 = the CUs the sweep leaves free)
-void set_debug_side_workgroups(int v) { g_side_wgs = v; }
+static int g_overlap = 1;             // tail of chunk c on a side stream under the sweep of chunk c-1; 0 = one stream (DEBUG, A/B)
+void set_debug_overlap_tail(int v) { g_overlap = v; }
 static int g_fast_records = 1;        // cluster hand-over: plain (L2-resident) records once same-XCD placement is proven; 0 = always write-through
 void set_debug_fast_records(int v) { g_fast_records = v; }
 
@@ -171,32 +169,27 @@ size_t workspace_bytes(const ttt_dims* d, bool mlp, bool backward) {
            nbh * (b2::XCH_BH_BYTES + 4 * b2::FLAG_STRIDE * sizeof(unsigned));
 }
 
-// Side stream (lowest priority: the sweep's workgroups are placed first, the recompute fills the CUs they leave) and the
-// events of the two-buffer hand-over, one set per device, created on first use.
+// Side stream and the events of the two-buffer hand-over, one set per device, created on first use.
 struct OverlapRes {
-    hipStream_t side = nullptr, side_low = nullptr, side_norm = nullptr;
+    hipStream_t side = nullptr;
+    hipEvent_t ready[2] = {nullptr, nullptr}, tail_done[2] = {nullptr, nullptr};
     int n_cu = 0;
-    hipEvent_t start = nullptr, filled[2] = {nullptr, nullptr}, drained[2] = {nullptr, nullptr};
 };
 static OverlapRes* overlap_resources() {
     static OverlapRes res[16];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
     OverlapRes& r = res[dev];
-    if (!r.side_low) {
-        int least = 0, greatest = 0;
-        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        if (hipStreamCreateWithPriority(&r.side_low, hipStreamNonBlocking, least) != hipSuccess) { r.side_low = nullptr; return nullptr; }
-        if (hipStreamCreateWithFlags(&r.side_norm, hipStreamNonBlocking) != hipSuccess) return nullptr;      // DEBUG A/B (overlap_recompute = 2)
-        bool ok = hipEventCreateWithFlags(&r.start, hipEventDisableTiming) == hipSuccess;
+    if (!r.side) {
+        if (hipStreamCreateWithFlags(&r.side, hipStreamNonBlocking) != hipSuccess) { r.side = nullptr; return nullptr; }
+        bool ok = true;
         for (int i = 0; i < 2; ++i) {
-            ok = ok && hipEventCreateWithFlags(&r.filled[i], hipEventDisableTiming) == hipSuccess;
-            ok = ok && hipEventCreateWithFlags(&r.drained[i], hipEventDisableTiming) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&r.ready[i], hipEventDisableTiming) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&r.tail_done[i], hipEventDisableTiming) == hipSuccess;
         }
         if (!ok) return nullptr;
         if (hipDeviceGetAttribute(&r.n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) r.n_cu = 0;
     }
-    r.side = g_overlap == 2 ? r.side_norm : r.side_low;
     return &r;
 }
 
@@ -242,42 +235,23 @@ void mlp_backward(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hipStr
         attr = true;
     }
     const int nchunks = (K + gpc - 1) / gpc;
+    // the side stream needs CUs beside the sweep's workgroups (one per CU): otherwise one stream
     OverlapRes* ov = (g_overlap && nchunks > 1) ? overlap_resources() : nullptr;
-    // CUs the sweep launch leaves free (one cluster workgroup per CU): the recompute that runs beside it gets that many
-    // workgroups, a multiple of 8 (one share per XCD); too few -> one stream
-    int side_wgs = 0;
-    if (ov) {
-        const int sweep_wgs = 4 * (nbh < SWEEP_BH_PER_LAUNCH ? nbh : SWEEP_BH_PER_LAUNCH);
-        side_wgs = g_side_wgs > 0 ? g_side_wgs : ((ov->n_cu - sweep_wgs) / 8) * 8;
-        if (side_wgs < 32) ov = nullptr;
-    }
-    auto recompute = [&](int ch, hipStream_t st, int max_wgs) {
+    if (ov && ov->n_cu - 4 * (nbh < SWEEP_BH_PER_LAUNCH ? nbh : SWEEP_BH_PER_LAUNCH) < 32) ov = nullptr;
+    auto recompute = [&](int ch) {
         const int g0 = ch * gpc, ng = (K - g0 < gpc) ? K - g0 : gpc;
         sp.chunk_group0 = g0; sp.chunk_groups = ng; sp.chunk_lo = g0 * G;
         sp.slots = slots + (size_t)(ch & 1) * slot_buf;
-        launch_group_recompute(sp, nbh, max_wgs, st);
+        launch_group_recompute(sp, nbh, s);
     };
-    if (ov) {
-        // the side stream joins the caller's stream here; every recompute it runs is waited for by a sweep on `s` below,
-        // so the call leaves nothing behind on the side stream.  The first chunk has nothing to hide under: whole grid, on `s`.
-        (void)hipEventRecord(ov->start, s);
-        (void)hipStreamWaitEvent(ov->side, ov->start, 0);
-        recompute(nchunks - 1, s, 0);
-    }
+    // Stream `s`:   A(n-1) B(n-1) A(n-2) B(n-2) ... A(0) B(0)          (chunk c in slot buffer c & 1)
+    // side stream:                C(n-1) under B(n-2), ...,  C(1) under B(0), C(0)
+    // C(c) starts when A(c-1) is complete - the moment B(c-1) starts, not earlier: beside the recompute there is no free CU -
+    // and A(c-2), which overwrites C(c)'s buffer, waits for it.  `s` joins the side stream before the call returns.
+    recompute(nchunks - 1);
     for (int ch = nchunks - 1; ch >= 0; --ch) {
         const int g0 = ch * gpc, ng = (K - g0 < gpc) ? K - g0 : gpc;
         const int buf = ch & 1;
-        if (ov) {
-            if (ch < nchunks - 1) (void)hipStreamWaitEvent(s, ov->filled[buf], 0);
-            if (ch > 0) {
-                // chunk ch-1 goes into the other buffer: free once the tail of chunk ch+1 has read it
-                if (ch + 1 < nchunks) (void)hipStreamWaitEvent(ov->side, ov->drained[buf ^ 1], 0);
-                recompute(ch - 1, ov->side, side_wgs);
-                (void)hipEventRecord(ov->filled[buf ^ 1], ov->side);
-            }
-        } else {
-            recompute(ch, s, 0);
-        }
         bp.slots = tp.slots = slots + (size_t)buf * slot_buf;
         bp.chunk_lo = g0 * G;
         bp.chunk_hi = ((g0 + ng) * G < NC) ? (g0 + ng) * G : NC;
@@ -291,9 +265,21 @@ void mlp_backward(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hipStr
             launch_sweep_cluster(bp, bp.nbh, s);
         }
         tp.chunk_lo = bp.chunk_lo; tp.chunk_n = bp.chunk_hi - bp.chunk_lo;
-        hipLaunchKernelGGL(b2::mlp_bwd_tail_kernel, dim3(nbh * tp.chunk_n), dim3(NT), b2::LDS_TAIL, s, tp);
-        if (ov) (void)hipEventRecord(ov->drained[buf], s);
+        if (ch > 0) {
+            // chunk ch-1 goes into the other buffer, last read by the tail of chunk ch+1
+            if (ov && ch + 1 < nchunks) (void)hipStreamWaitEvent(s, ov->tail_done[buf ^ 1], 0);
+            recompute(ch - 1);
+        }
+        if (ov) {
+            (void)hipEventRecord(ov->ready[buf], s);
+            (void)hipStreamWaitEvent(ov->side, ov->ready[buf], 0);
+            hipLaunchKernelGGL(b2::mlp_bwd_tail_kernel, dim3(nbh * tp.chunk_n), dim3(NT), b2::LDS_TAIL, ov->side, tp);
+            (void)hipEventRecord(ov->tail_done[buf], ov->side);
+        } else {
+            hipLaunchKernelGGL(b2::mlp_bwd_tail_kernel, dim3(nbh * tp.chunk_n), dim3(NT), b2::LDS_TAIL, s, tp);
+        }
     }
+    if (ov) (void)hipStreamWaitEvent(s, ov->tail_done[0], 0);      // C(0) is the side stream's last command
 }
 
 }  // namespace mfma

@@ -20,12 +20,11 @@ struct ScanParams {
     char* slots;                           // base of the slot area; slot s of (b,h) <-> step chunk_lo + s
     size_t slot_stride_bh;                 // bytes between consecutive (b,h) slot areas
     int chunk_group0, chunk_groups, chunk_lo;
-    int item0;                             // first (b,h,group) work item of this launch (set by launch_group_recompute)
     unsigned long long* dbg;               // optional per-phase cycle totals of workgroup 0
     float* dump;                           // DEBUG: intermediates of workgroup 0, step 0 (revision-2 forward)
 };
 
-void launch_group_recompute(const ScanParams& p, int n_bh, int max_workgroups, hipStream_t s);   // max_workgroups 0 = one launch
+void launch_group_recompute(const ScanParams& p, int n_bh, hipStream_t s);
 bool bwd_available();
 int groups_per_chunk(const ttt_dims* d);
 // revision-2 forward scan (ttt_mfma2.hip): 8 waves per (b,h), VGPR-form MFMA, LDS transposed reads
@@ -36,8 +35,7 @@ void launch_linear_forward_cs16(const wv::Lin16Params& p, int n_bh, hipStream_t 
 void launch_linear_backward_cs16(const wv::Lin16Params& p, int n_bh, hipStream_t s);
 void set_debug_dump(float* buf);
 unsigned long long* get_debug_timing();
-void set_debug_overlap_recompute(int v);   // backward: 1 (default) next chunk's recompute on a side stream under the sweep, 0 one stream
-void set_debug_side_workgroups(int v);    // DEBUG A/B: size of the recompute launch beside the sweep (0 = automatic)
+void set_debug_overlap_tail(int v);   // backward: 1 (default) tail of chunk c on a side stream under the sweep of chunk c-1, 0 one stream
 void set_debug_fast_records(int v);   // cluster sweep: 1 (default) plain records on a proven common XCD, 0 write-through always
 unsigned read_sweep_error();
 unsigned read_sweep_fast_count();   // DEBUG statistic (synchronises)           // 0, or 1 + (b,h) of a cluster workgroup whose partner never arrived (synchronises)
