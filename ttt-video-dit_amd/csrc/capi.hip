@@ -146,7 +146,7 @@ int ttt_hip_linear_backward(const ttt_dims* d, const ttt_linear_bwd_args* a, voi
 static int check_pp(int B, int L, int NH, int F) {
     if (B <= 0 || L <= 0 || NH <= 0) return fail("ttt_hip: non-positive dimension");
     if (F != 64) return fail("ttt_hip: fused pre/post kernels need head_dim 64");
-    if (NH * 8 > 1024) return fail("ttt_hip: too many heads for the post kernels");
+    if (NH * 8 > 512) return fail("ttt_hip: too many heads for the post kernels (one block of NH * 8 <= 512 threads per token)");
     return 0;
 }
 
@@ -296,7 +296,7 @@ int ttt_hip_attn_pre_backward(int B, int S, int NH, int n_text, float eps, const
 
 static int check_glue_dims(int B, int Lt, int Lv, int D) {
     if (B <= 0 || Lt < 0 || Lv < 0 || Lt + Lv <= 0 || D <= 0 || (D & 7)) return fail("ttt_hip: glue kernels: bad dimension (D must be a multiple of 8)");
-    if (D > 8 * 1024) return fail("ttt_hip: glue kernels: D too large for one block per token");
+    if (D > 8 * 512) return fail("ttt_hip: glue kernels: D too large for one block per token (D / 8 <= 512 threads)");
     return 0;
 }
 int ttt_hip_adaln_backward_partials(void) { return ttt::prepost::adaln_backward_partials(); }

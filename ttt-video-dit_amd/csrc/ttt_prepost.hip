@@ -226,6 +226,36 @@ __device__ __forceinline__ float block_sum(float v, float* sh, int nw) {
     return t;
 }
 
+// N sums at once (N values per thread, same summation order per value as block_sum): two barriers for all of them.
+// `sh` holds N x 16 floats.
+template <int N>
+__device__ __forceinline__ void block_sum_n(float (&v)[N], float* sh, int nw) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        float x = sum8(v[k]);
+        x += __shfl_xor(x, 8, 64);
+        x += __shfl_xor(x, 16, 64);
+        x += __shfl_xor(x, 32, 64);
+        v[k] = x;
+    }
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) sh[k * 16 + w] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        float t = 0.f;
+        for (int i = 0; i < nw; ++i) t += sh[k * 16 + i];
+        v[k] = t;
+    }
+}
+// tokens a block of the two LayerNorm backward kernels works on at once (their loads are issued one group ahead)
+constexpr int LN_BWD_T = 4;
+constexpr int LN_BWD_MAX_THREADS = 512;      // 8 features per thread: rows of up to 4096 features (two waves per SIMD, 256 VGPRs each)
+
 __global__ void post_fwd_kernel(PostArgs a) {
     __shared__ float sh[16];
     const int D = a.NH * 64, nw = blockDim.x >> 6;     // blockDim = NH*8 rounded up to whole waves
@@ -256,46 +286,94 @@ __global__ void post_fwd_kernel(PostArgs a) {
     }
 }
 
-__global__ void post_bwd_kernel(PostBwdArgs a) {
-    __shared__ float sh[16];
+// One block per token as in the forward, but LN_BWD_T tokens per iteration: their four row reductions share two barriers
+// each (three reductions: mean | variance | the two backward sums together), and the next group's loads are issued before the
+// current group is reduced.  (The one-token form spent a token's time in 8 barriers and one exposed HBM round trip: 1.9 TB/s.)
+// Per-token arithmetic and the order in which a block accumulates its parameter-gradient partials are those of the
+// one-token form.
+__global__ __launch_bounds__(LN_BWD_MAX_THREADS) void post_bwd_kernel(PostBwdArgs a) {
+    constexpr int T = LN_BWD_T;
+    __shared__ float sh[2 * T * 16];
     const int D = a.NH * 64, nw = blockDim.x >> 6;
     const int h = threadIdx.x >> 3, o = threadIdx.x & 7;
     const bool act = h < a.NH;
+    const long n_tok = (long)a.B * a.L, stride = gridDim.x;
     float w8[8], dw[8], db[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { dw[j] = 0.f; db[j] = 0.f; w8[j] = 0.f; }
     if (act) ldf8(a.w + h * 64 + 8 * o, w8);
-    for (long bt = blockIdx.x; bt < (long)a.B * a.L; bt += gridDim.x) {
-        const int tp = bt % a.L, b = bt / a.L;
-        const int src = a.src ? a.src[tp] : tp;
-        const size_t yoff = (((size_t)b * a.NH + h) * a.L + tp) * 64 + 8 * o;
-        float y[8], g[8];
+    float y[T][8], g[T][8], yn[T][8], gn[T][8];
+    auto load = [&](long bt0, float (&Y)[T][8], float (&G)[T][8]) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { y[j] = 0.f; g[j] = 0.f; }
-        if (act) { ld8(a.Y + yoff, y); ld8(a.dOut + ((size_t)b * a.L + src) * D + h * 64 + 8 * o, g); }
-        float s = 0.f;
+        for (int k = 0; k < T; ++k) {
+            const long bt = bt0 + k * stride;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s += y[j];
-        const float mean = block_sum(s, sh, nw) / D;
-        float vs = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { y[j] = act ? y[j] - mean : 0.f; vs += y[j] * y[j]; }
-        const float rstd = 1.0f / sqrtf(block_sum(vs, sh, nw) / D + a.eps);
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            y[j] *= rstd;                    // x_hat
-            dw[j] += g[j] * y[j];
-            db[j] += g[j];
-            g[j] *= w8[j];
-            s1 += g[j];
-            s2 += g[j] * y[j];
+            for (int j = 0; j < 8; ++j) { Y[k][j] = 0.f; G[k][j] = 0.f; }
+            if (act && bt < n_tok) {
+                const int tp = bt % a.L, b = bt / a.L;
+                const int src = a.src ? a.src[tp] : tp;
+                ld8(a.Y + (((size_t)b * a.NH + h) * a.L + tp) * 64 + 8 * o, Y[k]);
+                ld8(a.dOut + ((size_t)b * a.L + src) * D + h * 64 + 8 * o, G[k]);
+            }
         }
-        s1 = block_sum(s1, sh, nw) / D;
-        s2 = block_sum(s2, sh, nw) / D;
+    };
+    load(blockIdx.x, y, g);
+    for (long bt0 = blockIdx.x; bt0 < n_tok; bt0 += T * stride) {
+        const long nx = bt0 + T * stride;
+        if (nx < n_tok) load(nx, yn, gn);
+        float r[T];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) g[j] = (g[j] - s1 - y[j] * s2) * rstd;
-        if (act) st8(a.dY + yoff, g);
+        for (int k = 0; k < T; ++k) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += y[k][j];
+            r[k] = s;
+        }
+        block_sum_n<T>(r, sh, nw);
+        float rstd[T];
+#pragma unroll
+        for (int k = 0; k < T; ++k) {
+            const float mean = r[k] / D;
+            float vs = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { y[k][j] = act ? y[k][j] - mean : 0.f; vs += y[k][j] * y[k][j]; }
+            r[k] = vs;
+        }
+        block_sum_n<T>(r, sh, nw);
+        float r2[2 * T];
+#pragma unroll
+        for (int k = 0; k < T; ++k) {
+            rstd[k] = 1.0f / sqrtf(r[k] / D + a.eps);
+            const bool valid = bt0 + k * stride < n_tok;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                y[k][j] *= rstd[k];                    // x_hat
+                if (valid) { dw[j] += g[k][j] * y[k][j]; db[j] += g[k][j]; }
+                g[k][j] *= w8[j];
+                s1 += g[k][j];
+                s2 += g[k][j] * y[k][j];
+            }
+            r2[k] = s1;
+            r2[T + k] = s2;
+        }
+        block_sum_n<2 * T>(r2, sh, nw);
+#pragma unroll
+        for (int k = 0; k < T; ++k) {
+            const long bt = bt0 + k * stride;
+            if (act && bt < n_tok) {
+                const float s1 = r2[k] / D, s2 = r2[T + k] / D;
+                float out[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) out[j] = (g[k][j] - s1 - y[k][j] * s2) * rstd[k];
+                const int tp = bt % a.L, b = bt / a.L;
+                st8(a.dY + (((size_t)b * a.NH + h) * a.L + tp) * 64 + 8 * o, out);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < T; ++k)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { y[k][j] = yn[k][j]; g[k][j] = gn[k][j]; }
     }
     if (act) {
         float* pw = a.dw_part + (size_t)blockIdx.x * D + h * 64 + 8 * o;
@@ -401,51 +479,93 @@ __global__ void adaln_fwd_kernel(AdaLNArgs a) {
 // backward: d_in = LN'(dOut * scale1p) ; parameter-gradient partials, one row per block:
 //   part[blk][0] = dw, [1] = db (LayerNorm), [2] = d scale1p, [3] = d shift  for the (batch, group) the block works on
 // (block blk handles batch blk / (2 P), group (blk / P) % 2; the caller reduces over the P blocks of a (batch, group)).
-__global__ void adaln_bwd_kernel(AdaLNBwdArgs a) {
-    __shared__ float sh[16];
+// LN_BWD_T tokens per iteration, next group's loads in flight, as in post_bwd_kernel (the one-token form ran at 1.2 TB/s).
+__global__ __launch_bounds__(LN_BWD_MAX_THREADS) void adaln_bwd_kernel(AdaLNBwdArgs a) {
+    constexpr int T = LN_BWD_T;
+    __shared__ float sh[2 * T * 16];
     const int D = a.D, nw = blockDim.x >> 6, L = a.Lt + a.Lv;
     const int o8 = threadIdx.x * 8;
     const bool act = o8 < D;
     const int P = a.P;
     const int b = blockIdx.x / (2 * P), g = (blockIdx.x / P) % 2, pi = blockIdx.x % P;
     const int n_tok = g == 0 ? a.Lt : a.Lv, t0 = g == 0 ? 0 : a.Lt;
+    const __bf16* src0 = g == 0 ? a.text + (size_t)b * a.Lt * D : a.vid + (size_t)b * a.Lv * D;
+    __bf16* dst0 = g == 0 ? a.dtext + (size_t)b * a.Lt * D : a.dvid + (size_t)b * a.Lv * D;
+    const __bf16* dout0 = a.dout + ((size_t)b * L + t0) * D;
     float w8[8], b8[8], sc[8], dw[8], db[8], dsc[8], dsh[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { w8[j] = 0.f; b8[j] = 0.f; sc[j] = 0.f; dw[j] = 0.f; db[j] = 0.f; dsc[j] = 0.f; dsh[j] = 0.f; }
     if (act) { ldf8(a.w + o8, w8); ldf8(a.b + o8, b8); ldf8(a.scale1p + ((size_t)b * 2 + g) * D + o8, sc); }
-    for (int tt = pi; tt < n_tok; tt += P) {
-        const __bf16* src = g == 0 ? a.text + ((size_t)b * a.Lt + tt) * D : a.vid + ((size_t)b * a.Lv + tt) * D;
-        __bf16* dst = g == 0 ? a.dtext + ((size_t)b * a.Lt + tt) * D : a.dvid + ((size_t)b * a.Lv + tt) * D;
-        float x[8], gy[8];
+    float x[T][8], gy[T][8], xn[T][8], gn[T][8];
+    auto load = [&](int tt0, float (&X)[T][8], float (&G)[T][8]) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { x[j] = 0.f; gy[j] = 0.f; }
-        if (act) { ld8(src + o8, x); ld8(a.dout + ((size_t)b * L + t0 + tt) * D + o8, gy); }
-        float s = 0.f;
+        for (int k = 0; k < T; ++k) {
+            const int tt = tt0 + k * P;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s += x[j];
-        const float mean = block_sum(s, sh, nw) / D;
-        float vs = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { x[j] = act ? x[j] - mean : 0.f; vs += x[j] * x[j]; }
-        const float rstd = 1.0f / sqrtf(block_sum(vs, sh, nw) / D + a.eps);
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            x[j] *= rstd;                                                // x_hat
-            dsh[j] += gy[j];
-            dsc[j] += gy[j] * bf16_round(x[j] * w8[j] + b8[j]);          // d(scale1p): dOut * LN output
-            gy[j] *= sc[j];                                              // gradient w.r.t. the LN output
-            dw[j] += gy[j] * x[j];
-            db[j] += gy[j];
-            gy[j] *= w8[j];
-            s1 += gy[j];
-            s2 += gy[j] * x[j];
+            for (int j = 0; j < 8; ++j) { X[k][j] = 0.f; G[k][j] = 0.f; }
+            if (act && tt < n_tok) { ld8(src0 + (size_t)tt * D + o8, X[k]); ld8(dout0 + (size_t)tt * D + o8, G[k]); }
         }
-        s1 = block_sum(s1, sh, nw) / D;
-        s2 = block_sum(s2, sh, nw) / D;
+    };
+    load(pi, x, gy);
+    for (int tt0 = pi; tt0 < n_tok; tt0 += T * P) {
+        const int nx = tt0 + T * P;
+        if (nx < n_tok) load(nx, xn, gn);
+        float r[T];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) gy[j] = (gy[j] - s1 - x[j] * s2) * rstd;
-        if (act) st8(dst + o8, gy);
+        for (int k = 0; k < T; ++k) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += x[k][j];
+            r[k] = s;
+        }
+        block_sum_n<T>(r, sh, nw);
+#pragma unroll
+        for (int k = 0; k < T; ++k) {
+            const float mean = r[k] / D;
+            float vs = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { x[k][j] = act ? x[k][j] - mean : 0.f; vs += x[k][j] * x[k][j]; }
+            r[k] = vs;
+        }
+        block_sum_n<T>(r, sh, nw);
+        float rstd[T], r2[2 * T];
+#pragma unroll
+        for (int k = 0; k < T; ++k) {
+            rstd[k] = 1.0f / sqrtf(r[k] / D + a.eps);
+            const bool valid = tt0 + k * P < n_tok;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                x[k][j] *= rstd[k];                                              // x_hat
+                if (valid) {
+                    dsh[j] += gy[k][j];
+                    dsc[j] += gy[k][j] * bf16_round(x[k][j] * w8[j] + b8[j]);    // d(scale1p): dOut * LN output
+                }
+                gy[k][j] *= sc[j];                                               // gradient w.r.t. the LN output
+                if (valid) { dw[j] += gy[k][j] * x[k][j]; db[j] += gy[k][j]; }
+                gy[k][j] *= w8[j];
+                s1 += gy[k][j];
+                s2 += gy[k][j] * x[k][j];
+            }
+            r2[k] = s1;
+            r2[T + k] = s2;
+        }
+        block_sum_n<2 * T>(r2, sh, nw);
+#pragma unroll
+        for (int k = 0; k < T; ++k) {
+            const int tt = tt0 + k * P;
+            if (act && tt < n_tok) {
+                const float s1 = r2[k] / D, s2 = r2[T + k] / D;
+                float out[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) out[j] = (gy[k][j] - s1 - x[k][j] * s2) * rstd[k];
+                st8(dst0 + (size_t)tt * D + o8, out);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < T; ++k)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { x[k][j] = xn[k][j]; gy[k][j] = gn[k][j]; }
     }
     if (act) {
         float* pr = a.part + (size_t)blockIdx.x * 4 * D + o8;
