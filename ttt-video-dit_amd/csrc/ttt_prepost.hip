@@ -36,6 +36,42 @@ __device__ __forceinline__ void ld8(const __bf16* p, float (&o)[8]) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = (float)a[j];
 }
+__device__ __forceinline__ bf16x8 ld8_raw(const __bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ bf16x8 zero8_raw() {
+    bf16x8 z;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] = (__bf16)0.0f;
+    return z;
+}
+// The loads of the group in flight have landed - said to the COMPILER: the wait sits here, in front of the next group's
+// loads, and the registers leave the asm as plain values.  (Left to itself hipcc hoists the next group's loads above the
+// first use of this group's data and then has to wait for both: the prefetch never overlaps anything.)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void settle4(bf16x8 (&a)[4], bf16x8 (&b)[4]) {
+    u32x4 r[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { r[k] = __builtin_bit_cast(u32x4, a[k]); r[4 + k] = __builtin_bit_cast(u32x4, b[k]); }
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
+                 :: "memory");
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { a[k] = __builtin_bit_cast(bf16x8, r[k]); b[k] = __builtin_bit_cast(bf16x8, r[4 + k]); }
+}
+__device__ __forceinline__ void settle4(bf16x8 (&a)[4], bf16x8 (&b)[4], int (&c)[4]) {
+    u32x4 r[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { r[k] = __builtin_bit_cast(u32x4, a[k]); r[4 + k] = __builtin_bit_cast(u32x4, b[k]); }
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]),
+                   "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3])
+                 :: "memory");
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { a[k] = __builtin_bit_cast(bf16x8, r[k]); b[k] = __builtin_bit_cast(bf16x8, r[4 + k]); }
+}
+__device__ __forceinline__ void cvt8(const bf16x8& a, float (&o)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (float)a[j];
+}
 __device__ __forceinline__ void st8(__bf16* p, const float (&v)[8]) {
     bf16x8 a;
 #pragma unroll
@@ -227,7 +263,10 @@ __device__ __forceinline__ float block_sum(float v, float* sh, int nw) {
 }
 
 // N sums at once (N values per thread, same summation order per value as block_sum): two barriers for all of them.
-// `sh` holds N x 16 floats.
+// `sh` holds N x 16 floats.  The barriers order LDS accesses only and are written as `s_waitcnt lgkmcnt(0); s_barrier`:
+// a __syncthreads() carries a fence that waits for ALL outstanding memory operations (vmcnt(0)), which would pull the
+// callers' prefetched global loads of the next token group into every reduction.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 template <int N>
 __device__ __forceinline__ void block_sum_n(float (&v)[N], float* sh, int nw) {
 #pragma unroll
@@ -239,12 +278,12 @@ __device__ __forceinline__ void block_sum_n(float (&v)[N], float* sh, int nw) {
         v[k] = x;
     }
     const int w = threadIdx.x >> 6;
-    __syncthreads();
+    lds_barrier();
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
         for (int k = 0; k < N; ++k) sh[k * 16 + w] = v[k];
     }
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         float t = 0.f;
@@ -253,7 +292,7 @@ __device__ __forceinline__ void block_sum_n(float (&v)[N], float* sh, int nw) {
     }
 }
 // tokens a block of the two LayerNorm backward kernels works on at once (their loads are issued one group ahead)
-constexpr int LN_BWD_T = 4;
+constexpr int LN_BWD_T = 4;                  // (settle4 is written for four)
 constexpr int LN_BWD_MAX_THREADS = 512;      // 8 features per thread: rows of up to 4096 features (two waves per SIMD, 256 VGPRs each)
 
 __global__ void post_fwd_kernel(PostArgs a) {
@@ -297,30 +336,49 @@ __global__ __launch_bounds__(LN_BWD_MAX_THREADS) void post_bwd_kernel(PostBwdArg
     const int D = a.NH * 64, nw = blockDim.x >> 6;
     const int h = threadIdx.x >> 3, o = threadIdx.x & 7;
     const bool act = h < a.NH;
-    const long n_tok = (long)a.B * a.L, stride = gridDim.x;
+    const unsigned n_tok = (unsigned)a.B * a.L, stride = gridDim.x, uL = a.L;       // B * L < 2^31 (checked by the caller)
     float w8[8], dw[8], db[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { dw[j] = 0.f; db[j] = 0.f; w8[j] = 0.f; }
     if (act) ldf8(a.w + h * 64 + 8 * o, w8);
-    float y[T][8], g[T][8], yn[T][8], gn[T][8];
-    auto load = [&](long bt0, float (&Y)[T][8], float (&G)[T][8]) {
+    bf16x8 yr[T], gr[T];                       // the group in flight, as loaded (converted when its turn comes)
+    int srow[T];                               // token (row of dOut within the batch) of each position of the group AFTER that one: the token
+                                               // map is read one group further ahead, its latency must not sit in front of the loads
+    auto load_rows = [&](unsigned bt0) {
 #pragma unroll
         for (int k = 0; k < T; ++k) {
-            const long bt = bt0 + k * stride;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { Y[k][j] = 0.f; G[k][j] = 0.f; }
-            if (act && bt < n_tok) {
-                const int tp = bt % a.L, b = bt / a.L;
-                const int src = a.src ? a.src[tp] : tp;
-                ld8(a.Y + (((size_t)b * a.NH + h) * a.L + tp) * 64 + 8 * o, Y[k]);
-                ld8(a.dOut + ((size_t)b * a.L + src) * D + h * 64 + 8 * o, G[k]);
+            const unsigned bt = bt0 + k * stride;
+            srow[k] = 0;
+            if (bt < n_tok) {              // (nothing is computed from the loaded value here: that would wait for it)
+                const unsigned tp = bt % uL;
+                if (a.src) srow[k] = a.src[tp];
+                else srow[k] = (int)tp;
             }
         }
     };
-    load(blockIdx.x, y, g);
-    for (long bt0 = blockIdx.x; bt0 < n_tok; bt0 += T * stride) {
-        const long nx = bt0 + T * stride;
-        if (nx < n_tok) load(nx, yn, gn);
+    auto load = [&](unsigned bt0) {
+#pragma unroll
+        for (int k = 0; k < T; ++k) {
+            const unsigned bt = bt0 + k * stride;
+            yr[k] = zero8_raw();
+            gr[k] = zero8_raw();
+            if (act && bt < n_tok) {
+                const unsigned tp = bt % uL, b = bt / uL;
+                yr[k] = ld8_raw(a.Y + (((size_t)b * a.NH + h) * a.L + tp) * 64 + 8 * o);
+                gr[k] = ld8_raw(a.dOut + ((size_t)b * a.L + srow[k]) * D + h * 64 + 8 * o);
+            }
+        }
+    };
+    load_rows(blockIdx.x);
+    load(blockIdx.x);
+    load_rows(blockIdx.x + T * stride);
+    for (unsigned bt0 = blockIdx.x; bt0 < n_tok; bt0 += T * stride) {
+        float y[T][8], g[T][8];
+        settle4(yr, gr, srow);
+#pragma unroll
+        for (int k = 0; k < T; ++k) { cvt8(yr[k], y[k]); cvt8(gr[k], g[k]); }
+        const unsigned nx = bt0 + T * stride;
+        if (nx < n_tok) { load(nx); load_rows(nx + T * stride); }
         float r[T];
 #pragma unroll
         for (int k = 0; k < T; ++k) {
@@ -360,20 +418,16 @@ __global__ __launch_bounds__(LN_BWD_MAX_THREADS) void post_bwd_kernel(PostBwdArg
         block_sum_n<2 * T>(r2, sh, nw);
 #pragma unroll
         for (int k = 0; k < T; ++k) {
-            const long bt = bt0 + k * stride;
+            const unsigned bt = bt0 + k * stride;
             if (act && bt < n_tok) {
                 const float s1 = r2[k] / D, s2 = r2[T + k] / D;
                 float out[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) out[j] = (g[k][j] - s1 - y[k][j] * s2) * rstd[k];
-                const int tp = bt % a.L, b = bt / a.L;
+                const unsigned tp = bt % uL, b = bt / uL;
                 st8(a.dY + (((size_t)b * a.NH + h) * a.L + tp) * 64 + 8 * o, out);
             }
         }
-#pragma unroll
-        for (int k = 0; k < T; ++k)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { y[k][j] = yn[k][j]; g[k][j] = gn[k][j]; }
     }
     if (act) {
         float* pw = a.dw_part + (size_t)blockIdx.x * D + h * 64 + 8 * o;
@@ -496,20 +550,24 @@ __global__ __launch_bounds__(LN_BWD_MAX_THREADS) void adaln_bwd_kernel(AdaLNBwdA
 #pragma unroll
     for (int j = 0; j < 8; ++j) { w8[j] = 0.f; b8[j] = 0.f; sc[j] = 0.f; dw[j] = 0.f; db[j] = 0.f; dsc[j] = 0.f; dsh[j] = 0.f; }
     if (act) { ldf8(a.w + o8, w8); ldf8(a.b + o8, b8); ldf8(a.scale1p + ((size_t)b * 2 + g) * D + o8, sc); }
-    float x[T][8], gy[T][8], xn[T][8], gn[T][8];
-    auto load = [&](int tt0, float (&X)[T][8], float (&G)[T][8]) {
+    bf16x8 xr[T], gr[T];                       // the group in flight, as loaded (converted when its turn comes)
+    auto load = [&](int tt0) {
 #pragma unroll
         for (int k = 0; k < T; ++k) {
             const int tt = tt0 + k * P;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { X[k][j] = 0.f; G[k][j] = 0.f; }
-            if (act && tt < n_tok) { ld8(src0 + (size_t)tt * D + o8, X[k]); ld8(dout0 + (size_t)tt * D + o8, G[k]); }
+            xr[k] = zero8_raw();
+            gr[k] = zero8_raw();
+            if (act && tt < n_tok) { xr[k] = ld8_raw(src0 + (size_t)tt * D + o8); gr[k] = ld8_raw(dout0 + (size_t)tt * D + o8); }
         }
     };
-    load(pi, x, gy);
+    load(pi);
     for (int tt0 = pi; tt0 < n_tok; tt0 += T * P) {
+        float x[T][8], gy[T][8];
+        settle4(xr, gr);
+#pragma unroll
+        for (int k = 0; k < T; ++k) { cvt8(xr[k], x[k]); cvt8(gr[k], gy[k]); }
         const int nx = tt0 + T * P;
-        if (nx < n_tok) load(nx, xn, gn);
+        if (nx < n_tok) load(nx);
         float r[T];
 #pragma unroll
         for (int k = 0; k < T; ++k) {
@@ -562,10 +620,6 @@ __global__ __launch_bounds__(LN_BWD_MAX_THREADS) void adaln_bwd_kernel(AdaLNBwdA
                 st8(dst0 + (size_t)tt * D + o8, out);
             }
         }
-#pragma unroll
-        for (int k = 0; k < T; ++k)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { x[k][j] = xn[k][j]; gy[k][j] = gn[k][j]; }
     }
     if (act) {
         float* pr = a.part + (size_t)blockIdx.x * 4 * D + o8;
