@@ -95,6 +95,9 @@ def parse():
                          "on one GPU (falling back to FSDP2 should the replica path fail), FSDP2 on several; on = FSDP2 always")
     ap.add_argument("--no-fsdp", action="store_true", help="same as --fsdp off")
     ap.add_argument("--layers", type=int, default=None, help="DEBUG: fewer layers (result flagged invalid)")
+    ap.add_argument("--torch-profile", default=None, metavar="FILE",
+                    help="DEBUG: after the timed region run ONE more step under torch.profiler and write per-operator tables "
+                         "(device time by operator, and by operator + input shapes + call site) to FILE")
     return ap.parse_args()
 
 
@@ -471,6 +474,16 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False):
     dt = float(tmax)
     loss_val = float(loss.detach())
     peak_mem = torch.cuda.max_memory_allocated() / 2 ** 30
+    if args.torch_profile and rank == 0:
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
+            step()
+            torch.cuda.synchronize()
+        with open(args.torch_profile, "w") as fh:
+            fh.write(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=60, max_name_column_width=70))
+            fh.write("\n\n")
+            fh.write(prof.key_averages(group_by_input_shape=True, group_by_stack_n=8).table(
+                sort_by="self_cuda_time_total", row_limit=80, max_name_column_width=60, max_src_column_width=110, max_shapes_column_width=70))
 
     if rank == 0:
         ms_per_step = 1e3 * dt / args.steps
