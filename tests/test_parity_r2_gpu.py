@@ -295,15 +295,14 @@ def test_bwd_cluster_sweep_handover_forms_and_oracle(shape):
         check_per_head(f"cluster backward {shape}", o1, (), g1, ro, (), rg, 1e-2, 3e-2)
 
 
-@pytest.mark.parametrize("shape", [(1, 8, 40, 16, 1), (2, 3, 23, 3, 2), (1, 48, 200, 16, 0), (1, 48, 130, 16, 2), (2, 40, 9, 2, 1)])
-def test_bwd_side_stream_schedule_same_bits(shape):
-    """The backward walks the sequence in chunks (recompute A, sweep B, tail C).  Beside the sweep of chunk c-1 - on the CUs
-    it leaves free, from a side stream - run the tail of chunk c and then the first work items of the recompute of chunk c-2,
-    in two alternating slot buffers (csrc/ttt_mfma_bwd2.hip:mlp_backward).  Same kernels on the same data: every output must
-    equal the one-stream schedule bit for bit - also when the call is repeated (buffers and events are reused) and when other
-    work sits on the stream before and after the call.  3 - 5 chunks each; (1, 48, ...) is the benchmarked head count
-    (automatic chunking = 6 groups: 288 work items, 64 of them beside the sweep; 2 groups per chunk: 96 items, 64 + 32); with
-    8 or 6 (b,h) the whole recompute fits beside the sweep; 80 (b,h) leave no CU free: one stream by itself."""
+@pytest.mark.parametrize("shape", [(1, 8, 40, 16, 1), (2, 3, 23, 3, 2), (1, 48, 96, 16, 0), (1, 48, 130, 16, 2), (2, 40, 9, 2, 1)])
+def test_bwd_tail_under_next_sweep_same_bits(shape):
+    """The backward walks the sequence in chunks (recompute A, sweep B, tail C); the tail of chunk c runs on a side stream
+    underneath the sweep of chunk c-1, in two alternating slot buffers (csrc/ttt_mfma_bwd2.hip:mlp_backward).  Same
+    kernels on the same data: every output must equal the one-stream schedule bit for bit - also when the call is repeated
+    (buffers and events are reused) and when other work sits on the stream before and after the call.  2 - 5 chunks each;
+    (1, 48, ...) is the benchmarked head count (automatic chunking, and 2 groups per chunk = 5 chunks); 80 (b,h) leave no CU
+    free beside the sweep: there the schedule falls back to one stream by itself."""
     e = ext()
     B, NH, NC, G, gpc = shape
     d = round_acts(O.make_inputs("mlp", B, NH, NC, 64, 64, seed=900 + NC), torch.bfloat16)

@@ -1,9 +1,9 @@
 #!/bin/bash
-# round 2, calls M, P: tail kernel (M) + the first recompute items of the chunk after next (P) on a side stream beside the sweep - tests, A/B, kernel trace
-mkdir -p gpurun_out/${RUN:-r2m}
-O=$GRAFT_REPO_ROOT/gpurun_out/${RUN:-r2m}
-timeout 600 python -m pytest tests/test_parity_r2_gpu.py -m gpu -q -rf -k "side_stream_schedule" 2>&1 | tail -5 | cut -c1-400 | tee $O/pytest_new.txt
-for cfg in "282 0 5" "282 1 0" "282 1 5" "804 0 5" "804 1 0" "804 1 5" "804 1 7"; do
+# round 2, call M: tail kernel of a chunk on a side stream under the next sweep - tests, A/B, kernel trace
+mkdir -p gpurun_out/r2m
+O=$GRAFT_REPO_ROOT/gpurun_out/r2m
+timeout 600 python -m pytest tests/test_parity_r2_gpu.py -m gpu -q -rf -k "tail_under_next_sweep" 2>&1 | tail -5 | cut -c1-400 | tee $O/pytest_new.txt
+for cfg in "282 0 0" "282 1 0" "804 0 0" "804 1 0" "804 1 4" "804 1 8" "282 1 4" "282 1 3"; do
   set -- $cfg
   timeout 300 python tools/op_bench.py --nc $1 --overlap $2 --gpc $3 --iters 5 2>/dev/null | python tools/_fmt_phases.py "nc $1 overlap $2 gpc $3:" | tee -a $O/op_ab.txt
 done

@@ -91,11 +91,9 @@ __global__ __launch_bounds__(NT, 1) void mlp_scan_kernel(ScanParams p) {
 
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63, h = l >> 5, c = l & 31;
     const int NC = p.NC, G = p.G;
-    // forward: one workgroup per (b,h), all steps.  SAVE: one workgroup per work item (b,h,group of the chunk); a chunk may be
-    // spread over two launches (item0 = first item of this one).
-    const int item = SAVE ? p.item0 + (int)blockIdx.x : (int)blockIdx.x;
-    const int bh = SAVE ? item / p.chunk_groups : item;
-    const int grp = SAVE ? p.chunk_group0 + item % p.chunk_groups : 0;
+    // forward: one workgroup per (b,h), all steps.  SAVE: one workgroup per (b,h,group of the chunk).
+    const int bh = SAVE ? blockIdx.x / p.chunk_groups : blockIdx.x;
+    const int grp = SAVE ? p.chunk_group0 + blockIdx.x % p.chunk_groups : 0;
     const int i_lo = SAVE ? grp * G : 0;
     const int i_hi = SAVE ? min(i_lo + G, NC) : NC;
     const int head = bh % p.NH;
@@ -502,14 +500,11 @@ static void set_lds_attr_once() {
     }
 }
 
-// work items [item0, item1) of the chunk (item = (b,h) * chunk_groups + group), one workgroup each
-void launch_group_recompute(const ScanParams& p0, int item0, int item1, hipStream_t s) {
-    if (item1 <= item0) return;
+void launch_group_recompute(const ScanParams& p0, int n_bh, hipStream_t s) {
     ScanParams p = p0;
     p.dbg = nullptr;
-    p.item0 = item0;
     set_lds_attr_once();
-    hipLaunchKernelGGL(mlp_scan_kernel<true>, dim3(item1 - item0), dim3(NT), LDS_FWD, s, p);
+    hipLaunchKernelGGL(mlp_scan_kernel<true>, dim3(n_bh * p.chunk_groups), dim3(NT), LDS_FWD, s, p);
 }
 
 bool supports(const ttt_dims* d, bool mlp, bool backward) {

@@ -142,22 +142,12 @@ void set_debug_overlap_tail(int v) { g_overlap = v; }
 static int g_fast_records = 1;        // cluster hand-over: plain (L2-resident) records once same-XCD placement is proven; 0 = always write-through
 void set_debug_fast_records(int v) { g_fast_records = v; }
 
-constexpr int N_CU = 256;                          // MI355X; the launch geometry below (one big-LDS workgroup per CU) is sized for it
-constexpr int SWEEP_BH_PER_LAUNCH = 64;            // 4 workgroups per (b,h), one per CU, all co-resident: 256 CUs
-// CUs a sweep launch leaves free (a multiple of 8: one share per XCD); they host the side stream's work
-static int free_cus_beside_sweep(int nbh) {
-    const int f = N_CU - 4 * (nbh < SWEEP_BH_PER_LAUNCH ? nbh : SWEEP_BH_PER_LAUNCH);
-    return f < 32 ? 0 : (f / 8) * 8;
-}
-
 int groups_per_chunk(const ttt_dims* d) {
     const int nbh = d->B * d->NH;
     const int K = (d->NC + d->G - 1) / d->G;
-    // recompute workgroups (one per (b,h,group), one per CU: 135 KiB of LDS; a workgroup takes ~0.5 ms for 16 steps however
-    // many run - its own CU's store path is the limit) should go through the chip in ONE wave: 256 of them on the caller's
-    // stream + as many as the sweep of the chunk before leaves CUs free, which run beside that sweep (mlp_backward).
-    // One too many and the stragglers run alone and the launch takes twice as long.
-    int g = nbh < N_CU ? (N_CU + free_cus_beside_sweep(nbh)) / nbh : 1;
+    // recompute workgroups (one per (b,h,group), one per CU: 135 KiB of LDS) should fill the 256 CUs in ONE wave: with
+    // ceil(256/nbh) groups (288 workgroups at nbh = 48) the last 32 run alone and the launch takes twice as long
+    int g = nbh < 256 ? 256 / nbh : 1;
     if (g_forced_gpc > 0) g = g_forced_gpc;   // DEBUG knob (tests exercise the chunk hand-over at small sizes)
     // bound the slot area to ~4 GiB
     const size_t per_group = (size_t)nbh * d->G * SLOT_BYTES;
@@ -168,6 +158,8 @@ int groups_per_chunk(const ttt_dims* d) {
 }
 
 static size_t align128(size_t v) { return (v + 127) & ~(size_t)127; }
+constexpr int SWEEP_BH_PER_LAUNCH = 64;            // 4 workgroups per (b,h), one per CU, all co-resident: 256 CUs
+
 size_t workspace_bytes(const ttt_dims* d, bool mlp, bool backward) {
     if (!mlp || !backward) return 0;
     const size_t nbh = (size_t)d->B * d->NH;
@@ -180,7 +172,8 @@ size_t workspace_bytes(const ttt_dims* d, bool mlp, bool backward) {
 // Side stream and the events of the two-buffer hand-over, one set per device, created on first use.
 struct OverlapRes {
     hipStream_t side = nullptr;
-    hipEvent_t ready[2] = {nullptr, nullptr}, side_done[2] = {nullptr, nullptr};
+    hipEvent_t ready[2] = {nullptr, nullptr}, tail_done[2] = {nullptr, nullptr};
+    int n_cu = 0;
 };
 static OverlapRes* overlap_resources() {
     static OverlapRes res[16];
@@ -192,9 +185,10 @@ static OverlapRes* overlap_resources() {
         bool ok = true;
         for (int i = 0; i < 2; ++i) {
             ok = ok && hipEventCreateWithFlags(&r.ready[i], hipEventDisableTiming) == hipSuccess;
-            ok = ok && hipEventCreateWithFlags(&r.side_done[i], hipEventDisableTiming) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&r.tail_done[i], hipEventDisableTiming) == hipSuccess;
         }
         if (!ok) return nullptr;
+        if (hipDeviceGetAttribute(&r.n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) r.n_cu = 0;
     }
     return &r;
 }
@@ -241,23 +235,20 @@ void mlp_backward(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hipStr
         attr = true;
     }
     const int nchunks = (K + gpc - 1) / gpc;
-    // The side stream's work runs on the CUs the sweep leaves free: none free -> one stream.
-    const int n_side = free_cus_beside_sweep(nbh);
-    OverlapRes* ov = (g_overlap && nchunks > 1 && n_side > 0) ? overlap_resources() : nullptr;
-    auto chunk_items = [&](int ch) { const int g0 = ch * gpc; return nbh * ((K - g0 < gpc) ? K - g0 : gpc); };
-    auto recompute = [&](int ch, int item0, int item1, hipStream_t st) {
+    // the side stream needs CUs beside the sweep's workgroups (one per CU): otherwise one stream
+    OverlapRes* ov = (g_overlap && nchunks > 1) ? overlap_resources() : nullptr;
+    if (ov && ov->n_cu - 4 * (nbh < SWEEP_BH_PER_LAUNCH ? nbh : SWEEP_BH_PER_LAUNCH) < 32) ov = nullptr;
+    auto recompute = [&](int ch) {
         const int g0 = ch * gpc, ng = (K - g0 < gpc) ? K - g0 : gpc;
         sp.chunk_group0 = g0; sp.chunk_groups = ng; sp.chunk_lo = g0 * G;
         sp.slots = slots + (size_t)(ch & 1) * slot_buf;
-        launch_group_recompute(sp, item0, item1, st);
+        launch_group_recompute(sp, nbh, s);
     };
-    // Chunk c lives in slot buffer c & 1.  A = recompute, B = sweep, C = tail;  A' = the first n_side work items of A, A" the rest:
-    //   stream `s`:   A(n-1) B(n-1) A(n-2) B(n-2)  A"(n-3) B(n-3)  A"(n-4) B(n-4) ...  A"(0) B(0)
-    //   side stream:                       C(n-1) A'(n-3)  C(n-2) A'(n-4)  ...           C(1)  C(0)
-    // C(c) and then A'(c-2) - same buffer, C(c) is its last reader - run BESIDE B(c-1): C(c) is released when A"(c-1) is complete,
-    // the moment B(c-1) starts (beside the recompute there is no free CU), and the sweep is long enough to cover both.
-    // A"(c-2) and B(c-2) wait for the side stream; `s` joins it before the call returns.
-    recompute(nchunks - 1, 0, chunk_items(nchunks - 1), s);
+    // Stream `s`:   A(n-1) B(n-1) A(n-2) B(n-2) ... A(0) B(0)          (chunk c in slot buffer c & 1)
+    // side stream:                C(n-1) under B(n-2), ...,  C(1) under B(0), C(0)
+    // C(c) starts when A(c-1) is complete - the moment B(c-1) starts, not earlier: beside the recompute there is no free CU -
+    // and A(c-2), which overwrites C(c)'s buffer, waits for it.  `s` joins the side stream before the call returns.
+    recompute(nchunks - 1);
     for (int ch = nchunks - 1; ch >= 0; --ch) {
         const int g0 = ch * gpc, ng = (K - g0 < gpc) ? K - g0 : gpc;
         const int buf = ch & 1;
@@ -275,26 +266,20 @@ void mlp_backward(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hipStr
         }
         tp.chunk_lo = bp.chunk_lo; tp.chunk_n = bp.chunk_hi - bp.chunk_lo;
         if (ch > 0) {
-            // chunk ch-1 goes into the other buffer: last read by C(ch+1), and A'(ch-1) ran behind that on the side stream
-            const bool has_part = ov && ch + 1 < nchunks;
-            if (has_part) (void)hipStreamWaitEvent(s, ov->side_done[buf ^ 1], 0);
-            const int n = chunk_items(ch - 1);
-            recompute(ch - 1, has_part ? (n_side < n ? n_side : n) : 0, n, s);
+            // chunk ch-1 goes into the other buffer, last read by the tail of chunk ch+1
+            if (ov && ch + 1 < nchunks) (void)hipStreamWaitEvent(s, ov->tail_done[buf ^ 1], 0);
+            recompute(ch - 1);
         }
         if (ov) {
             (void)hipEventRecord(ov->ready[buf], s);
             (void)hipStreamWaitEvent(ov->side, ov->ready[buf], 0);
             hipLaunchKernelGGL(b2::mlp_bwd_tail_kernel, dim3(nbh * tp.chunk_n), dim3(NT), b2::LDS_TAIL, ov->side, tp);
-            if (ch >= 2) {
-                const int n = chunk_items(ch - 2);
-                recompute(ch - 2, 0, n_side < n ? n_side : n, ov->side);
-            }
-            (void)hipEventRecord(ov->side_done[buf], ov->side);
+            (void)hipEventRecord(ov->tail_done[buf], ov->side);
         } else {
             hipLaunchKernelGGL(b2::mlp_bwd_tail_kernel, dim3(nbh * tp.chunk_n), dim3(NT), b2::LDS_TAIL, s, tp);
         }
     }
-    if (ov) (void)hipStreamWaitEvent(s, ov->side_done[0], 0);      // C(0) is the side stream's last command
+    if (ov) (void)hipStreamWaitEvent(s, ov->tail_done[0], 0);      // C(0) is the side stream's last command
 }
 
 }  // namespace mfma

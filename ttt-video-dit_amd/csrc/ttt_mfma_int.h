@@ -20,12 +20,11 @@ struct ScanParams {
     char* slots;                           // base of the slot area; slot s of (b,h) <-> step chunk_lo + s
     size_t slot_stride_bh;                 // bytes between consecutive (b,h) slot areas
     int chunk_group0, chunk_groups, chunk_lo;
-    int item0;                             // first (b,h,group) work item of this launch (set by launch_group_recompute)
     unsigned long long* dbg;               // optional per-phase cycle totals of workgroup 0
     float* dump;                           // DEBUG: intermediates of workgroup 0, step 0 (revision-2 forward)
 };
 
-void launch_group_recompute(const ScanParams& p, int item0, int item1, hipStream_t s);   // work items [item0, item1) of the chunk
+void launch_group_recompute(const ScanParams& p, int n_bh, hipStream_t s);
 bool bwd_available();
 int groups_per_chunk(const ttt_dims* d);
 // revision-2 forward scan (ttt_mfma2.hip): 8 waves per (b,h), VGPR-form MFMA, LDS transposed reads
