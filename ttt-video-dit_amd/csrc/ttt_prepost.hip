@@ -57,17 +57,6 @@ __device__ __forceinline__ void settle4(bf16x8 (&a)[4], bf16x8 (&b)[4]) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) { a[k] = __builtin_bit_cast(bf16x8, r[k]); b[k] = __builtin_bit_cast(bf16x8, r[4 + k]); }
 }
-__device__ __forceinline__ void settle4(bf16x8 (&a)[4], bf16x8 (&b)[4], int (&c)[4]) {
-    u32x4 r[8];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { r[k] = __builtin_bit_cast(u32x4, a[k]); r[4 + k] = __builtin_bit_cast(u32x4, b[k]); }
-    asm volatile("s_waitcnt vmcnt(0)"
-                 : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]),
-                   "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3])
-                 :: "memory");
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { a[k] = __builtin_bit_cast(bf16x8, r[k]); b[k] = __builtin_bit_cast(bf16x8, r[4 + k]); }
-}
 __device__ __forceinline__ void cvt8(const bf16x8& a, float (&o)[8]) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = (float)a[j];
@@ -291,7 +280,7 @@ __device__ __forceinline__ void block_sum_n(float (&v)[N], float* sh, int nw) {
         v[k] = t;
     }
 }
-// tokens a block of the two LayerNorm backward kernels works on at once (their loads are issued one group ahead)
+// tokens a block of adaln_bwd_kernel works on at once (their loads are issued one group ahead)
 constexpr int LN_BWD_T = 4;                  // (settle4 is written for four)
 constexpr int LN_BWD_MAX_THREADS = 512;      // 8 features per thread: rows of up to 4096 features (two waves per SIMD, 256 VGPRs each)
 
@@ -325,109 +314,49 @@ __global__ void post_fwd_kernel(PostArgs a) {
     }
 }
 
-// One block per token as in the forward, but LN_BWD_T tokens per iteration: their four row reductions share two barriers
-// each (three reductions: mean | variance | the two backward sums together), and the next group's loads are issued before the
-// current group is reduced.  (The one-token form spent a token's time in 8 barriers and one exposed HBM round trip: 1.9 TB/s.)
-// Per-token arithmetic and the order in which a block accumulates its parameter-gradient partials are those of the
-// one-token form.
-__global__ __launch_bounds__(LN_BWD_MAX_THREADS) void post_bwd_kernel(PostBwdArgs a) {
-    constexpr int T = LN_BWD_T;
-    __shared__ float sh[2 * T * 16];
+// One block per token, as the forward.  (The four-tokens-per-iteration form of adaln_bwd_kernel below was measured here too:
+// 0.52 ms against 0.46 ms for this one at the 9 s geometry - 1024 blocks of 40 VGPRs hide the latency better than four
+// 196-VGPR blocks per CU do, and the token map adds an integer division per token.)
+__global__ void post_bwd_kernel(PostBwdArgs a) {
+    __shared__ float sh[16];
     const int D = a.NH * 64, nw = blockDim.x >> 6;
     const int h = threadIdx.x >> 3, o = threadIdx.x & 7;
     const bool act = h < a.NH;
-    const unsigned n_tok = (unsigned)a.B * a.L, stride = gridDim.x, uL = a.L;       // B * L < 2^31 (checked by the caller)
     float w8[8], dw[8], db[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { dw[j] = 0.f; db[j] = 0.f; w8[j] = 0.f; }
     if (act) ldf8(a.w + h * 64 + 8 * o, w8);
-    bf16x8 yr[T], gr[T];                       // the group in flight, as loaded (converted when its turn comes)
-    int srow[T];                               // token (row of dOut within the batch) of each position of the group AFTER that one: the token
-                                               // map is read one group further ahead, its latency must not sit in front of the loads
-    auto load_rows = [&](unsigned bt0) {
+    for (long bt = blockIdx.x; bt < (long)a.B * a.L; bt += gridDim.x) {
+        const int tp = bt % a.L, b = bt / a.L;
+        const int src = a.src ? a.src[tp] : tp;
+        const size_t yoff = (((size_t)b * a.NH + h) * a.L + tp) * 64 + 8 * o;
+        float y[8], g[8];
 #pragma unroll
-        for (int k = 0; k < T; ++k) {
-            const unsigned bt = bt0 + k * stride;
-            srow[k] = 0;
-            if (bt < n_tok) {              // (nothing is computed from the loaded value here: that would wait for it)
-                const unsigned tp = bt % uL;
-                if (a.src) srow[k] = a.src[tp];
-                else srow[k] = (int)tp;
-            }
+        for (int j = 0; j < 8; ++j) { y[j] = 0.f; g[j] = 0.f; }
+        if (act) { ld8(a.Y + yoff, y); ld8(a.dOut + ((size_t)b * a.L + src) * D + h * 64 + 8 * o, g); }
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += y[j];
+        const float mean = block_sum(s, sh, nw) / D;
+        float vs = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { y[j] = act ? y[j] - mean : 0.f; vs += y[j] * y[j]; }
+        const float rstd = 1.0f / sqrtf(block_sum(vs, sh, nw) / D + a.eps);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            y[j] *= rstd;                    // x_hat
+            dw[j] += g[j] * y[j];
+            db[j] += g[j];
+            g[j] *= w8[j];
+            s1 += g[j];
+            s2 += g[j] * y[j];
         }
-    };
-    auto load = [&](unsigned bt0) {
+        s1 = block_sum(s1, sh, nw) / D;
+        s2 = block_sum(s2, sh, nw) / D;
 #pragma unroll
-        for (int k = 0; k < T; ++k) {
-            const unsigned bt = bt0 + k * stride;
-            yr[k] = zero8_raw();
-            gr[k] = zero8_raw();
-            if (act && bt < n_tok) {
-                const unsigned tp = bt % uL, b = bt / uL;
-                yr[k] = ld8_raw(a.Y + (((size_t)b * a.NH + h) * a.L + tp) * 64 + 8 * o);
-                gr[k] = ld8_raw(a.dOut + ((size_t)b * a.L + srow[k]) * D + h * 64 + 8 * o);
-            }
-        }
-    };
-    load_rows(blockIdx.x);
-    load(blockIdx.x);
-    load_rows(blockIdx.x + T * stride);
-    for (unsigned bt0 = blockIdx.x; bt0 < n_tok; bt0 += T * stride) {
-        float y[T][8], g[T][8];
-        settle4(yr, gr, srow);
-#pragma unroll
-        for (int k = 0; k < T; ++k) { cvt8(yr[k], y[k]); cvt8(gr[k], g[k]); }
-        const unsigned nx = bt0 + T * stride;
-        if (nx < n_tok) { load(nx); load_rows(nx + T * stride); }
-        float r[T];
-#pragma unroll
-        for (int k = 0; k < T; ++k) {
-            float s = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) s += y[k][j];
-            r[k] = s;
-        }
-        block_sum_n<T>(r, sh, nw);
-        float rstd[T];
-#pragma unroll
-        for (int k = 0; k < T; ++k) {
-            const float mean = r[k] / D;
-            float vs = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { y[k][j] = act ? y[k][j] - mean : 0.f; vs += y[k][j] * y[k][j]; }
-            r[k] = vs;
-        }
-        block_sum_n<T>(r, sh, nw);
-        float r2[2 * T];
-#pragma unroll
-        for (int k = 0; k < T; ++k) {
-            rstd[k] = 1.0f / sqrtf(r[k] / D + a.eps);
-            const bool valid = bt0 + k * stride < n_tok;
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                y[k][j] *= rstd[k];                    // x_hat
-                if (valid) { dw[j] += g[k][j] * y[k][j]; db[j] += g[k][j]; }
-                g[k][j] *= w8[j];
-                s1 += g[k][j];
-                s2 += g[k][j] * y[k][j];
-            }
-            r2[k] = s1;
-            r2[T + k] = s2;
-        }
-        block_sum_n<2 * T>(r2, sh, nw);
-#pragma unroll
-        for (int k = 0; k < T; ++k) {
-            const unsigned bt = bt0 + k * stride;
-            if (act && bt < n_tok) {
-                const float s1 = r2[k] / D, s2 = r2[T + k] / D;
-                float out[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) out[j] = (g[k][j] - s1 - y[k][j] * s2) * rstd[k];
-                const unsigned tp = bt % uL, b = bt / uL;
-                st8(a.dY + (((size_t)b * a.NH + h) * a.L + tp) * 64 + 8 * o, out);
-            }
-        }
+        for (int j = 0; j < 8; ++j) g[j] = (g[j] - s1 - y[j] * s2) * rstd;
+        if (act) st8(a.dY + yoff, g);
     }
     if (act) {
         float* pw = a.dw_part + (size_t)blockIdx.x * D + h * 64 + 8 * o;
@@ -533,7 +462,11 @@ __global__ void adaln_fwd_kernel(AdaLNArgs a) {
 // backward: d_in = LN'(dOut * scale1p) ; parameter-gradient partials, one row per block:
 //   part[blk][0] = dw, [1] = db (LayerNorm), [2] = d scale1p, [3] = d shift  for the (batch, group) the block works on
 // (block blk handles batch blk / (2 P), group (blk / P) % 2; the caller reduces over the P blocks of a (batch, group)).
-// LN_BWD_T tokens per iteration, next group's loads in flight, as in post_bwd_kernel (the one-token form ran at 1.2 TB/s).
+// One block per token as in the forward, but LN_BWD_T tokens per iteration: their row reductions share two barriers each
+// (three reductions: mean | variance | the two backward sums together), and the next group's loads are in flight while the
+// current group is reduced.  (The one-token form spent a token's time in 8 barriers and one exposed HBM round trip: 0.76 ms =
+// 1.3 TB/s at the 9 s geometry; this form 0.52 ms.)  Per-token arithmetic and the order in which a block accumulates its
+// parameter-gradient partials are those of the one-token form.
 __global__ __launch_bounds__(LN_BWD_MAX_THREADS) void adaln_bwd_kernel(AdaLNBwdArgs a) {
     constexpr int T = LN_BWD_T;
     __shared__ float sh[2 * T * 16];

@@ -321,7 +321,7 @@ class TransformerLayer(nn.Module):
         return vid_emb, text_emb
 
     def forward(self, vid_emb, text_emb, seq_metadata: SequenceMetadata):
-        if self.use_fused_glue and fused_available(vid_emb, 64) and vid_emb.shape[-1] % 8 == 0 and vid_emb.shape[-1] <= 8192:
+        if self.use_fused_glue and fused_available(vid_emb, 64) and vid_emb.shape[-1] % 8 == 0 and vid_emb.shape[-1] <= 4096:
             return self._forward_fused(vid_emb, text_emb, seq_metadata)
         n_text = seq_metadata.seq_text_length
         t = seq_metadata.t_emb
