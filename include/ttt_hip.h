@@ -16,7 +16,9 @@
  *     and owns nothing; results are written through the given pointers;
  *   - all pointers are DEVICE pointers on the current device;
  *   - kernels are enqueued on `stream` (a hipStream_t, NULL = default stream) and the call
- *     returns without synchronising;
+ *     returns without synchronising; ttt_hip_mlp_backward may run part of its work on an internal
+ *     stream of the library, ordered after everything queued on `stream` before the call and joined
+ *     into `stream` before the call returns (stream semantics for the caller are unchanged);
  *   - return value 0 = enqueued; negative = argument/launch error, message via ttt_hip_last_error().
  *
  * Tensor shapes use the reference's names: B batch, NH heads, NC mini-batches, CS mini-batch
@@ -246,7 +248,9 @@ void        ttt_hip_debug_groups_per_chunk(int groups);
  * kept so that binaries built against ABI version 1 keep loading. */
 void        ttt_hip_debug_variant(int revision);
 void        ttt_hip_debug_helpers(int helpers);
-/* DEBUG / A-B knobs by name: "groups_per_chunk" (checkpoint groups per backward chunk, 0 = automatic), "fast_records" (TTT-MLP
+/* DEBUG / A-B knobs by name: "groups_per_chunk" (checkpoint groups per backward chunk, 0 = automatic), "overlap_tail" (TTT-MLP
+ * backward: 1 (default) = the tail kernel of a chunk runs on an internal side stream beside the next chunk's sweep and the
+ * caller's stream joins it before the call returns; 0 = everything on the caller's stream; identical results), "fast_records" (TTT-MLP
  * backward sweep hand-over: 1 (default) = plain, L2-resident records once the four workgroups of a cluster have proven that they
  * share an XCD; 0 = write-through records always), "sweep_fast_count" (query: returns -2 - the number of cluster workgroup
  * launches that took the plain form).  Returns 0, or -1 for an unknown name.  (The round-1 knobs - kernel revisions, prefetch
