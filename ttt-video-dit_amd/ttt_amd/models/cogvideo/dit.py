@@ -57,6 +57,71 @@ class GeluLinear(torch.autograd.Function):
         return dz, dw, db
 
 
+def _segment_geometry(meta: SequenceMetadata, n_video: int, attn_length: int, prefix: int):
+    """(tl, [(lo, hi)] video-token range of every attention segment, tokens of a shared block): segment i attends over
+    ``[text_i, frames attn_length*i .. attn_length*(i+1) + prefix)``; consecutive segments share ``prefix`` frames."""
+    tl, tpf = meta.text_length, meta.tokens_per_frame
+    rng = [(i * attn_length * tpf, (prefix + (i + 1) * attn_length) * tpf) for i in range(meta.num_chunks)]
+    assert 0 < prefix < attn_length and rng[0][0] == 0 and rng[-1][1] == n_video, "segments must tile the video with one shared block"
+    return tl, rng, prefix * tpf
+
+
+class SegmentSplit(torch.autograd.Function):
+    """``[text | video]`` sequence -> the per-segment inputs ``[text_i | video[lo_i:hi_i]]`` (the reference builds them with
+    slice + cat, dit.py:163-211).  One node instead of 2 n slice nodes: its backward writes the input gradient ONCE (every row
+    from its segment, the shared frames as the sum of their two segments) where autograd's slice backward materialises a
+    zero-padded full-length tensor per slice and adds them up - 3 GB of traffic per layer at the 9 s geometry.  Same bits."""
+
+    @staticmethod
+    def forward(ctx, x, n_text, tl, rng, shared):
+        ctx.geo = (n_text, tl, rng, shared, x.shape)
+        return tuple(torch.cat((x[:, i * tl:(i + 1) * tl], x[:, n_text + lo:n_text + hi]), dim=1) for i, (lo, hi) in enumerate(rng))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        n_text, tl, rng, shared, shape = ctx.geo
+        ref = next(g for g in gs if g is not None)
+        gs = [g if g is not None else ref.new_zeros(shape[0], tl + hi - lo, shape[2]) for g, (lo, hi) in zip(gs, rng)]
+        dx = ref.new_empty(shape)
+        for i, (lo, hi) in enumerate(rng):
+            dx[:, i * tl:(i + 1) * tl] = gs[i][:, :tl]
+            dx[:, n_text + lo:n_text + hi] = gs[i][:, tl:]          # a later segment overwrites the block it shares ...
+        for i in range(1, len(rng)):                                # ... which then gets the sum of both
+            lo = rng[i][0]
+            torch.add(gs[i - 1][:, -shared:], gs[i][:, tl:tl + shared], out=dx[:, n_text + lo:n_text + lo + shared])
+        return dx, None, None, None, None
+
+
+class SegmentMerge(torch.autograd.Function):
+    """Per-segment outputs -> one ``[text | video]`` sequence, the shared frames averaged (reference dit.py:199-211: accumulate
+    into zeros, count, divide, cat).  Written once: every row copied from its segment, the shared blocks as ``(a + b) / 2`` -
+    the same roundings as accumulate-then-divide-by-count."""
+
+    @staticmethod
+    def forward(ctx, n_text, tl, rng, shared, *outs):
+        ctx.geo = (n_text, tl, rng, shared)
+        b, _, d = outs[0].shape
+        out = outs[0].new_empty(b, n_text + rng[-1][1], d)
+        for i, (lo, hi) in enumerate(rng):
+            out[:, i * tl:(i + 1) * tl] = outs[i][:, :tl]
+            out[:, n_text + lo:n_text + hi] = outs[i][:, tl:]
+        for i in range(1, len(rng)):
+            lo = rng[i][0]
+            blk = out[:, n_text + lo:n_text + lo + shared]
+            torch.add(outs[i - 1][:, -shared:], outs[i][:, tl:tl + shared], out=blk)
+            blk.div_(2)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        n_text, tl, rng, shared = ctx.geo
+        gs = [torch.cat((g[:, i * tl:(i + 1) * tl], g[:, n_text + lo:n_text + hi]), dim=1) for i, (lo, hi) in enumerate(rng)]
+        for i in range(1, len(rng)):
+            gs[i - 1][:, -shared:].div_(2)
+            gs[i][:, tl:tl + shared].div_(2)
+        return (None, None, None, None, *gs)
+
+
 class PatchEmbedding(nn.Module):
     """2x2 patch conv for video latents + Linear for text (reference :17-40)."""
 
@@ -174,18 +239,11 @@ class SeqModelingBlock(nn.Module):
         tl, tpf = seq_metadata.text_length, seq_metadata.tokens_per_frame
         if seq_metadata.num_chunks == 1:     # one segment: nothing overlaps, the accumulate / average below is the identity
             return self._segment(cat if cat is not None else torch.cat((text_emb, vid_emb), dim=1), tl)
-        out_vid = torch.zeros_like(vid_emb)
-        out_txt = torch.zeros_like(text_emb)
-        count = torch.zeros_like(vid_emb[..., :1])
-        for i in range(seq_metadata.num_chunks):
-            lo = i * self.attn_length * tpf
-            hi = (self.prefix_temporal_length + (i + 1) * self.attn_length) * tpf
-            seg = torch.cat((text_emb[:, i * tl:(i + 1) * tl], vid_emb[:, lo:hi]), dim=1)
-            o = self._segment(seg, tl)
-            out_txt[:, i * tl:(i + 1) * tl] = o[:, :tl]
-            out_vid[:, lo:hi] += o[:, tl:]
-            count[:, lo:hi] += 1
-        return torch.cat((out_txt, out_vid / count), dim=1)
+        x = cat if cat is not None else torch.cat((text_emb, vid_emb), dim=1)
+        n_text = text_emb.shape[1]
+        tl, rng, shared = _segment_geometry(seq_metadata, vid_emb.shape[1], self.attn_length, self.prefix_temporal_length)
+        segs = SegmentSplit.apply(x, n_text, tl, rng, shared)
+        return SegmentMerge.apply(n_text, tl, rng, shared, *(self._segment(seg, tl) for seg in segs))
 
     # -- bidirectional TTT ------------------------------------------------------------------------
     def _gate(self, text_gate, video_gate, residual, ssm_output, n_text):
