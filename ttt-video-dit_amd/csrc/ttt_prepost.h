@@ -40,6 +40,7 @@ struct PostBwdArgs {
     float *dw_part, *db_part;                 // [P, NH*64]
     int B, L, NH;
     float eps;
+    int wt;                                   // waves per token team (set by post_backward)
 };
 struct GateArgs {
     const __bf16 *res, *y;                    // [B, L, D]
@@ -70,6 +71,7 @@ struct AdaLNBwdArgs {
     float* part;                              // [B * 2 * P, 4, D]: dw, db, d scale1p, d shift per block
     int B, Lt, Lv, D, P;
     float eps;
+    int wt;                                   // waves per token team (set by adaln_backward)
 };
 struct ResGateArgs {
     const __bf16 *vid, *text, *y;             // residual streams and y = [text | video] [B, Lt + Lv, D]

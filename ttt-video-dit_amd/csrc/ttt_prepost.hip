@@ -43,20 +43,6 @@ __device__ __forceinline__ bf16x8 zero8_raw() {
     for (int j = 0; j < 8; ++j) z[j] = (__bf16)0.0f;
     return z;
 }
-// The loads of the group in flight have landed - said to the COMPILER: the wait sits here, in front of the next group's
-// loads, and the registers leave the asm as plain values.  (Left to itself hipcc hoists the next group's loads above the
-// first use of this group's data and then has to wait for both: the prefetch never overlaps anything.)
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void settle4(bf16x8 (&a)[4], bf16x8 (&b)[4]) {
-    u32x4 r[8];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { r[k] = __builtin_bit_cast(u32x4, a[k]); r[4 + k] = __builtin_bit_cast(u32x4, b[k]); }
-    asm volatile("s_waitcnt vmcnt(0)"
-                 : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
-                 :: "memory");
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { a[k] = __builtin_bit_cast(bf16x8, r[k]); b[k] = __builtin_bit_cast(bf16x8, r[4 + k]); }
-}
 __device__ __forceinline__ void cvt8(const bf16x8& a, float (&o)[8]) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = (float)a[j];
@@ -251,13 +237,23 @@ __device__ __forceinline__ float block_sum(float v, float* sh, int nw) {
     return t;
 }
 
-// N sums at once (N values per thread, same summation order per value as block_sum): two barriers for all of them.
-// `sh` holds N x 16 floats.  The barriers order LDS accesses only and are written as `s_waitcnt lgkmcnt(0); s_barrier`:
-// a __syncthreads() carries a fence that waits for ALL outstanding memory operations (vmcnt(0)), which would pull the
-// callers' prefetched global loads of the next token group into every reduction.
+// ---- LayerNorm-over-D backward kernels: token teams ----------------------------------------------------------------------
+// A block of 8 waves is split into TEAMS of wt waves (wt = 1, 2, 4: the smallest that covers D / 8 / LN_E threads); a team works
+// on one token at a time and each of its threads holds LN_E chunks of 8 features (chunk c = e * team_threads + t, so every e is a
+// coalesced sweep over the row).  Why: one block of D / 8 threads per token with 8 features per thread spends ~70 instructions per
+// feature on reductions, index arithmetic and conversions and is VALU-issue-bound at 1.3 - 2 TB/s; 24 features per thread cut
+// that threefold, the three row reductions of a token cost one barrier each (three LDS buffers, written in turn), and the next
+// token's rows are in flight while the current one is reduced.  All teams of a block run the same number of iterations (tokens
+// past the end are masked), so the barriers are block-wide.
+constexpr int LN_E = 3;
+constexpr int LN_BLOCK = 512;
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// (a __syncthreads() carries a fence that waits for ALL outstanding memory operations - it would pull the prefetched rows of the
+// next token into every reduction; these barriers order LDS accesses only)
+
+// team totals of N per-thread values; buf = float[8 * N] of this reduction round
 template <int N>
-__device__ __forceinline__ void block_sum_n(float (&v)[N], float* sh, int nw) {
+__device__ __forceinline__ void team_sum(float (&v)[N], float* buf, int wt, int team) {
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         float x = sum8(v[k]);
@@ -266,23 +262,59 @@ __device__ __forceinline__ void block_sum_n(float (&v)[N], float* sh, int nw) {
         x += __shfl_xor(x, 32, 64);
         v[k] = x;
     }
-    const int w = threadIdx.x >> 6;
-    lds_barrier();
+    const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int k = 0; k < N; ++k) sh[k * 16 + w] = v[k];
+        for (int k = 0; k < N; ++k) buf[wave * N + k] = v[k];
     }
     lds_barrier();
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         float t = 0.f;
-        for (int i = 0; i < nw; ++i) t += sh[k * 16 + i];
+        for (int i = 0; i < wt; ++i) t += buf[(team * wt + i) * N + k];
         v[k] = t;
     }
 }
-// tokens a block of adaln_bwd_kernel works on at once (their loads are issued one group ahead)
-constexpr int LN_BWD_T = 4;                  // (settle4 is written for four)
-constexpr int LN_BWD_MAX_THREADS = 512;      // 8 features per thread: rows of up to 4096 features (two waves per SIMD, 256 VGPRs each)
+// The rows in flight have landed - said to the COMPILER: the wait sits here, in front of the next token's loads, and the registers
+// leave the asm as plain values.  (Left to itself hipcc hoists the next loads above the first use of this token's data and then
+// has to wait for both: the prefetch never overlaps anything.)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void settle(bf16x8 (&a)[LN_E], bf16x8 (&b)[LN_E], int& c) {
+    static_assert(LN_E == 3, "operand list below");
+    u32x4 r[2 * LN_E];
+#pragma unroll
+    for (int k = 0; k < LN_E; ++k) { r[k] = __builtin_bit_cast(u32x4, a[k]); r[LN_E + k] = __builtin_bit_cast(u32x4, b[k]); }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(c) :: "memory");
+#pragma unroll
+    for (int k = 0; k < LN_E; ++k) { a[k] = __builtin_bit_cast(bf16x8, r[k]); b[k] = __builtin_bit_cast(bf16x8, r[LN_E + k]); }
+}
+// block-level sum of a per-thread accumulator array over the teams -> global row `dst` [D]; dyn = float[nt * D]
+__device__ __forceinline__ void teams_to_global(const float (&acc)[LN_E][8], const bool (&act)[LN_E], const int (&off)[LN_E], float* dyn,
+                                                int team, int nt, int D, float* dst) {
+    lds_barrier();                                   // the previous array's readers are done
+#pragma unroll
+    for (int e = 0; e < LN_E; ++e)
+        if (act[e]) {
+            f32x4 lo = {acc[e][0], acc[e][1], acc[e][2], acc[e][3]}, hi = {acc[e][4], acc[e][5], acc[e][6], acc[e][7]};
+            *reinterpret_cast<f32x4*>(dyn + (size_t)team * D + off[e]) = lo;
+            *reinterpret_cast<f32x4*>(dyn + (size_t)team * D + off[e] + 4) = hi;
+        }
+    lds_barrier();
+    for (int c = threadIdx.x * 4; c < D; c += LN_BLOCK * 4) {
+        f32x4 t = *reinterpret_cast<const f32x4*>(dyn + c);
+        for (int j = 1; j < nt; ++j) {
+            const f32x4 u = *reinterpret_cast<const f32x4*>(dyn + (size_t)j * D + c);
+            t[0] += u[0]; t[1] += u[1]; t[2] += u[2]; t[3] += u[3];
+        }
+        *reinterpret_cast<f32x4*>(dst + c) = t;
+    }
+}
+static int ln_team_waves(int D) {                    // host: waves per team
+    const int need = (D / 8 + LN_E - 1) / LN_E;
+    int wt = 1;
+    while (wt * 64 < need) wt *= 2;
+    return wt;                                       // D <= 4096 (checked by the C API): wt <= 4
+}
 
 __global__ void post_fwd_kernel(PostArgs a) {
     __shared__ float sh[16];
@@ -314,56 +346,109 @@ __global__ void post_fwd_kernel(PostArgs a) {
     }
 }
 
-// One block per token, as the forward.  (The four-tokens-per-iteration form of adaln_bwd_kernel below was measured here too:
-// 0.52 ms against 0.46 ms for this one at the 9 s geometry - 1024 blocks of 40 VGPRs hide the latency better than four
-// 196-VGPR blocks per CU do, and the token map adds an integer division per token.)
-__global__ void post_bwd_kernel(PostBwdArgs a) {
-    __shared__ float sh[16];
-    const int D = a.NH * 64, nw = blockDim.x >> 6;
-    const int h = threadIdx.x >> 3, o = threadIdx.x & 7;
-    const bool act = h < a.NH;
-    float w8[8], dw[8], db[8];
+// Token teams (above).  Block blk works on tokens (it * gridDim + blk) * nt + team; the token map `src` is read one iteration
+// further ahead than the rows (its latency must not sit in front of their loads).  Partials: one row per block, as before.
+__global__ __launch_bounds__(LN_BLOCK) void post_bwd_kernel(PostBwdArgs a) {
+    constexpr int E = LN_E;
+    extern __shared__ __attribute__((aligned(16))) float dyn[];
+    __shared__ float rbuf[3][16];
+    const int D = a.NH * 64, chunks = D >> 3;
+    const int wt = a.wt, nt = 8 / wt, tthreads = 64 * wt;
+    const int team = threadIdx.x / tthreads, t = threadIdx.x % tthreads;
+    const unsigned n_tok = (unsigned)a.B * a.L, uL = a.L, per_it = gridDim.x * nt;       // B * L < 2^31
+    const unsigned n_it = (n_tok + per_it - 1) / per_it;
+    bool act[E];
+    int off[E];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { dw[j] = 0.f; db[j] = 0.f; w8[j] = 0.f; }
-    if (act) ldf8(a.w + h * 64 + 8 * o, w8);
-    for (long bt = blockIdx.x; bt < (long)a.B * a.L; bt += gridDim.x) {
-        const int tp = bt % a.L, b = bt / a.L;
-        const int src = a.src ? a.src[tp] : tp;
-        const size_t yoff = (((size_t)b * a.NH + h) * a.L + tp) * 64 + 8 * o;
-        float y[8], g[8];
+    for (int e = 0; e < E; ++e) { const int c = e * tthreads + t; act[e] = c < chunks; off[e] = act[e] ? c * 8 : 0; }
+    float w8[E][8], dw[E][8], db[E][8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { y[j] = 0.f; g[j] = 0.f; }
-        if (act) { ld8(a.Y + yoff, y); ld8(a.dOut + ((size_t)b * a.L + src) * D + h * 64 + 8 * o, g); }
-        float s = 0.f;
+    for (int e = 0; e < E; ++e) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s += y[j];
-        const float mean = block_sum(s, sh, nw) / D;
-        float vs = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { y[j] = act ? y[j] - mean : 0.f; vs += y[j] * y[j]; }
-        const float rstd = 1.0f / sqrtf(block_sum(vs, sh, nw) / D + a.eps);
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            y[j] *= rstd;                    // x_hat
-            dw[j] += g[j] * y[j];
-            db[j] += g[j];
-            g[j] *= w8[j];
-            s1 += g[j];
-            s2 += g[j] * y[j];
+        for (int j = 0; j < 8; ++j) { w8[e][j] = 0.f; dw[e][j] = 0.f; db[e][j] = 0.f; }
+        if (act[e]) ldf8(a.w + off[e], w8[e]);
+    }
+    auto token_of = [&](unsigned it) { return (it * gridDim.x + blockIdx.x) * nt + team; };
+    bf16x8 yr[E], gr[E];
+    int srow = 0;                                    // token (row of dOut within its batch) of the position AFTER the one in flight
+    auto load_row = [&](unsigned it) {
+        const unsigned bt = token_of(it);
+        srow = 0;
+        if (it < n_it && bt < n_tok) {               // (nothing is computed from the loaded value here: that would wait for it)
+            const unsigned tp = bt % uL;
+            if (a.src) srow = a.src[tp];
+            else srow = (int)tp;
         }
-        s1 = block_sum(s1, sh, nw) / D;
-        s2 = block_sum(s2, sh, nw) / D;
+    };
+    auto load = [&](unsigned it) {
+        const unsigned bt = token_of(it);
+        const unsigned tp = bt % uL, b = bt / uL;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) g[j] = (g[j] - s1 - y[j] * s2) * rstd;
-        if (act) st8(a.dY + yoff, g);
+        for (int e = 0; e < E; ++e) {
+            yr[e] = zero8_raw();
+            gr[e] = zero8_raw();
+            if (act[e] && bt < n_tok) {
+                const int h = off[e] >> 6, o8 = off[e] & 63;
+                yr[e] = ld8_raw(a.Y + (((size_t)b * a.NH + h) * a.L + tp) * 64 + o8);
+                gr[e] = ld8_raw(a.dOut + ((size_t)b * a.L + srow) * D + off[e]);
+            }
+        }
+    };
+    if (n_it > 0) {
+        load_row(0);
+        load(0);
+        load_row(1);
     }
-    if (act) {
-        float* pw = a.dw_part + (size_t)blockIdx.x * D + h * 64 + 8 * o;
-        float* pb = a.db_part + (size_t)blockIdx.x * D + h * 64 + 8 * o;
+    for (unsigned it = 0; it < n_it; ++it) {
+        const unsigned bt = token_of(it);
+        const bool valid = bt < n_tok;
+        float y[E][8], g[E][8];
+        settle(yr, gr, srow);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { pw[j] = dw[j]; pb[j] = db[j]; }
+        for (int e = 0; e < E; ++e) { cvt8(yr[e], y[e]); cvt8(gr[e], g[e]); }
+        if (it + 1 < n_it) { load(it + 1); load_row(it + 2); }
+        float r[1] = {0.f};
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[0] += y[e][j];
+        team_sum<1>(r, rbuf[0], wt, team);
+        const float mean = r[0] / D;
+        r[0] = 0.f;
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { y[e][j] = act[e] ? y[e][j] - mean : 0.f; r[0] += y[e][j] * y[e][j]; }
+        team_sum<1>(r, rbuf[1], wt, team);
+        const float rstd = 1.0f / sqrtf(r[0] / D + a.eps);
+        float r2[2] = {0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                y[e][j] *= rstd;                     // x_hat
+                if (valid) { dw[e][j] += g[e][j] * y[e][j]; db[e][j] += g[e][j]; }
+                g[e][j] *= w8[e][j];
+                r2[0] += g[e][j];
+                r2[1] += g[e][j] * y[e][j];
+            }
+        team_sum<2>(r2, rbuf[2], wt, team);
+        if (valid) {
+            const float s1 = r2[0] / D, s2 = r2[1] / D;
+            const unsigned tp = bt % uL, b = bt / uL;
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+                if (act[e]) {
+                    float out[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) out[j] = (g[e][j] - s1 - y[e][j] * s2) * rstd;
+                    const int h = off[e] >> 6, o8 = off[e] & 63;
+                    st8(a.dY + (((size_t)b * a.NH + h) * a.L + tp) * 64 + o8, out);
+                }
+        }
     }
+    teams_to_global(dw, act, off, dyn, team, nt, D, a.dw_part + (size_t)blockIdx.x * D);
+    teams_to_global(db, act, off, dyn, team, nt, D, a.db_part + (size_t)blockIdx.x * D);
 }
 
 // ------------------------------------------------------------------------------------------------ gate
@@ -462,103 +547,123 @@ __global__ void adaln_fwd_kernel(AdaLNArgs a) {
 // backward: d_in = LN'(dOut * scale1p) ; parameter-gradient partials, one row per block:
 //   part[blk][0] = dw, [1] = db (LayerNorm), [2] = d scale1p, [3] = d shift  for the (batch, group) the block works on
 // (block blk handles batch blk / (2 P), group (blk / P) % 2; the caller reduces over the P blocks of a (batch, group)).
-// One block per token as in the forward, but LN_BWD_T tokens per iteration: their row reductions share two barriers each
-// (three reductions: mean | variance | the two backward sums together), and the next group's loads are in flight while the
-// current group is reduced.  (The one-token form spent a token's time in 8 barriers and one exposed HBM round trip: 0.76 ms =
-// 1.3 TB/s at the 9 s geometry; this form 0.52 ms.)  Per-token arithmetic and the order in which a block accumulates its
-// parameter-gradient partials are those of the one-token form.
-__global__ __launch_bounds__(LN_BWD_MAX_THREADS) void adaln_bwd_kernel(AdaLNBwdArgs a) {
-    constexpr int T = LN_BWD_T;
-    __shared__ float sh[2 * T * 16];
-    const int D = a.D, nw = blockDim.x >> 6, L = a.Lt + a.Lv;
-    const int o8 = threadIdx.x * 8;
-    const bool act = o8 < D;
-    const int P = a.P;
+// Token teams (above).  Block pi of a (batch, group) works on tokens (it * P + pi) * nt + team of that group.
+__global__ __launch_bounds__(LN_BLOCK) void adaln_bwd_kernel(AdaLNBwdArgs a) {
+    constexpr int E = LN_E;
+    extern __shared__ __attribute__((aligned(16))) float dyn[];
+    __shared__ float rbuf[3][16];
+    const int D = a.D, chunks = D >> 3, L = a.Lt + a.Lv, P = a.P;
+    const int wt = a.wt, nt = 8 / wt, tthreads = 64 * wt;
+    const int team = threadIdx.x / tthreads, t = threadIdx.x % tthreads;
     const int b = blockIdx.x / (2 * P), g = (blockIdx.x / P) % 2, pi = blockIdx.x % P;
     const int n_tok = g == 0 ? a.Lt : a.Lv, t0 = g == 0 ? 0 : a.Lt;
+    const int n_it = (n_tok + P * nt - 1) / (P * nt);
     const __bf16* src0 = g == 0 ? a.text + (size_t)b * a.Lt * D : a.vid + (size_t)b * a.Lv * D;
     __bf16* dst0 = g == 0 ? a.dtext + (size_t)b * a.Lt * D : a.dvid + (size_t)b * a.Lv * D;
     const __bf16* dout0 = a.dout + ((size_t)b * L + t0) * D;
-    float w8[8], b8[8], sc[8], dw[8], db[8], dsc[8], dsh[8];
+    bool act[E];
+    int off[E];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { w8[j] = 0.f; b8[j] = 0.f; sc[j] = 0.f; dw[j] = 0.f; db[j] = 0.f; dsc[j] = 0.f; dsh[j] = 0.f; }
-    if (act) { ldf8(a.w + o8, w8); ldf8(a.b + o8, b8); ldf8(a.scale1p + ((size_t)b * 2 + g) * D + o8, sc); }
-    bf16x8 xr[T], gr[T];                       // the group in flight, as loaded (converted when its turn comes)
-    auto load = [&](int tt0) {
+    for (int e = 0; e < E; ++e) { const int c = e * tthreads + t; act[e] = c < chunks; off[e] = act[e] ? c * 8 : 0; }
+    // accumulated over the block's tokens: dsh = sum dOut, gxh = sum dOut * x_hat, dsc = sum dOut * LN(x).  The LayerNorm
+    // parameter gradients follow at the end, scale1p being constant over the block: dw = scale1p * gxh, db = scale1p * dsh.
+    float gxh[E][8], dsc[E][8], dsh[E][8];
 #pragma unroll
-        for (int k = 0; k < T; ++k) {
-            const int tt = tt0 + k * P;
-            xr[k] = zero8_raw();
-            gr[k] = zero8_raw();
-            if (act && tt < n_tok) { xr[k] = ld8_raw(src0 + (size_t)tt * D + o8); gr[k] = ld8_raw(dout0 + (size_t)tt * D + o8); }
+    for (int e = 0; e < E; ++e)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { gxh[e][j] = 0.f; dsc[e][j] = 0.f; dsh[e][j] = 0.f; }
+    // LayerNorm weight / bias and scale1p of this (batch, group): 3 x D floats in LDS for the token loop (72 registers per thread
+    // otherwise, which spill); the area is re-used for the team reduction afterwards (the host sizes it for the larger of the two)
+    float* cw = dyn;
+    float* cb = dyn + D;
+    float* cs = dyn + 2 * (size_t)D;
+    for (int c = threadIdx.x * 4; c < D; c += LN_BLOCK * 4) {
+        *reinterpret_cast<f32x4*>(cw + c) = *reinterpret_cast<const f32x4*>(a.w + c);
+        *reinterpret_cast<f32x4*>(cb + c) = *reinterpret_cast<const f32x4*>(a.b + c);
+        *reinterpret_cast<f32x4*>(cs + c) = *reinterpret_cast<const f32x4*>(a.scale1p + ((size_t)b * 2 + g) * D + c);
+    }
+    __syncthreads();
+    auto token_of = [&](int it) { return (it * P + pi) * nt + team; };
+    bf16x8 xr[E], gr[E];
+    int unused = 0;
+    auto load = [&](int it) {
+        const int tt = token_of(it);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            xr[e] = zero8_raw();
+            gr[e] = zero8_raw();
+            if (act[e] && tt < n_tok) { xr[e] = ld8_raw(src0 + (size_t)tt * D + off[e]); gr[e] = ld8_raw(dout0 + (size_t)tt * D + off[e]); }
         }
     };
-    load(pi);
-    for (int tt0 = pi; tt0 < n_tok; tt0 += T * P) {
-        float x[T][8], gy[T][8];
-        settle4(xr, gr);
+    if (n_it > 0) load(0);
+    for (int it = 0; it < n_it; ++it) {
+        const int tt = token_of(it);
+        const bool valid = tt < n_tok;
+        float x[E][8], gy[E][8];
+        settle(xr, gr, unused);
 #pragma unroll
-        for (int k = 0; k < T; ++k) { cvt8(xr[k], x[k]); cvt8(gr[k], gy[k]); }
-        const int nx = tt0 + T * P;
-        if (nx < n_tok) load(nx);
-        float r[T];
+        for (int e = 0; e < E; ++e) { cvt8(xr[e], x[e]); cvt8(gr[e], gy[e]); }
+        if (it + 1 < n_it) load(it + 1);
+        float r[1] = {0.f};
 #pragma unroll
-        for (int k = 0; k < T; ++k) {
-            float s = 0.f;
+        for (int e = 0; e < E; ++e)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) s += x[k][j];
-            r[k] = s;
-        }
-        block_sum_n<T>(r, sh, nw);
+            for (int j = 0; j < 8; ++j) r[0] += x[e][j];
+        team_sum<1>(r, rbuf[0], wt, team);
+        const float mean = r[0] / D;
+        r[0] = 0.f;
 #pragma unroll
-        for (int k = 0; k < T; ++k) {
-            const float mean = r[k] / D;
-            float vs = 0.f;
+        for (int e = 0; e < E; ++e)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { x[k][j] = act ? x[k][j] - mean : 0.f; vs += x[k][j] * x[k][j]; }
-            r[k] = vs;
-        }
-        block_sum_n<T>(r, sh, nw);
-        float rstd[T], r2[2 * T];
+            for (int j = 0; j < 8; ++j) { x[e][j] = act[e] ? x[e][j] - mean : 0.f; r[0] += x[e][j] * x[e][j]; }
+        team_sum<1>(r, rbuf[1], wt, team);
+        const float rstd = 1.0f / sqrtf(r[0] / D + a.eps);
+        float r2[2] = {0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < T; ++k) {
-            rstd[k] = 1.0f / sqrtf(r[k] / D + a.eps);
-            const bool valid = tt0 + k * P < n_tok;
-            float s1 = 0.f, s2 = 0.f;
+        for (int e = 0; e < E; ++e) {
+            float w8[8], b8[8], sc[8];
+            ldf8(cw + off[e], w8);
+            ldf8(cb + off[e], b8);
+            ldf8(cs + off[e], sc);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                x[k][j] *= rstd[k];                                              // x_hat
+                x[e][j] *= rstd;                                                     // x_hat
                 if (valid) {
-                    dsh[j] += gy[k][j];
-                    dsc[j] += gy[k][j] * bf16_round(x[k][j] * w8[j] + b8[j]);    // d(scale1p): dOut * LN output
+                    dsh[e][j] += gy[e][j];
+                    gxh[e][j] += gy[e][j] * x[e][j];
+                    dsc[e][j] += gy[e][j] * bf16_round(x[e][j] * w8[j] + b8[j]);     // d(scale1p): dOut * LN output
                 }
-                gy[k][j] *= sc[j];                                               // gradient w.r.t. the LN output
-                if (valid) { dw[j] += gy[k][j] * x[k][j]; db[j] += gy[k][j]; }
-                gy[k][j] *= w8[j];
-                s1 += gy[k][j];
-                s2 += gy[k][j] * x[k][j];
-            }
-            r2[k] = s1;
-            r2[T + k] = s2;
-        }
-        block_sum_n<2 * T>(r2, sh, nw);
-#pragma unroll
-        for (int k = 0; k < T; ++k) {
-            const int tt = tt0 + k * P;
-            if (act && tt < n_tok) {
-                const float s1 = r2[k] / D, s2 = r2[T + k] / D;
-                float out[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) out[j] = (gy[k][j] - s1 - x[k][j] * s2) * rstd[k];
-                st8(dst0 + (size_t)tt * D + o8, out);
+                gy[e][j] *= sc[j] * w8[j];                                           // gradient w.r.t. x_hat
+                r2[0] += gy[e][j];
+                r2[1] += gy[e][j] * x[e][j];
             }
         }
-    }
-    if (act) {
-        float* pr = a.part + (size_t)blockIdx.x * 4 * D + o8;
+        team_sum<2>(r2, rbuf[2], wt, team);
+        if (valid) {
+            const float s1 = r2[0] / D, s2 = r2[1] / D;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { pr[j] = dw[j]; pr[D + j] = db[j]; pr[2 * D + j] = dsc[j]; pr[3 * D + j] = dsh[j]; }
+            for (int e = 0; e < E; ++e)
+                if (act[e]) {
+                    float out[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) out[j] = (gy[e][j] - s1 - x[e][j] * s2) * rstd;
+                    st8(dst0 + (size_t)tt * D + off[e], out);
+                }
+        }
     }
+    float* pr = a.part + (size_t)blockIdx.x * 4 * D;
+    float dsh_s[E][8];                               // db = scale1p * dsh, dw = scale1p * gxh (the constants are still in LDS here)
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        float sc[8];
+        ldf8(cs + off[e], sc);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { gxh[e][j] *= sc[j]; dsh_s[e][j] = dsh[e][j] * sc[j]; }
+    }
+    teams_to_global(gxh, act, off, dyn, team, nt, D, pr);                    // (its first barrier: every thread has read `cs`)
+    teams_to_global(dsh_s, act, off, dyn, team, nt, D, pr + D);
+    teams_to_global(dsc, act, off, dyn, team, nt, D, pr + 2 * (size_t)D);
+    teams_to_global(dsh, act, off, dyn, team, nt, D, pr + 3 * (size_t)D);
 }
 
 // ------------------------------------------------------------------------------------------------ gated residual (TransformerLayer glue)
@@ -648,8 +753,11 @@ int post_blocks(int B, int L) {
 void post_forward(const PostArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(post_fwd_kernel, dim3(post_blocks(a.B, a.L)), dim3((a.NH * 8 + 63) / 64 * 64), 0, s, a);
 }
-void post_backward(const PostBwdArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(post_bwd_kernel, dim3(post_blocks(a.B, a.L)), dim3((a.NH * 8 + 63) / 64 * 64), 0, s, a);
+void post_backward(const PostBwdArgs& a0, hipStream_t s) {
+    PostBwdArgs a = a0;
+    const int D = a.NH * 64;
+    a.wt = ln_team_waves(D);
+    hipLaunchKernelGGL(post_bwd_kernel, dim3(post_blocks(a.B, a.L)), dim3(LN_BLOCK), (size_t)(8 / a.wt) * D * sizeof(float), s, a);
 }
 void gate_forward(const GateArgs& a, hipStream_t s) {
     const long total = (long)a.B * a.L * (a.D / 8);
@@ -680,7 +788,9 @@ int adaln_backward_partials() { return 256; }          // P blocks per (batch, g
 void adaln_backward(const AdaLNBwdArgs& a0, hipStream_t s) {
     AdaLNBwdArgs a = a0;
     a.P = adaln_backward_partials();
-    hipLaunchKernelGGL(adaln_bwd_kernel, dim3(a.B * 2 * a.P), dim3((a.D / 8 + 63) / 64 * 64), 0, s, a);
+    a.wt = ln_team_waves(a.D);
+    const int rows = 8 / a.wt > 3 ? 8 / a.wt : 3;          // team reduction [nt][D] / constants [3][D] share the area
+    hipLaunchKernelGGL(adaln_bwd_kernel, dim3(a.B * 2 * a.P), dim3(LN_BLOCK), (size_t)rows * a.D * sizeof(float), s, a);
 }
 void resgate_forward(const ResGateArgs& a, hipStream_t s) {
     const long total = (long)a.B * (a.Lt + a.Lv) * (a.D / 8);
