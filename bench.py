@@ -363,7 +363,7 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False):
     # ---- activation re-materialisation sized for this GPU (untimed) -------------------------------------------------------
     # The reference checkpoints every transformer layer (configs/train/ttt-mlp/3s.toml:31, tuned for 80 GB GPUs).  With 288 GB
     # per MI355X most layers can keep their activations: probe the per-layer activation footprint with two untimed steps
-    # and keep as many layers un-checkpointed as fit under 80 % of the device memory.  Same arithmetic, same results.
+    # and keep as many layers un-checkpointed as fit under `cap` of the device memory (below).  Same arithmetic, same results.
     dit = model.dit if hasattr(model, "dit") else model
     total_mem = torch.cuda.get_device_properties(dev).total_memory
     # share of the device memory the activations may fill: multi-rank runs stay further from the edge, because an
@@ -474,7 +474,7 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False):
     dt = float(tmax)
     loss_val = float(loss.detach())
     peak_mem = torch.cuda.max_memory_allocated() / 2 ** 30
-    if args.torch_profile and rank == 0:
+    if args.torch_profile and world == 1:        # (one process only: a lone extra step would hang the others' collectives)
         from torch.profiler import ProfilerActivity, profile
         with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
             step()
