@@ -1,4 +1,5 @@
 #!/bin/bash
+# (historical: the --overlap modes / --side-wgs option of tools/op_bench.py that this call exercised were removed with the schedule they tested; results under profiles/)
 # round 2, call J: A/B of the backward's recompute-under-sweep schedule (op level, 3 s and 9 s scan lengths), the new GPU tests,
 # and the bench lines with the schedule + the 9 s GEMM selections + the 0.92 memory cap
 mkdir -p gpurun_out/r2j

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (historical: the --overlap modes / --side-wgs option of tools/op_bench.py that this call exercised were removed with the schedule they tested; results under profiles/)
 # round 2, call K: does the group recompute really run UNDER the sweep?  Kernel trace (begin / end timestamps per dispatch) of
 # tools/op_bench.py at the 9 s scan length with the side-stream schedule, and the sweep's stage cycle stamps with / without it
 mkdir -p gpurun_out/r2k

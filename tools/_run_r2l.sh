@@ -1,4 +1,5 @@
 #!/bin/bash
+# (historical: the --overlap modes / --side-wgs option of tools/op_bench.py that this call exercised were removed with the schedule they tested; results under profiles/)
 # round 2, call L: the recompute beside the sweep in launches limited to the CUs the sweep leaves free - tests, kernel trace, A/B
 mkdir -p gpurun_out/r2l
 O=$GRAFT_REPO_ROOT/gpurun_out/r2l
