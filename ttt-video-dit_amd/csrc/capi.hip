@@ -146,7 +146,8 @@ int ttt_hip_linear_backward(const ttt_dims* d, const ttt_linear_bwd_args* a, voi
 static int check_pp(int B, int L, int NH, int F) {
     if (B <= 0 || L <= 0 || NH <= 0) return fail("ttt_hip: non-positive dimension");
     if (F != 64) return fail("ttt_hip: fused pre/post kernels need head_dim 64");
-    if (NH * 8 > 1024) return fail("ttt_hip: too many heads for the post kernels");
+    if (NH * 8 > 512) return fail("ttt_hip: too many heads for the post kernels (NH * 64 <= 4096 features)");
+    if ((long long)B * L >= (1ll << 31) / 4) return fail("ttt_hip: B * L too large for the pre / post kernels' 32-bit token arithmetic");
     return 0;
 }
 
