@@ -447,6 +447,7 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False):
         # ---- timed region.  (One GPU, automatic setting: an out-of-memory error here - allocator fragmentation that the
         # warm-up step did not show - costs one layer and the whole region is warmed and timed again; nothing of a
         # failed attempt enters the result.)
+        fast0 = ext.sweep_fast_count()           # (synchronises: outside the timed region)
         dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
         if rank == 0:
@@ -474,6 +475,7 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False):
     dt = float(tmax)
     loss_val = float(loss.detach())
     peak_mem = torch.cuda.max_memory_allocated() / 2 ** 30
+    fast_wgs = ext.sweep_fast_count() - fast0
     if args.torch_profile and world == 1:        # (one process only: a lone extra step would hang the others' collectives)
         from torch.profiler import ProfilerActivity, profile
         with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
@@ -503,6 +505,9 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False):
         a_flops = 4.0 * LB * seg_S * seg_S * cfg.head_dim * cfg.num_heads
         flops["attn_fwd"], flops["attn_bwd"] = a_flops / (B * NH * NC), 2.5 * a_flops / (B * NH * NC)     # per (b,h,step) units like the scan
         scan_keys = [k for k in ks if k in ("fwd", "bwd")]
+        Kg = -(-NC // max(1, min(cfg.scan_checkpoint_group_size, NC)))                  # checkpoint groups
+        gpc = max(1, min(256 // (B * NH) if B * NH < 256 else 1, Kg))                   # groups per backward chunk (csrc/ttt_mfma_bwd2.hip)
+        sweep_chunks = -(-Kg // gpc)
         dom = max(scan_keys, key=lambda k: ks[k]["total_ms"]) if scan_keys else None
         roof = None
         if dom:
@@ -519,6 +524,10 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False):
                     "other": {k: {"avg_ms": v["avg_ms"], "launches": v["launches"],
                                   "achieved_tflops": B * NH * NC * flops[k] / (v["avg_ms"] * 1e-3) / 1e12} for k, v in ks.items() if k != dom},
                     "scan_share_of_step": sum(ks[k]["total_ms"] for k in scan_keys) / (1e3 * dt),
+                    # TTT-MLP backward sweep: cluster workgroups of the timed region that PROVED same-XCD placement and used
+                    # plain (L2-resident) hand-over records, out of all launched (4 per (b,h) and chunk)
+                    "sweep_same_xcd_frac": (fast_wgs / (ks["bwd"]["launches"] * sweep_chunks * 4 * B * NH)
+                                            if args.ssm_layer == "ttt_mlp" and "bwd" in ks and CS == 64 else None),
                     "attention_share_of_step": sum(v["total_ms"] for k, v in ks.items() if k.startswith("attn")) / (1e3 * dt)}
         line = {"metric": "DiT+TTT fwd/bwd video-tokens/sec", "value": value, "unit": "video-tokens/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
