@@ -34,11 +34,11 @@ def node_form(vid_emb, text_emb, meta, attn_length, prefix, segment):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("geo", [(2, 3, 4, 1, 5, 7), (1, 4, 3, 1, 8, 5), (2, 2, 5, 2, 3, 4)])
+@pytest.mark.parametrize("geo", [(2, 3, 4, 1, 5, 7, 0), (1, 4, 3, 1, 8, 5, 0), (2, 2, 5, 2, 3, 4, 0), (1, 3, 4, 1, 6, 3, 2)])
 def test_segment_nodes_equal_statement_form_bitwise(geo, dtype):
-    B, n_seg, attn_length, prefix, tpf, tl = geo
+    B, n_seg, attn_length, prefix, tpf, tl, cut = geo            # cut: frames the video ends short of the last segment
     D = 16
-    frames = prefix + n_seg * attn_length
+    frames = prefix + n_seg * attn_length - cut
     meta = SequenceMetadata(text_length=tl, seq_text_length=n_seg * tl, num_frames=frames, num_chunks=n_seg, tokens_per_frame=tpf,
                             latent_height=1, latent_width=tpf, t_emb=torch.zeros(1, 4))
     g = torch.Generator().manual_seed(sum(geo))
@@ -62,5 +62,8 @@ def test_segment_geometry_rejects_layouts_that_do_not_tile_the_video():
     meta = SequenceMetadata(text_length=2, seq_text_length=4, num_frames=9, num_chunks=2, tokens_per_frame=3, latent_height=1,
                             latent_width=3, t_emb=torch.zeros(1, 4))
     _segment_geometry(meta, 9 * 3, 4, 1)
+    _segment_geometry(meta, 8 * 3, 4, 1)              # last segment cut short by the end of the video: as the reference's slices
     with pytest.raises(AssertionError):
-        _segment_geometry(meta, 10 * 3, 4, 1)
+        _segment_geometry(meta, 10 * 3, 4, 1)         # a frame no segment covers
+    with pytest.raises(AssertionError):
+        _segment_geometry(meta, 5 * 3, 4, 1)          # second segment = its shared frame only

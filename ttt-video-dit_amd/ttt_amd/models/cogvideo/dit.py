@@ -61,9 +61,13 @@ def _segment_geometry(meta: SequenceMetadata, n_video: int, attn_length: int, pr
     """(tl, [(lo, hi)] video-token range of every attention segment, tokens of a shared block): segment i attends over
     ``[text_i, frames attn_length*i .. attn_length*(i+1) + prefix)``; consecutive segments share ``prefix`` frames."""
     tl, tpf = meta.text_length, meta.tokens_per_frame
-    rng = [(i * attn_length * tpf, (prefix + (i + 1) * attn_length) * tpf) for i in range(meta.num_chunks)]
-    assert 0 < prefix < attn_length and rng[0][0] == 0 and rng[-1][1] == n_video, "segments must tile the video with one shared block"
-    return tl, rng, prefix * tpf
+    rng = [(i * attn_length * tpf, min((prefix + (i + 1) * attn_length) * tpf, n_video)) for i in range(meta.num_chunks)]
+    shared = prefix * tpf
+    # (a last segment cut short by the end of the video is fine - the reference's slices clip the same way -, an uncovered tail
+    # or a segment that consists of its shared block only is not)
+    assert 0 < prefix < attn_length and rng[-1][1] == n_video and all(hi - lo > shared for lo, hi in rng), \
+        "segments must tile the video, consecutive ones sharing `prefix` frames"
+    return tl, rng, shared
 
 
 class SegmentSplit(torch.autograd.Function):
