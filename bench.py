@@ -49,6 +49,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
+HBM_PEAK_GBPS = 8000.0              # HBM3E, same table
 TOKENS_PER_FRAME = 30 * 45
 
 
@@ -476,6 +477,11 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False):
     loss_val = float(loss.detach())
     peak_mem = torch.cuda.max_memory_allocated() / 2 ** 30
     fast_wgs = ext.sweep_fast_count() - fast0
+    # a cluster hand-over of the TTT-MLP backward that gave up inside the timed region poisons that step's gradients (NaN) and
+    # makes the next extension call raise; a line measured with one is not a measurement (synchronises: region is over)
+    sweep_err = torch.tensor([ext.sweep_error()], device=dev, dtype=torch.int64)
+    dist.all_reduce(sweep_err, op=dist.ReduceOp.MAX)
+    sweep_err = int(sweep_err)
     if args.torch_profile and world == 1:        # (one process only: a lone extra step would hang the others' collectives)
         from torch.profiler import ProfilerActivity, profile
         with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
@@ -517,10 +523,22 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False):
                                      mlp=args.ssm_layer == "ttt_mlp", backward=dom == "bwd")
             kname = f"{args.ssm_layer}_{dom}_scan[{impl}]"
             traffic, traffic_src = pmc_traffic(kname, B, NH, NC)
+            # algorithmic bytes per launch: forward Q, K, V, out tiles + eta + one checkpoint per G steps;
+            # backward Q, K, V, dOut in, dQ, dK, dV out + eta, d(eta) + one checkpoint read per G steps
+            tile_b, ck_b = CS * F * 2, ((2 * F * 4 * F + 4 * F + F) * 4 if args.ssm_layer == "ttt_mlp" else (F * F + F) * 4)
+            per_step = ((4 * tile_b + CS * 2) if dom == "fwd" else (7 * tile_b + 2 * CS * 2)) + ck_b / max(1, min(cfg.scan_checkpoint_group_size, NC))
+            alg_bytes = B * NH * NC * per_step
             roof = {"bound": "mfma", "kernel": kname, "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                     "flops_per_launch": per_launch, "avg_launch_ms": ks[dom]["avg_ms"], "launches_timed": ks[dom]["launches"],
-                    "occupied_cu_frac": ach / (MFMA_BF16_PEAK_TFLOPS * min(B * NH, 256) / 256.0),
+                    # CUs the timed kernel actually occupies: one workgroup per (b,h) for the forward scans, a cluster of FOUR
+                    # workgroups (one per CU) per (b,h) for the TTT-MLP backward sweep at mini-batches of 64
+                    "occupied_cus": (occ_cus := min((4 if (dom == "bwd" and args.ssm_layer == "ttt_mlp" and CS == 64) else 1) * B * NH, 256)),
+                    "occupied_cu_frac": ach / (MFMA_BF16_PEAK_TFLOPS * occ_cus / 256.0),
+                    # which roof the kernel leans on: counter bytes / launch time against the HBM peak
+                    "hbm_gbps": (traffic / (ks[dom]["avg_ms"] * 1e-3) / 1e9) if traffic else None,
+                    "hbm_frac": (traffic / (ks[dom]["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+                    "algorithmic_bytes_per_launch": alg_bytes,
                     "other": {k: {"avg_ms": v["avg_ms"], "launches": v["launches"],
                                   "achieved_tflops": B * NH * NC * flops[k] / (v["avg_ms"] * 1e-3) / 1e12} for k, v in ks.items() if k != dom},
                     "scan_share_of_step": sum(ks[k]["total_ms"] for k in scan_keys) / (1e3 * dt),
@@ -536,7 +554,7 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False):
                                        f"{cfg.num_layers} layers, L={L} tokens/sample, adapter={args.adapter}",
                            "global_batch": world * LB, "seq_len": L, "parallelism": "replica1" if no_fsdp else f"fsdp{world}", "ttt_impl": args.impl,
                            "remat_free_layers": n_free, "fsdp_reshard_after_forward": bool(args.reshard_after_forward), "tuned_gemm_selections": bool(tuned),
-                           "valid": args.layers is None},
+                           "sweep_error": sweep_err, "valid": args.layers is None and sweep_err == 0},
                 "roofline": roof, "loss": loss_val, "peak_mem_gib": peak_mem, "peak_reserved_gib": torch.cuda.max_memory_reserved() / 2 ** 30, "total_tokens_per_s": world * L / (dt / args.steps)}
         return line
     return None

@@ -244,22 +244,24 @@ void        ttt_hip_debug_timing(void* device_buffer);
 /* DEBUG: force the number of checkpoint groups the MFMA backward re-materialises per chunk (0 = automatic,
  * sized to cover the 256 CUs); lets tests exercise the chunk-to-chunk gradient hand-over at small sizes. */
 void        ttt_hip_debug_groups_per_chunk(int groups);
-/* No-ops since round 2 (one kernel revision per entry point; the backward sweep has no helper workgroups any more):
- * kept so that binaries built against ABI version 1 keep loading. */
-void        ttt_hip_debug_variant(int revision);
-void        ttt_hip_debug_helpers(int helpers);
 /* DEBUG / A-B knobs by name: "groups_per_chunk" (checkpoint groups per backward chunk, 0 = automatic), "overlap_tail" (TTT-MLP
  * backward: 1 (default) = the tail kernel of a chunk runs on an internal side stream beside the next chunk's sweep and the
  * caller's stream joins it before the call returns; 0 = everything on the caller's stream; identical results), "fast_records" (TTT-MLP
  * backward sweep hand-over: 1 (default) = plain, L2-resident records once the four workgroups of a cluster have proven that they
  * share an XCD; 0 = write-through records always), "sweep_fast_count" (query: returns -2 - the number of cluster workgroup
- * launches that took the plain form).  Returns 0, or -1 for an unknown name.  (The round-1 knobs - kernel revisions, prefetch
+ * launches that took the plain form), "sweep_fault" (fault injection for the tests of the hand-over failure path: workgroup 3 of
+ * every backward cluster leaves before its first hand-over).  Returns 0, or -1 for an unknown name.  (The round-1 knobs - kernel revisions, prefetch
  * helpers, attention / scan variants - were A/B-ed on hardware in round 2 and removed together with the losing code.) */
 int         ttt_hip_debug_option(const char* name, int value);
 /* DEBUG: device buffer (>= 120000 floats) receiving the step-0 intermediates of workgroup 0 (NULL = off). */
-/* TTT-MLP backward, cluster form (four workgroups per (b,h) exchanging partial tiles inside the launch): 0 when no bounded
- * hand-over poll has ever given up in this process, else 1 + the (b,h) index that did.  Synchronises the device. */
+/* TTT-MLP backward, cluster form (four workgroups per (b,h) exchanging partial tiles inside the launch; at most n_cu / 4
+ * clusters per launch, so that the four are co-resident).  A bounded hand-over poll that gives up - a partner workgroup that is
+ * never scheduled - is a HARD error: the kernel fills what it still writes (dV, d(eta), the state / LayerNorm gradients) with
+ * NaN and records 1 + the (b,h) index in a host-mapped word; from then on ttt_hip_mlp_forward / ttt_hip_mlp_backward return -3 on
+ * entry (no synchronisation) until ttt_hip_sweep_error_clear() acknowledges it.  ttt_hip_debug_sweep_error() synchronises the
+ * device and returns the word (0 = no hand-over has given up). */
 unsigned    ttt_hip_debug_sweep_error(void);
+void        ttt_hip_sweep_error_clear(void);
 void        ttt_hip_debug_dump(float* device_buffer);
 
 int         ttt_hip_abi_version(void);

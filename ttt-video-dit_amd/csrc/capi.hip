@@ -51,18 +51,29 @@ extern "C" {
 int ttt_hip_abi_version(void) { return TTT_HIP_ABI_VERSION; }
 void ttt_hip_debug_timing(void* device_buffer) { ttt::mfma::set_debug_timing(device_buffer); }
 void ttt_hip_debug_groups_per_chunk(int groups) { ttt::mfma::set_debug_groups_per_chunk(groups); }
-void ttt_hip_debug_variant(int) {}       // (one kernel revision per entry point since round 2: kept for ABI stability)
-void ttt_hip_debug_helpers(int) {}      // (no helpers any more: kept for ABI stability)
 int ttt_hip_debug_option(const char* name, int value) {
     if (!name) return -1;
     if (!strcmp(name, "fast_records")) ttt::mfma::set_debug_fast_records(value);              // cluster sweep hand-over: 1 (default) / 0 = write-through records always
     else if (!strcmp(name, "sweep_fast_count")) return -2 - (int)ttt::mfma::read_sweep_fast_count();      // query: returns -2 - count
     else if (!strcmp(name, "overlap_tail")) ttt::mfma::set_debug_overlap_tail(value);            // backward: 1 (default) / 0 = tail kernel on the caller's stream
     else if (!strcmp(name, "groups_per_chunk")) ttt::mfma::set_debug_groups_per_chunk(value);
+    else if (!strcmp(name, "sweep_fault")) ttt::mfma::set_debug_sweep_fault(value);              // fault injection: workgroup 3 of every sweep cluster leaves early
     else return -1;
     return 0;
 }
 unsigned ttt_hip_debug_sweep_error(void) { return ttt::mfma::read_sweep_error(); }
+void ttt_hip_sweep_error_clear(void) { ttt::mfma::clear_sweep_error(); }
+
+// A hand-over of the TTT-MLP backward that gave up has poisoned that call's gradients (NaN); it is also STICKY: every later
+// TTT-MLP call of the process fails here, on entry, until the caller acknowledges it (no synchronisation: the word is host-mapped).
+static int check_sweep_error(const char* what) {
+    const unsigned e = ttt::mfma::peek_sweep_error();
+    if (!e) return 0;
+    snprintf(g_err, sizeof(g_err), "ttt_hip: %s refused: an earlier TTT-MLP backward hand-over timed out in this process (cluster of (b,h) %u: a "
+             "partner workgroup was never scheduled); that call's gradients were poisoned with NaN.  Acknowledge with ttt_hip_sweep_error_clear().",
+             what, e - 1u);
+    return -3;
+}
 void ttt_hip_debug_dump(float* buf) { ttt::mfma::set_debug_dump(buf); }
 const char* ttt_hip_last_error(void) { return g_err; }
 
@@ -92,6 +103,7 @@ int ttt_hip_mlp_forward(const ttt_dims* d, const ttt_mlp_fwd_args* a, void* ws, 
     int r = resolve(d, true, false);
     if (r < 0) return fail("ttt_hip: mlp_forward: unsupported geometry/dtype for the requested impl");
     if (wsb < ws_bytes(d, true, false) || (ws_bytes(d, true, false) && !ws)) return fail("ttt_hip: mlp_forward: workspace too small");
+    if (check_sweep_error("mlp_forward")) return -3;
     if (r == TTT_IMPL_MFMA) ttt::mfma::mlp_forward(d, a, ws, (hipStream_t)stream);
     else ttt::generic::mlp_forward(d, a, ws, (hipStream_t)stream);
     return post_launch("mlp_forward");
@@ -109,8 +121,12 @@ int ttt_hip_mlp_backward(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws,
     int r = resolve(d, true, true);
     if (r < 0) return fail("ttt_hip: mlp_backward: unsupported geometry/dtype for the requested impl");
     if (wsb < ws_bytes(d, true, true) || (ws_bytes(d, true, true) && !ws)) return fail("ttt_hip: mlp_backward: workspace too small");
-    if (r == TTT_IMPL_MFMA) ttt::mfma::mlp_backward(d, a, ws, (hipStream_t)stream);
-    else ttt::generic::mlp_backward(d, a, ws, (hipStream_t)stream);
+    if (check_sweep_error("mlp_backward")) return -3;
+    if (r == TTT_IMPL_MFMA) {
+        const int rc = ttt::mfma::mlp_backward(d, a, ws, (hipStream_t)stream);
+        if (rc == -10) return fail("ttt_hip: mlp_backward: the MFMA backward needs at least 4 visible compute units (four co-resident workgroups per (b,h))");
+        if (rc) return fail("ttt_hip: mlp_backward: could not allocate the host-mapped error word");
+    } else ttt::generic::mlp_backward(d, a, ws, (hipStream_t)stream);
     return post_launch("mlp_backward");
 }
 

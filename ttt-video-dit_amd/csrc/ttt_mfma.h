@@ -11,7 +11,7 @@ void set_debug_timing(void* device_buffer_16_u64);
 void set_debug_groups_per_chunk(int groups);   // 0 = automatic
 void set_debug_dump(float* device_buffer);     // revision-2 forward: intermediates of workgroup 0, step 0 (>= 120000 floats)
 void mlp_forward(const ttt_dims* d, const ttt_mlp_fwd_args* a, void* ws, hipStream_t s);
-void mlp_backward(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hipStream_t s);
+int  mlp_backward(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hipStream_t s);   // 0, or < 0: no kernel was launched
 void linear_forward(const ttt_dims* d, const ttt_linear_fwd_args* a, void* ws, hipStream_t s);
 void linear_backward(const ttt_dims* d, const ttt_linear_bwd_args* a, void* ws, hipStream_t s);
 }  // namespace mfma

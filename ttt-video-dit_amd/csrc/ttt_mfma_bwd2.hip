@@ -141,6 +141,23 @@ static int g_overlap = 1;             // tail of chunk c on a side stream under 
 void set_debug_overlap_tail(int v) { g_overlap = v; }
 static int g_fast_records = 1;        // cluster hand-over: plain (L2-resident) records once same-XCD placement is proven; 0 = always write-through
 void set_debug_fast_records(int v) { g_fast_records = v; }
+static int g_sweep_fault = 0;         // DEBUG fault injection (tests of the hand-over failure path)
+void set_debug_sweep_fault(int v) { g_sweep_fault = v; }
+
+// Compute units of the current device (cached per device): the cluster sweep needs its four workgroups co-resident, one per
+// CU (157 KiB of LDS each), so a launch carries at most n_cu / 4 clusters.
+static int device_cus() {
+    static int cus[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
+    if (!cus[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+        cus[dev] = n;
+    }
+    return cus[dev];
+}
+int sweep_clusters_per_launch() { return device_cus() / 4; }
 
 int groups_per_chunk(const ttt_dims* d) {
     const int nbh = d->B * d->NH;
@@ -158,7 +175,6 @@ int groups_per_chunk(const ttt_dims* d) {
 }
 
 static size_t align128(size_t v) { return (v + 127) & ~(size_t)127; }
-constexpr int SWEEP_BH_PER_LAUNCH = 64;            // 4 workgroups per (b,h), one per CU, all co-resident: 256 CUs
 
 size_t workspace_bytes(const ttt_dims* d, bool mlp, bool backward) {
     if (!mlp || !backward) return 0;
@@ -173,28 +189,40 @@ size_t workspace_bytes(const ttt_dims* d, bool mlp, bool backward) {
 struct OverlapRes {
     hipStream_t side = nullptr;
     hipEvent_t ready[2] = {nullptr, nullptr}, tail_done[2] = {nullptr, nullptr};
-    int n_cu = 0;
+    int state = 0;                      // 0 = not tried, 1 = usable, -1 = creation failed (one stream from then on)
 };
 static OverlapRes* overlap_resources() {
     static OverlapRes res[16];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
     OverlapRes& r = res[dev];
-    if (!r.side) {
-        if (hipStreamCreateWithFlags(&r.side, hipStreamNonBlocking) != hipSuccess) { r.side = nullptr; return nullptr; }
-        bool ok = true;
-        for (int i = 0; i < 2; ++i) {
+    if (r.state == 0) {
+        bool ok = hipStreamCreateWithFlags(&r.side, hipStreamNonBlocking) == hipSuccess;
+        for (int i = 0; ok && i < 2; ++i) {
             ok = ok && hipEventCreateWithFlags(&r.ready[i], hipEventDisableTiming) == hipSuccess;
             ok = ok && hipEventCreateWithFlags(&r.tail_done[i], hipEventDisableTiming) == hipSuccess;
         }
-        if (!ok) return nullptr;
-        if (hipDeviceGetAttribute(&r.n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) r.n_cu = 0;
+        if (!ok) {                      // usable only when EVERY object exists: release what was created
+            for (int i = 0; i < 2; ++i) {
+                if (r.ready[i]) (void)hipEventDestroy(r.ready[i]);
+                if (r.tail_done[i]) (void)hipEventDestroy(r.tail_done[i]);
+                r.ready[i] = r.tail_done[i] = nullptr;
+            }
+            if (r.side) (void)hipStreamDestroy(r.side);
+            r.side = nullptr;
+            (void)hipGetLastError();
+        }
+        r.state = ok ? 1 : -1;
     }
-    return &r;
+    return r.state == 1 ? &r : nullptr;
 }
 
-void mlp_backward(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hipStream_t s) {
+int mlp_backward(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hipStream_t s) {
     const int nbh = d->B * d->NH, G = d->G, NC = d->NC;
+    const int per_launch = sweep_clusters_per_launch();
+    if (per_launch < 1) return -10;      // fewer than 4 compute units visible: the cluster sweep cannot be co-resident
+    unsigned* err_word = sweep_error_word();
+    if (!err_word) return -11;
     const int K = (NC + G - 1) / G;
     const int gpc = groups_per_chunk(d);
     const size_t slot_stride = ((size_t)gpc * G + 1) * SLOT_BYTES;
@@ -223,6 +251,7 @@ void mlp_backward(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hipStr
     bp.dlnw = a->grad_L_ttt_norm_weight; bp.dlnb = a->grad_L_ttt_norm_bias;
     bp.NH = d->NH; bp.NC = NC;
     bp.xch = xch; bp.flags = flags; bp.fast_records = g_fast_records;
+    bp.err = err_word; bp.fault = g_sweep_fault;
 
     b2::TailParams tp = {};
     tp.dOut = (const __bf16*)a->grad_L_XQW; tp.eta = (const __bf16*)a->last_eta; tp.dXV = (const __bf16*)a->grad_L_XV;
@@ -237,7 +266,7 @@ void mlp_backward(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hipStr
     const int nchunks = (K + gpc - 1) / gpc;
     // the side stream needs CUs beside the sweep's workgroups (one per CU): otherwise one stream
     OverlapRes* ov = (g_overlap && nchunks > 1) ? overlap_resources() : nullptr;
-    if (ov && ov->n_cu - 4 * (nbh < SWEEP_BH_PER_LAUNCH ? nbh : SWEEP_BH_PER_LAUNCH) < 32) ov = nullptr;
+    if (ov && device_cus() - 4 * (nbh < per_launch ? nbh : per_launch) < 32) ov = nullptr;
     auto recompute = [&](int ch) {
         const int g0 = ch * gpc, ng = (K - g0 < gpc) ? K - g0 : gpc;
         sp.chunk_group0 = g0; sp.chunk_groups = ng; sp.chunk_lo = g0 * G;
@@ -259,9 +288,9 @@ void mlp_backward(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hipStr
         bp.last = (ch == 0);
         bp.dbg = get_debug_timing();
         (void)hipMemsetAsync(flags, 0, flag_bytes, s);        // hand-over flags restart at 0 for every launch (a memset node)
-        for (int bh0 = 0; bh0 < nbh; bh0 += SWEEP_BH_PER_LAUNCH) {
+        for (int bh0 = 0; bh0 < nbh; bh0 += per_launch) {
             bp.bh0 = bh0;
-            bp.nbh = nbh - bh0 < SWEEP_BH_PER_LAUNCH ? nbh - bh0 : SWEEP_BH_PER_LAUNCH;
+            bp.nbh = nbh - bh0 < per_launch ? nbh - bh0 : per_launch;
             launch_sweep_cluster(bp, bp.nbh, s);
         }
         tp.chunk_lo = bp.chunk_lo; tp.chunk_n = bp.chunk_hi - bp.chunk_lo;
@@ -280,6 +309,7 @@ void mlp_backward(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hipStr
         }
     }
     if (ov) (void)hipStreamWaitEvent(s, ov->tail_done[0], 0);      // C(0) is the side stream's last command
+    return 0;
 }
 
 }  // namespace mfma

@@ -17,8 +17,12 @@
 // flags (relaxed, agent scope, one lane each, bounded), then reads the payload with sc1 loads (never served by the reading
 // CU's L1).  Nothing depends on where the four workgroups run (blocks bh + q nbh share an XCD when nbh % 8 == 0: speed only).
 // Records are double-buffered by step parity - a workgroup can be at most one hand-over ahead of its slowest partner -, the
-// flags are zeroed by a memset node ahead of every launch, a poll that gives up reports through g_sweep_err instead of
-// hanging the GPU.  The four workgroups must be co-resident: the host uses this form only when 4 B NH <= 256 CUs.
+// flags are zeroed by a memset node ahead of every launch.  A poll that gives up (a partner that is not running) does not hang
+// the GPU and does not return plausible numbers either: it stores 1 + (b,h) into the process's host-mapped error word
+// (p.err, system scope), POISONS the workgroup - every later poll returns at once, everything it writes from then on (dV,
+// d(eta), the carried / final state gradients, dgamma / dbeta) is NaN - and the next extension call fails on entry
+// (capi.hip reads the word without synchronising).  The four workgroups must be co-resident: the host launches at most
+// n_cu / 4 clusters at a time.
 //
 // Workgroup = 6 waves:
 //   waves 0, 1  COMPUTE: wave pp owns the 32 hidden units [64 cq + 32 pp, +32): the carried dW1 / dW2 (both orientations) /
@@ -74,7 +78,6 @@ static_assert(LDS_CL <= 160 * 1024, "LDS budget");
 static_assert(2 * TILE_B >= 256 * 16 * 4, "the final dgamma / dbeta reduction re-uses the K / gZ2 tiles");
 
 __device__ unsigned g_fast_count = 0;       // DEBUG statistic: cluster workgroups that proved same-XCD placement and switched to plain records
-__device__ unsigned g_sweep_err = 0;        // 1 + (b,h) of a cluster workgroup whose bounded hand-over poll gave up (0 = never)
 
 template <int CTRL>
 __device__ __forceinline__ float dppq(float v) {
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster_kernel(SweepParams2 p) {
     float* db1L = etaL2 + 128;
     float* db2L = db1L + 64;
     float* gamL = db2L + 64;
-    unsigned* syncw = reinterpret_cast<unsigned*>(gamL + 64);      // [0] hand-over number the owners have seen complete, [1] fast-path verdict
+    unsigned* syncw = reinterpret_cast<unsigned*>(gamL + 64);      // [0] hand-over number the owners have seen complete, [1] fast-path verdict, [2] poisoned
 
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -144,6 +147,7 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster_kernel(SweepParams2 p) {
     auto slot_off = [&](int step) { return (step - p.chunk_lo) * (int)SLOT_BYTES; };
     const int i0 = p.chunk_hi - 1;
     unsigned* const my_flag = p.flags + ((size_t)bh * 4 + cq) * FLAG_STRIDE;
+    if (p.fault && cq == 3) return;             // DEBUG fault injection (tests): this workgroup's partners must time out loudly
 
     if (wv < 2) {
         // =========================================================================================================== COMPUTE
@@ -434,16 +438,18 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster_kernel(SweepParams2 p) {
             float* o2 = p.last ? p.dW2 + (size_t)bh * 256 * 64 : carry + C_DW2;
             float* ob1 = p.last ? p.db1 + (size_t)bh * 256 : carry + C_DB1;
             float* ob2 = p.last ? p.db2 + (size_t)bh * 64 : carry + C_DB2;
+            // (the last Bd ordered the owners' poison word before this read)
+            const float poison = syncw[2] != 0u ? __builtin_nanf("") : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ro = row_of(r, h);
-                o1[(size_t)ro * 256 + nO + c] = dW1t[0][r];
-                o1[(size_t)(32 + ro) * 256 + nO + c] = dW1t[1][r];
-                o2[(size_t)(nO + ro) * 64 + fO + c] = dW2t[0][r];
-                o2[(size_t)(nO + ro) * 64 + fX + c] = dW2t[1][r];
+                o1[(size_t)ro * 256 + nO + c] = dW1t[0][r] + poison;
+                o1[(size_t)(32 + ro) * 256 + nO + c] = dW1t[1][r] + poison;
+                o2[(size_t)(nO + ro) * 64 + fO + c] = dW2t[0][r] + poison;
+                o2[(size_t)(nO + ro) * 64 + fX + c] = dW2t[1][r] + poison;
             }
-            if (h == 0) ob1[nO + c] = db1v;
-            if (cq == 0 && h == 0) ob2[fO + c] = db2v;
+            if (h == 0) ob1[nO + c] = db1v + poison;
+            if (cq == 0 && h == 0) ob2[fO + c] = db2v + poison;
         }
         if (p.last) __syncthreads();           // (the owners' final reduction)
     } else {
@@ -463,7 +469,7 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster_kernel(SweepParams2 p) {
         load16_f32(p.ln_w + (size_t)head * 64 + of0, gam);
         const unsigned my_xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));      // HW_REG_XCC_ID[3:0]: the XCD this workgroup runs on
         if (ow == 0) {
-            syncw[0] = 0u; syncw[1] = 0u;
+            syncw[0] = 0u; syncw[1] = 0u; syncw[2] = 0u;
             __hip_atomic_store(my_flag + 1, my_xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // drained before P1, i.e. before flag 1
         }
 
@@ -580,11 +586,13 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster_kernel(SweepParams2 p) {
                 const int l = tid & 63;
                 if (l < 3) {
                     const unsigned* f = p.flags + ((size_t)bh * 4 + ((cq + 1 + l) & 3)) * FLAG_STRIDE;
-                    unsigned spins = 0;
+                    // a poisoned workgroup (an earlier poll of this launch gave up) does not wait any more
+                    unsigned spins = syncw[2] != 0u ? (1u << 22) : 0u;
                     while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
                         __builtin_amdgcn_s_sleep(1);
-                        if (++spins > (1u << 22)) {        // a partner is not running: give up loudly instead of hanging the GPU
-                            __hip_atomic_store(&g_sweep_err, 1u + (unsigned)bh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (++spins > (1u << 22)) {        // a partner is not running: give up LOUDLY instead of hanging the GPU
+                            __hip_atomic_store(p.err, 1u + (unsigned)bh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            __hip_atomic_store(syncw + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             break;
                         }
                     }
@@ -679,6 +687,12 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster_kernel(SweepParams2 p) {
                 for (int k = 0; k < 16; ++k) G_[k] = dxh[k] * r - a1 * r * (1.0f / 64.0f) + a2 * xh[k] * (1.0f / 64.0f);   // dZ2
                 store16_bf16(Bt + ot * TS + of0, G_);
                 if (cq == 0) {
+                    // (ordered after the polling wave's poison store by the acquire of syncw[0] above)
+                    if (__hip_atomic_load(syncw + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) { dv0[k] = (__bf16)__builtin_nanf(""); dv1[k] = (__bf16)__builtin_nanf(""); }
+                        se = __builtin_nanf("");
+                    }
                     bst8(rV, ow * 32, i * 8192, dv0);
                     bst8(rV, ow * 32 + 16, i * 8192, dv1);
                     if ((ow & 3) == 0) {      // workgroup 0 finishes d(eta): the eight per-wave partials of the four records
@@ -703,6 +717,10 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster_kernel(SweepParams2 p) {
         }
 
         // ---- dgamma / dbeta: to the next chunk, or reduced over the 64 tokens ----------------------------------------------------
+        if (syncw[2] != 0u) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { dgam[k] = __builtin_nanf(""); dbet[k] = __builtin_nanf(""); }
+        }
         if (!p.last) {
             if (cq == 0) {
 #pragma unroll
@@ -733,10 +751,31 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster_kernel(SweepParams2 p) {
 }  // namespace b3
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// The error word lives in host-mapped memory: the kernels store to it with system scope, the host reads it without a copy -
+// at the entry of every TTT-MLP call without synchronising (a hand-over that gave up makes the NEXT call fail), or after a
+// device synchronisation when a test / bench asks.
+static unsigned* g_err_host = nullptr;
+static unsigned* g_err_dev = nullptr;
+unsigned* sweep_error_word() {
+    if (!g_err_host) {
+        void* h = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess) return nullptr;
+        *(volatile unsigned*)h = 0u;
+        void* d = nullptr;
+        if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipHostFree(h); return nullptr; }
+        g_err_host = (unsigned*)h;
+        g_err_dev = (unsigned*)d;
+    }
+    return g_err_dev;
+}
+unsigned peek_sweep_error() { return g_err_host ? *(volatile unsigned*)g_err_host : 0u; }
 unsigned read_sweep_error() {
-    unsigned v = 0;
-    (void)hipMemcpyFromSymbol(&v, HIP_SYMBOL(b3::g_sweep_err), sizeof(v));
-    return v;
+    (void)hipDeviceSynchronize();
+    return peek_sweep_error();
+}
+void clear_sweep_error() {
+    (void)hipDeviceSynchronize();
+    if (g_err_host) *(volatile unsigned*)g_err_host = 0u;
 }
 unsigned read_sweep_fast_count() {
     unsigned v = 0;

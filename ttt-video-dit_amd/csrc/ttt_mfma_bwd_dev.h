@@ -122,6 +122,8 @@ struct SweepParams2 {
     int fast_records;                       // 1: plain (L2-resident) records once same-XCD placement is proven; 0: always write-through
     char* xch;                              // exchange area, XCH_BH_BYTES per (b,h)
     unsigned* flags;                        // [B NH][4] hand-over flags, one 128-byte line each (zeroed before every launch)
+    unsigned* err;                          // host-mapped error word of the process: 1 + (b,h) of a cluster whose hand-over poll gave up (sticky)
+    int fault;                              // DEBUG fault injection: workgroup 3 of every cluster leaves before its first hand-over
 };
 
 

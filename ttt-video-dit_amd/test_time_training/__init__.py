@@ -67,7 +67,7 @@ EXPORTED_SYMBOLS = (
     "ttt_hip_mlp_forward_workspace", "ttt_hip_mlp_backward_workspace", "ttt_hip_linear_forward_workspace",
     "ttt_hip_linear_backward_workspace", "ttt_hip_mlp_forward", "ttt_hip_mlp_backward", "ttt_hip_linear_forward",
     "ttt_hip_linear_backward", "ttt_hip_resolve_impl", "ttt_hip_abi_version", "ttt_hip_last_error",
-    "ttt_hip_debug_timing", "ttt_hip_debug_groups_per_chunk", "ttt_hip_debug_variant", "ttt_hip_debug_dump", "ttt_hip_debug_helpers", "ttt_hip_debug_option", "ttt_hip_debug_sweep_error",
+    "ttt_hip_debug_timing", "ttt_hip_debug_groups_per_chunk", "ttt_hip_debug_dump", "ttt_hip_debug_option", "ttt_hip_debug_sweep_error", "ttt_hip_sweep_error_clear",
     "ttt_hip_pre_forward", "ttt_hip_pre_backward_partials", "ttt_hip_pre_backward", "ttt_hip_post_partials",
     "ttt_hip_post_forward", "ttt_hip_post_backward", "ttt_hip_gate_forward", "ttt_hip_gate_backward_partials",
     "ttt_hip_gate_backward", "ttt_hip_attn_forward", "ttt_hip_attn_backward",
@@ -136,6 +136,11 @@ def sweep_error() -> int:
     lib = load_library()
     lib.ttt_hip_debug_sweep_error.restype = ctypes.c_uint
     return int(lib.ttt_hip_debug_sweep_error())
+
+
+def sweep_error_clear() -> None:
+    """Acknowledge a hand-over time-out (synchronises): TTT-MLP calls are accepted again."""
+    load_library().ttt_hip_sweep_error_clear()
 
 
 def sweep_fast_count() -> int:
@@ -367,8 +372,10 @@ def _req_maps(rope, src, pos, L, F, n_pos):
     """Token maps / RoPE table of the fused pre kernels: the kernel indexes ``rope[pos[t]]`` and ``x[src[t]]`` unchecked, so
     the table must cover every position (the reference's apply_rotary_emb raises a shape error for a video longer than
     config.compressed_num_frames, ssm/utils.py:82-108) and the maps must be int32 of length L.  ``n_pos`` = 1 + the largest
-    position the maps address, as a host integer (the module caches it with the maps; no device synchronisation here);
-    None skips the bound check (the backward re-runs with maps its forward has validated)."""
+    position the maps address, as a host integer (the module caches it with the maps; no device synchronisation here).
+    With ``pos`` given and ``n_pos`` unknown (a direct user of the binding, or maps that lost the module's cache through
+    ``.to()`` / ``clone()``) the bound is taken from the map itself, once per map tensor (one synchronising ``max()``, cached on
+    the tensor); with no ``pos`` the kernels rotate nothing (every token is text: position -1) and there is nothing to check."""
     for t, n in ((src, "src"), (pos, "pos")):
         if t is None:
             continue
@@ -381,9 +388,17 @@ def _req_maps(rope, src, pos, L, F, n_pos):
     if rope.numel() % F != 0:
         raise RuntimeError(f"rope: expected [n_pos, {F // 2}, 2] (cos, sin) pairs, got {tuple(rope.shape)}")
     n_rows = rope.numel() // F
-    if n_pos is None and pos is None:
-        n_pos = L
-    if n_pos is not None and n_pos > n_rows:
+    if pos is None:
+        return
+    if n_pos is None:
+        n_pos = getattr(pos, "_ttt_max_pos", None)
+        if n_pos is None:
+            n_pos = int(pos.max()) + 1
+            try:
+                pos._ttt_max_pos = n_pos
+            except Exception:
+                pass
+    if n_pos > n_rows:
         raise RuntimeError(f"rope table has {n_rows} positions but the sequence addresses {n_pos} (video longer than "
                            f"config.compressed_num_frames?)")
 
