@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--overlap", type=int, default=1, help="DEBUG A/B: TTT-MLP backward, tail kernel of a chunk 1 = on a side stream under the next sweep (default), 0 = one stream")
     ap.add_argument("--gpc", type=int, default=0, help="DEBUG A/B: checkpoint groups per backward chunk (0 = automatic)")
     ap.add_argument("--write-through-records", action="store_true", help="DEBUG A/B: the backward sweep's hand-over records always write-through (sc1), never plain")
+    ap.add_argument("--bwd-rev", type=int, default=4, help="A/B: TTT-MLP backward revision, 4 = slim step record + deriver waves (default), 3 = round 2's register-image slots")
     ap.add_argument("--phases", action="store_true", help="also print per-phase cycle totals of workgroup 0")
     a = ap.parse_args()
     import test_time_training as ext
@@ -40,6 +41,7 @@ def main():
     ext.load_library()
     ext.set_impl(a.impl)
     ext.debug_option("fast_records", 0 if a.write_through_records else 1)
+    ext.debug_option("bwd_rev", a.bwd_rev)
     ext.debug_option("overlap_tail", a.overlap)
     ext.debug_option("groups_per_chunk", a.gpc)
     dev = torch.device("cuda:0")

@@ -23,6 +23,7 @@
 #include "ttt_mfma_dev.h"
 #include "ttt_mfma_int.h"
 #include "ttt_mfma_bwd_dev.h"
+#include "ttt_bwd4_dev.h"
 
 namespace ttt {
 namespace mfma {
@@ -141,6 +142,9 @@ static int g_overlap = 1;             // tail of chunk c on a side stream under 
 void set_debug_overlap_tail(int v) { g_overlap = v; }
 static int g_fast_records = 1;        // cluster hand-over: plain (L2-resident) records once same-XCD placement is proven; 0 = always write-through
 void set_debug_fast_records(int v) { g_fast_records = v; }
+static int g_bwd_rev = 4;             // 4 = slim step record + deriver waves (round 3), 3 = round 2's register-image slots (A/B, to be removed)
+void set_debug_bwd_rev(int v) { g_bwd_rev = (v == 3) ? 3 : 4; }
+int get_debug_bwd_rev() { return g_bwd_rev; }
 static int g_sweep_fault = 0;         // DEBUG fault injection (tests of the hand-over failure path)
 void set_debug_sweep_fault(int v) { g_sweep_fault = v; }
 
@@ -167,7 +171,7 @@ int groups_per_chunk(const ttt_dims* d) {
     int g = nbh < 256 ? 256 / nbh : 1;
     if (g_forced_gpc > 0) g = g_forced_gpc;   // DEBUG knob (tests exercise the chunk hand-over at small sizes)
     // bound the slot area to ~4 GiB
-    const size_t per_group = (size_t)nbh * d->G * SLOT_BYTES;
+    const size_t per_group = (size_t)nbh * d->G * (g_bwd_rev == 4 ? s4::SLOT4_BYTES : SLOT_BYTES);
     const size_t cap = (size_t)4 << 30;
     while (g > 1 && per_group * g > cap) --g;
     if (g > K) g = K;
@@ -180,9 +184,11 @@ size_t workspace_bytes(const ttt_dims* d, bool mlp, bool backward) {
     if (!mlp || !backward) return 0;
     const size_t nbh = (size_t)d->B * d->NH;
     const size_t slots = (size_t)groups_per_chunk(d) * d->G + 1;
-    // two slot buffers + carried state gradient + exchange records and flag lines of the cluster sweep
-    return nbh * (2 * slots * SLOT_BYTES + b2::CARRY_FLOATS2 * sizeof(float)) + align128(nbh * 64) +
-           nbh * (b2::XCH_BH_BYTES + 4 * b2::FLAG_STRIDE * sizeof(unsigned));
+    // two slot buffers + carried state gradient + exchange records and flag lines of the cluster sweep (+ revision 4: the
+    // state after the last step)
+    const size_t slot_b = g_bwd_rev == 4 ? s4::SLOT4_BYTES : SLOT_BYTES;
+    return nbh * (2 * slots * slot_b + b2::CARRY_FLOATS2 * sizeof(float)) + align128(nbh * 64) +
+           nbh * (b2::XCH_BH_BYTES + 4 * b2::FLAG_STRIDE * sizeof(unsigned)) + (g_bwd_rev == 4 ? nbh * s4::FINAL_FLOATS * sizeof(float) : 0);
 }
 
 // Side stream and the events of the two-buffer hand-over, one set per device, created on first use.
@@ -217,12 +223,96 @@ static OverlapRes* overlap_resources() {
     return r.state == 1 ? &r : nullptr;
 }
 
+// Revision 4 (round 3): the same chunk walk and the same two-stream schedule over the slim step record:
+//   A  s4::launch_recompute4   (ttt_mfma_rc4.hip: 8-wave recompute, 120.5 KiB per step)
+//   B  s4::launch_sweep_cluster4 (ttt_mfma_bwd4.hip: cluster sweep with deriver waves)
+//   C  s4::launch_tail4        (dK / dQ; beside the next chunk's sweep)
+static int mlp_backward4(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hipStream_t s, int per_launch, unsigned* err_word) {
+    const int nbh = d->B * d->NH, G = d->G, NC = d->NC;
+    const int K = (NC + G - 1) / G;
+    const int gpc = groups_per_chunk(d);
+    const size_t slot_stride = ((size_t)gpc * G + 1) * s4::SLOT4_BYTES;
+    char* slots = (char*)ws;                                   // two buffers of nbh * slot_stride bytes
+    const size_t slot_buf = (size_t)nbh * slot_stride;
+    float* carry = (float*)(slots + 2 * slot_buf);
+    char* xch = (char*)(carry + (size_t)nbh * b2::CARRY_FLOATS2) + align128((size_t)nbh * 64);
+    unsigned* flags = (unsigned*)(xch + (size_t)nbh * b2::XCH_BH_BYTES);
+    const size_t flag_bytes = (size_t)nbh * 4 * b2::FLAG_STRIDE * sizeof(unsigned);
+    float* wfinal = (float*)((char*)flags + flag_bytes);
+
+    s4::RecomputeParams rp = {};
+    rp.XQ = (const __bf16*)a->XQ; rp.XK = (const __bf16*)a->XK; rp.XV = (const __bf16*)a->XV; rp.eta = (const __bf16*)a->last_eta;
+    rp.ln_w = a->ttt_norm_weight; rp.ln_b = a->ttt_norm_bias;
+    rp.W1c = a->W1_checkpoints; rp.b1c = a->b1_checkpoints; rp.W2c = a->W2_checkpoints; rp.b2c = a->b2_checkpoints;
+    rp.slot_stride_bh = slot_stride; rp.wfinal = wfinal;
+    rp.NH = d->NH; rp.NC = NC; rp.G = G; rp.K = K; rp.eps = d->eps;
+
+    s4::SweepParams4 bp = {};
+    bp.XQ = (const __bf16*)a->XQ; bp.XK = (const __bf16*)a->XK; bp.dOut = (const __bf16*)a->grad_L_XQW; bp.eta = (const __bf16*)a->last_eta;
+    bp.ln_w = a->ttt_norm_weight;
+    bp.uW1 = a->grad_L_W1_last; bp.ub1 = a->grad_L_b1_last; bp.uW2 = a->grad_L_W2_last; bp.ub2 = a->grad_L_b2_last;
+    bp.slot_stride_bh = slot_stride; bp.carry = carry;
+    bp.dXV = (__bf16*)a->grad_L_XV; bp.deta = (__bf16*)a->grad_L_last_eta;
+    bp.dW1 = a->grad_L_W1_init; bp.db1 = a->grad_L_b1_init; bp.dW2 = a->grad_L_W2_init; bp.db2 = a->grad_L_b2_init;
+    bp.dlnw = a->grad_L_ttt_norm_weight; bp.dlnb = a->grad_L_ttt_norm_bias;
+    bp.NH = d->NH; bp.NC = NC;
+    bp.xch = xch; bp.flags = flags; bp.fast_records = g_fast_records;
+    bp.err = err_word; bp.fault = g_sweep_fault;
+    bp.W1c = a->W1_checkpoints; bp.W2c = a->W2_checkpoints; bp.wfinal = wfinal; bp.G = G; bp.K = K;
+
+    const int nchunks = (K + gpc - 1) / gpc;
+    OverlapRes* ov = (g_overlap && nchunks > 1) ? overlap_resources() : nullptr;
+    if (ov && device_cus() - 4 * (nbh < per_launch ? nbh : per_launch) < 32) ov = nullptr;
+    auto recompute = [&](int ch) {
+        const int g0 = ch * gpc, ng = (K - g0 < gpc) ? K - g0 : gpc;
+        rp.chunk_group0 = g0; rp.chunk_groups = ng; rp.chunk_lo = g0 * G;
+        rp.slots = slots + (size_t)(ch & 1) * slot_buf;
+        s4::launch_recompute4(rp, nbh, s);
+    };
+    // same schedule as revision 3 (below): chunk c in slot buffer c & 1, C(c) on the side stream beside B(c-1)
+    recompute(nchunks - 1);
+    for (int ch = nchunks - 1; ch >= 0; --ch) {
+        const int g0 = ch * gpc, ng = (K - g0 < gpc) ? K - g0 : gpc;
+        const int buf = ch & 1;
+        char* cslots = slots + (size_t)buf * slot_buf;
+        bp.slots = cslots;
+        bp.chunk_lo = g0 * G;
+        bp.chunk_hi = ((g0 + ng) * G < NC) ? (g0 + ng) * G : NC;
+        bp.first = (ch == nchunks - 1);
+        bp.last = (ch == 0);
+        bp.dbg = get_debug_timing();
+        (void)hipMemsetAsync(flags, 0, flag_bytes, s);
+        for (int bh0 = 0; bh0 < nbh; bh0 += per_launch) {
+            bp.bh0 = bh0;
+            bp.nbh = nbh - bh0 < per_launch ? nbh - bh0 : per_launch;
+            s4::launch_sweep_cluster4(bp, bp.nbh, s);
+        }
+        const int chunk_n = bp.chunk_hi - bp.chunk_lo;
+        if (ch > 0) {
+            if (ov && ch + 1 < nchunks) (void)hipStreamWaitEvent(s, ov->tail_done[buf ^ 1], 0);
+            recompute(ch - 1);
+        }
+        hipStream_t ts = s;
+        if (ov) {
+            (void)hipEventRecord(ov->ready[buf], s);
+            (void)hipStreamWaitEvent(ov->side, ov->ready[buf], 0);
+            ts = ov->side;
+        }
+        s4::launch_tail4((const __bf16*)a->grad_L_XQW, (const __bf16*)a->last_eta, (const __bf16*)a->grad_L_XV, cslots, slot_stride,
+                         (__bf16*)a->grad_L_XQ, (__bf16*)a->grad_L_XK, NC, bp.chunk_lo, chunk_n, nbh, ts);
+        if (ov) (void)hipEventRecord(ov->tail_done[buf], ov->side);
+    }
+    if (ov) (void)hipStreamWaitEvent(s, ov->tail_done[0], 0);
+    return 0;
+}
+
 int mlp_backward(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hipStream_t s) {
     const int nbh = d->B * d->NH, G = d->G, NC = d->NC;
     const int per_launch = sweep_clusters_per_launch();
     if (per_launch < 1) return -10;      // fewer than 4 compute units visible: the cluster sweep cannot be co-resident
     unsigned* err_word = sweep_error_word();
     if (!err_word) return -11;
+    if (g_bwd_rev == 4) return mlp_backward4(d, a, ws, s, per_launch, err_word);
     const int K = (NC + G - 1) / G;
     const int gpc = groups_per_chunk(d);
     const size_t slot_stride = ((size_t)gpc * G + 1) * SLOT_BYTES;

@@ -1,57 +1,38 @@
-// MFMA TTT-MLP backward for gfx950, CLUSTER form of the reverse sweep (round 2): the sweep of one (b,h) runs on FOUR
-// workgroups - four CUs - with role-specialised waves.
-//
-// Why (profiles/r1f, r2a): the single-workgroup sweep (ttt_mfma_bwd2.hip) is bound by what ONE CU can pull from memory - a
-// step reads ~430 KiB of slot data and a CU sustains ~10 bytes / cycle of misses - and by one CU's issue slots; 48 scans
-// occupy 48 of 256 CUs.  Everything the sweep carries or loads is sliced by hidden unit: dW1[:, H], dW2[H, :], db1[H] and the
-// slot fragment arrays of the wave pair w (ttt_mfma_dev.h).  So workgroup cq of a cluster takes the wave pair w = cq of the
-// 8-wave decomposition (64 hidden units: a quarter of the slot bytes, of the state and of the MFMAs per CU).  The ONLY
-// quantity that crosses the slices per step is the partial d(gZ2)^T [64 x 64] fp32 that the single-CU form reduces over w
-// through LDS (+ the per-token d(eta) partials): every workgroup publishes its partial and reads the other three (an
-// all-gather), and all four run the cheap owner stage redundantly with the same summation order, so dZ2 is bit-identical on
-// the four CUs and ONE hand-over per step suffices.
-//
-// Hand-over = the placement-independent recipe of the CDNA4 guide (cdna_hip_programming.md Guideline 16, form R1): payload
-// stored write-through (16-byte sc1 buffer stores), every storing wave drains (s_waitcnt vmcnt(0)), workgroup barrier, ONE
-// lane stores the step number into the workgroup's flag word (relaxed, agent scope); the consumer polls the three partner
-// flags (relaxed, agent scope, one lane each, bounded), then reads the payload with sc1 loads (never served by the reading
-// CU's L1).  Nothing depends on where the four workgroups run (blocks bh + q nbh share an XCD when nbh % 8 == 0: speed only).
-// Records are double-buffered by step parity - a workgroup can be at most one hand-over ahead of its slowest partner -, the
-// flags are zeroed by a memset node ahead of every launch.  A poll that gives up (a partner that is not running) does not hang
-// the GPU and does not return plausible numbers either: it stores 1 + (b,h) into the process's host-mapped error word
-// (p.err, system scope), POISONS the workgroup - every later poll returns at once, everything it writes from then on (dV,
-// d(eta), the carried / final state gradients, dgamma / dbeta) is NaN - and the next extension call fails on entry
-// (capi.hip reads the word without synchronising).  The four workgroups must be co-resident: the host launches at most
-// n_cu / 4 clusters at a time.
-//
-// Workgroup = 6 waves:
-//   waves 0, 1  COMPUTE: wave pp owns the 32 hidden units [64 cq + 32 pp, +32): the carried dW1 / dW2 (both orientations) /
-//               db1 tiles and every MFMA of the step (same algebra and products as the 8-wave sweep);
-//   waves 2..5  OWNERS (256 threads = 64 tokens x 4 lanes x 16 features): staging of the next step's K / gZ2 / Q / eta tiles
-//               into LDS (double-buffered), the output-LayerNorm backward of the next step, the hand-over (flag, poll,
-//               partner reads), the fused-LN / L2 backward-of-backward -> dZ2, dV, d(eta), dgamma / dbeta, and - while the
-//               compute waves finish the step - L2 prefetch touches of the slot lines two steps ahead.
-// Per step i (j = i - 1), 4 workgroup barriers:
-//   compute:  S1 (u^T, d(eta) partial, first half of d(gZ2)^T)  |Ba|  S2 (second half -> published record), drain  |Bb|
-//             snapshot of the state operands, OUTPUT PATH OF STEP j (it needs no partner data: it fills the hand-over
-//             latency)  |Bc|  S4a (dZ1, state updates of step i), publish state for step j  |Bd|
-//   owners:   tiles / output-LN of step j, own-array loads of step i  |Ba| |Bb|  flag, poll, partner records, owner math ->
-//             dZ2_i  |Bc|  prefetch touches  |Bd|
+// MFMA TTT-MLP backward for gfx950, revision 4 (round 3): the cluster sweep of revision 3 (ttt_mfma_bwd3.hip - four workgroups
+// per (b,h), one hand-over per step, role-specialised waves; that header explains the decomposition and the hand-over protocol,
+// which are unchanged) fed from the SLIM step record of ttt_bwd4_dev.h instead of 570-KiB register images:
+//   * the owners' LDS-DMA staging of ten fragment arrays per step is gone; TWO DERIVER WAVES per workgroup (waves 6, 7; wave pp
+//     owns the 32 hidden units of compute wave pp) load the slice's Z1 / Z1b fragments (16 KiB per step instead of 80), re-derive
+//     X2, gelu', gelu'', X2b, gelu'(Z1b), gX2, gZ1, M and the second orientations, REVERSE the state update to obtain the
+//     per-step W1 / W2 (fp32, re-anchored at every forward checkpoint) and write exactly the operand fragments the compute
+//     waves used to receive by DMA into the same staging regions R1 .. R4 - the compute waves' code is revision 3's, unchanged;
+//     the per-step arithmetic of a deriver wave is ttt_bwd4_aux_body.h (also executed on the CPU wave emulator);
+//   * the sweep additionally stores gZ1 (N) and the packed W1 per step for the parallel dK / dQ tail kernel (below), which
+//     revision 3 read from the phase-A images.
+// Deriver schedule against the four workgroup barriers of a step i (j = i - 1; every staging region keeps ONE buffer, each
+// write sits between the region's last reader and its next reader):
+//   after Bd(i+1)  R4 <- D1 | M | X2 of step i (held in registers since they were derived), R3.W2T <- W2_i^T, loads of Z1_j, Z1b_j
+//   after Ba(i)    R3 <- gelu'(Z1b_j) | X2b_j                                   (the output path of step i read R3 before Bc(i+1))
+//   after Bb(i)    (K_j, gZ2_j, eta_j tiles are visible)  derive_z1(j), reverse_step(j): R1 <- gZ1 | D1 | X2 (N) of step j, R2 <- W2_j
+//   Bc(i), Bd(i)   nothing of the derivers is due
 // Math: SURVEY.md Appendix A backward; oracle/ttt_oracle.py:_mlp_step_bwd is the executable spec.
 #include "ttt_mfma.h"
 #include "ttt_mfma_dev.h"
 #include "ttt_mfma_int.h"
 #include "ttt_mfma_bwd_dev.h"
 #include "ttt_bwd4_dev.h"
+#define TTT_WV_FN __device__ __forceinline__
+#include "ttt_bwd4_aux_body.h"
 
 namespace ttt {
 namespace mfma {
 using namespace ttt::mf;
 
-namespace b3 {
+namespace b4 {
 using namespace ttt::mfma::b2;
+using namespace ttt::mfma::s4;
 
-constexpr int NTC = 384;                                  // 2 compute waves + 4 owner waves
+constexpr int NTC = 512;                                  // 2 compute waves + 4 owner waves + 2 deriver waves
 constexpr int TILE_B = TILE_ELEMS * 2;                    // 9216 bytes: one padded [64][64] bf16 tile
 constexpr int L_K = 0;                                    // K   [2][t][f]  (by step parity)
 constexpr int L_G = L_K + 2 * TILE_B;                     // gZ2 [2][t][f]
@@ -62,13 +43,12 @@ constexpr int L_XU = L_B + TILE_B;                        // u^T exchange betwee
 constexpr int L_XD = L_XU + 2 * 4 * 1024;                 // dW2 block exchange: 2 x 2 fragments
 constexpr int L_SM = L_XD + 2 * 2 * 1024;                 // floats: eta[2][64], db1[64], db2[64], gamma[64], sync word
 constexpr int SM_FLOATS = 2 * 64 + 64 + 64 + 64 + 4;
-// Fragment staging regions, filled by the owners' LDS-DMA (global_load_lds_dwordx4: one 1-KiB fragment image per wave
-// instruction, lane-linear = exactly the slot layout) one stage or more ahead of the compute waves, which read every slot
-// operand from here (ds_read_b128 at fragment * 1024 + lane * 16) and never wait for global memory:
-//   R1  S1 operands of the step        GZ1T | D1N | XT           refilled (next step) after Ba
-//   R2  S2 operand                     W2                        refilled after Bb
-//   R3  output-path operands           D1B(j) | X2B(j) | W2T(i)  refilled at the top of the iteration (W2T also feeds S4a)
-//   R4  S4a operands                   D1 | GX2 | X2             refilled at the top of the iteration
+// Fragment staging regions, written by the deriver waves (lane-linear fragment images: fragment f of an array at f * 1 KiB +
+// lane * 16, the layout of round 2's slot arrays) and read by the compute waves with ds_read_b128:
+//   R1  S1 operands of the step        GZ1T | D1N | XT           written for step j after Bb(i)
+//   R2  S2 operand                     W2                        written for step j after Bb(i)
+//   R3  output-path operands           D1B(j) | X2B(j) | W2T(i)  D1B / X2B after Ba(i), W2T after Bd(i+1) (W2T also feeds S4a)
+//   R4  S4a operands                   D1 | GX2 | X2             written for step i after Bd(i+1)
 constexpr int FRK = 8 * 1024;                             // one fragment array of a wave pair
 constexpr int L_R1 = (L_SM + SM_FLOATS * 4 + 1023) / 1024 * 1024;
 constexpr int L_R2 = L_R1 + 3 * FRK;
@@ -78,7 +58,7 @@ constexpr int LDS_CL = L_R4 + 3 * FRK;
 static_assert(LDS_CL <= 160 * 1024, "LDS budget");
 static_assert(2 * TILE_B >= 256 * 16 * 4, "the final dgamma / dbeta reduction re-uses the K / gZ2 tiles");
 
-__device__ unsigned g_fast_count = 0;       // DEBUG statistic: cluster workgroups that proved same-XCD placement and switched to plain records
+__device__ unsigned g_fast_count4 = 0;       // DEBUG statistic: cluster workgroups that proved same-XCD placement and switched to plain records
 
 template <int CTRL>
 __device__ __forceinline__ float dppq(float v) {
@@ -103,7 +83,7 @@ typedef __attribute__((address_space(1))) void glb_void;
 __device__ __forceinline__ bf16x8 lfr(const char* smem, int off, int idx, int l) {
     return *reinterpret_cast<const bf16x8*>(smem + off + idx * 1024 + l * 16);
 }
-// owner-wave barrier that leaves LDS-DMA requests in flight (a plain __syncthreads() would drain them: its fence waits vmcnt(0))
+// owner / deriver barrier that leaves global loads in flight (a plain __syncthreads() would drain them: its fence waits vmcnt(0))
 __device__ __forceinline__ void owner_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 #define TTT_STAMP4(k)                                                        \
@@ -113,8 +93,22 @@ __device__ __forceinline__ void owner_barrier() { asm volatile("s_waitcnt lgkmcn
         t_last = _t;                                                         \
     }
 
+// the wave backend of ttt_bwd4_aux_body.h on the device
+struct DeriverBackend {
+    char* base;
+    __device__ __forceinline__ int lane() const { return threadIdx.x & 63; }
+    __device__ __forceinline__ float exp2(float x) const { return __builtin_amdgcn_exp2f(x); }
+    __device__ __forceinline__ float rcp(float x) const { return __builtin_amdgcn_rcpf(x); }
+    template <class T> __device__ __forceinline__ T lds_load(int byte_off) const { return *reinterpret_cast<const T*>(base + byte_off); }
+    template <class T> __device__ __forceinline__ void lds_store(int byte_off, T v) const { *reinterpret_cast<T*>(base + byte_off) = v; }
+    __device__ __forceinline__ f32x16 mma3216(bf16x8 a, bf16x8 b, f32x16 c) const { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+    __device__ __forceinline__ bf16x4 tr_read(int byte_addr) const {
+        return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(base + byte_addr));
+    }
+};
+
 template <bool DBG>
-__global__ __launch_bounds__(NTC) void mlp_bwd_cluster_kernel(SweepParams2 p) {
+__global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __bf16* Kt2 = reinterpret_cast<__bf16*>(smem + L_K);
     __bf16* Gt2 = reinterpret_cast<__bf16*>(smem + L_G);
@@ -144,8 +138,8 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster_kernel(SweepParams2 p) {
     const __amdgpu_buffer_rsrc_t rV = make_srd(p.dXV + (size_t)bh * NC * 4096, act_bytes);
     const __amdgpu_buffer_rsrc_t rE = make_srd(p.eta + (size_t)bh * NC * 64, (size_t)NC * 64 * 2);
     const __amdgpu_buffer_rsrc_t rX = make_srd(p.xch + (size_t)bh * XCH_BH_BYTES, XCH_BH_BYTES);
-    const int WREG = cq * (int)SLOT_WAVE_FR;
-    auto slot_off = [&](int step) { return (step - p.chunk_lo) * (int)SLOT_BYTES; };
+    const int WREG = cq * (int)SLICE_BYTES;
+    auto slot_off = [&](int step) { return (step - p.chunk_lo) * (int)SLOT4_BYTES; };
     const int i0 = p.chunk_hi - 1;
     unsigned* const my_flag = p.flags + ((size_t)bh * 4 + cq) * FLAG_STRIDE;
     if (p.fault && cq == 3) return;             // DEBUG fault injection (tests): this workgroup's partners must time out loudly
@@ -201,7 +195,7 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster_kernel(SweepParams2 p) {
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const bf16x8 zf = pack(dz, s);                       // dZ1b (k = t rows, j = n lane)
-                    bst8(rS, l16, sj + fro(FR_DZ1B, fr_idx(ti, pp, s)), zf);
+                    bst8(rS, l16, sj + fro4(A_DZ1B, fr_idx(ti, pp, s)), zf);
                     dW1t[0] = mma(tr_pi(Qt, 32 * ti, s, 0, l), zf, dW1t[0]);
                     dW1t[1] = mma(tr_pi(Qt, 32 * ti, s, 32, l), zf, dW1t[1]);
                     const bf16x8 xb = lfr(smem, L_R3 + FRK, fr_idx(ti, pp, s), l);          // X2b (m = n lane, k = t rows)
@@ -222,7 +216,7 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster_kernel(SweepParams2 p) {
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int s = 0; s < 2; ++s) bst8(rS, l * 16, sj + fro(FR_DW1, fr_idx(a, pp, s)), pack(dW1t[a], s));
+                for (int s = 0; s < 2; ++s) bst8(rS, l * 16, sj + fro4(A_DW1, fr_idx(a, pp, s)), pack(dW1t[a], s));
 #pragma unroll
             for (int s = 0; s < 2; ++s) *reinterpret_cast<bf16x8*>(exd + ((size_t)(pp * 2 + s) * 64 + l) * 16) = pack(dW2t[1], s);
             if (h == 0) { db1L[32 * pp + c] = db1v; db2L[fO + c] = db2v; }
@@ -408,7 +402,7 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster_kernel(SweepParams2 p) {
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const bf16x8 zf = pack(dz, s);                        // dZ1 (k = t rows, j = n lane)
-                    bst8(rS, l16, sw + fro(FR_DZ1, fr_idx(ti, pp, s)), zf);
+                    bst8(rS, l16, sw + fro4(A_DZ1, fr_idx(ti, pp, s)), zf);
                     dW1t[0] = mma(tr_pi(Kt, 32 * ti, s, 0, l), zf, dW1t[0]);
                     dW1t[1] = mma(tr_pi(Kt, 32 * ti, s, 32, l), zf, dW1t[1]);
                     const bf16x8 gO = tr_pi(Gt, 32 * ti, s, fO, l), gX = tr_pi(Gt, 32 * ti, s, fX, l);
@@ -453,7 +447,7 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster_kernel(SweepParams2 p) {
             if (cq == 0 && h == 0) ob2[fO + c] = db2v + poison;
         }
         if (p.last) __syncthreads();           // (the owners' final reduction)
-    } else {
+    } else if (wv < 6) {
         // =========================================================================================================== OWNERS
         const int ow = tid - 128;                               // 0 .. 255
         const int ot = ow >> 2, of0 = 16 * (ow & 3);            // token, first of this thread's 16 features
@@ -488,14 +482,14 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster_kernel(SweepParams2 p) {
             const int vo = ow * 32;
             L.k0 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rK, vo, step * 8192, 0));
             L.k1 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rK, vo + 16, step * 8192, 0));
-            const int sg = slot_off(step) + (int)(SLOT_FR + SLOT_OWN);
+            const int sg = slot_off(step) + (int)(SLOT4_FR + SLOT4_OWN);
             L.g0 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rS, vo, sg, 0));
             L.g1 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rS, vo + 16, sg, 0));
             L.q0 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rQ, vo, step * 8192, 0));
             L.q1 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rQ, vo + 16, step * 8192, 0));
             L.ev = 0;
             if (ow < 64) L.ev = __builtin_amdgcn_raw_buffer_load_b16(rE, ow * 2, step * 128, 0);
-            const int so = slot_off(step) + (int)SLOT_FR;
+            const int so = slot_off(step) + (int)SLOT4_FR;
             L.da = bld8(rO, vo, step * 8192);
             L.db = bld8(rO, vo + 16, step * 8192);
             ld16f(rS, ow * 64, so + 2 * (int)SLOT_OWN_ARR, L.xl);
@@ -526,28 +520,12 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster_kernel(SweepParams2 p) {
             for (int k = 0; k < 16; ++k) g[k] = (64.0f * g[k] - s1 - L.xl[k] * s2) * L.rstdl * (1.0f / 64.0f);
             store16_bf16(At + ot * TS + of0, g);
         };
-        // LDS-DMA of one fragment array (8 fragments of this workgroup's wave pair) of slot `step` into a staging region: two
-        // fragments per owner wave, 1 KiB per instruction, destination lane-linear
-        auto dma8 = [&](int lds_off, int arr, int step) {
-            const int l = tid & 63;
-            const char* src = slots + (size_t)slot_off(step) + WREG + (size_t)arr * 8 * FRAG_BYTES + (size_t)l * 16;
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int f = 2 * (wv - 2) + u;
-                __builtin_amdgcn_global_load_lds((glb_void*)(src + (size_t)f * FRAG_BYTES), (lds_void*)(smem + lds_off + f * 1024), 16, 0, 0);
-            }
-        };
-
         __syncthreads();                       // P0: gamma row, sync word visible to all owner waves
-        dma8(L_R1, FR_GZ1T, i0); dma8(L_R1 + FRK, FR_D1N, i0); dma8(L_R1 + 2 * FRK, FR_XT, i0);
-        dma8(L_R2, FR_W2, i0);
-        dma8(L_R3, FR_D1B, i0); dma8(L_R3 + FRK, FR_X2B, i0); dma8(L_R3 + 2 * FRK, FR_W2T, i0 + 1);
         {
             StepLoads L0;
             request_step(i0, L0);
             consume_step(0, L0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         owner_barrier();                       // P1
         owner_barrier();                       // P2
 
@@ -557,13 +535,10 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster_kernel(SweepParams2 p) {
             const int sI = slot_off(i);
             const unsigned epoch = (unsigned)(i0 - i) + 1;
             const int xrec = (int)(epoch & 1) * 4 * XCH_REC_BYTES;
-            // ---- requests of this iteration: LDS-DMA staging for its later stages (R3: consumed after Bb, R4: after Bc), the
-            //      owner inputs of step i, the tiles / output-LayerNorm inputs of step j - all in flight across Ba ---------------------
-            if (more) { dma8(L_R3, FR_D1B, i - 1); dma8(L_R3 + FRK, FR_X2B, i - 1); }
-            dma8(L_R3 + 2 * FRK, FR_W2T, i);
-            dma8(L_R4, FR_D1, i); dma8(L_R4 + FRK, FR_GX2, i); dma8(L_R4 + 2 * FRK, FR_X2, i);
+            // ---- requests of this iteration: the owner inputs of step i, the tiles / output-LayerNorm inputs of step j - all in
+            //      flight across Ba ------------------------------------------------------------------------------------------------
             float xh[16], go[16];
-            const int so = sI + (int)SLOT_FR;
+            const int so = sI + (int)SLOT4_FR;
             ld16f(rS, ow * 64, so, xh);
             ld16f(rS, ow * 64, so + (int)SLOT_OWN_ARR, go);
             const float r = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rS, ot * 8, so + 3 * (int)SLOT_OWN_ARR, 0));
@@ -571,7 +546,6 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster_kernel(SweepParams2 p) {
             if (more) request_step(i - 1, Lj);
             owner_barrier();                   // Ba (nothing of the owners is due yet: they arrive at once)
             if (more) consume_step(cur ^ 1, Lj);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // R3 / R4 have landed
             owner_barrier();                   // Bb: this workgroup's record is complete and drained; At / Q_j / R3 visible
             unsigned long long t_o = 0;
             if (DBG && p.dbg != nullptr && blockIdx.x == 0 && ow == 0) t_o = __builtin_readcyclecounter();
@@ -609,7 +583,7 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster_kernel(SweepParams2 p) {
                     const bool use_fast = all_same && p.fast_records != 0;
                     if (l == 0) {
                         __hip_atomic_store(syncw + 1, use_fast ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (use_fast) atomicAdd(&g_fast_count, 1u);
+                        if (use_fast) atomicAdd(&g_fast_count4, 1u);
                     }
                 }
                 if (l == 0) __hip_atomic_store(syncw, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -704,16 +678,9 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster_kernel(SweepParams2 p) {
                     }
                 }
             }
-            // staging of the next step's S1 / S2 operands: requested only after the hand-over (VMEM returns in order, and even the
-            // ISSUE of a request blocks while the CU's queues are full); R1 / R2 were last read before Ba / Bb of this iteration
             TTT_OSTAMP(2)                      // owner math, dZ2 / dV / d(eta) stores
             owner_barrier();                   // Bc: dZ2_i visible to the compute waves
             TTT_OSTAMP(3)                      // wait for the compute waves at Bc
-            if (more) {
-                dma8(L_R1, FR_GZ1T, i - 1); dma8(L_R1 + FRK, FR_D1N, i - 1); dma8(L_R1 + 2 * FRK, FR_XT, i - 1);
-                dma8(L_R2, FR_W2, i - 1);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // R1 / R2 of the next step have landed
             owner_barrier();                   // Bd
         }
 
@@ -746,55 +713,220 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster_kernel(SweepParams2 p) {
                 p.dlnb[(size_t)bh * 64 + ow] = b;
             }
         }
+    } else {
+        // =========================================================================================================== DERIVERS
+        const int pp = wv - 6;                                  // the 32 hidden units of compute wave pp
+        const int l = tid & 63, h = l >> 5, c = l & 31;
+        const int nO = 64 * cq + 32 * pp;
+        DeriverBackend bk{smem};
+        bwd4::AuxState st;
+        // the state entering step `step` (a multiple of the checkpoint group size, or the end of the sequence): the forward's
+        // checkpoint, or the state phase A wrote after the last step
+        auto load_anchor = [&](int step) {
+            const float *W1g, *W2g;
+            if (step >= NC) {
+                W1g = p.wfinal + (size_t)bh * FINAL_FLOATS;
+                W2g = W1g + 64 * 256;
+            } else {
+                const size_t ck = (size_t)bh * p.K + step / p.G;
+                W1g = p.W1c + ck * 64 * 256;
+                W2g = p.W2c + ck * 256 * 64;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ro = row_of(r, h);
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    st.W1t[a][r] = W1g[(size_t)(32 * a + ro) * 256 + nO + c];
+                    st.W2t[a][r] = W2g[(size_t)(nO + ro) * 64 + 32 * a + c];
+                }
+            }
+        };
+        auto load_frags = [&](int step, int arr, bwd4::Frags4& F) {
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) F.f[ti][s] = bld8(rS, l * 16, slot_off(step) + WREG + fro4(arr, fr_idx(ti, pp, s)));
+        };
+        load_anchor(p.chunk_hi);
+        {   // W1 entering step chunk_hi = W1' of the chunk's last step, for the tail (slot index chunk_hi - chunk_lo)
+            char* sl = slots + (size_t)slot_off(p.chunk_hi) + WREG;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) *reinterpret_cast<bf16x8*>(sl + fro4(A_W1, fr_idx(a, pp, s)) + l * 16) = pack(st.W1t[a], s);
+        }
+        bwd4::Frags4 Z1, Z1B, X2, D1, M;
+        load_frags(i0, A_Z1, Z1);
+        load_frags(i0, A_Z1B, Z1B);
+        owner_barrier();                       // P0
+        bwd4::stage_w2t(bk, st, pp, L_R3 + 2 * FRK);                  // W2' of the chunk's last step (its output path runs before P2)
+        bwd4::derive_z1b(bk, Z1B, pp, L_R3, L_R3 + FRK);
+        owner_barrier();                       // P1: the tiles of step i0 (K, gZ2, eta) are visible
+        bwd4::reverse_step(bk, st, pp, L_K, L_G, L_SM, Z1, X2, D1, M, L_R1, L_R2, slots + (size_t)slot_off(i0) + WREG,
+                           fro4(A_GZ1T, 0), fro4(A_W1, 0));
+        owner_barrier();                       // P2
+
+        for (int i = i0; i >= p.chunk_lo; --i) {
+            const bool more = i > p.chunk_lo;
+            const int nxt = ((i0 - i) & 1) ^ 1;                 // tile buffer of step j = i - 1
+            bwd4::stage_r4(bk, pp, L_R4, D1, M, X2);            // of step i: S4a of the step before is behind Bd / P2
+            bwd4::stage_w2t(bk, st, pp, L_R3 + 2 * FRK);        // W2_i^T: S4a of step i, output path of step j
+            if (more) {
+                load_frags(i - 1, A_Z1, Z1);
+                load_frags(i - 1, A_Z1B, Z1B);
+            }
+            owner_barrier();                   // Ba
+            if (more) bwd4::derive_z1b(bk, Z1B, pp, L_R3, L_R3 + FRK);
+            owner_barrier();                   // Bb: K_j, gZ2_j, eta_j staged by the owners are visible
+            if (more) {
+                if (i % p.G == 0) load_anchor(i);               // group boundary: the exact state entering step i
+                bwd4::reverse_step(bk, st, pp, L_K + nxt * TILE_B, L_G + nxt * TILE_B, L_SM + nxt * 64 * 4, Z1, X2, D1, M, L_R1, L_R2,
+                                   slots + (size_t)slot_off(i - 1) + WREG, fro4(A_GZ1T, 0), fro4(A_W1, 0));
+            }
+            owner_barrier();                   // Bc
+            owner_barrier();                   // Bd
+        }
+        if (p.last) owner_barrier();           // (the owners' final reduction)
     }
 }
 
-}  // namespace b3
+
+// =========================================================================================================================
+// Tail kernel (phase C): one workgroup (4 waves, wave w <-> hidden slice w) per (b, h, step of the chunk):
+//   dK = -eta (gZ1 dW1'^T) + dZ1 W1^T - dV        dQ = dOut + dZ1b W1'^T      (W1' = state entering the next step)
+// Revision 3's kernel reading the sweep-written arrays of the slim record: dZ1, dZ1b, dW1' (compute waves), gZ1 (N) and the
+// packed W1 of the step and of the next step (deriver waves).
+struct TailParams4 {
+    const __bf16 *dOut, *eta, *dXV;
+    char* slots; size_t slot_stride_bh;
+    __bf16 *dXQ, *dXK;
+    int NC, chunk_lo, chunk_n;
+};
+constexpr int LDS_TAIL4 = 4 * 64 * PS * 4;
+__device__ __forceinline__ bf16x8 ld_frag4(const char* slice, int arr, int idx, int lane) {
+    return *reinterpret_cast<const bf16x8*>(slice + fro4(arr, idx) + lane * 16);
+}
+
+__global__ __launch_bounds__(NT) void mlp_bwd_tail4_kernel(TailParams4 p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, h = l >> 5, c = l & 31;
+    const int bh = blockIdx.x / p.chunk_n, si = blockIdx.x % p.chunk_n;
+    const int i = p.chunk_lo + si;
+    const size_t tile = (size_t)bh * p.NC + i;
+    const char* slot_w = p.slots + (size_t)bh * p.slot_stride_bh + (size_t)si * SLOT4_BYTES + (size_t)w * SLICE_BYTES;
+    const char* next_w = slot_w + SLOT4_BYTES;
+    const bf16x8 I0 = ident_pi(0, h, c), I1 = ident_pi(1, h, c);
+    const int ot = 16 * w + (l & 15), of0 = 16 * (l >> 4);
+
+    for (int pass = 0; pass < 2; ++pass) {           // 0: dK, 1: dQ
+        f32x16 PA[2][2];                             // [fj][ti]  partial (rows = f, lane = t) over this wave's hidden slice
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) PA[a][b] = zero16();
+        if (pass == 0) {
+            // -eta * (dW1'^T)^T-contraction: A = dW1'^T tile (rows = n, lane = f) in place, B = gZ1^T (k = n, j = t)
+#pragma unroll
+            for (int nj = 0; nj < 2; ++nj) {
+                bf16x8 dWt[2][2];
+#pragma unroll
+                for (int fj = 0; fj < 2; ++fj) {
+                    const f32x16 t = transpose_tile(ld_frag4(slot_w, A_DW1, fr_idx(fj, nj, 0), l), ld_frag4(slot_w, A_DW1, fr_idx(fj, nj, 1), l), I0, I1);
+                    dWt[fj][0] = pack(t, 0);
+                    dWt[fj][1] = pack(t, 1);
+                }
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const bf16x8 gt = ld_frag4(slot_w, A_GZ1T, fr_idx(nj, ti, s), l);
+                        PA[0][ti] = mma(dWt[0][s], gt, PA[0][ti]);
+                        PA[1][ti] = mma(dWt[1][s], gt, PA[1][ti]);
+                    }
+            }
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                const float el = -(float)p.eta[tile * 64 + 32 * ti + c];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { PA[0][ti][r] *= el; PA[1][ti][r] *= el; }
+            }
+        }
+        // + W^T-contraction with dZ^T:  pass 0: W1 (entering state), dZ1 ; pass 1: W1' (next slot), dZ1b
+        const char* wsrc = pass == 0 ? slot_w : next_w;
+        const int zarr = pass == 0 ? A_DZ1 : A_DZ1B;
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj) {
+            bf16x8 W1T[2][2];
+#pragma unroll
+            for (int fj = 0; fj < 2; ++fj) {
+                const f32x16 t = transpose_tile(ld_frag4(wsrc, A_W1, fr_idx(fj, nj, 0), l), ld_frag4(wsrc, A_W1, fr_idx(fj, nj, 1), l), I0, I1);
+                W1T[fj][0] = pack(t, 0);
+                W1T[fj][1] = pack(t, 1);
+            }
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                const f32x16 zt = transpose_tile(ld_frag4(slot_w, zarr, fr_idx(ti, nj, 0), l), ld_frag4(slot_w, zarr, fr_idx(ti, nj, 1), l), I0, I1);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const bf16x8 zb = pack(zt, s);
+                    PA[0][ti] = mma(W1T[0][s], zb, PA[0][ti]);
+                    PA[1][ti] = mma(W1T[1][s], zb, PA[1][ti]);
+                }
+            }
+        }
+        if (pass == 1) __syncthreads();              // owners of pass 0 finished reading `red`
+        write_partial(red + (size_t)w * 64 * PS, PA, h, c);
+        __syncthreads();
+        {
+            float z[16], d[16];
+            gather_partial(red, nullptr, ot, of0, z);
+            const size_t off = tile * 4096 + (size_t)ot * 64 + of0;
+            if (pass == 0) {
+                load16_bf16(p.dXV + off, d);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) z[j] -= d[j];                // dK -= dt, dt = dV
+                store16_bf16(p.dXK + off, z);
+            } else {
+                load16_bf16(p.dOut + off, d);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) z[j] += d[j];
+                store16_bf16(p.dXQ + off, z);
+            }
+        }
+    }
+}
+
+}  // namespace b4
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// The error word lives in host-mapped memory: the kernels store to it with system scope, the host reads it without a copy -
-// at the entry of every TTT-MLP call without synchronising (a hand-over that gave up makes the NEXT call fail), or after a
-// device synchronisation when a test / bench asks.
-static unsigned* g_err_host = nullptr;
-static unsigned* g_err_dev = nullptr;
-unsigned* sweep_error_word() {
-    if (!g_err_host) {
-        void* h = nullptr;
-        if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess) return nullptr;
-        *(volatile unsigned*)h = 0u;
-        void* d = nullptr;
-        if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipHostFree(h); return nullptr; }
-        g_err_host = (unsigned*)h;
-        g_err_dev = (unsigned*)d;
-    }
-    return g_err_dev;
-}
-unsigned peek_sweep_error() { return g_err_host ? *(volatile unsigned*)g_err_host : 0u; }
-unsigned read_sweep_error() {
-    (void)hipDeviceSynchronize();
-    return peek_sweep_error();
-}
-void clear_sweep_error() {
-    (void)hipDeviceSynchronize();
-    if (g_err_host) *(volatile unsigned*)g_err_host = 0u;
-}
-unsigned read_sweep_fast_count() {
+namespace s4 {
+unsigned read_sweep_fast_count4() {
     unsigned v = 0;
-    (void)hipMemcpyFromSymbol(&v, HIP_SYMBOL(b3::g_fast_count), sizeof(v));
-    return v + s4::read_sweep_fast_count4();
+    (void)hipMemcpyFromSymbol(&v, HIP_SYMBOL(b4::g_fast_count4), sizeof(v));
+    return v;
 }
 
-void launch_sweep_cluster(const b2::SweepParams2& bp, int nbh, hipStream_t s) {
+void launch_sweep_cluster4(const SweepParams4& bp, int nbh, hipStream_t s) {
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)b3::mlp_bwd_cluster_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, b3::LDS_CL);
-        (void)hipFuncSetAttribute((const void*)b3::mlp_bwd_cluster_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, b3::LDS_CL);
+        (void)hipFuncSetAttribute((const void*)b4::mlp_bwd_cluster4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, b4::LDS_CL);
+        (void)hipFuncSetAttribute((const void*)b4::mlp_bwd_cluster4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, b4::LDS_CL);
+        (void)hipFuncSetAttribute((const void*)b4::mlp_bwd_tail4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, b4::LDS_TAIL4);
         attr = true;
     }
-    const dim3 grid(nbh * 4), blk(b3::NTC);
-    if (bp.dbg) hipLaunchKernelGGL((b3::mlp_bwd_cluster_kernel<true>), grid, blk, b3::LDS_CL, s, bp);
-    else hipLaunchKernelGGL((b3::mlp_bwd_cluster_kernel<false>), grid, blk, b3::LDS_CL, s, bp);
+    const dim3 grid(nbh * 4), blk(b4::NTC);
+    if (bp.dbg) hipLaunchKernelGGL((b4::mlp_bwd_cluster4_kernel<true>), grid, blk, b4::LDS_CL, s, bp);
+    else hipLaunchKernelGGL((b4::mlp_bwd_cluster4_kernel<false>), grid, blk, b4::LDS_CL, s, bp);
 }
+
+void launch_tail4(const __bf16* dOut, const __bf16* eta, const __bf16* dXV, char* slots, size_t slot_stride_bh, __bf16* dXQ, __bf16* dXK,
+                  int NC, int chunk_lo, int chunk_n, int nbh, hipStream_t s) {
+    b4::TailParams4 tp = {dOut, eta, dXV, slots, slot_stride_bh, dXQ, dXK, NC, chunk_lo, chunk_n};
+    hipLaunchKernelGGL(b4::mlp_bwd_tail4_kernel, dim3(nbh * chunk_n), dim3(NT), b4::LDS_TAIL4, s, tp);
+}
+}  // namespace s4
 
 }  // namespace mfma
 }  // namespace ttt

@@ -127,6 +127,38 @@ __device__ __forceinline__ void gelu_fwd_grad2(float x, float& y, float& dy, flo
     d2y = q * du + 0.5f * x * q * (d2u - 2.0f * t * du * du);
 }
 
+// store the two halves of a packed C-tile fragment (regs 8s..8s+7 of a tile with rows = R, lane = C) into the
+// image img[C][R]: lane c writes rows (16s + 4h .. +3) and (16s + 8 + 4h .. +3) of its image row as 2 x 8 bytes
+__device__ __forceinline__ void st_image(__bf16* img_row, int rbase, int s, int h, bf16x8 v) {
+    bf16x4 lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
+    *reinterpret_cast<bf16x4*>(img_row + rbase + 16 * s + 4 * h) = lo;
+    *reinterpret_cast<bf16x4*>(img_row + rbase + 16 * s + 8 + 4 * h) = hi;
+}
+
+// gelu_tanh over a C tile in place, on ALIGNED register pairs (r, r + 1) with the packed f32 instructions: the same IEEE
+// operations in the same order as gelu_fwd(), two elements per v_pk_mul / v_pk_fma / v_pk_add.  Why (tools/isa_mix.py): left
+// to itself the SLP vectorizer pairs the scalar form's multiplies across MISALIGNED registers of the tile and then spends
+// 24 v_mov + 12 v_alignbit + 4 v_perm per step and wave (in this block and again around the fragment packs) to realign
+// them - 230 VALU for 32 elements where ~120 do.  Round-2 A/B on an MI355X (NH = 48, NC = 282): 2.368 -> 2.195 ms per scan;
+// the scalar form was removed.  (Not bit-identical to it - the contraction of mul + add into fma differs - but the same
+// distance from the fp64 oracle.)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gelu_fwd_tile_pk(f32x16& z) {
+    const f32x2 k0 = {GELU_K0, GELU_K0}, k1 = {GELU_K1, GELU_K1}, one = {1.0f, 1.0f};
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        f32x2 x = {z[r], z[r + 1]};
+        const f32x2 x2 = x * x;
+        const f32x2 a = x * __builtin_elementwise_fma(x2, k1, k0);
+        const f32x2 e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+        const f32x2 d = one + e;
+        const f32x2 sg = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+        x = x * sg;
+        z[r] = x[0];
+        z[r + 1] = x[1];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // LDS geometry shared by the scan kernels
 constexpr int NT = 256;

@@ -41,7 +41,9 @@ unsigned read_sweep_error();           // 0, or 1 + (b,h) of a cluster workgroup
 unsigned peek_sweep_error();           // the same word without synchronising (entry check of the TTT-MLP calls)
 void clear_sweep_error();              // acknowledge (synchronises)
 unsigned* sweep_error_word();          // device pointer of the host-mapped word (allocated on first use; nullptr on failure)
-void set_debug_sweep_fault(int v);     // DEBUG fault injection: workgroup 3 of every sweep cluster leaves before its first hand-over
+void set_debug_sweep_fault(int v);
+void set_debug_bwd_rev(int v);        // TTT-MLP backward: 4 (default) = slim step record + deriver waves, 3 = round 2's register-image slots
+int get_debug_bwd_rev();     // DEBUG fault injection: workgroup 3 of every sweep cluster leaves before its first hand-over
 unsigned read_sweep_fast_count();   // DEBUG statistic (synchronises)
 
 }  // namespace mfma
