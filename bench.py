@@ -235,6 +235,106 @@ def cpu_baseline(ssm_layer, budget_s=25.0):
                       f"(L={L}; the 3 s segment is 13 frames, L=18048): {dt:.2f} s on {threads} threads; scaled by 42 layers"}
 
 
+def size_warm_and_time(step, hk, remat_free_layers, warmup, steps, world):
+    """Activation re-materialisation sized for this GPU, warm-up and the timed region - the control flow every rank of an
+    N-GPU run must walk IDENTICALLY (a rank that takes another branch leaves the others in a collective).  `hk` supplies the
+    device: memory statistics, synchronisation, the MIN all-reduce, barriers (tests/test_bench_policy_gloo.py drives this
+    function on two gloo ranks with a fake device).  Returns (remat_free_layers used, seconds of the timed region, last loss).
+
+    The reference checkpoints every transformer layer (configs/train/ttt-mlp/3s.toml:31, tuned for 80 GB GPUs).  With 288 GB
+    per MI355X most layers can keep their activations: probe the per-layer activation footprint with two untimed steps and
+    keep as many layers un-checkpointed as fit under `cap` of the device memory.  Same arithmetic, same results."""
+    # share of the device memory the activations may fill: multi-rank runs stay further from the edge, because an
+    # out-of-memory error on ONE rank cannot be recovered from while the others sit in a collective
+    cap = 0.88 if world == 1 else 0.80
+    auto = remat_free_layers == "auto"
+    peak0 = 0
+    if auto:
+        # layers in the second probe step: 4 at the 3 s geometry (2.7 GB of activations per layer and sample), 1 for the long
+        # videos, whose layers are 3 - 20 x larger; an out-of-memory error in the probe means "none fit"
+        probe = hk.probe_layers
+        hk.reset_peak()
+        hk.set_free_layers(0)
+        step()
+        hk.synchronize()
+        peak0 = hk.max_allocated()
+        n_free = 0
+        if probe:
+            hk.reset_peak()
+            hk.set_free_layers(probe)
+            try:
+                step()
+                hk.synchronize()
+                per_layer = max((hk.max_allocated() - peak0) / probe, 1.0)
+                n_free = int(max(0, min(hk.num_layers, (cap * hk.total_memory - peak0) // per_layer)))
+            except hk.oom:
+                if world > 1:
+                    raise                  # the other ranks sit in a collective: not recoverable
+                hk.release()
+                n_free = 0
+        if world > 1:       # every rank must take the same decision
+            n_free = hk.all_reduce_min(n_free)
+    else:
+        n_free = int(remat_free_layers)
+    # warm-up with the chosen setting; if the caching allocator's fragmentation pushes it over the edge, back off and retry
+    # (still untimed).  With an explicit --remat-free-layers N an out-of-memory error is fatal, as it should be.
+    refined = False
+
+    def back_off():
+        hk.release()
+        return max(0, n_free - max(1, n_free // 10))
+
+    while True:
+        hk.set_free_layers(n_free)
+        hk.reset_peak()
+        try:
+            for _ in range(max(warmup, 1 if auto else 0)):
+                step()
+            hk.synchronize()
+            ok = 1
+        except hk.oom:
+            if not auto:
+                raise
+            ok = 0
+        if world > 1:
+            ok = hk.all_reduce_min(ok)
+        if ok and auto and not refined and 0 < n_free < hk.num_layers:
+            # one refinement with the footprint measured at the chosen setting (the 4-layer probe over-estimates it)
+            refined = True
+            per_layer = max((hk.max_allocated() - peak0) / n_free, 1.0)
+            better = int(max(0, min(hk.num_layers, (cap * hk.total_memory - peak0) // per_layer)))
+            if world > 1:
+                better = hk.all_reduce_min(better)
+            if better > n_free:
+                n_free = better
+                continue
+        if not ok:
+            n_free = back_off()
+            continue
+        # ---- timed region.  (One GPU, automatic setting: an out-of-memory error here - allocator fragmentation that the
+        # warm-up step did not show - costs one layer and the whole region is warmed and timed again; nothing of a
+        # failed attempt enters the result.)
+        hk.barrier()
+        hk.synchronize()
+        hk.before_timed(n_free)
+        try:
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                loss = step()
+            hk.synchronize()
+        except hk.oom:
+            hk.after_timed()
+            if not auto or world > 1:
+                raise
+            log(f"out of memory inside the timed region at remat_free_layers={n_free}: backing off, timing again")
+            n_free = back_off()
+            continue
+        hk.barrier()
+        dt = time.perf_counter() - t0
+        hk.after_timed()
+        return n_free, dt, loss
+
+
 def main():
     args = parse()
     if args.cpu_baseline_only:
@@ -361,116 +461,63 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False):
             replica.publish()                       # fp32 masters -> bf16 compute copies (what FSDP's all-gather does)
         return loss
 
-    # ---- activation re-materialisation sized for this GPU (untimed) -------------------------------------------------------
-    # The reference checkpoints every transformer layer (configs/train/ttt-mlp/3s.toml:31, tuned for 80 GB GPUs).  With 288 GB
-    # per MI355X most layers can keep their activations: probe the per-layer activation footprint with two untimed steps
-    # and keep as many layers un-checkpointed as fit under `cap` of the device memory (below).  Same arithmetic, same results.
+    # ---- activation re-materialisation sized for this GPU (untimed), warm-up, timed region: size_warm_and_time() ------------
     dit = model.dit if hasattr(model, "dit") else model
-    total_mem = torch.cuda.get_device_properties(dev).total_memory
-    # share of the device memory the activations may fill: multi-rank runs stay further from the edge, because an
-    # out-of-memory error on ONE rank cannot be recovered from while the others sit in a collective
-    cap = 0.88 if world == 1 else 0.80
-    if args.remat_free_layers == "auto":
-        # layers in the second probe step: 4 at the 3 s geometry (2.7 GB of activations per layer and sample), 1 for the long
-        # videos, whose layers are 3 - 20 x larger; an out-of-memory error in the probe means "none fit"
-        probe = (4 if frames <= 13 and LB == 1 else 1) if cfg.num_layers >= 8 else 0
-        torch.cuda.reset_peak_memory_stats()
-        dit.remat_free_layers = 0
-        step()
-        torch.cuda.synchronize()
-        peak0 = torch.cuda.max_memory_allocated()
-        n_free = 0
-        if probe:
+    fast0 = [0]
+
+    class Hooks:
+        oom = torch.cuda.OutOfMemoryError
+        total_memory = torch.cuda.get_device_properties(dev).total_memory
+        num_layers = cfg.num_layers
+        probe_layers = (4 if frames <= 13 and LB == 1 else 1) if cfg.num_layers >= 8 else 0
+
+        @staticmethod
+        def set_free_layers(n):
+            dit.remat_free_layers = n
+
+        @staticmethod
+        def reset_peak():
             torch.cuda.reset_peak_memory_stats()
-            dit.remat_free_layers = probe
-            try:
-                step()
-                torch.cuda.synchronize()
-                per_layer = max((torch.cuda.max_memory_allocated() - peak0) / probe, 1.0)
-                n_free = int(max(0, min(cfg.num_layers, (cap * total_mem - peak0) // per_layer)))
-            except torch.cuda.OutOfMemoryError:
-                if world > 1:
-                    raise                  # the other ranks sit in a collective: not recoverable
-                opt.zero_grad(set_to_none=True)
-                if replica:
-                    replica.zero_grad()
-                torch.cuda.empty_cache()
-                n_free = 0
-        if world > 1:       # every rank must take the same decision
-            t = torch.tensor([n_free], device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            n_free = int(t)
-    else:
-        n_free = int(args.remat_free_layers)
-    # warm-up with the chosen setting; if the caching allocator's fragmentation pushes it over the edge, back off and retry
-    # (still untimed).  With an explicit --remat-free-layers N an out-of-memory error is fatal, as it should be.
-    refined = False
-    auto = args.remat_free_layers == "auto"
 
-    def back_off():
-        opt.zero_grad(set_to_none=True)
-        if replica:
-            replica.zero_grad()
-        torch.cuda.empty_cache()
-        return max(0, n_free - max(1, n_free // 10))
+        @staticmethod
+        def max_allocated():
+            return torch.cuda.max_memory_allocated()
 
-    while True:
-        dit.remat_free_layers = n_free
-        torch.cuda.reset_peak_memory_stats()
-        try:
-            for _ in range(max(args.warmup, 1 if auto else 0)):
-                step()
+        @staticmethod
+        def synchronize():
             torch.cuda.synchronize()
-            ok = 1
-        except torch.cuda.OutOfMemoryError:
-            if not auto:
-                raise
-            ok = 0
-        if world > 1:
-            t = torch.tensor([ok], device=dev)
+
+        @staticmethod
+        def release():
+            opt.zero_grad(set_to_none=True)
+            if replica:
+                replica.zero_grad()
+            torch.cuda.empty_cache()
+
+        @staticmethod
+        def all_reduce_min(v):
+            t = torch.tensor([v], device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            ok = int(t)
-        if ok and auto and not refined and 0 < n_free < cfg.num_layers:
-            # one refinement with the footprint measured at the chosen setting (the 4-layer probe over-estimates it)
-            refined = True
-            per_layer = max((torch.cuda.max_memory_allocated() - peak0) / n_free, 1.0)
-            better = int(max(0, min(cfg.num_layers, (cap * total_mem - peak0) // per_layer)))
-            if world > 1:
-                t = torch.tensor([better], device=dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MIN)
-                better = int(t)
-            if better > n_free:
-                n_free = better
-                continue
-        if not ok:
-            n_free = back_off()
-            continue
-        # ---- timed region.  (One GPU, automatic setting: an out-of-memory error here - allocator fragmentation that the
-        # warm-up step did not show - costs one layer and the whole region is warmed and timed again; nothing of a
-        # failed attempt enters the result.)
-        fast0 = ext.sweep_fast_count()           # (synchronises: outside the timed region)
-        dist.barrier(device_ids=[local_rank])
-        torch.cuda.synchronize()
-        if rank == 0:
-            log(f"timed region: {args.steps} steps, remat_free_layers={n_free}")
-        timer.reset()
-        timer.active = True
-        try:
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                loss = step()
-            torch.cuda.synchronize()
-        except torch.cuda.OutOfMemoryError:
+            return int(t)
+
+        @staticmethod
+        def barrier():
+            dist.barrier(device_ids=[local_rank])
+
+        @staticmethod
+        def before_timed(n_free):
+            fast0[0] = ext.sweep_fast_count()           # (synchronises: outside the timed region)
+            if rank == 0:
+                log(f"timed region: {args.steps} steps, remat_free_layers={n_free}")
+            timer.reset()
+            timer.active = True
+
+        @staticmethod
+        def after_timed():
             timer.active = False
-            if not auto or world > 1:
-                raise
-            log(f"out of memory inside the timed region at remat_free_layers={n_free}: backing off, timing again")
-            n_free = back_off()
-            continue
-        dist.barrier(device_ids=[local_rank])
-        dt = time.perf_counter() - t0
-        timer.active = False
-        break
+
+    n_free, dt, loss = size_warm_and_time(step, Hooks, args.remat_free_layers, args.warmup, args.steps, world)
+    fast0 = fast0[0]
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)

@@ -26,6 +26,7 @@ extern "C" {
 // returns the number of LDS races the detector saw
 int emul_bwd4_aux_step(float* W1, float* W2, const unsigned short* z1, const unsigned short* z1b, const unsigned short* K,
                        const unsigned short* G, const float* eta, char* lds_out, char* gslice, char* msg, int msg_len) {
+    static char park[2 * bwd4::PARK_BYTES];
     const emul::RaceReport rep = emul::run_group(2, [&](emul::EmulWave& w) {
         const int pp = w.wave(), l = w.lane(), h = l >> 5, c = l & 31;
         // stage the tiles (wave 0 only, then a barrier)
@@ -47,14 +48,14 @@ int emul_bwd4_aux_step(float* W1, float* W2, const unsigned short* z1, const uns
                 st.W2t[a][r] = W2[(32 * pp + ro) * 64 + 32 * a + c];
             }
         }
-        bwd4::Frags4 Z1, Z1B, X2, D1, M;
+        bwd4::Frags4 Z1, Z1B;
         for (int ti = 0; ti < 2; ++ti)
             for (int s = 0; s < 2; ++s) {
                 std::memcpy(&Z1.f[ti][s], z1 + ((size_t)bwd4::fr_idx(ti, pp, s) * 64 + l) * 8, 16);
                 std::memcpy(&Z1B.f[ti][s], z1b + ((size_t)bwd4::fr_idx(ti, pp, s) * 64 + l) * 8, 16);
             }
-        bwd4::reverse_step(w, st, pp, L_K, L_G, L_ETA, Z1, X2, D1, M, L_R1, L_R2, gslice, 0, 8 * 1024);
-        bwd4::stage_r4(w, pp, L_R4, D1, M, X2);
+        bwd4::reverse_step(w, st, pp, L_K, L_G, L_ETA, Z1, L_R1, L_R2, gslice, 0, 8 * 1024, park + pp * bwd4::PARK_BYTES);
+        bwd4::stage_r4(w, pp, L_R4, park + pp * bwd4::PARK_BYTES);
         bwd4::derive_z1b(w, Z1B, pp, L_R3, L_R3 + 8 * 1024);
         bwd4::stage_w2t(w, st, pp, L_R3 + 16 * 1024);
         for (int r = 0; r < 16; ++r) {

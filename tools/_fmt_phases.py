@@ -7,5 +7,5 @@ for k in ("fwd", "bwd"):
         out += [k, f'{d[k]["avg_ms"]:.3f} ms (min {d[k]["min_ms"]:.3f})', f'{d[k]["us_per_step"]:.2f} us/step']
 ph = d.get("phase_cycles_per_step")
 if ph:
-    out += ["| sweep stages", str(ph[16:24]), "| owner hand-over", str(ph[24:28])]
+    out += ["| sweep stages", str(ph[16:24]), "| owner hand-over", str(ph[24:28]), "| deriver (stage, z1b, reverse, barriers)", str(ph[28:32])]
 print(" ".join(out))

@@ -156,16 +156,27 @@ TTT_WV_FN void stage_w2t(BK& bk, const AuxState& st, int pp, int off_w2t, Frags4
     }
 }
 
-// (1) .. (7): one reverse step, ordered for short live ranges (the deriver shares its 256 registers with 64 of fp32 state).
+// (1) .. (7): one reverse step, ordered for SHORT LIVE RANGES: the deriver role shares the kernel's 256 registers per lane with
+// 64 registers of fp32 state, and a first version that kept the step's T fragments in registers until their staging region
+// was free made hipcc spill ~200 dwords per step, each reload a serialised round trip (measured: 52 k cycles per step).  So:
+//   * the T fragments D1 | M | X2 (R4 material, wanted only after the NEXT barrier Bd) are parked in a small per-wave global
+//     scratch (12 KiB, rewritten every step: it lives in L2) as soon as a token tile is done, and fetched by stage_r4() later;
+//   * the sigmoid of Z1 is evaluated twice (X2 for the W2 update, then gelu' / gelu'' per token tile) instead of carrying 32
+//     registers across the W2 update (`opaque8` keeps hipcc from merging the two evaluations);
+//   * W2^T is re-derived per token tile (two MFMAs per 32 x 32 block) instead of living through the whole step.
 // LDS inputs: K tile, gZ2 tile (row-major [t][TS] bf16), eta[64] fp32 of the step; Z1: the step's pre-activation fragments.
-// On return `st` is the state ENTERING the step, X2 / D1 / M hold the step's T fragments (R4 material), R1 / R2 are written,
-// and gZ1 (N) and the packed W1 have been stored to the step's slice region `g_slice` (byte offsets off_gz1t / off_w1).
+// On return `st` is the state ENTERING the step, R1 / R2 are written, `r4_park` holds D1 | M | X2 ([array][ti][s] fragments of
+// this wave), and gZ1 (N) and the packed W1 have been stored to the step's slice region `g_slice` (byte offsets off_gz1t /
+// off_w1).
 template <class BK>
 TTT_WV_FN float gelu1(BK& bk, float x) { return x * bk.rcp(1.0f + bk.exp2(x * (x * x * GELU_K1 + GELU_K0))); }
 
+constexpr int PARK_BYTES = 12 * FRAG;                    // per deriver wave
+TTT_WV_FN int park_off(int arr, int ti, int s) { return ((arr * 2 + ti) * 2 + s) * FRAG; }
+
 template <class BK>
-TTT_WV_FN void reverse_step(BK& bk, AuxState& st, int pp, int tile_k, int tile_g, int vec_eta, const Frags4& Z1, Frags4& X2, Frags4& D1,
-                            Frags4& M, int off_r1, int off_r2, char* g_slice, int off_gz1t, int off_w1) {
+TTT_WV_FN void reverse_step(BK& bk, AuxState& st, int pp, int tile_k, int tile_g, int vec_eta, const Frags4& Z1, int off_r1, int off_r2,
+                            char* g_slice, int off_gz1t, int off_w1, char* r4_park) {
     const int l = bk.lane(), h = l >> 5, c = l & 31;
     constexpr int FRK = 8 * FRAG;
 
@@ -180,51 +191,51 @@ TTT_WV_FN void reverse_step(BK& bk, AuxState& st, int pp, int tile_k, int tile_g
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const __bf16 y = (__bf16)gelu1(bk, (float)Z1.f[ti][s][e]);
-                X2.f[ti][s][e] = y;
                 xs[e] = (__bf16)((float)y * etaR[8 * s + e]);
             }
 #pragma unroll
             for (int b = 0; b < 2; ++b) st.W2t[b] = bk.mma3216(xs, tr_pi(bk, tile_g, 32 * ti, s, 32 * b), st.W2t[b]);
         }
     }
-    // R2: W2_i (rows = n, lane = f), FR_W2 order [ni][fj][s] ; W2^T tiles for the contraction over f below
-    bf16x8 W2T[2][2];
-    {
-        const bf16x8 I0 = ident_pi(0, h, c), I1 = ident_pi(1, h, c);
+    // R2: W2_i (rows = n, lane = f), FR_W2 order [ni][fj][s]
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const bf16x8 p0 = pack(st.W2t[b], 0), p1 = pack(st.W2t[b], 1);
-            st_frag(bk, off_r2, fr_idx(pp, b, 0), p0);
-            st_frag(bk, off_r2, fr_idx(pp, b, 1), p1);
-            const f32x16 t = transpose_tile(bk, p0, p1, I0, I1);
-            W2T[b][0] = pack(t, 0);
-            W2T[b][1] = pack(t, 1);
-        }
-    }
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) st_frag(bk, off_r2, fr_idx(pp, b, s), pack(st.W2t[b], s));
     // (1b), (3), (4), (5) per token tile
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti) {
+        const bf16x8 I0 = ident_pi(0, h, c), I1 = ident_pi(1, h, c);
         f32x16 gx = zero16();                                     // gX2 = gZ2 W2^T   (rows = t, lane = n)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < 2; ++b) {
+            const f32x16 t = transpose_tile(bk, pack(st.W2t[b], 0), pack(st.W2t[b], 1), I0, I1);      // W2^T block (rows = f, lane = n)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) gx = bk.mma3216(pi_row(bk, tile_g, 32 * ti + c, 32 * b, s, h), W2T[b][s], gx);
-        bf16x8 g1p[2], g1sp[2];
+            for (int s = 0; s < 2; ++s) gx = bk.mma3216(pi_row(bk, tile_g, 32 * ti + c, 32 * b, s, h), pack(t, s), gx);
+        }
+        bf16x8 g1p[2], g1sp[2], x2[2], d1[2];
         {
             const f32x16 etaR = rows_from_lds(bk, vec_eta, 32 * ti, h);
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 z = bk.opaque8(Z1.f[ti][s]);
+                bf16x8 m;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float y, dy, d2y;
-                    gelu3(bk, (float)Z1.f[ti][s][e], y, dy, d2y);
+                    gelu3(bk, (float)z[e], y, dy, d2y);
                     const __bf16 db = (__bf16)dy;
-                    D1.f[ti][s][e] = db;
+                    x2[s][e] = (__bf16)y;
+                    d1[s][e] = db;
                     const float g1 = gx[8 * s + e] * (float)db;            // gZ1, from the rounded gelu' the compute waves multiply with too
                     g1p[s][e] = (__bf16)g1;
                     g1sp[s][e] = (__bf16)(g1 * etaR[8 * s + e]);
-                    M.f[ti][s][e] = (__bf16)(gx[8 * s + e] * d2y);
+                    m[e] = (__bf16)(gx[8 * s + e] * d2y);
                 }
+                *reinterpret_cast<bf16x8*>(r4_park + park_off(0, ti, s) + l * 16) = d1[s];
+                *reinterpret_cast<bf16x8*>(r4_park + park_off(1, ti, s) + l * 16) = m;
+                *reinterpret_cast<bf16x8*>(r4_park + park_off(2, ti, s) + l * 16) = x2[s];
+            }
         }
         // (4) W1_i = W1_{i+1} + (eta K)^T gZ1 :  A = K^T by transposed reads (m = f, k = t), B = eta gZ1 in place (k = t, j = n)
 #pragma unroll
@@ -232,7 +243,6 @@ TTT_WV_FN void reverse_step(BK& bk, AuxState& st, int pp, int tile_k, int tile_g
 #pragma unroll
             for (int a = 0; a < 2; ++a) st.W1t[a] = bk.mma3216(tr_pi(bk, tile_k, 32 * ti, s, 32 * a), g1sp[s], st.W1t[a]);
         // (5) N orientation: gZ1^T | gelu'(Z1)^T | X2^T  -> R1 (FR_GZ1T | FR_D1N | FR_XT order [nj][ti][s]), one tile at a time
-        const bf16x8 I0 = ident_pi(0, h, c), I1 = ident_pi(1, h, c);
         {
             const f32x16 t = transpose_tile(bk, g1p[0], g1p[1], I0, I1);
 #pragma unroll
@@ -243,12 +253,12 @@ TTT_WV_FN void reverse_step(BK& bk, AuxState& st, int pp, int tile_k, int tile_g
             }
         }
         {
-            const f32x16 t = transpose_tile(bk, D1.f[ti][0], D1.f[ti][1], I0, I1);
+            const f32x16 t = transpose_tile(bk, d1[0], d1[1], I0, I1);
 #pragma unroll
             for (int s = 0; s < 2; ++s) st_frag(bk, off_r1 + FRK, fr_idx(pp, ti, s), pack(t, s));
         }
         {
-            const f32x16 t = transpose_tile(bk, X2.f[ti][0], X2.f[ti][1], I0, I1);
+            const f32x16 t = transpose_tile(bk, x2[0], x2[1], I0, I1);
 #pragma unroll
             for (int s = 0; s < 2; ++s) st_frag(bk, off_r1 + 2 * FRK, fr_idx(pp, ti, s), pack(t, s));
         }
@@ -260,18 +270,20 @@ TTT_WV_FN void reverse_step(BK& bk, AuxState& st, int pp, int tile_k, int tile_g
         for (int s = 0; s < 2; ++s) *reinterpret_cast<bf16x8*>(g_slice + off_w1 + fr_idx(a, pp, s) * FRAG + l * 16) = pack(st.W1t[a], s);
 }
 
-// R4: the step's T fragments D1 | M | X2 (FR_D1 | FR_GX2 | FR_X2 order [ti][nj][s])
+// R4: the step's T fragments D1 | M | X2 (FR_D1 | FR_GX2 | FR_X2 order [ti][nj][s]) from the wave's parking area
 template <class BK>
-TTT_WV_FN void stage_r4(BK& bk, int pp, int off_r4, const Frags4& D1, const Frags4& M, const Frags4& X2) {
+TTT_WV_FN void stage_r4(BK& bk, int pp, int off_r4, const char* r4_park) {
     constexpr int FRK = 8 * FRAG;
+    const int l = bk.lane();
+    bf16x8 v[12];
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
+    for (int k = 0; k < 12; ++k) v[k] = *reinterpret_cast<const bf16x8*>(r4_park + k * FRAG + l * 16);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            st_frag(bk, off_r4, fr_idx(ti, pp, s), D1.f[ti][s]);
-            st_frag(bk, off_r4 + FRK, fr_idx(ti, pp, s), M.f[ti][s]);
-            st_frag(bk, off_r4 + 2 * FRK, fr_idx(ti, pp, s), X2.f[ti][s]);
-        }
+    for (int arr = 0; arr < 3; ++arr)
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) st_frag(bk, off_r4 + arr * FRK, fr_idx(ti, pp, s), v[(arr * 2 + ti) * 2 + s]);
 }
 
 }  // namespace bwd4

@@ -56,8 +56,10 @@ void launch_recompute4(const RecomputeParams& p, int n_bh, hipStream_t s);
 struct SweepParams4 : b2::SweepParams2 {
     const float *W1c, *W2c;                // forward checkpoints [B NH][K][64][256], [B NH][K][256][64]
     const float* wfinal;                   // [B NH][FINAL_FLOATS]: the state after the last step of the sequence (phase A)
+    char* park;                            // [B NH][4 workgroups][2 deriver waves][PARK4_BYTES]: R4 fragments between derivation and staging
     int G, K;
 };
+constexpr size_t PARK4_BYTES = 12 * FRAG_BYTES;
 void launch_sweep_cluster4(const SweepParams4& bp, int nbh, hipStream_t s);
 void launch_tail4(const __bf16* dOut, const __bf16* eta, const __bf16* dXV, char* slots, size_t slot_stride_bh, __bf16* dXQ, __bf16* dXK,
                   int NC, int chunk_lo, int chunk_n, int nbh, hipStream_t s);      // (after launch_sweep_cluster4 has run once: attributes)

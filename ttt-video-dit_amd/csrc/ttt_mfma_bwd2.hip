@@ -188,7 +188,7 @@ size_t workspace_bytes(const ttt_dims* d, bool mlp, bool backward) {
     // state after the last step)
     const size_t slot_b = g_bwd_rev == 4 ? s4::SLOT4_BYTES : SLOT_BYTES;
     return nbh * (2 * slots * slot_b + b2::CARRY_FLOATS2 * sizeof(float)) + align128(nbh * 64) +
-           nbh * (b2::XCH_BH_BYTES + 4 * b2::FLAG_STRIDE * sizeof(unsigned)) + (g_bwd_rev == 4 ? nbh * s4::FINAL_FLOATS * sizeof(float) : 0);
+           nbh * (b2::XCH_BH_BYTES + 4 * b2::FLAG_STRIDE * sizeof(unsigned)) + (g_bwd_rev == 4 ? nbh * (s4::FINAL_FLOATS * sizeof(float) + 8 * s4::PARK4_BYTES) : 0);
 }
 
 // Side stream and the events of the two-buffer hand-over, one set per device, created on first use.
@@ -239,6 +239,7 @@ static int mlp_backward4(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws,
     unsigned* flags = (unsigned*)(xch + (size_t)nbh * b2::XCH_BH_BYTES);
     const size_t flag_bytes = (size_t)nbh * 4 * b2::FLAG_STRIDE * sizeof(unsigned);
     float* wfinal = (float*)((char*)flags + flag_bytes);
+    char* park = (char*)(wfinal + (size_t)nbh * s4::FINAL_FLOATS);
 
     s4::RecomputeParams rp = {};
     rp.XQ = (const __bf16*)a->XQ; rp.XK = (const __bf16*)a->XK; rp.XV = (const __bf16*)a->XV; rp.eta = (const __bf16*)a->last_eta;
@@ -258,7 +259,7 @@ static int mlp_backward4(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws,
     bp.NH = d->NH; bp.NC = NC;
     bp.xch = xch; bp.flags = flags; bp.fast_records = g_fast_records;
     bp.err = err_word; bp.fault = g_sweep_fault;
-    bp.W1c = a->W1_checkpoints; bp.W2c = a->W2_checkpoints; bp.wfinal = wfinal; bp.G = G; bp.K = K;
+    bp.W1c = a->W1_checkpoints; bp.W2c = a->W2_checkpoints; bp.wfinal = wfinal; bp.park = park; bp.G = G; bp.K = K;
 
     const int nchunks = (K + gpc - 1) / gpc;
     OverlapRes* ov = (g_overlap && nchunks > 1) ? overlap_resources() : nullptr;

@@ -33,6 +33,11 @@ using namespace ttt::mfma::b2;
 using namespace ttt::mfma::s4;
 
 constexpr int NTC = 512;                                  // 2 compute waves + 4 owner waves + 2 deriver waves
+// Wave roles.  Waves are placed on the CU's four SIMDs round-robin (wave w on SIMD w % 4): the compute waves 0, 1 and the
+// deriver waves DW0, DW0 + 1 = 4, 5 share SIMDs 0 / 1 - the compute waves idle there during the hand-over, which is when the
+// derivers do most of their (VALU-heavy) work -, the owner waves 2, 3, 6, 7 have SIMDs 2 / 3 to themselves: their hand-over
+// chain (poll, record reads, LayerNorm backward-of-backward) is the critical path of a step.
+constexpr int DW0 = 4;
 constexpr int TILE_B = TILE_ELEMS * 2;                    // 9216 bytes: one padded [64][64] bf16 tile
 constexpr int L_K = 0;                                    // K   [2][t][f]  (by step parity)
 constexpr int L_G = L_K + 2 * TILE_B;                     // gZ2 [2][t][f]
@@ -105,6 +110,7 @@ struct DeriverBackend {
     __device__ __forceinline__ bf16x4 tr_read(int byte_addr) const {
         return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(base + byte_addr));
     }
+    __device__ __forceinline__ bf16x8 opaque8(bf16x8 v) const { asm volatile("" : "+v"(v)); return v; }
 };
 
 template <bool DBG>
@@ -447,9 +453,9 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
             if (cq == 0 && h == 0) ob2[fO + c] = db2v + poison;
         }
         if (p.last) __syncthreads();           // (the owners' final reduction)
-    } else if (wv < 6) {
+    } else if (wv != DW0 && wv != DW0 + 1) {
         // =========================================================================================================== OWNERS
-        const int ow = tid - 128;                               // 0 .. 255
+        const int ow = ((wv < DW0 ? wv - 2 : wv - 4) << 6) | (tid & 63);      // 0 .. 255 over the four owner waves
         const int ot = ow >> 2, of0 = 16 * (ow & 3);            // token, first of this thread's 16 features
         float dgam[16], dbet[16];
         if (p.first) {
@@ -715,7 +721,7 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
         }
     } else {
         // =========================================================================================================== DERIVERS
-        const int pp = wv - 6;                                  // the 32 hidden units of compute wave pp
+        const int pp = wv - DW0;                                // the 32 hidden units of compute wave pp
         const int l = tid & 63, h = l >> 5, c = l & 31;
         const int nO = 64 * cq + 32 * pp;
         DeriverBackend bk{smem};
@@ -756,36 +762,52 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
 #pragma unroll
                 for (int s = 0; s < 2; ++s) *reinterpret_cast<bf16x8*>(sl + fro4(A_W1, fr_idx(a, pp, s)) + l * 16) = pack(st.W1t[a], s);
         }
-        bwd4::Frags4 Z1, Z1B, X2, D1, M;
+        bwd4::Frags4 Z1, Z1B;
+        char* const park = p.park + ((size_t)(bh * 4 + cq) * 2 + pp) * bwd4::PARK_BYTES;     // this wave's R4 parking area (L2-resident)
         load_frags(i0, A_Z1, Z1);
         load_frags(i0, A_Z1B, Z1B);
         owner_barrier();                       // P0
         bwd4::stage_w2t(bk, st, pp, L_R3 + 2 * FRK);                  // W2' of the chunk's last step (its output path runs before P2)
         bwd4::derive_z1b(bk, Z1B, pp, L_R3, L_R3 + FRK);
         owner_barrier();                       // P1: the tiles of step i0 (K, gZ2, eta) are visible
-        bwd4::reverse_step(bk, st, pp, L_K, L_G, L_SM, Z1, X2, D1, M, L_R1, L_R2, slots + (size_t)slot_off(i0) + WREG,
-                           fro4(A_GZ1T, 0), fro4(A_W1, 0));
+        bwd4::reverse_step(bk, st, pp, L_K, L_G, L_SM, Z1, L_R1, L_R2, slots + (size_t)slot_off(i0) + WREG,
+                           fro4(A_GZ1T, 0), fro4(A_W1, 0), park);
         owner_barrier();                       // P2
 
+        // DEBUG cycle stamps of deriver wave 0 of workgroup 0 (entries 28 .. 31: staging after Bd, derive_z1b, reverse_step, barriers)
+        unsigned long long t_d = 0;
+#define TTT_DSTAMP(k)                                                                \
+        if (DBG && p.dbg != nullptr && blockIdx.x == 0 && tid == 64 * DW0) {              \
+            const unsigned long long _t = __builtin_readcyclecounter();              \
+            p.dbg[28 + (k)] += _t - t_d;                                             \
+            t_d = _t;                                                                \
+        }
+        if (DBG && p.dbg != nullptr && blockIdx.x == 0 && tid == 64 * DW0) t_d = __builtin_readcyclecounter();
         for (int i = i0; i >= p.chunk_lo; --i) {
             const bool more = i > p.chunk_lo;
             const int nxt = ((i0 - i) & 1) ^ 1;                 // tile buffer of step j = i - 1
-            bwd4::stage_r4(bk, pp, L_R4, D1, M, X2);            // of step i: S4a of the step before is behind Bd / P2
+            bwd4::stage_r4(bk, pp, L_R4, park);                 // of step i: S4a of the step before is behind Bd / P2
             bwd4::stage_w2t(bk, st, pp, L_R3 + 2 * FRK);        // W2_i^T: S4a of step i, output path of step j
-            if (more) {
-                load_frags(i - 1, A_Z1, Z1);
-                load_frags(i - 1, A_Z1B, Z1B);
-            }
+            if (more) load_frags(i - 1, A_Z1B, Z1B);
+            TTT_DSTAMP(0)
             owner_barrier();                   // Ba
-            if (more) bwd4::derive_z1b(bk, Z1B, pp, L_R3, L_R3 + FRK);
+            TTT_DSTAMP(3)
+            if (more) {
+                bwd4::derive_z1b(bk, Z1B, pp, L_R3, L_R3 + FRK);
+                load_frags(i - 1, A_Z1, Z1);                    // in flight across Bb
+            }
+            TTT_DSTAMP(1)
             owner_barrier();                   // Bb: K_j, gZ2_j, eta_j staged by the owners are visible
+            TTT_DSTAMP(3)
             if (more) {
                 if (i % p.G == 0) load_anchor(i);               // group boundary: the exact state entering step i
-                bwd4::reverse_step(bk, st, pp, L_K + nxt * TILE_B, L_G + nxt * TILE_B, L_SM + nxt * 64 * 4, Z1, X2, D1, M, L_R1, L_R2,
-                                   slots + (size_t)slot_off(i - 1) + WREG, fro4(A_GZ1T, 0), fro4(A_W1, 0));
+                bwd4::reverse_step(bk, st, pp, L_K + nxt * TILE_B, L_G + nxt * TILE_B, L_SM + nxt * 64 * 4, Z1, L_R1, L_R2,
+                                   slots + (size_t)slot_off(i - 1) + WREG, fro4(A_GZ1T, 0), fro4(A_W1, 0), park);
             }
+            TTT_DSTAMP(2)
             owner_barrier();                   // Bc
             owner_barrier();                   // Bd
+            TTT_DSTAMP(3)
         }
         if (p.last) owner_barrier();           // (the owners' final reduction)
     }

@@ -175,12 +175,21 @@ class TTTBase(nn.Module):
     def tp_sync_gradients(self):
         """After backward under ``init_device_mesh``: sum the gradients of the per-head parameters over the tensor-parallel
         group (every rank holds its own heads' rows, zeros elsewhere); the replicated tail (``post_norm``, ``wo``) sees the
-        same gathered activations on every rank and needs nothing."""
+        same gathered activations on every rank and needs nothing.
+
+        Call it ONCE per optimizer step, after the last micro-batch's backward (calling it per micro-batch would re-sum what
+        was already summed), and only on plain-tensor gradients: under FSDP2 a gradient is a sharded DTensor after the
+        reduce-scatter and this flat all-reduce would mix shards - that combination is refused here (the reference composes
+        TP with FSDP through DTensor placements, parallelisms.py:106-175; this explicit-collective form does not)."""
         import torch.distributed as dist
         if getattr(self, "_tp", None) is None or self._tp.size == 1:
             return
         params = dict(self.named_parameters())
         grads = [params[n].grad for n in self._HEAD_SLICED if n in params and params[n].grad is not None]
+        for g in grads:
+            if type(g) is not torch.Tensor:
+                raise RuntimeError(f"tp_sync_gradients: gradient of type {type(g).__name__} (FSDP-sharded?): the head-sharded tensor "
+                                   "parallelism of this layer keeps whole parameters per rank and does not compose with FSDP2")
         if grads:
             flat = torch.cat([g.reshape(-1).float() for g in grads])
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self._tp.group)
