@@ -1,0 +1,52 @@
+"""Register / scratch budget of the revision-4 TTT-MLP backward kernels (cross-compiled for gfx950, no GPU needed).
+
+The cluster sweep (csrc/ttt_mfma_bwd4.hip) packs three wave roles into one kernel at 256 registers per lane; its speed is bound
+by what a CU's memory pipeline moves per step, and spilled registers are part of that traffic.  Round 3 measured it twice: a
+version with ~500 spilled dwords on the deriver path ran 52 k cycles per step instead of 13 k and was not even deterministic
+(profiles/r3c_*), and an innocent-looking refactor of the prefetch code took the kernel from 186 to 399 spilled dwords and
+from 15.4 to 24.4 ms per backward (profiles/r3f_*).  So the budget is pinned here; the recompute kernel must not spill at all."""
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "ttt-video-dit_amd", "csrc")
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+def kernel_resources(src):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    tmp = tempfile.mkdtemp()
+    try:
+        out = os.path.join(tmp, "k.s")
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-result", "--cuda-device-only", "-S",
+                               os.path.join(CSRC, src), "-o", out], cwd=CSRC)
+        txt = open(out).read()
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    res = {}
+    for blk in re.findall(r"- \.agpr_count:.*?\.wavefront_size:\s+\d+", txt, flags=re.S):
+        name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+        res[name] = {k: int(re.search(rf"\.{k}:\s+(\d+)", blk).group(1)) for k in ("vgpr_count", "vgpr_spill_count", "private_segment_fixed_size")}
+    return res
+
+
+def test_recompute_kernel_does_not_spill():
+    res = kernel_resources("ttt_mfma_rc4.hip")
+    ks = {k: v for k, v in res.items() if "mlp_recompute8_kernel" in k}
+    assert len(ks) == 2, list(res)
+    for k, v in ks.items():
+        assert v["vgpr_spill_count"] == 0 and v["private_segment_fixed_size"] == 0 and v["vgpr_count"] <= 256, (k, v)
+
+
+def test_cluster_sweep_spill_budget():
+    res = kernel_resources("ttt_mfma_bwd4.hip")
+    k = next(k for k in res if "mlp_bwd_cluster4_kernel" in k and "Lb0E" in k)          # the production instantiation (no stamps)
+    v = res[k]
+    assert v["vgpr_count"] <= 256, v
+    assert v["vgpr_spill_count"] <= 160, f"the cluster sweep spills {v['vgpr_spill_count']} dwords (budget 160; measured good: 138)"

@@ -249,7 +249,7 @@ TTT_WV_FN void reverse_step(BK& bk, AuxState& st, int pp, int tile_k, int tile_g
             for (int s = 0; s < 2; ++s) {
                 const bf16x8 v = pack(t, s);
                 st_frag(bk, off_r1, fr_idx(pp, ti, s), v);
-                *reinterpret_cast<bf16x8*>(g_slice + off_gz1t + fr_idx(pp, ti, s) * FRAG + l * 16) = v;
+                bk.store_stream(g_slice + off_gz1t + fr_idx(pp, ti, s) * FRAG + l * 16, v);
             }
         }
         {
@@ -267,7 +267,7 @@ TTT_WV_FN void reverse_step(BK& bk, AuxState& st, int pp, int tile_k, int tile_g
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) *reinterpret_cast<bf16x8*>(g_slice + off_w1 + fr_idx(a, pp, s) * FRAG + l * 16) = pack(st.W1t[a], s);
+        for (int s = 0; s < 2; ++s) bk.store_stream(g_slice + off_w1 + fr_idx(a, pp, s) * FRAG + l * 16, pack(st.W1t[a], s));
 }
 
 // R4: the step's T fragments D1 | M | X2 (FR_D1 | FR_GX2 | FR_X2 order [ti][nj][s]) from the wave's parking area

@@ -48,9 +48,13 @@ struct RecomputeParams {
     float* wfinal;                         // [B NH][FINAL_FLOATS]
     int NH, NC, G, K;
     int chunk_group0, chunk_groups, chunk_lo;
+    int nt;                                // 1: non-temporal stores of the step records
+    int item0;                             // (set by the launcher) first work item of this launch; item = item0 + blockIdx.x
     float eps;
 };
-void launch_recompute4(const RecomputeParams& p, int n_bh, hipStream_t s);
+// max_workgroups > 0: the B NH chunk_groups work items are covered by consecutive launches of at most that many workgroups
+// (beside a cluster sweep: never more workgroups in flight than CUs are free)
+void launch_recompute4(const RecomputeParams& p, int n_bh, int max_workgroups, hipStream_t s);
 
 // the cluster sweep of revision 4: revision 3's parameters + what the deriver waves need to anchor the reversed state update
 struct SweepParams4 : b2::SweepParams2 {
@@ -58,6 +62,7 @@ struct SweepParams4 : b2::SweepParams2 {
     const float* wfinal;                   // [B NH][FINAL_FLOATS]: the state after the last step of the sequence (phase A)
     char* park;                            // [B NH][4 workgroups][2 deriver waves][PARK4_BYTES]: R4 fragments between derivation and staging
     int G, K;
+    int prefetch;                          // 1: owners / derivers touch the records of step i - 2 (L2 prefetch); 0: off (A/B)
 };
 constexpr size_t PARK4_BYTES = 12 * FRAG_BYTES;
 void launch_sweep_cluster4(const SweepParams4& bp, int nbh, hipStream_t s);

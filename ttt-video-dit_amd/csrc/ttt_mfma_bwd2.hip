@@ -138,13 +138,17 @@ bool bwd_available() { return true; }
 
 static int g_forced_gpc = 0;
 void set_debug_groups_per_chunk(int g) { g_forced_gpc = g; }
-static int g_overlap = 1;             // tail of chunk c on a side stream under the sweep of chunk c-1; 0 = one stream (DEBUG, A/B)
+static int g_overlap = 1;             // 1: tail of chunk c on a side stream beside the sweep of chunk c-1; 2 (revision 4): the recompute of chunk c-2 too; 0 = one stream
 void set_debug_overlap_tail(int v) { g_overlap = v; }
 static int g_fast_records = 1;        // cluster hand-over: plain (L2-resident) records once same-XCD placement is proven; 0 = always write-through
 void set_debug_fast_records(int v) { g_fast_records = v; }
 static int g_bwd_rev = 4;             // 4 = slim step record + deriver waves (round 3), 3 = round 2's register-image slots (A/B, to be removed)
 void set_debug_bwd_rev(int v) { g_bwd_rev = (v == 3) ? 3 : 4; }
 int get_debug_bwd_rev() { return g_bwd_rev; }
+static int g_rc_nt = 1;               // revision-4 recompute: 1 (default) = non-temporal stores of the step records (they are read a launch later, from HBM: keep them out of the sweep's L2 working set), 0 = plain (A/B)
+void set_debug_rc_nt(int v) { g_rc_nt = v; }
+static int g_sweep_prefetch = 1;      // revision-4 sweep: L2 prefetch touches two steps ahead (0 = off, A/B)
+void set_debug_sweep_prefetch(int v) { g_sweep_prefetch = v; }
 static int g_sweep_fault = 0;         // DEBUG fault injection (tests of the hand-over failure path)
 void set_debug_sweep_fault(int v) { g_sweep_fault = v; }
 
@@ -194,7 +198,7 @@ size_t workspace_bytes(const ttt_dims* d, bool mlp, bool backward) {
 // Side stream and the events of the two-buffer hand-over, one set per device, created on first use.
 struct OverlapRes {
     hipStream_t side = nullptr;
-    hipEvent_t ready[2] = {nullptr, nullptr}, tail_done[2] = {nullptr, nullptr};
+    hipEvent_t ready[2] = {nullptr, nullptr}, tail_done[2] = {nullptr, nullptr}, entry = nullptr;
     int state = 0;                      // 0 = not tried, 1 = usable, -1 = creation failed (one stream from then on)
 };
 static OverlapRes* overlap_resources() {
@@ -204,6 +208,7 @@ static OverlapRes* overlap_resources() {
     OverlapRes& r = res[dev];
     if (r.state == 0) {
         bool ok = hipStreamCreateWithFlags(&r.side, hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&r.entry, hipEventDisableTiming) == hipSuccess;
         for (int i = 0; ok && i < 2; ++i) {
             ok = ok && hipEventCreateWithFlags(&r.ready[i], hipEventDisableTiming) == hipSuccess;
             ok = ok && hipEventCreateWithFlags(&r.tail_done[i], hipEventDisableTiming) == hipSuccess;
@@ -214,6 +219,8 @@ static OverlapRes* overlap_resources() {
                 if (r.tail_done[i]) (void)hipEventDestroy(r.tail_done[i]);
                 r.ready[i] = r.tail_done[i] = nullptr;
             }
+            if (r.entry) (void)hipEventDestroy(r.entry);
+            r.entry = nullptr;
             if (r.side) (void)hipStreamDestroy(r.side);
             r.side = nullptr;
             (void)hipGetLastError();
@@ -246,7 +253,7 @@ static int mlp_backward4(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws,
     rp.ln_w = a->ttt_norm_weight; rp.ln_b = a->ttt_norm_bias;
     rp.W1c = a->W1_checkpoints; rp.b1c = a->b1_checkpoints; rp.W2c = a->W2_checkpoints; rp.b2c = a->b2_checkpoints;
     rp.slot_stride_bh = slot_stride; rp.wfinal = wfinal;
-    rp.NH = d->NH; rp.NC = NC; rp.G = G; rp.K = K; rp.eps = d->eps;
+    rp.NH = d->NH; rp.NC = NC; rp.G = G; rp.K = K; rp.eps = d->eps; rp.nt = g_rc_nt;
 
     s4::SweepParams4 bp = {};
     bp.XQ = (const __bf16*)a->XQ; bp.XK = (const __bf16*)a->XK; bp.dOut = (const __bf16*)a->grad_L_XQW; bp.eta = (const __bf16*)a->last_eta;
@@ -259,51 +266,99 @@ static int mlp_backward4(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws,
     bp.NH = d->NH; bp.NC = NC;
     bp.xch = xch; bp.flags = flags; bp.fast_records = g_fast_records;
     bp.err = err_word; bp.fault = g_sweep_fault;
-    bp.W1c = a->W1_checkpoints; bp.W2c = a->W2_checkpoints; bp.wfinal = wfinal; bp.park = park; bp.G = G; bp.K = K;
+    bp.W1c = a->W1_checkpoints; bp.W2c = a->W2_checkpoints; bp.wfinal = wfinal; bp.park = park; bp.G = G; bp.K = K; bp.prefetch = g_sweep_prefetch;
 
     const int nchunks = (K + gpc - 1) / gpc;
     OverlapRes* ov = (g_overlap && nchunks > 1) ? overlap_resources() : nullptr;
-    if (ov && device_cus() - 4 * (nbh < per_launch ? nbh : per_launch) < 32) ov = nullptr;
-    auto recompute = [&](int ch) {
+    const int free_cus = device_cus() - 4 * (nbh < per_launch ? nbh : per_launch);
+    if (ov && (free_cus < 32 || nbh > per_launch)) ov = nullptr;      // nothing free beside the sweep, or several sweep launches per chunk
+    auto recompute = [&](int ch, int max_wg, hipStream_t st) {
         const int g0 = ch * gpc, ng = (K - g0 < gpc) ? K - g0 : gpc;
         rp.chunk_group0 = g0; rp.chunk_groups = ng; rp.chunk_lo = g0 * G;
         rp.slots = slots + (size_t)(ch & 1) * slot_buf;
-        s4::launch_recompute4(rp, nbh, s);
+        s4::launch_recompute4(rp, nbh, max_wg, st);
     };
-    // same schedule as revision 3 (below): chunk c in slot buffer c & 1, C(c) on the side stream beside B(c-1)
-    recompute(nchunks - 1);
-    for (int ch = nchunks - 1; ch >= 0; --ch) {
+    auto tail = [&](int ch, hipStream_t st) {
         const int g0 = ch * gpc, ng = (K - g0 < gpc) ? K - g0 : gpc;
-        const int buf = ch & 1;
-        char* cslots = slots + (size_t)buf * slot_buf;
-        bp.slots = cslots;
+        const int lo = g0 * G, hi = ((g0 + ng) * G < NC) ? (g0 + ng) * G : NC;
+        s4::launch_tail4((const __bf16*)a->grad_L_XQW, (const __bf16*)a->last_eta, (const __bf16*)a->grad_L_XV, slots + (size_t)(ch & 1) * slot_buf,
+                         slot_stride, (__bf16*)a->grad_L_XQ, (__bf16*)a->grad_L_XK, NC, lo, hi - lo, nbh, st);
+    };
+    auto sweep = [&](int ch) {
+        const int g0 = ch * gpc, ng = (K - g0 < gpc) ? K - g0 : gpc;
+        bp.slots = slots + (size_t)(ch & 1) * slot_buf;
         bp.chunk_lo = g0 * G;
         bp.chunk_hi = ((g0 + ng) * G < NC) ? (g0 + ng) * G : NC;
         bp.first = (ch == nchunks - 1);
         bp.last = (ch == 0);
         bp.dbg = get_debug_timing();
-        (void)hipMemsetAsync(flags, 0, flag_bytes, s);
+        (void)hipMemsetAsync(flags, 0, flag_bytes, s);        // hand-over flags restart at 0 for every launch
         for (int bh0 = 0; bh0 < nbh; bh0 += per_launch) {
             bp.bh0 = bh0;
             bp.nbh = nbh - bh0 < per_launch ? nbh - bh0 : per_launch;
             s4::launch_sweep_cluster4(bp, bp.nbh, s);
         }
-        const int chunk_n = bp.chunk_hi - bp.chunk_lo;
-        if (ch > 0) {
-            if (ov && ch + 1 < nchunks) (void)hipStreamWaitEvent(s, ov->tail_done[buf ^ 1], 0);
-            recompute(ch - 1);
+    };
+    if (ov) {           // the side stream starts after everything queued on `s` before this call (the inputs), not after A(n-1)
+        (void)hipEventRecord(ov->entry, s);
+        (void)hipStreamWaitEvent(ov->side, ov->entry, 0);
+    }
+    recompute(nchunks - 1, 0, s);
+    if (!ov) {          // one stream: A(c) B(c) C(c) per chunk (chunk c in slot buffer c & 1)
+        for (int ch = nchunks - 1; ch >= 0; --ch) {
+            sweep(ch);
+            if (ch > 0) recompute(ch - 1, 0, s);
+            tail(ch, s);
         }
-        hipStream_t ts = s;
-        if (ov) {
+        return 0;
+    }
+    if (g_overlap == 1) {
+        // Tail beside the next sweep only (round 2's schedule): stream s: A(n-1) B(n-1) A(n-2) B(n-2) ... ; side: C(c) beside B(c-1).
+        // C(c) is released when A(c-1) is complete - the moment B(c-1) starts -, and A(c-2), which overwrites C(c)'s buffer, waits.
+        for (int ch = nchunks - 1; ch >= 0; --ch) {
+            const int buf = ch & 1;
+            sweep(ch);
+            if (ch > 0) {
+                if (ch + 1 < nchunks) (void)hipStreamWaitEvent(s, ov->tail_done[buf ^ 1], 0);
+                recompute(ch - 1, 0, s);
+            }
             (void)hipEventRecord(ov->ready[buf], s);
             (void)hipStreamWaitEvent(ov->side, ov->ready[buf], 0);
-            ts = ov->side;
+            tail(ch, ov->side);
+            (void)hipEventRecord(ov->tail_done[buf], ov->side);
         }
-        s4::launch_tail4((const __bf16*)a->grad_L_XQW, (const __bf16*)a->last_eta, (const __bf16*)a->grad_L_XV, cslots, slot_stride,
-                         (__bf16*)a->grad_L_XQ, (__bf16*)a->grad_L_XK, NC, bp.chunk_lo, chunk_n, nbh, ts);
-        if (ov) (void)hipEventRecord(ov->tail_done[buf], ov->side);
+        (void)hipStreamWaitEvent(s, ov->tail_done[0], 0);
+        return 0;
     }
-    if (ov) (void)hipStreamWaitEvent(s, ov->tail_done[0], 0);
+    // Two streams.  The sweep B(c) occupies 4 nbh CUs with latency-bound work; everything else of the backward runs BESIDE it on
+    // the CUs it leaves free: the tail C(c+1) of the chunk before, then the recompute A(c-1) of the chunk after - in launches
+    // of at most `free_cus` workgroups (a recompute workgroup needs a CU to itself, and more workgroups than free CUs would
+    // queue in front of the NEXT sweep's clusters).  Phase A is 0.17 ms per chunk in a full launch, 4 rounds of
+    // that on 64 CUs: it fits under a 1.1-ms sweep together with the 0.4-ms tail, so a backward is the chain of its sweeps.
+    // (the side stream first waits for everything queued on `s` before this call: the inputs of the recompute)
+    //   stream s:     A(n-1) B(n-1)        B(n-2)             B(n-3)           ...  B(0)
+    //   side stream:         A(n-2)        C(n-1) A(n-3)      C(n-2) A(n-4)    ...  C(1)      C(0)
+    // Buffer of chunk c = c & 1: A(c-1) overwrites the buffer of chunk c+1, read by B(c+1) (done: stream order of B(c)) and by
+    // C(c+1) (done: side-stream order).  Events: ready[k] = "B of the chunk in buffer k is complete", tail_done[k] doubles as
+    // "A of the chunk in buffer k is complete".
+    for (int ch = nchunks - 1; ch >= 0; --ch) {
+        const int buf = ch & 1;
+        if (ch != nchunks - 1) (void)hipStreamWaitEvent(s, ov->tail_done[buf], 0);          // A(ch) ran on the side stream
+        sweep(ch);
+        (void)hipEventRecord(ov->ready[buf], s);
+        if (ch + 1 <= nchunks - 1) {
+            (void)hipStreamWaitEvent(ov->side, ov->ready[buf ^ 1], 0);                         // B(ch+1) complete
+            tail(ch + 1, ov->side);
+        }
+        if (ch - 1 >= 0) {
+            recompute(ch - 1, free_cus, ov->side);
+            (void)hipEventRecord(ov->tail_done[buf ^ 1], ov->side);
+        }
+    }
+    (void)hipStreamWaitEvent(ov->side, ov->ready[0], 0);
+    tail(0, ov->side);
+    (void)hipEventRecord(ov->tail_done[0], ov->side);
+    (void)hipStreamWaitEvent(s, ov->tail_done[0], 0);              // the caller's stream joins the side stream
     return 0;
 }
 

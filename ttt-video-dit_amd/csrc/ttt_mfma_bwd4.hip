@@ -98,10 +98,18 @@ __device__ __forceinline__ void owner_barrier() { asm volatile("s_waitcnt lgkmcn
         t_last = _t;                                                         \
     }
 
+// fragment stores that only the tail kernel (a later launch) reads: non-temporal, so that they do not displace the hand-over
+// records, the parked R4 fragments and the prefetched lines of the next steps from this XCD's L2
+__device__ __forceinline__ void bst8_nt(__amdgpu_buffer_rsrc_t r, int voff, int soff, bf16x8 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 2);      // aux bit 1 = nt
+}
 // the wave backend of ttt_bwd4_aux_body.h on the device
 struct DeriverBackend {
     char* base;
-    __device__ __forceinline__ int lane() const { return threadIdx.x & 63; }
+    int l;                                  // lane id, re-made opaque every step: everything derived from it (fragment / tile addresses)
+                                            // is then recomputed inside the step instead of being hoisted out of the loop and spilled
+    __device__ __forceinline__ int lane() const { return l; }
+    __device__ __forceinline__ void refresh() { int v = threadIdx.x & 63; asm volatile("" : "+v"(v)); l = v; }
     __device__ __forceinline__ float exp2(float x) const { return __builtin_amdgcn_exp2f(x); }
     __device__ __forceinline__ float rcp(float x) const { return __builtin_amdgcn_rcpf(x); }
     template <class T> __device__ __forceinline__ T lds_load(int byte_off) const { return *reinterpret_cast<const T*>(base + byte_off); }
@@ -111,6 +119,8 @@ struct DeriverBackend {
         return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(base + byte_addr));
     }
     __device__ __forceinline__ bf16x8 opaque8(bf16x8 v) const { asm volatile("" : "+v"(v)); return v; }
+    // global store of data that only a LATER kernel reads (the tail): non-temporal
+    __device__ __forceinline__ void store_stream(char* p, bf16x8 v) const { __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(p)); }
 };
 
 template <bool DBG>
@@ -201,7 +211,7 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const bf16x8 zf = pack(dz, s);                       // dZ1b (k = t rows, j = n lane)
-                    bst8(rS, l16, sj + fro4(A_DZ1B, fr_idx(ti, pp, s)), zf);
+                    bst8_nt(rS, l16, sj + fro4(A_DZ1B, fr_idx(ti, pp, s)), zf);
                     dW1t[0] = mma(tr_pi(Qt, 32 * ti, s, 0, l), zf, dW1t[0]);
                     dW1t[1] = mma(tr_pi(Qt, 32 * ti, s, 32, l), zf, dW1t[1]);
                     const bf16x8 xb = lfr(smem, L_R3 + FRK, fr_idx(ti, pp, s), l);          // X2b (m = n lane, k = t rows)
@@ -222,7 +232,7 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int s = 0; s < 2; ++s) bst8(rS, l * 16, sj + fro4(A_DW1, fr_idx(a, pp, s)), pack(dW1t[a], s));
+                for (int s = 0; s < 2; ++s) bst8_nt(rS, l * 16, sj + fro4(A_DW1, fr_idx(a, pp, s)), pack(dW1t[a], s));
 #pragma unroll
             for (int s = 0; s < 2; ++s) *reinterpret_cast<bf16x8*>(exd + ((size_t)(pp * 2 + s) * 64 + l) * 16) = pack(dW2t[1], s);
             if (h == 0) { db1L[32 * pp + c] = db1v; db2L[fO + c] = db2v; }
@@ -408,7 +418,7 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const bf16x8 zf = pack(dz, s);                        // dZ1 (k = t rows, j = n lane)
-                    bst8(rS, l16, sw + fro4(A_DZ1, fr_idx(ti, pp, s)), zf);
+                    bst8_nt(rS, l16, sw + fro4(A_DZ1, fr_idx(ti, pp, s)), zf);
                     dW1t[0] = mma(tr_pi(Kt, 32 * ti, s, 0, l), zf, dW1t[0]);
                     dW1t[1] = mma(tr_pi(Kt, 32 * ti, s, 32, l), zf, dW1t[1]);
                     const bf16x8 gO = tr_pi(Gt, 32 * ti, s, fO, l), gX = tr_pi(Gt, 32 * ti, s, fX, l);
@@ -687,7 +697,24 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
             TTT_OSTAMP(2)                      // owner math, dZ2 / dV / d(eta) stores
             owner_barrier();                   // Bc: dZ2_i visible to the compute waves
             TTT_OSTAMP(3)                      // wait for the compute waves at Bc
+            // ---- L2 prefetch, two steps ahead: one dword per 128-byte line of what the owners of this CU will request for step
+            // i - 2 (owner rows, gZ2 tile: 452 lines; K, Q, dOut tiles: 192 lines).  Issued HERE, behind Bc: the owners idle
+            // during S4a, and the issue of an instruction whose 64 lanes miss 64 different lines blocks the wave for a while
+            // (in front of Bc it cost the step 7 k cycles, profiles/r3e_*); a wave's vector loads return in order, and the next
+            // loads of these waves are the requests at the top of the next iteration.  (Round 2 tried touches with the 570-KiB
+            // records and lost - three steps of six heads did not fit an XCD's 4-MB L2; with the slim record they are 2.7 MB.)
+            unsigned touch = 0u;
+            if (p.prefetch && i - 2 >= p.chunk_lo) {
+                const int s2 = slot_off(i - 2) + (int)SLOT4_FR;
+                touch = __builtin_amdgcn_raw_buffer_load_b32(rS, ow * 128, s2, 0);
+                if (ow < 452 - 256) touch += __builtin_amdgcn_raw_buffer_load_b32(rS, (256 + ow) * 128, s2, 0);
+                if (ow < 192) {
+                    const __amdgpu_buffer_rsrc_t rT = ow < 64 ? rK : ow < 128 ? rQ : rO;
+                    touch += __builtin_amdgcn_raw_buffer_load_b32(rT, (ow & 63) * 128, (i - 2) * 8192, 0);
+                }
+            }
             owner_barrier();                   // Bd
+            asm volatile("" :: "v"(touch));    // (keeps the prefetch loads alive; they landed long ago)
         }
 
         // ---- dgamma / dbeta: to the next chunk, or reduced over the 64 tokens ----------------------------------------------------
@@ -724,7 +751,7 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
         const int pp = wv - DW0;                                // the 32 hidden units of compute wave pp
         const int l = tid & 63, h = l >> 5, c = l & 31;
         const int nO = 64 * cq + 32 * pp;
-        DeriverBackend bk{smem};
+        DeriverBackend bk{smem, (int)(threadIdx.x & 63)};
         bwd4::AuxState st;
         // the state entering step `step` (a multiple of the checkpoint group size, or the end of the sequence): the forward's
         // checkpoint, or the state phase A wrote after the last step
@@ -786,6 +813,7 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
         for (int i = i0; i >= p.chunk_lo; --i) {
             const bool more = i > p.chunk_lo;
             const int nxt = ((i0 - i) & 1) ^ 1;                 // tile buffer of step j = i - 1
+            bk.refresh();
             bwd4::stage_r4(bk, pp, L_R4, park);                 // of step i: S4a of the step before is behind Bd / P2
             bwd4::stage_w2t(bk, st, pp, L_R3 + 2 * FRK);        // W2_i^T: S4a of step i, output path of step j
             if (more) load_frags(i - 1, A_Z1B, Z1B);
@@ -804,9 +832,14 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
                 bwd4::reverse_step(bk, st, pp, L_K + nxt * TILE_B, L_G + nxt * TILE_B, L_SM + nxt * 64 * 4, Z1, L_R1, L_R2,
                                    slots + (size_t)slot_off(i - 1) + WREG, fro4(A_GZ1T, 0), fro4(A_W1, 0), park);
             }
+            // L2 prefetch of this wave's share of the slice's Z1 / Z1b fragments of step i - 2 (two consecutive 8-KiB arrays)
+            unsigned touch = 0u;
+            if (p.prefetch && i - 2 >= p.chunk_lo)
+                touch = __builtin_amdgcn_raw_buffer_load_b32(rS, (pp * 64 + l) * 128, slot_off(i - 2) + WREG + fro4(A_Z1, 0), 0);
             TTT_DSTAMP(2)
             owner_barrier();                   // Bc
             owner_barrier();                   // Bd
+            asm volatile("" :: "v"(touch));
             TTT_DSTAMP(3)
         }
         if (p.last) owner_barrier();           // (the owners' final reduction)

@@ -42,6 +42,8 @@ unsigned peek_sweep_error();           // the same word without synchronising (e
 void clear_sweep_error();              // acknowledge (synchronises)
 unsigned* sweep_error_word();          // device pointer of the host-mapped word (allocated on first use; nullptr on failure)
 void set_debug_sweep_fault(int v);
+void set_debug_rc_nt(int v);           // revision-4 recompute: non-temporal stores of the step records (A/B)
+void set_debug_sweep_prefetch(int v);  // revision-4 sweep: 1 (default) L2 prefetch touches two steps ahead, 0 off
 void set_debug_bwd_rev(int v);        // TTT-MLP backward: 4 (default) = slim step record + deriver waves, 3 = round 2's register-image slots
 int get_debug_bwd_rev();     // DEBUG fault injection: workgroup 3 of every sweep cluster leaves before its first hand-over
 unsigned read_sweep_fast_count();   // DEBUG statistic (synchronises)

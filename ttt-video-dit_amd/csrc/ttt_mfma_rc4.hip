@@ -43,14 +43,27 @@ __device__ __forceinline__ bf16x8 tr_frag_pi(const __bf16* img, int stride, int 
     return tr_frag(img, stride, row0 + 16 * s + 4 * h, row0 + 16 * s + 8 + 4 * h, col0, l);
 }
 // fragment `idx` of array `arr` of a hidden slice region: one 16-byte store per lane, lane-linear (1 KiB per wave instruction)
-__device__ __forceinline__ void st_frag4(char* slice, int arr, int idx, bf16x8 v, int lane) {
-    *reinterpret_cast<bf16x8*>(slice + fro4(arr, idx) + lane * 16) = v;
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+template <bool NTS>
+__device__ __forceinline__ void st16(void* p, u32x4v v) {
+    if (NTS) __builtin_nontemporal_store(v, reinterpret_cast<u32x4v*>(p));
+    else *reinterpret_cast<u32x4v*>(p) = v;
 }
-template <int N>
+template <bool NTS>
+__device__ __forceinline__ void st_frag4(char* slice, int arr, int idx, bf16x8 v, int lane) {
+    st16<NTS>(slice + fro4(arr, idx) + lane * 16, __builtin_bit_cast(u32x4v, v));
+}
+template <bool NTS, int N>
 __device__ __forceinline__ void st_rows(char* own, int arr, int ot, int of0, const float (&v)[N]) {
-    st_own<N>(own, arr, ot, of0, v);
+    float* p = reinterpret_cast<float*>(own + (size_t)arr * SLOT_OWN_ARR) + ot * 64 + of0;
+#pragma unroll
+    for (int q = 0; q < N / 4; ++q) {
+        const f32x4 x = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+        st16<NTS>(p + 4 * q, __builtin_bit_cast(u32x4v, x));
+    }
 }
 
+template <bool NTS>
 __global__ __launch_bounds__(NT8) void mlp_recompute8_kernel(RecomputeParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __bf16* Kt = reinterpret_cast<__bf16*>(smem + L_K);
@@ -71,7 +84,10 @@ __global__ __launch_bounds__(NT8) void mlp_recompute8_kernel(RecomputeParams p) 
     const int nO = 64 * w + 32 * pp, nX = 64 * w + 32 * (1 - pp);
     const int fO = 32 * pp, fX = 32 * (1 - pp);
     const int NC = p.NC, G = p.G;
-    const int bh = blockIdx.x / p.chunk_groups, grp = p.chunk_group0 + blockIdx.x % p.chunk_groups, head = bh % p.NH;
+    // Work item = (b, h, checkpoint group of the chunk).  Beside a cluster sweep the host covers the items with several launches
+    // of at most as many workgroups as CUs are free (a workgroup needs a CU of its own: 145 KiB of LDS): item0 = first item.
+    const int item = p.item0 + (int)blockIdx.x;
+    const int bh = item / p.chunk_groups, grp = p.chunk_group0 + item % p.chunk_groups, head = bh % p.NH;
     const int i_lo = grp * G, i_hi = (i_lo + G < NC) ? i_lo + G : NC;
     char* slots = p.slots + (size_t)bh * p.slot_stride_bh;
 
@@ -155,8 +171,8 @@ __global__ __launch_bounds__(NT8) void mlp_recompute8_kernel(RecomputeParams p) 
                     Z = mma(pi_read(Kt + (32 * ti + c) * TS, 32 * a, s, h), W1F[a][s], Z);
 #pragma unroll
             for (int r = 0; r < 16; ++r) Z[r] += b1v;
-            st_frag4(slice, A_Z1, fr_idx(ti, pp, 0), pack(Z, 0), l);
-            st_frag4(slice, A_Z1, fr_idx(ti, pp, 1), pack(Z, 1), l);
+            st_frag4<NTS>(slice, A_Z1, fr_idx(ti, pp, 0), pack(Z, 0), l);
+            st_frag4<NTS>(slice, A_Z1, fr_idx(ti, pp, 1), pack(Z, 1), l);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float y, dy;
@@ -228,9 +244,9 @@ __global__ __launch_bounds__(NT8) void mlp_recompute8_kernel(RecomputeParams p) 
                 gu[j] = (__bf16)(t * su);
             }
             *reinterpret_cast<bf16x8*>(Gs + ot * TS + of0) = o;
-            *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(slot + SLOT4_FR + SLOT4_OWN) + ot * 64 + of0) = gu;
-            st_rows<8>(own, 0, ot, of0, z);
-            st_rows<8>(own, 1, ot, of0, go);
+            st16<NTS>(reinterpret_cast<__bf16*>(slot + SLOT4_FR + SLOT4_OWN) + ot * 64 + of0, __builtin_bit_cast(u32x4v, gu));
+            st_rows<NTS, 8>(own, 0, ot, of0, z);
+            st_rows<NTS, 8>(own, 1, ot, of0, go);
             if ((tid & 7) == 0) own_stats(own, ot)[0] = rstd;
         }
         __syncthreads();              // B2: Gs visible
@@ -304,8 +320,8 @@ __global__ __launch_bounds__(NT8) void mlp_recompute8_kernel(RecomputeParams p) 
                         zb = mma(pi_read(Qt + (32 * ti + c) * TS, 32 * a, s, h), W1F[a][s], zb);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) zb[r] += b1v;
-                st_frag4(slice, A_Z1B, fr_idx(ti, pp, 0), pack(zb, 0), l);
-                st_frag4(slice, A_Z1B, fr_idx(ti, pp, 1), pack(zb, 1), l);
+                st_frag4<NTS>(slice, A_Z1B, fr_idx(ti, pp, 0), pack(zb, 0), l);
+                st_frag4<NTS>(slice, A_Z1B, fr_idx(ti, pp, 1), pack(zb, 1), l);
                 gelu_fwd_tile_pk(zb);
                 X2bF[ti][0] = pack(zb, 0);
                 X2bF[ti][1] = pack(zb, 1);
@@ -381,19 +397,27 @@ __global__ __launch_bounds__(NT8) void mlp_recompute8_kernel(RecomputeParams p) 
             const float rstd = __builtin_amdgcn_rsqf(sum8(v) * (1.0f / 64.0f) + p.eps);
 #pragma unroll
             for (int j = 0; j < 8; ++j) z[j] = (z[j] - mu) * rstd;
-            st_rows<8>(own, 2, ot, of0, z);
+            st_rows<NTS, 8>(own, 2, ot, of0, z);
             if ((tid & 7) == 0) own_stats(own, ot)[1] = rstd;
         }
     }
 }
 
-void launch_recompute4(const RecomputeParams& p, int n_bh, hipStream_t s) {
+void launch_recompute4(const RecomputeParams& p, int n_bh, int max_workgroups, hipStream_t s) {
     static bool done = false;
     if (!done) {
-        (void)hipFuncSetAttribute((const void*)mlp_recompute8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_RC4);
+        (void)hipFuncSetAttribute((const void*)mlp_recompute8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_RC4);
+        (void)hipFuncSetAttribute((const void*)mlp_recompute8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_RC4);
         done = true;
     }
-    hipLaunchKernelGGL(mlp_recompute8_kernel, dim3(n_bh * p.chunk_groups), dim3(NT8), LDS_RC4, s, p);
+    RecomputeParams q = p;
+    const int n_items = n_bh * p.chunk_groups;
+    const int per = (max_workgroups > 0 && max_workgroups < n_items) ? max_workgroups : n_items;
+    for (q.item0 = 0; q.item0 < n_items; q.item0 += per) {
+        const int grid = n_items - q.item0 < per ? n_items - q.item0 : per;
+        if (q.nt) hipLaunchKernelGGL(mlp_recompute8_kernel<true>, dim3(grid), dim3(NT8), LDS_RC4, s, q);
+        else hipLaunchKernelGGL(mlp_recompute8_kernel<false>, dim3(grid), dim3(NT8), LDS_RC4, s, q);
+    }
 }
 
 }  // namespace s4
