@@ -78,6 +78,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     # debugging knobs: anything that shrinks the workload marks the result invalid
+    ap.add_argument("--remat-keep", default="attn,scan",
+                    help="kernel outputs a re-materialised layer keeps instead of recomputing them (comma list of attn, scan; 'none' = "
+                         "the reference's behaviour: the whole layer is recomputed) - ttt_amd/infra/remat_cache.py")
     ap.add_argument("--remat-free-layers", default="auto",
                     help="transformer layers that keep their activations instead of being re-materialised in backward: "
                          "'auto' (sized to the free HBM of this GPU), or an integer; 0 = the reference's 80-GB-GPU setting")
@@ -421,6 +424,7 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False):
         over["num_layers"] = args.layers
     if args.ssm_layer == "ttt_linear":      # the reference trains TTT-Linear with these (configs/train/ttt-linear/3s.toml:9,32)
         over.update(mini_batch_size=16, scan_checkpoint_group_size=4)
+    over["remat_keep"] = tuple(k for k in args.remat_keep.split(",") if k and k != "none")
     cfg = ModelConfig.get_preset("5B", args.video_length, ssm_layer=args.ssm_layer, adapter_method=args.adapter, **over)
     frames, text_len = cfg.compressed_num_frames, TEXT_LEN[args.video_length]
     scenes = max((frames - 1) // 12, 1)
@@ -600,7 +604,7 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False):
                 "config": {"workload": f"CogVideoX-5B+{args.ssm_layer} {args.video_length} training step (fwd+bwd+AdamW), "
                                        f"{cfg.num_layers} layers, L={L} tokens/sample, adapter={args.adapter}",
                            "global_batch": world * LB, "seq_len": L, "parallelism": "replica1" if no_fsdp else f"fsdp{world}", "ttt_impl": args.impl,
-                           "remat_free_layers": n_free, "fsdp_reshard_after_forward": bool(args.reshard_after_forward), "tuned_gemm_selections": bool(tuned),
+                           "remat_free_layers": n_free, "remat_keep": list(cfg.remat_keep), "fsdp_reshard_after_forward": bool(args.reshard_after_forward), "tuned_gemm_selections": bool(tuned),
                            "sweep_error": sweep_err, "valid": args.layers is None and sweep_err == 0},
                 "roofline": roof, "loss": loss_val, "peak_mem_gib": peak_mem, "peak_reserved_gib": torch.cuda.max_memory_reserved() / 2 ** 30, "total_tokens_per_s": world * L / (dt / args.steps)}
         return line

@@ -188,6 +188,40 @@ def test_dit_multiscene_on_hip_path_vs_reference_lastrow():
     assert not bad, bad
 
 
+# ---------------------------------------------------------------------------------- 3a. selective re-materialisation
+@pytest.mark.parametrize("name", ["dit_mlp64_1scene.pt", "dit_mlp64_3scene_lastrow.pt"])
+def test_remat_keep_is_bit_identical(name):
+    """A re-materialised layer that KEEPS its attention / scan kernel outputs (ttt_amd/infra/remat_cache.py, bench.py's
+    default) must give the bits of the reference's behaviour (the whole layer recomputed): same kernels, run once instead
+    of twice."""
+    from ttt_amd.models.cogvideo.dit import DiffusionTransformer
+    from ttt_amd.models.configs import ModelConfig
+    ext()
+    g = load_golden(name)
+    m = DiffusionTransformer(ModelConfig(**g["cfg"]))
+    m.load_state_dict(g["state_dict"], strict=True)
+    m = m.to(DEV).to(torch.bfloat16)
+    for mod in m.modules():
+        if hasattr(mod, "init_freqs"):
+            mod.init_freqs()
+    m.remat_free_layers = 0
+    res = {}
+    for keep in ((), ("attn", "scan"), ("attn",)):
+        m.remat_keep = keep
+        m.zero_grad(set_to_none=True)
+        out = m(g["video"].to(DEV, torch.bfloat16), g["text"].to(DEV, torch.bfloat16), g["timesteps"].to(DEV))
+        out.backward(g["dout"].to(DEV, out.dtype))
+        torch.cuda.synchronize()
+        res[keep] = (out.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+    o0, g0 = res[()]
+    for keep in (("attn", "scan"), ("attn",)):
+        o1, g1 = res[keep]
+        assert torch.equal(o0, o1)
+        assert set(g0) == set(g1)
+        bad = [k for k in g0 if not torch.equal(g0[k], g1[k])]
+        assert not bad, (keep, bad[:5])
+
+
 # ---------------------------------------------------------------------------------- 3b. run-to-run determinism
 @pytest.mark.parametrize("overlap", [0, 1])
 def test_backward_is_run_to_run_deterministic_at_the_benchmarked_head_count(overlap):

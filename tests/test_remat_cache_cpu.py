@@ -1,0 +1,90 @@
+"""Selective re-materialisation (ttt_amd/infra/remat_cache.py): inside a checkpointed region the outputs of the expensive
+sequence kernels are kept and handed back to the recomputation instead of being computed again.  The mechanism is checked here
+with a toy autograd node that counts its 'kernel launches': same outputs, same gradients, one launch per call instead of two for
+the kept kind; kinds that are not kept, nested checkpoints and plain (un-checkpointed) calls behave as before.  The GPU test
+tests/test_parity_r3_gpu.py::test_remat_keep_is_bit_identical runs the real DiT both ways."""
+import torch
+from torch.utils.checkpoint import checkpoint
+
+from ttt_amd.infra import remat_cache
+
+LAUNCHES = {"attn": 0, "scan": 0}
+
+
+class Node(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, kind):
+        def run():
+            LAUNCHES[kind] += 1
+            return (torch.tanh(x @ w),)
+        (y,) = remat_cache.kernel_result(kind, run)
+        ctx.save_for_backward(x, w, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        dz = dy * (1 - y * y)
+        return dz @ w.t(), x.t() @ dz, None
+
+
+def block(x, w1, w2):
+    h = Node.apply(x, w1, "attn")
+    h = torch.relu(h) + x
+    return Node.apply(h, w2, "scan").sum(dim=-1, keepdim=True) * h
+
+
+def run(keep, ckpt=True):
+    for k in LAUNCHES:
+        LAUNCHES[k] = 0
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(5, 8, generator=g, requires_grad=True)
+    w1 = torch.randn(8, 8, generator=g, requires_grad=True)
+    w2 = torch.randn(8, 8, generator=g, requires_grad=True)
+    if ckpt:
+        kw = lambda: {"context_fn": remat_cache.context_fn(keep)} if keep else {}       # one region (one queue) per checkpoint call
+        y = checkpoint(block, x, w1, w2, use_reentrant=False, **kw())
+        y = checkpoint(block, y, w1, w2, use_reentrant=False, **kw())
+    else:
+        y = block(block(x, w1, w2), w1, w2)
+    y.sum().backward()
+    return y.detach(), x.grad, w1.grad, w2.grad, dict(LAUNCHES)
+
+
+def test_kept_kernel_outputs_are_not_recomputed_and_nothing_else_changes():
+    ref = run((), ckpt=False)
+    assert ref[4] == {"attn": 2, "scan": 2}
+    plain = run(())
+    assert plain[4] == {"attn": 4, "scan": 4}                       # the reference's behaviour: everything runs twice
+    both = run(("attn", "scan"))
+    assert both[4] == {"attn": 2, "scan": 2}
+    attn = run(("attn",))
+    assert attn[4] == {"attn": 2, "scan": 4}
+    for got in (plain, both, attn):
+        for a, r in zip(got[:4], ref[:4]):
+            assert torch.equal(a, r)
+
+
+def test_nested_checkpoint_keeps_nothing_and_order_violations_are_loud():
+    import pytest
+    # a nested checkpoint (dit._ckpt) suspends keeping: its recomputation order is its own
+    def nested(x, w1, w2):
+        inner = lambda a: checkpoint(block, a, w1, w2, use_reentrant=False,
+                                     context_fn=lambda: (remat_cache.suspended(), remat_cache.suspended()))
+        return inner(x)
+    for k in LAUNCHES:
+        LAUNCHES[k] = 0
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(3, 8, generator=g, requires_grad=True)
+    w1 = torch.randn(8, 8, generator=g, requires_grad=True)
+    w2 = torch.randn(8, 8, generator=g, requires_grad=True)
+    y = checkpoint(nested, x, w1, w2, use_reentrant=False, context_fn=remat_cache.context_fn(("attn", "scan")))
+    y.sum().backward()
+    assert LAUNCHES["attn"] >= 2 and LAUNCHES["scan"] >= 2          # recomputed, not handed back
+    # a recomputation that asks for another kind than the forward produced is an error, not a silent mix-up
+    fwd, rec = remat_cache.context_fn(("attn", "scan"))()
+    with fwd:
+        remat_cache.kernel_result("attn", lambda: (torch.zeros(1),))
+    with rec:
+        with pytest.raises(RuntimeError, match="recomputation asked"):
+            remat_cache.kernel_result("scan", lambda: (torch.zeros(1),))

@@ -588,10 +588,10 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster_kernel(SweepParams2 p) {
                 if (l < 3) {
                     const unsigned* f = p.flags + ((size_t)bh * 4 + ((cq + 1 + l) & 3)) * FLAG_STRIDE;
                     // a poisoned workgroup (an earlier poll of this launch gave up) does not wait any more
-                    unsigned spins = syncw[2] != 0u ? (1u << 22) : 0u;
+                    unsigned spins = syncw[2] != 0u ? (1u << 22) : 0u;      // (a poisoned workgroup does not wait at all)
                     while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
                         __builtin_amdgcn_s_sleep(1);
-                        if (++spins > (1u << 22)) {        // a partner is not running: give up LOUDLY instead of hanging the GPU
+                        if (++spins > (p.fault ? (1u << 16) : (1u << 22))) {        // a partner is not running: give up LOUDLY instead of hanging the GPU (fault injection: sooner)
                             __hip_atomic_store(p.err, 1u + (unsigned)bh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                             __hip_atomic_store(syncw + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             break;

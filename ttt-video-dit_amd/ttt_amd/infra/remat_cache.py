@@ -1,0 +1,70 @@
+"""Selective re-materialisation: inside a checkpointed region the RESULTS of the expensive sequence kernels are kept.
+
+The reference checkpoints every transformer layer (``configs/train/ttt-mlp/*.toml: remat_transformer_layer_group_size = 1``,
+``ttt/models/cogvideo/dit.py:493-499``): in backward the layer's whole forward runs again - projections, attention, both TTT
+scans, MLP.  On a 288-GB MI355X the memory that decides how many layers must do so is better spent per byte: a layer's
+local-attention outputs (+ log-sum-exp) are 0.34 GB at the 9 s geometry and save 12.8 ms of the 41 ms a re-materialised layer
+costs (37 ms per GB), its two TTT scan outputs with their state checkpoints 1.3 GB for 12.4 ms (9.7 ms per GB) - against 5 ms per
+GB for keeping a whole layer's activations (``remat_free_layers``).  So a checkpointed region may KEEP these kernel outputs:
+the autograd nodes around the kernels (``FusedSegmentAttention``, ``FusedPreScanMLP``) ask ``kernel_result(kind, compute)``;
+in the region's forward pass the outputs are remembered, in its recomputation they are handed back instead of launching the
+kernel again.  Same tensors, same bits; the cheap elementwise / projection work around them is still re-materialised, so the
+node's own saved inputs are rebuilt as before.
+
+``DiffusionTransformer.remat_keep`` selects the kinds (``("attn", "scan")`` by default in bench.py; ``()`` = the reference's
+behaviour)."""
+from __future__ import annotations
+
+import threading
+from collections import deque
+from contextlib import contextmanager
+
+_state = threading.local()
+
+
+class _Region:
+    __slots__ = ("kinds", "queue")
+
+    def __init__(self, kinds):
+        self.kinds, self.queue = frozenset(kinds), deque()
+
+
+@contextmanager
+def _scope(region, mode):
+    prev = getattr(_state, "cur", None)
+    _state.cur = None if region is None else (region, mode)
+    try:
+        yield
+    finally:
+        _state.cur = prev
+
+
+def context_fn(kinds):
+    """``context_fn`` for ``torch.utils.checkpoint.checkpoint(..., use_reentrant=False)``: one region per checkpoint call."""
+    region = _Region(kinds)
+    return lambda: (_scope(region, "forward"), _scope(region, "recompute"))
+
+
+def suspended():
+    """Context in which nothing is kept (nested checkpoints recompute in an order of their own)."""
+    return _scope(None, None)
+
+
+def kernel_result(kind: str, compute):
+    """``compute() -> tuple of tensors`` (the kernel's outputs).  Outside a keeping region: just ``compute()``.  In the forward
+    pass of a region that keeps ``kind``: compute and remember.  In its recomputation: hand the remembered tuple back (the
+    calls of a region recur in the same order; the kind is checked)."""
+    cur = getattr(_state, "cur", None)
+    if cur is None or kind not in cur[0].kinds:
+        return compute()
+    region, mode = cur
+    # (detached aliases on both sides: the tensor object a Function returns gets that call's autograd identity stamped on it,
+    #  and the recomputation's node must not be handed an object that already carries the forward pass's)
+    if mode == "forward":
+        out = compute()
+        region.queue.append((kind, tuple(t.detach() for t in out)))
+        return out
+    got, out = region.queue.popleft()
+    if got != kind:
+        raise RuntimeError(f"remat_cache: recomputation asked for {kind!r} where the forward pass produced {got!r}")
+    return tuple(t.detach() for t in out)

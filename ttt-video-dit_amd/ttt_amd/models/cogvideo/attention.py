@@ -15,6 +15,8 @@ import math
 import torch
 import torch.nn.functional as F
 
+from ttt_amd.infra.remat_cache import kernel_result
+
 
 def _ext():
     import test_time_training
@@ -115,13 +117,19 @@ class FusedSegmentAttention(torch.autograd.Function):
         v = v if v.stride(3) == 1 else v.contiguous()
         f32 = lambda t: t.detach().to(torch.float32).contiguous()
         p32 = (f32(wq), f32(bq), f32(wk), f32(bk))
-        q, k = torch.empty_like(qr), torch.empty_like(kr)
-        ext.attn_pre_forward(qr, kr, *p32, cos, sin, q, k, NH, n_text, float(eps))
-        view = lambda t: t.view(B, S, NH, Dh).transpose(1, 2)
         scale = 1.0 / math.sqrt(Dh)
-        out = torch.empty(B, S, NH, Dh, device=qr.device, dtype=qr.dtype).transpose(1, 2)
-        lse = torch.empty(B, NH, S, device=qr.device, dtype=torch.float32)
-        ext.attn_forward(view(q), view(k), v, out, lse, scale)
+
+        def run():
+            q, k = torch.empty_like(qr), torch.empty_like(kr)
+            ext.attn_pre_forward(qr, kr, *p32, cos, sin, q, k, NH, n_text, float(eps))
+            view = lambda t: t.view(B, S, NH, Dh).transpose(1, 2)
+            out = torch.empty(B, S, NH, Dh, device=qr.device, dtype=qr.dtype).transpose(1, 2)
+            lse = torch.empty(B, NH, S, device=qr.device, dtype=torch.float32)
+            ext.attn_forward(view(q), view(k), v, out, lse, scale)
+            return out, lse
+
+        # (inside a checkpointed region that keeps "attn" the recomputation gets the remembered output back: no kernel runs)
+        out, lse = kernel_result("attn", run)
         ctx.save_for_backward(qr, kr, v, out, lse, *p32, cos, sin)
         ctx.meta = (NH, n_text, float(eps), scale, wq.dtype)
         return out

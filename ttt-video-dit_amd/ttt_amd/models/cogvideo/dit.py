@@ -15,6 +15,7 @@ import torch.nn.functional as F
 from torch import nn
 from torch.utils.checkpoint import checkpoint
 
+from ttt_amd.infra import remat_cache
 from ttt_amd.infra.fused_linear import linear3
 from ttt_amd.models.cogvideo.attention import FusedSegmentAttention, attn_pre_available, segment_attention
 from ttt_amd.models.cogvideo.utils import (Rotary3DPositionEmbedding, SequenceMetadata, modulate,
@@ -27,7 +28,8 @@ from ttt_amd.models.ssm.ttt_layer import TTTWrapper
 def _ckpt(fn, enabled: bool):
     if not enabled:
         return fn
-    return lambda *a: checkpoint(fn, *a, use_reentrant=False)
+    # (a checkpoint nested in a region that keeps kernel outputs recomputes in an order of its own: nothing is kept inside it)
+    return lambda *a: checkpoint(fn, *a, use_reentrant=False, context_fn=lambda: (remat_cache.suspended(), remat_cache.suspended()))
 
 
 class GeluLinear(torch.autograd.Function):
@@ -434,6 +436,9 @@ class DiffusionTransformer(nn.Module):
         self.frames_per_chunk = config.attn_length
         self.remat_transformer_layer_group_size = config.remat_transformer_layer_group_size
         self.remat_free_layers = getattr(config, "remat_free_layers", 0)
+        # kernel outputs a re-materialised layer group keeps instead of recomputing them: any of "attn" (local-attention outputs),
+        # "scan" (TTT scan outputs + state checkpoints); () = the reference's behaviour (ttt_amd/infra/remat_cache.py)
+        self.remat_keep = tuple(getattr(config, "remat_keep", ()))
         assert config.num_layers % self.remat_transformer_layer_group_size == 0, "Remat group size must be divisible into num layers"
         self.model_dim = config.model_dim
         self.shard_transformer_inputs = config.shard_transformer_inputs
@@ -477,7 +482,11 @@ class DiffusionTransformer(nn.Module):
             return unpatchify(y, c=fl.out_channels, p=fl.patch_size, w=width // fl.patch_size, h=height // fl.patch_size)
         for i in range(0, len(self.layers), self.remat_transformer_layer_group_size):
             if torch.is_grad_enabled() and i >= self.remat_free_layers:
-                vid_emb, text_emb = checkpoint(self._run_group, i, vid_emb, text_emb, meta, use_reentrant=False)
+                if self.remat_keep:
+                    vid_emb, text_emb = checkpoint(self._run_group, i, vid_emb, text_emb, meta, use_reentrant=False,
+                                                   context_fn=remat_cache.context_fn(self.remat_keep))
+                else:
+                    vid_emb, text_emb = checkpoint(self._run_group, i, vid_emb, text_emb, meta, use_reentrant=False)
             else:
                 vid_emb, text_emb = self._run_group(i, vid_emb, text_emb, meta)
         return self.final_layer(self.transformer_norm(vid_emb), meta)

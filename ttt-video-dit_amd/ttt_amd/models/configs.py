@@ -57,6 +57,8 @@ class ModelConfig:
     # MI355X (288 GB HBM3E): the first `remat_free_layers` transformer layers keep their activations instead of being
     # re-materialised in backward (0 = the reference's behaviour: every layer group is checkpointed, dit.py:493-499).
     remat_free_layers: int = 0
+    # MI355X: kernel outputs a re-materialised layer keeps instead of recomputing them ("attn", "scan"; () = reference behaviour)
+    remat_keep: tuple = ()
     remat_forward_ssm: bool = False
     remat_reverse_ssm: bool = False
     remat_attention: bool = False

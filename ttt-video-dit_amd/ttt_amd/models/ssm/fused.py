@@ -11,6 +11,9 @@ import torch
 _BF16, _F32 = torch.bfloat16, torch.float32
 
 
+from ttt_amd.infra.remat_cache import kernel_result
+
+
 def _ext():
     import test_time_training
     return test_time_training
@@ -126,19 +129,25 @@ class FusedPreScanMLP(torch.autograd.Function):
         Fh = D // NH
         q, k, v = XQ_raw.contiguous(), XK_raw.contiguous(), XV_raw.contiguous()
         w32, b32 = ln_w.detach().to(_F32).contiguous(), ln_b.detach().to(_F32).contiguous()
-        XQ, XK, XV = (torch.empty(B, NH, L, Fh, device=q.device, dtype=_BF16) for _ in range(3))
-        ext.pre_forward(q, k, v, rope, src, pos, w32, b32, XQ, XK, XV, NH, n_pos=getattr(pos, "_ttt_max_pos", None))
         CS = eta.shape[-1]
         NC = L // CS
         K = math.ceil(NC / G)
-        mb = lambda t: t.view(B, NH, NC, CS, Fh)
         last_eta = eta.to(_BF16)[:, :, :, -1, :, None].contiguous()
-        lw, lb = w32.reshape(1, NH, 1, Fh), b32.reshape(1, NH, 1, Fh)
-        state = [t.to(_F32).contiguous() for t in (W1, b1, W2, b2)]
-        out = torch.empty(B, NH, NC, CS, Fh, device=q.device, dtype=_BF16)
-        cks = (torch.empty(B, NH, K, Fh, 4 * Fh, device=q.device, dtype=_F32), torch.empty(B, NH, K, 1, 4 * Fh, device=q.device, dtype=_F32),
-               torch.empty(B, NH, K, 4 * Fh, Fh, device=q.device, dtype=_F32), torch.empty(B, NH, K, 1, Fh, device=q.device, dtype=_F32))
-        ext.ttt_forward(mb(XQ), mb(XK), mb(XV), last_eta, lw, lb, *state, *cks, out, G)
+
+        def run():
+            XQ, XK, XV = (torch.empty(B, NH, L, Fh, device=q.device, dtype=_BF16) for _ in range(3))
+            ext.pre_forward(q, k, v, rope, src, pos, w32, b32, XQ, XK, XV, NH, n_pos=getattr(pos, "_ttt_max_pos", None))
+            mb = lambda t: t.view(B, NH, NC, CS, Fh)
+            lw, lb = w32.reshape(1, NH, 1, Fh), b32.reshape(1, NH, 1, Fh)
+            state = [t.to(_F32).contiguous() for t in (W1, b1, W2, b2)]
+            out = torch.empty(B, NH, NC, CS, Fh, device=q.device, dtype=_BF16)
+            cks = (torch.empty(B, NH, K, Fh, 4 * Fh, device=q.device, dtype=_F32), torch.empty(B, NH, K, 1, 4 * Fh, device=q.device, dtype=_F32),
+                   torch.empty(B, NH, K, 4 * Fh, Fh, device=q.device, dtype=_F32), torch.empty(B, NH, K, 1, Fh, device=q.device, dtype=_F32))
+            ext.ttt_forward(mb(XQ), mb(XK), mb(XV), last_eta, lw, lb, *state, *cks, out, G)
+            return (out, *cks)
+
+        # (inside a checkpointed region that keeps "scan" the recomputation gets the scan output and the state checkpoints back)
+        out, *cks = kernel_result("scan", run)
         ctx.save_for_backward(q, k, v, w32, b32, rope, src, pos, last_eta, *cks)
         ctx.meta = (NH, G, tuple(eta.shape), ln_w.dtype, W1.dtype, eta.dtype)
         return out
