@@ -281,7 +281,7 @@ def size_warm_and_time(step, hk, remat_free_layers, warmup, steps, world):
         n_free = int(remat_free_layers)
     # warm-up with the chosen setting; if the caching allocator's fragmentation pushes it over the edge, back off and retry
     # (still untimed).  With an explicit --remat-free-layers N an out-of-memory error is fatal, as it should be.
-    refined = False
+    refinements, fail_at = 0, None      # settings at or above `fail_at` ran out of memory in a warm-up: never tried again
 
     def back_off():
         hk.release()
@@ -301,17 +301,24 @@ def size_warm_and_time(step, hk, remat_free_layers, warmup, steps, world):
             ok = 0
         if world > 1:
             ok = hk.all_reduce_min(ok)
-        if ok and auto and not refined and 0 < n_free < hk.num_layers:
-            # one refinement with the footprint measured at the chosen setting (the 4-layer probe over-estimates it)
-            refined = True
+        if ok and auto and refinements < 2 and 0 < n_free < hk.num_layers:
+            # up to two refinements with the footprint measured at the chosen setting (the probe over-estimates a layer's
+            # footprint - by a third when re-materialised layers keep their kernel outputs, which a layer that keeps everything
+            # no longer needs)
+            refinements += 1
             per_layer = max((hk.max_allocated() - peak0) / n_free, 1.0)
             better = int(max(0, min(hk.num_layers, (cap * hk.total_memory - peak0) // per_layer)))
+            if fail_at is not None:
+                better = min(better, fail_at - 1)
             if world > 1:
                 better = hk.all_reduce_min(better)
             if better > n_free:
                 n_free = better
                 continue
         if not ok:
+            fail_at = n_free if fail_at is None else min(fail_at, n_free)
+            if world > 1:
+                fail_at = hk.all_reduce_min(fail_at)
             n_free = back_off()
             continue
         # ---- timed region.  (One GPU, automatic setting: an out-of-memory error here - allocator fragmentation that the
@@ -330,6 +337,7 @@ def size_warm_and_time(step, hk, remat_free_layers, warmup, steps, world):
             if not auto or world > 1:
                 raise
             log(f"out of memory inside the timed region at remat_free_layers={n_free}: backing off, timing again")
+            fail_at = n_free if fail_at is None else min(fail_at, n_free)
             n_free = back_off()
             continue
         hk.barrier()
