@@ -246,7 +246,9 @@ void        ttt_hip_debug_timing(void* device_buffer);
 void        ttt_hip_debug_groups_per_chunk(int groups);
 /* DEBUG / A-B knobs by name: "groups_per_chunk" (checkpoint groups per backward chunk, 0 = automatic), "overlap_tail" (TTT-MLP
  * backward: 1 (default) = the tail kernel of a chunk runs on an internal side stream beside the next chunk's sweep and the
- * caller's stream joins it before the call returns; 0 = everything on the caller's stream; identical results), "fast_records" (TTT-MLP
+ * caller's stream joins it before the call returns; 2 = the recompute of the chunk after next runs there too; 0 = everything on
+ * the caller's stream; identical results), "sweep_prefetch" (1 default / 0: L2 prefetch touches of the backward sweep), "rc_nt"
+ * (1 default / 0: non-temporal stores of the backward's step records), "fast_records" (TTT-MLP
  * backward sweep hand-over: 1 (default) = plain, L2-resident records once the four workgroups of a cluster have proven that they
  * share an XCD; 0 = write-through records always), "sweep_fast_count" (query: returns -2 - the number of cluster workgroup
  * launches that took the plain form), "sweep_fault" (fault injection for the tests of the hand-over failure path: workgroup 3 of

@@ -29,10 +29,9 @@ def main():
     ap.add_argument("--g", type=int, default=16)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--fwd-only", action="store_true")
-    ap.add_argument("--overlap", type=int, default=1, help="DEBUG A/B: TTT-MLP backward, tail kernel of a chunk 1 = on a side stream under the next sweep (default), 0 = one stream")
+    ap.add_argument("--overlap", type=int, default=1, help="A/B: TTT-MLP backward schedule, 0 = one stream, 1 = tail kernel of a chunk beside the next sweep (default), 2 = the next recompute too")
     ap.add_argument("--gpc", type=int, default=0, help="DEBUG A/B: checkpoint groups per backward chunk (0 = automatic)")
     ap.add_argument("--write-through-records", action="store_true", help="DEBUG A/B: the backward sweep's hand-over records always write-through (sc1), never plain")
-    ap.add_argument("--bwd-rev", type=int, default=4, help="A/B: TTT-MLP backward revision, 4 = slim step record + deriver waves (default), 3 = round 2's register-image slots")
     ap.add_argument("--rc-nt", type=int, default=1, help="A/B: revision-4 recompute, non-temporal stores of the step records")
     ap.add_argument("--prefetch", type=int, default=1, help="A/B: revision-4 sweep, L2 prefetch touches two steps ahead (1 default, 0 off)")
     ap.add_argument("--phases", action="store_true", help="also print per-phase cycle totals of workgroup 0")
@@ -43,7 +42,6 @@ def main():
     ext.load_library()
     ext.set_impl(a.impl)
     ext.debug_option("fast_records", 0 if a.write_through_records else 1)
-    ext.debug_option("bwd_rev", a.bwd_rev)
     ext.debug_option("sweep_prefetch", a.prefetch)
     ext.debug_option("rc_nt", a.rc_nt)
     ext.debug_option("overlap_tail", a.overlap)

@@ -68,7 +68,6 @@ constexpr size_t PARK4_BYTES = 12 * FRAG_BYTES;
 void launch_sweep_cluster4(const SweepParams4& bp, int nbh, hipStream_t s);
 void launch_tail4(const __bf16* dOut, const __bf16* eta, const __bf16* dXV, char* slots, size_t slot_stride_bh, __bf16* dXQ, __bf16* dXK,
                   int NC, int chunk_lo, int chunk_n, int nbh, hipStream_t s);      // (after launch_sweep_cluster4 has run once: attributes)
-unsigned read_sweep_fast_count4();
 
 }  // namespace s4
 }  // namespace mfma

@@ -1,23 +1,20 @@
-// MFMA TTT-MLP backward for gfx950: host-side orchestration + the parallel dK / dQ tail kernel.
+// MFMA TTT-MLP backward for gfx950 (revision 4, round 3): host-side orchestration.
 //
 // A backward call walks the sequence in CHUNKS of `gpc` checkpoint groups, last chunk first; per chunk three launches:
-//   A  group recompute (ttt_mfma.hip, mlp_scan_kernel<true>): one workgroup per (b, h, group) re-runs the group's forward from
-//      its checkpoint and stores every intermediate the reverse sweep needs as MFMA register images ("slots", ttt_mfma_dev.h);
-//   B  reverse sweep (ttt_mfma_bwd3.hip): sequential over the chunk's steps, carrying dW1 / dW2 / db1 / db2 / dgamma / dbeta;
-//      FOUR workgroups per (b, h) with role-specialised waves, at most 64 (b, h) per launch (one workgroup per CU);
-//   C  tail (below): dK and dQ need the carried dW1 and the step's dZ1 but nothing downstream needs them, so the sweep stores
-//      those two (bf16 fragment images) and this fully parallel kernel (one workgroup per step) finishes
+//   A  group recompute (ttt_mfma_rc4.hip): one workgroup per (b, h, group) re-runs the group's forward from its checkpoint in the
+//      8-wave register-resident form and stores the SLIM step record (ttt_bwd4_dev.h: Z1, Z1b, gZ2, the LayerNorm rows);
+//   B  reverse sweep (ttt_mfma_bwd4.hip): sequential over the chunk's steps, carrying dW1 / dW2 / db1 / db2 / dgamma / dbeta; FOUR
+//      workgroups per (b, h) with role-specialised waves (compute, owners, derivers), at most n_cu / 4 (b, h) per launch;
+//   C  tail (ttt_mfma_bwd4.hip): dK and dQ need the carried dW1 and the step's dZ1 but nothing downstream needs them, so the
+//      sweep stores those and this fully parallel kernel (one workgroup per step) finishes
 //      dK = -eta (gZ1 dW1'^T) + dZ1 W1^T - dt   and   dQ = dOut + dZ1b W1'^T.
-//      The tail of chunk c runs on a side stream UNDER the sweep of chunk c-1 (two slot buffers): the sweep is latency-bound on
-//      4 nbh <= 256 CUs, the tail's small workgroups fill the CUs it leaves free.  (The other pairing - the recompute of the
-//      next chunk under the sweep - was measured and removed: each recompute workgroup is bound by its own CU's store path,
-//      ~0.5 ms for 16 steps however many run, so on the 64 free CUs the chunk takes 1.9 ms, longer than the sweep it would
-//      hide under, and without a limit its 240 workgroups win the dispatch race and the sweep waits: profiles/r2k_*, r2l_*.)
-// History: revision 1 (4-wave sweep, 17.3 ms per backward at the 3 s geometry), revision 2 (8-wave single-workgroup sweep with
-// prefetch-helper workgroups, 8.4 ms) were removed in round 2; revision 2's sweep was found to be inaccurate on model-like inputs
-// (output bias dominating Z2: dW1 / dW2 / dK off by 20 - 50 % although every random-input oracle test passed; found by the
-// DiffusionTransformer golden test, tests/test_parity_r2_gpu.py) - the cluster sweep and revision 1 agree with the fp64 oracle
-// there to 3e-3.
+// Schedules (debug option "overlap_tail"; measured on one MI355X at NC = 804, profiles/r3g_*): 0 = one stream, 15.8 ms;
+// 1 (default) = the tail of chunk c on a side stream beside the sweep of chunk c-1 (two record buffers), 14.3 ms; 2 = the
+// recompute of chunk c-2 beside that sweep too, in launches of at most as many workgroups as CUs are free: 14.6 ms - it hides
+// 0.17 ms per chunk and slows the sweep, which is bound by what its CUs' memory pipelines move, by as much.
+// History: revisions 1 - 3 (4-wave sweep; 8-wave single-workgroup sweep; cluster sweep over 570-KiB register-image records)
+// were removed in rounds 2 and 3, each after losing its A/B on hardware; revision 2's sweep was also found to be inaccurate on
+// model-like inputs.
 // Math: SURVEY.md Appendix A backward; oracle/ttt_oracle.py:_mlp_step_bwd is the executable spec.
 #include "ttt_mfma.h"
 #include "ttt_mfma_dev.h"
@@ -29,109 +26,6 @@ namespace ttt {
 namespace mfma {
 using namespace ttt::mf;
 
-namespace b2 {
-// =========================================================================================================================
-// Tail kernel: one workgroup (4 waves, wave w <-> hidden slice H_w as in the slot images) per (b, h, step of the chunk):
-//   dK = -eta (gZ1 dW1'^T) + dZ1 W1^T - dV        dQ = dOut + dZ1b W1'^T      (W1' = state entering the next step)
-struct TailParams {
-    const __bf16 *dOut, *eta, *dXV;
-    char* slots; size_t slot_stride_bh;
-    __bf16 *dXQ, *dXK;
-    int NC, chunk_lo, chunk_n;
-};
-constexpr int LDS_TAIL = 4 * 64 * PS * 4;
-
-__global__ __launch_bounds__(NT) void mlp_bwd_tail_kernel(TailParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* red = reinterpret_cast<float*>(smem);
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, h = l >> 5, c = l & 31;
-    const int bh = blockIdx.x / p.chunk_n, si = blockIdx.x % p.chunk_n;
-    const int i = p.chunk_lo + si;
-    const size_t tile = (size_t)bh * p.NC + i;
-    const char* slot_w = p.slots + (size_t)bh * p.slot_stride_bh + (size_t)si * SLOT_BYTES + (size_t)w * SLOT_WAVE_FR;
-    const char* next_w = slot_w + SLOT_BYTES;
-    const bf16x8 I0 = ident_pi(0, h, c), I1 = ident_pi(1, h, c);
-    const int ot = 16 * w + (l & 15), of0 = 16 * (l >> 4);
-
-    for (int pass = 0; pass < 2; ++pass) {           // 0: dK, 1: dQ
-        f32x16 PA[2][2];                             // [fj][ti]  partial (rows = f, lane = t) over this wave's hidden slice
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) PA[a][b] = zero16();
-        if (pass == 0) {
-            // -eta * (dW1'^T)^T-contraction: A = dW1'^T tile (rows = n, lane = f) in place, B = gZ1^T (k = n, j = t)
-#pragma unroll
-            for (int nj = 0; nj < 2; ++nj) {
-                bf16x8 dWt[2][2];
-#pragma unroll
-                for (int fj = 0; fj < 2; ++fj) {
-                    const f32x16 t = transpose_tile(ld_frag(slot_w, FR_DW1, fr_idx(fj, nj, 0), l), ld_frag(slot_w, FR_DW1, fr_idx(fj, nj, 1), l), I0, I1);
-                    dWt[fj][0] = pack(t, 0);
-                    dWt[fj][1] = pack(t, 1);
-                }
-#pragma unroll
-                for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        const bf16x8 gt = ld_frag(slot_w, FR_GZ1T, fr_idx(nj, ti, s), l);
-                        PA[0][ti] = mma(dWt[0][s], gt, PA[0][ti]);
-                        PA[1][ti] = mma(dWt[1][s], gt, PA[1][ti]);
-                    }
-            }
-#pragma unroll
-            for (int ti = 0; ti < 2; ++ti) {
-                const float el = -(float)p.eta[tile * 64 + 32 * ti + c];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { PA[0][ti][r] *= el; PA[1][ti][r] *= el; }
-            }
-        }
-        // + W^T-contraction with dZ^T:  pass 0: W1 (entering state), dZ1 ; pass 1: W1' (next slot), dZ1b
-        const char* wsrc = pass == 0 ? slot_w : next_w;
-        const int zarr = pass == 0 ? FR_DZ1 : FR_DZ1B;
-#pragma unroll
-        for (int nj = 0; nj < 2; ++nj) {
-            bf16x8 W1T[2][2];
-#pragma unroll
-            for (int fj = 0; fj < 2; ++fj) {
-                const f32x16 t = transpose_tile(ld_frag(wsrc, FR_W1, fr_idx(fj, nj, 0), l), ld_frag(wsrc, FR_W1, fr_idx(fj, nj, 1), l), I0, I1);
-                W1T[fj][0] = pack(t, 0);
-                W1T[fj][1] = pack(t, 1);
-            }
-#pragma unroll
-            for (int ti = 0; ti < 2; ++ti) {
-                const f32x16 zt = transpose_tile(ld_frag(slot_w, zarr, fr_idx(ti, nj, 0), l), ld_frag(slot_w, zarr, fr_idx(ti, nj, 1), l), I0, I1);
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const bf16x8 zb = pack(zt, s);
-                    PA[0][ti] = mma(W1T[0][s], zb, PA[0][ti]);
-                    PA[1][ti] = mma(W1T[1][s], zb, PA[1][ti]);
-                }
-            }
-        }
-        if (pass == 1) __syncthreads();              // owners of pass 0 finished reading `red`
-        write_partial(red + (size_t)w * 64 * PS, PA, h, c);
-        __syncthreads();
-        {
-            float z[16], d[16];
-            gather_partial(red, nullptr, ot, of0, z);
-            const size_t off = tile * 4096 + (size_t)ot * 64 + of0;
-            if (pass == 0) {
-                load16_bf16(p.dXV + off, d);
-#pragma unroll
-                for (int j = 0; j < 16; ++j) z[j] -= d[j];                // dK -= dt, dt = dV
-                store16_bf16(p.dXK + off, z);
-            } else {
-                load16_bf16(p.dOut + off, d);
-#pragma unroll
-                for (int j = 0; j < 16; ++j) z[j] += d[j];
-                store16_bf16(p.dXQ + off, z);
-            }
-        }
-    }
-}
-
-}  // namespace b2
 
 // ---------------------------------------------------------------------------------------------------------------------------
 bool bwd_available() { return true; }
@@ -142,9 +36,6 @@ static int g_overlap = 1;             // 1: tail of chunk c on a side stream bes
 void set_debug_overlap_tail(int v) { g_overlap = v; }
 static int g_fast_records = 1;        // cluster hand-over: plain (L2-resident) records once same-XCD placement is proven; 0 = always write-through
 void set_debug_fast_records(int v) { g_fast_records = v; }
-static int g_bwd_rev = 4;             // 4 = slim step record + deriver waves (round 3), 3 = round 2's register-image slots (A/B, to be removed)
-void set_debug_bwd_rev(int v) { g_bwd_rev = (v == 3) ? 3 : 4; }
-int get_debug_bwd_rev() { return g_bwd_rev; }
 static int g_rc_nt = 1;               // revision-4 recompute: 1 (default) = non-temporal stores of the step records (they are read a launch later, from HBM: keep them out of the sweep's L2 working set), 0 = plain (A/B)
 void set_debug_rc_nt(int v) { g_rc_nt = v; }
 static int g_sweep_prefetch = 1;      // revision-4 sweep: L2 prefetch touches two steps ahead (0 = off, A/B)
@@ -175,7 +66,7 @@ int groups_per_chunk(const ttt_dims* d) {
     int g = nbh < 256 ? 256 / nbh : 1;
     if (g_forced_gpc > 0) g = g_forced_gpc;   // DEBUG knob (tests exercise the chunk hand-over at small sizes)
     // bound the slot area to ~4 GiB
-    const size_t per_group = (size_t)nbh * d->G * (g_bwd_rev == 4 ? s4::SLOT4_BYTES : SLOT_BYTES);
+    const size_t per_group = (size_t)nbh * d->G * s4::SLOT4_BYTES;
     const size_t cap = (size_t)4 << 30;
     while (g > 1 && per_group * g > cap) --g;
     if (g > K) g = K;
@@ -188,11 +79,10 @@ size_t workspace_bytes(const ttt_dims* d, bool mlp, bool backward) {
     if (!mlp || !backward) return 0;
     const size_t nbh = (size_t)d->B * d->NH;
     const size_t slots = (size_t)groups_per_chunk(d) * d->G + 1;
-    // two slot buffers + carried state gradient + exchange records and flag lines of the cluster sweep (+ revision 4: the
-    // state after the last step)
-    const size_t slot_b = g_bwd_rev == 4 ? s4::SLOT4_BYTES : SLOT_BYTES;
-    return nbh * (2 * slots * slot_b + b2::CARRY_FLOATS2 * sizeof(float)) + align128(nbh * 64) +
-           nbh * (b2::XCH_BH_BYTES + 4 * b2::FLAG_STRIDE * sizeof(unsigned)) + (g_bwd_rev == 4 ? nbh * (s4::FINAL_FLOATS * sizeof(float) + 8 * s4::PARK4_BYTES) : 0);
+    // two record buffers + carried state gradient + exchange records and flag lines of the cluster sweep + the state after the
+    // last step + the derivers' parking areas
+    return nbh * (2 * slots * s4::SLOT4_BYTES + b2::CARRY_FLOATS2 * sizeof(float)) + align128(nbh * 64) +
+           nbh * (b2::XCH_BH_BYTES + 4 * b2::FLAG_STRIDE * sizeof(unsigned)) + nbh * (s4::FINAL_FLOATS * sizeof(float) + 8 * s4::PARK4_BYTES);
 }
 
 // Side stream and the events of the two-buffer hand-over, one set per device, created on first use.
@@ -368,94 +258,7 @@ int mlp_backward(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hipStre
     if (per_launch < 1) return -10;      // fewer than 4 compute units visible: the cluster sweep cannot be co-resident
     unsigned* err_word = sweep_error_word();
     if (!err_word) return -11;
-    if (g_bwd_rev == 4) return mlp_backward4(d, a, ws, s, per_launch, err_word);
-    const int K = (NC + G - 1) / G;
-    const int gpc = groups_per_chunk(d);
-    const size_t slot_stride = ((size_t)gpc * G + 1) * SLOT_BYTES;
-    char* slots = (char*)ws;                                   // two buffers of nbh * slot_stride bytes
-    const size_t slot_buf = (size_t)nbh * slot_stride;
-    float* carry = (float*)(slots + 2 * slot_buf);
-    char* xch = (char*)(carry + (size_t)nbh * b2::CARRY_FLOATS2) + align128((size_t)nbh * 64);
-    unsigned* flags = (unsigned*)(xch + (size_t)nbh * b2::XCH_BH_BYTES);
-    const size_t flag_bytes = (size_t)nbh * 4 * b2::FLAG_STRIDE * sizeof(unsigned);
-
-    ScanParams sp = {};
-    sp.XQ = (const __bf16*)a->XQ; sp.XK = (const __bf16*)a->XK; sp.XV = (const __bf16*)a->XV; sp.eta = (const __bf16*)a->last_eta;
-    sp.ln_w = a->ttt_norm_weight; sp.ln_b = a->ttt_norm_bias;
-    sp.W1c = const_cast<float*>(a->W1_checkpoints); sp.b1c = const_cast<float*>(a->b1_checkpoints);
-    sp.W2c = const_cast<float*>(a->W2_checkpoints); sp.b2c = const_cast<float*>(a->b2_checkpoints);
-    sp.NH = d->NH; sp.NC = NC; sp.G = G; sp.K = K; sp.eps = d->eps;
-    sp.slot_stride_bh = slot_stride;
-
-    b2::SweepParams2 bp = {};
-    bp.XQ = (const __bf16*)a->XQ; bp.XK = (const __bf16*)a->XK; bp.dOut = (const __bf16*)a->grad_L_XQW; bp.eta = (const __bf16*)a->last_eta;
-    bp.ln_w = a->ttt_norm_weight;
-    bp.uW1 = a->grad_L_W1_last; bp.ub1 = a->grad_L_b1_last; bp.uW2 = a->grad_L_W2_last; bp.ub2 = a->grad_L_b2_last;
-    bp.slot_stride_bh = slot_stride; bp.carry = carry;
-    bp.dXV = (__bf16*)a->grad_L_XV; bp.deta = (__bf16*)a->grad_L_last_eta;
-    bp.dW1 = a->grad_L_W1_init; bp.db1 = a->grad_L_b1_init; bp.dW2 = a->grad_L_W2_init; bp.db2 = a->grad_L_b2_init;
-    bp.dlnw = a->grad_L_ttt_norm_weight; bp.dlnb = a->grad_L_ttt_norm_bias;
-    bp.NH = d->NH; bp.NC = NC;
-    bp.xch = xch; bp.flags = flags; bp.fast_records = g_fast_records;
-    bp.err = err_word; bp.fault = g_sweep_fault;
-
-    b2::TailParams tp = {};
-    tp.dOut = (const __bf16*)a->grad_L_XQW; tp.eta = (const __bf16*)a->last_eta; tp.dXV = (const __bf16*)a->grad_L_XV;
-    tp.slot_stride_bh = slot_stride;
-    tp.dXQ = (__bf16*)a->grad_L_XQ; tp.dXK = (__bf16*)a->grad_L_XK; tp.NC = NC;
-
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)b2::mlp_bwd_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, b2::LDS_TAIL);
-        attr = true;
-    }
-    const int nchunks = (K + gpc - 1) / gpc;
-    // the side stream needs CUs beside the sweep's workgroups (one per CU): otherwise one stream
-    OverlapRes* ov = (g_overlap && nchunks > 1) ? overlap_resources() : nullptr;
-    if (ov && device_cus() - 4 * (nbh < per_launch ? nbh : per_launch) < 32) ov = nullptr;
-    auto recompute = [&](int ch) {
-        const int g0 = ch * gpc, ng = (K - g0 < gpc) ? K - g0 : gpc;
-        sp.chunk_group0 = g0; sp.chunk_groups = ng; sp.chunk_lo = g0 * G;
-        sp.slots = slots + (size_t)(ch & 1) * slot_buf;
-        launch_group_recompute(sp, nbh, s);
-    };
-    // Stream `s`:   A(n-1) B(n-1) A(n-2) B(n-2) ... A(0) B(0)          (chunk c in slot buffer c & 1)
-    // side stream:                C(n-1) under B(n-2), ...,  C(1) under B(0), C(0)
-    // C(c) starts when A(c-1) is complete - the moment B(c-1) starts, not earlier: beside the recompute there is no free CU -
-    // and A(c-2), which overwrites C(c)'s buffer, waits for it.  `s` joins the side stream before the call returns.
-    recompute(nchunks - 1);
-    for (int ch = nchunks - 1; ch >= 0; --ch) {
-        const int g0 = ch * gpc, ng = (K - g0 < gpc) ? K - g0 : gpc;
-        const int buf = ch & 1;
-        bp.slots = tp.slots = slots + (size_t)buf * slot_buf;
-        bp.chunk_lo = g0 * G;
-        bp.chunk_hi = ((g0 + ng) * G < NC) ? (g0 + ng) * G : NC;
-        bp.first = (ch == nchunks - 1);
-        bp.last = (ch == 0);
-        bp.dbg = get_debug_timing();
-        (void)hipMemsetAsync(flags, 0, flag_bytes, s);        // hand-over flags restart at 0 for every launch (a memset node)
-        for (int bh0 = 0; bh0 < nbh; bh0 += per_launch) {
-            bp.bh0 = bh0;
-            bp.nbh = nbh - bh0 < per_launch ? nbh - bh0 : per_launch;
-            launch_sweep_cluster(bp, bp.nbh, s);
-        }
-        tp.chunk_lo = bp.chunk_lo; tp.chunk_n = bp.chunk_hi - bp.chunk_lo;
-        if (ch > 0) {
-            // chunk ch-1 goes into the other buffer, last read by the tail of chunk ch+1
-            if (ov && ch + 1 < nchunks) (void)hipStreamWaitEvent(s, ov->tail_done[buf ^ 1], 0);
-            recompute(ch - 1);
-        }
-        if (ov) {
-            (void)hipEventRecord(ov->ready[buf], s);
-            (void)hipStreamWaitEvent(ov->side, ov->ready[buf], 0);
-            hipLaunchKernelGGL(b2::mlp_bwd_tail_kernel, dim3(nbh * tp.chunk_n), dim3(NT), b2::LDS_TAIL, ov->side, tp);
-            (void)hipEventRecord(ov->tail_done[buf], ov->side);
-        } else {
-            hipLaunchKernelGGL(b2::mlp_bwd_tail_kernel, dim3(nbh * tp.chunk_n), dim3(NT), b2::LDS_TAIL, s, tp);
-        }
-    }
-    if (ov) (void)hipStreamWaitEvent(s, ov->tail_done[0], 0);      // C(0) is the side stream's last command
-    return 0;
+    return mlp_backward4(d, a, ws, s, per_launch, err_word);
 }
 
 }  // namespace mfma

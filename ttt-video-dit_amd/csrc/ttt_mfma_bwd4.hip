@@ -1,20 +1,54 @@
-// MFMA TTT-MLP backward for gfx950, revision 4 (round 3): the cluster sweep of revision 3 (ttt_mfma_bwd3.hip - four workgroups
-// per (b,h), one hand-over per step, role-specialised waves; that header explains the decomposition and the hand-over protocol,
-// which are unchanged) fed from the SLIM step record of ttt_bwd4_dev.h instead of 570-KiB register images:
-//   * the owners' LDS-DMA staging of ten fragment arrays per step is gone; TWO DERIVER WAVES per workgroup (waves 6, 7; wave pp
-//     owns the 32 hidden units of compute wave pp) load the slice's Z1 / Z1b fragments (16 KiB per step instead of 80), re-derive
-//     X2, gelu', gelu'', X2b, gelu'(Z1b), gX2, gZ1, M and the second orientations, REVERSE the state update to obtain the
-//     per-step W1 / W2 (fp32, re-anchored at every forward checkpoint) and write exactly the operand fragments the compute
-//     waves used to receive by DMA into the same staging regions R1 .. R4 - the compute waves' code is revision 3's, unchanged;
-//     the per-step arithmetic of a deriver wave is ttt_bwd4_aux_body.h (also executed on the CPU wave emulator);
-//   * the sweep additionally stores gZ1 (N) and the packed W1 per step for the parallel dK / dQ tail kernel (below), which
-//     revision 3 read from the phase-A images.
-// Deriver schedule against the four workgroup barriers of a step i (j = i - 1; every staging region keeps ONE buffer, each
-// write sits between the region's last reader and its next reader):
-//   after Bd(i+1)  R4 <- D1 | M | X2 of step i (held in registers since they were derived), R3.W2T <- W2_i^T, loads of Z1_j, Z1b_j
-//   after Ba(i)    R3 <- gelu'(Z1b_j) | X2b_j                                   (the output path of step i read R3 before Bc(i+1))
-//   after Bb(i)    (K_j, gZ2_j, eta_j tiles are visible)  derive_z1(j), reverse_step(j): R1 <- gZ1 | D1 | X2 (N) of step j, R2 <- W2_j
-//   Bc(i), Bd(i)   nothing of the derivers is due
+// MFMA TTT-MLP backward for gfx950, revision 4 (round 3): the reverse sweep in CLUSTER form - the sweep of one (b,h) runs on
+// FOUR workgroups (four CUs) with role-specialised waves - over the SLIM step record of ttt_bwd4_dev.h, and the dK / dQ tail.
+//
+// Why a cluster (round 2, profiles/r1f, r2a): one workgroup per (b,h) is bound by what ONE CU can pull from memory (a CU sustains
+// ~10 bytes / cycle of misses) and by one CU's issue slots; 48 scans occupy 48 of 256 CUs.  Everything the sweep carries or
+// loads is sliced by hidden unit: dW1[:, H], dW2[H, :], db1[H] and the step record's fragment arrays.  So workgroup cq of a
+// cluster takes hidden slice cq (64 units: a quarter of the record, of the state and of the MFMAs per CU).  The ONLY quantity
+// that crosses the slices per step is the partial d(gZ2)^T [64 x 64] fp32 (+ the per-token d(eta) partials): every workgroup
+// publishes its partial and reads all four (an all-gather), and all four run the cheap owner stage redundantly with the same
+// summation order, so dZ2 is bit-identical on the four CUs and ONE hand-over per step suffices.
+//
+// Hand-over = the placement-independent recipe of the CDNA4 guide (cdna_hip_programming.md Guideline 16, form R1): payload
+// stored write-through (16-byte sc1 buffer stores), every storing wave drains (s_waitcnt vmcnt(0)), workgroup barrier, ONE
+// lane stores the step number into the workgroup's flag word (relaxed, agent scope); the consumer polls the three partner
+// flags (relaxed, agent scope, one lane each, bounded), then reads the payload with sc1 loads (never served by the reading
+// CU's L1).  Nothing depends on where the four workgroups run; when the first hand-over PROVES that they share an XCD (they
+// exchange HW_REG_XCC_ID; blocks bh + q nbh do when nbh % 8 == 0) later records are stored plain and stay in that XCD's L2.
+// Records are double-buffered by step parity - a workgroup can be at most one hand-over ahead of its slowest partner -, the
+// flags are zeroed by a memset node ahead of every launch.  A poll that gives up (a partner that is not running) does not hang
+// the GPU and does not return plausible numbers either: it stores 1 + (b,h) into the process's host-mapped error word
+// (p.err, system scope), POISONS the workgroup - every later poll returns at once, everything it writes from then on (dV,
+// d(eta), the carried / final state gradients, dgamma / dbeta) is NaN - and the next extension call fails on entry
+// (capi.hip reads the word without synchronising).  The four workgroups must be co-resident: the host launches at most
+// n_cu / 4 clusters at a time.
+//
+// Workgroup = 8 waves (wave w on SIMD w % 4):
+//   waves 0, 1  COMPUTE: wave pp owns the 32 hidden units [64 cq + 32 pp, +32): the carried dW1 / dW2 (both orientations) /
+//               db1 tiles and every MFMA of the gradient chain;
+//   waves 2, 3, 6, 7  OWNERS (256 threads = 64 tokens x 4 lanes x 16 features): staging of the next step's K / gZ2 / Q / eta
+//               tiles into LDS (double-buffered), the output-LayerNorm backward of the next step, the hand-over (flag, poll,
+//               record reads), the fused-LN / L2 backward-of-backward -> dZ2, dV, d(eta), dgamma / dbeta, L2 prefetch touches;
+//   waves 4, 5  DERIVERS (round 3; beside the compute waves on SIMDs 0 / 1, which idle during the hand-over): wave pp loads the
+//               slice's Z1 / Z1b fragments (16 KiB per step and CU where round 2's owners DMA-staged 80 KiB of register
+//               images), re-derives X2, gelu', gelu'', X2b, gelu'(Z1b), gX2, gZ1, M and the second orientations, REVERSES the
+//               state update to obtain the per-step W1 / W2 (fp32, re-anchored at every forward checkpoint) and writes exactly
+//               the operand fragments the compute waves read into the staging regions R1 .. R4; its per-step arithmetic is
+//               ttt_bwd4_aux_body.h (also executed on the CPU wave emulator).  It additionally stores gZ1 (N) and the packed
+//               W1 per step for the tail kernel.
+// Per step i (j = i - 1), 4 workgroup barriers; every staging region keeps ONE buffer, each write sits between the region's
+// last reader and its next reader:
+//   compute:  S1 (u^T, d(eta) partial, first half of d(gZ2)^T)  |Ba|  S2 (second half -> published record), drain  |Bb|
+//             snapshot of the state operands, OUTPUT PATH OF STEP j (it needs no partner data: it fills the hand-over
+//             latency)  |Bc|  S4a (dZ1, state updates of step i), publish state for step j  |Bd|
+//   owners:   requests of step j's tiles / step i's rows  |Ba|  tiles -> LDS, output-LN backward of step j  |Bb|  flag, poll,
+//             records, owner math -> dZ2_i  |Bc|  prefetch touches of step i - 2  |Bd|
+//   derivers: R4 <- D1 | M | X2 of step i (parked in L2 since they were derived), R3.W2T <- W2_i^T, loads of Z1b_j  |Ba|
+//             R3 <- gelu'(Z1b_j) | X2b_j, loads of Z1_j  |Bb|  (K_j, gZ2_j, eta_j tiles are visible) reverse_step(j): R1 <- gZ1 |
+//             D1 | X2 (N) of step j, R2 <- W2_j, park D1 | M | X2 of step j  |Bc|  |Bd|
+// What bounds it (round 3, profiles/r3d - r3g): per CU and step ~330 KiB pass through the memory pipeline in ~36 k cycles - the
+// step is a chain of dependent memory phases, not of MFMAs; spilled registers are part of that traffic (a build with 399
+// spilled dwords ran 24.4 ms per backward, the 138-dword build 14.3 ms: tests/test_kernel_resources_cpu.py pins the budget).
 // Math: SURVEY.md Appendix A backward; oracle/ttt_oracle.py:_mlp_step_bwd is the executable spec.
 #include "ttt_mfma.h"
 #include "ttt_mfma_dev.h"
@@ -850,7 +884,7 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
 // =========================================================================================================================
 // Tail kernel (phase C): one workgroup (4 waves, wave w <-> hidden slice w) per (b, h, step of the chunk):
 //   dK = -eta (gZ1 dW1'^T) + dZ1 W1^T - dV        dQ = dOut + dZ1b W1'^T      (W1' = state entering the next step)
-// Revision 3's kernel reading the sweep-written arrays of the slim record: dZ1, dZ1b, dW1' (compute waves), gZ1 (N) and the
+// Round 2's tail kernel reading the sweep-written arrays of the slim record: dZ1, dZ1b, dW1' (compute waves), gZ1 (N) and the
 // packed W1 of the step and of the next step (deriver waves).
 struct TailParams4 {
     const __bf16 *dOut, *eta, *dXV;
@@ -956,12 +990,39 @@ __global__ __launch_bounds__(NT) void mlp_bwd_tail4_kernel(TailParams4 p) {
 }  // namespace b4
 
 // ---------------------------------------------------------------------------------------------------------------------------
-namespace s4 {
-unsigned read_sweep_fast_count4() {
+// The error word lives in host-mapped memory: the kernels store to it with system scope, the host reads it without a copy -
+// at the entry of every TTT-MLP call without synchronising (a hand-over that gave up makes the NEXT call fail), or after a
+// device synchronisation when a test / bench asks.
+static unsigned* g_err_host = nullptr;
+static unsigned* g_err_dev = nullptr;
+unsigned* sweep_error_word() {
+    if (!g_err_host) {
+        void* h = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess) return nullptr;
+        *(volatile unsigned*)h = 0u;
+        void* d = nullptr;
+        if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipHostFree(h); return nullptr; }
+        g_err_host = (unsigned*)h;
+        g_err_dev = (unsigned*)d;
+    }
+    return g_err_dev;
+}
+unsigned peek_sweep_error() { return g_err_host ? *(volatile unsigned*)g_err_host : 0u; }
+unsigned read_sweep_error() {
+    (void)hipDeviceSynchronize();
+    return peek_sweep_error();
+}
+void clear_sweep_error() {
+    (void)hipDeviceSynchronize();
+    if (g_err_host) *(volatile unsigned*)g_err_host = 0u;
+}
+unsigned read_sweep_fast_count() {      // DEBUG statistic: cluster workgroup launches that published plain (same-XCD) records (synchronises)
     unsigned v = 0;
     (void)hipMemcpyFromSymbol(&v, HIP_SYMBOL(b4::g_fast_count4), sizeof(v));
     return v;
 }
+
+namespace s4 {
 
 void launch_sweep_cluster4(const SweepParams4& bp, int nbh, hipStream_t s) {
     static bool attr = false;

@@ -1,4 +1,4 @@
-// Device helpers shared by the TTT-MLP backward sweeps (single-workgroup form ttt_mfma_bwd2.hip, cluster form ttt_mfma_bwd3.hip).
+// Device helpers shared by the TTT-MLP backward kernels (recompute ttt_mfma_rc4.hip, cluster sweep and tail ttt_mfma_bwd4.hip).
 #pragma once
 #include "ttt_mfma_dev.h"
 
@@ -65,9 +65,6 @@ __device__ __forceinline__ void write_partial2(float* redw, const f32x16& P, int
         *reinterpret_cast<f32x4*>(redw + (32 * ti + c) * PS + 32 * p + 8 * q + 4 * h) = v;
     }
 }
-__device__ __forceinline__ f32x16 ld_tile(const char* wave_base, int arr, int a, int b, int lane) {
-    return unpack2(ld_frag(wave_base, arr, fr_idx(a, b, 0), lane), ld_frag(wave_base, arr, fr_idx(a, b, 1), lane));
-}
 __device__ __forceinline__ float tile_colsum(const f32x16& t) {
     float s = 0.f;
 #pragma unroll
@@ -102,7 +99,6 @@ __device__ __forceinline__ void bst4f_sc1(__amdgpu_buffer_rsrc_t r, int voff, in
 __device__ __forceinline__ f32x4 bld4f_sc1(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 16));
 }
-constexpr int fro(int arr, int idx) { return (arr * 8 + idx) * (int)FRAG_BYTES; }       // byte offset of a fragment in a wave region
 
 // carry area per (b,h), floats: natural-layout dW1 [64][256], dW2 [256][64], db1 [256], db2 [64], then per-thread dgamma / dbeta
 constexpr size_t C_DW1 = 0, C_DW2 = 64 * 256, C_DB1 = 2 * 64 * 256, C_DB2 = C_DB1 + 256, C_DG = C_DB2 + 64, C_DBT = C_DG + NT2 * 8,
@@ -136,6 +132,5 @@ constexpr int FLAG_STRIDE = 32;             // unsigned words: one 128-byte line
 static_assert(XCH_REC_BYTES % 128 == 0, "exchange records are line aligned");
 
 }  // namespace b2
-void launch_sweep_cluster(const b2::SweepParams2& bp, int nbh, hipStream_t s);     // ttt_mfma_bwd3.hip: four workgroups per (b,h)
 }  // namespace mfma
 }  // namespace ttt

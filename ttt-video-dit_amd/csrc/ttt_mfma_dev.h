@@ -15,9 +15,6 @@
 //   ("pi read").  Contraction over the LANE index is impossible in place; a 32x32 tile is
 //   transposed with two MFMAs against constant identity fragments:  X^T = (X as A) * I_pi.
 #pragma once
-#ifndef TTT_SLOT_STORE_SC1
-#define TTT_SLOT_STORE_SC1 0
-#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "ttt_common.h"
@@ -244,48 +241,19 @@ __device__ __forceinline__ f32x16 unpack2(bf16x8 lo, bf16x8 hi) {   // inverse o
 }
 
 // ------------------------------------------------------------------------------------------------
-// Backward workspace: one "slot" per scan step holds everything the reverse sweep needs, written
-// by the (parallel) group-recompute kernel as register images (16 B per lane per fragment).
-// Fragment arrays are laid out per wave w of the 4-wave decomposition (hidden slice H_w = [64w, 64w+64)), 8 fragments
-// each, index fr_idx(a, b, s); layouts: T = tile (rows = t, lane = n), N = tile (rows = n, lane = t).
-//   FR_W1   [fi][nj][s]  W1 (rows=f, lane=n)            FR_W2   [ni][fj][s]  W2 (rows=n, lane=f)
-//   FR_X2   [ti][nj][s]  X2, T                          FR_XT   [ni][ti][s]  X2, N
-//   FR_D1   [ti][nj][s]  gelu'(Z1), T                   FR_D2   [ti][nj][s]  gelu''(Z1), T        (revision-1 sweep only)
-//   FR_GX2  [ti][nj][s]  gX2, T (revision 1) / M = gX2*gelu''(Z1), T (revision 2)
-//   FR_GZ1  [ti][nj][s]  gZ1, T (revision 1 only)       FR_GZ1T [nj][ti][s]  gZ1, N
-//   FR_X2B  [ti][nj][s]  X2b, T                         FR_D1B  [ti][nj][s]  gelu'(Z1b), T
-//   revision 2 additions -
-//   FR_W2T  [fj][ni][s]  W2^T (rows=f, lane=n)          FR_D1N  [nj][ti][s]  gelu'(Z1), N
-//   written by the revision-2 sweep for the parallel dK / dQ tail kernel:
-//   FR_DZ1  [ti][nj][s]  dZ1, T      FR_DZ1B [ti][nj][s]  dZ1b, T      FR_DW1 [fi][nj][s]  dW1' complete (rows=f, lane=n)
-enum { FR_W1 = 0, FR_W2, FR_X2, FR_XT, FR_D1, FR_D2, FR_GX2, FR_GZ1, FR_GZ1T, FR_X2B, FR_D1B,
-       FR_W2T, FR_D1N, FR_DZ1, FR_DZ1B, FR_DW1, FR_COUNT };
+// Pieces of the backward's per-step record shared by its kernels (the record itself: ttt_bwd4_dev.h).  A fragment image is what
+// one wave holds of a packed 32 x 16 operand: 64 lanes x 16 bytes, lane-linear; fragment arrays of a hidden slice hold 8 of
+// them, index fr_idx(a, b, s).  (Round 2's 570-KiB record of 16 such arrays per wave - per-step W1 / W2 / W2^T images and
+// second-orientation copies - was replaced in round 3: ttt_bwd4_dev.h.)
 constexpr size_t FRAG_BYTES = 64 * 16;
-constexpr size_t SLOT_WAVE_FR = (size_t)FR_COUNT * 8 * FRAG_BYTES;      // 128 KiB per wave
-constexpr size_t SLOT_FR = 4 * SLOT_WAVE_FR;
 // owner data: three row-major fp32 [64 t][64 f] arrays (0 = x_hat of the inner LN, 1 = go = y - target, 2 = x_hat of
 // the output LN) + per-token (rstd, rstd_out)
 constexpr size_t SLOT_OWN_ARR = 64 * 64 * 4;
 constexpr size_t SLOT_OWN = 3 * SLOT_OWN_ARR + 64 * 8;
 constexpr size_t SLOT_G = 64 * 64 * 2;                                   // gZ2 tile, bf16 row-major
-constexpr size_t SLOT_BYTES = SLOT_FR + SLOT_OWN + SLOT_G;
 
 __device__ __forceinline__ int fr_idx(int a, int b, int s) { return (a * 2 + b) * 2 + s; }
-// TTT_SLOT_STORE_SC1 = 1 makes the slot stores write-through (sc1: the line leaves the XCD's L2).  Measured slower (8.50 vs
-// 8.22 ms per backward at the 3 s geometry), kept as a build option for the record.
-__device__ __forceinline__ void st_frag(char* wave_base, int arr, int idx, bf16x8 v, int lane) {
-    bf16x8* p = reinterpret_cast<bf16x8*>(wave_base + ((size_t)(arr * 8 + idx) * 64 + lane) * 16);
-#if TTT_SLOT_STORE_SC1
-    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(__builtin_bit_cast(u32x4_t, v)) : "memory");
-#else
-    *p = v;
-#endif
-}
-__device__ __forceinline__ bf16x8 ld_frag(const char* wave_base, int arr, int idx, int lane) {
-    return *reinterpret_cast<const bf16x8*>(wave_base + ((size_t)(arr * 8 + idx) * 64 + lane) * 16);
-}
-// owner rows: `own` = slot + SLOT_FR; token ot, features of0 .. of0 + N - 1
+// owner rows: `own` = the record's owner area; token ot, features of0 .. of0 + N - 1
 template <int N>
 __device__ __forceinline__ void st_own(char* own, int arr, int ot, int of0, const float (&v)[N]) {
     float* p = reinterpret_cast<float*>(own + (size_t)arr * SLOT_OWN_ARR) + ot * 64 + of0;

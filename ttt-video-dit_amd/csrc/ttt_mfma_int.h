@@ -16,15 +16,10 @@ struct ScanParams {
     __bf16* out;                           // XQW (forward only)
     int NH, NC, G, K;
     float eps;
-    // group-recompute (SAVE) mode: groups [chunk_group0, chunk_group0 + chunk_groups) -> slots
-    char* slots;                           // base of the slot area; slot s of (b,h) <-> step chunk_lo + s
-    size_t slot_stride_bh;                 // bytes between consecutive (b,h) slot areas
-    int chunk_group0, chunk_groups, chunk_lo;
     unsigned long long* dbg;               // optional per-phase cycle totals of workgroup 0
     float* dump;                           // DEBUG: intermediates of workgroup 0, step 0 (revision-2 forward)
 };
 
-void launch_group_recompute(const ScanParams& p, int n_bh, hipStream_t s);
 bool bwd_available();
 int groups_per_chunk(const ttt_dims* d);
 // revision-2 forward scan (ttt_mfma2.hip): 8 waves per (b,h), VGPR-form MFMA, LDS transposed reads
@@ -35,17 +30,15 @@ void launch_linear_forward_cs16(const wv::Lin16Params& p, int n_bh, hipStream_t 
 void launch_linear_backward_cs16(const wv::Lin16Params& p, int n_bh, hipStream_t s);
 void set_debug_dump(float* buf);
 unsigned long long* get_debug_timing();
-void set_debug_overlap_tail(int v);   // backward: 1 (default) tail of chunk c on a side stream under the sweep of chunk c-1, 0 one stream
+void set_debug_overlap_tail(int v);   // backward schedule: 0 one stream, 1 (default) tail of chunk c beside the sweep of chunk c-1, 2 the next recompute too
 void set_debug_fast_records(int v);   // cluster sweep: 1 (default) plain records on a proven common XCD, 0 write-through always
 unsigned read_sweep_error();           // 0, or 1 + (b,h) of a cluster workgroup whose partner never arrived (synchronises)
 unsigned peek_sweep_error();           // the same word without synchronising (entry check of the TTT-MLP calls)
 void clear_sweep_error();              // acknowledge (synchronises)
 unsigned* sweep_error_word();          // device pointer of the host-mapped word (allocated on first use; nullptr on failure)
-void set_debug_sweep_fault(int v);
+void set_debug_sweep_fault(int v);     // DEBUG fault injection: workgroup 3 of every sweep cluster leaves before its first hand-over
 void set_debug_rc_nt(int v);           // revision-4 recompute: non-temporal stores of the step records (A/B)
 void set_debug_sweep_prefetch(int v);  // revision-4 sweep: 1 (default) L2 prefetch touches two steps ahead, 0 off
-void set_debug_bwd_rev(int v);        // TTT-MLP backward: 4 (default) = slim step record + deriver waves, 3 = round 2's register-image slots
-int get_debug_bwd_rev();     // DEBUG fault injection: workgroup 3 of every sweep cluster leaves before its first hand-over
 unsigned read_sweep_fast_count();   // DEBUG statistic (synchronises)
 
 }  // namespace mfma
