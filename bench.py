@@ -78,6 +78,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     # debugging knobs: anything that shrinks the workload marks the result invalid
+    ap.add_argument("--tp", type=int, default=1,
+                    help="tensor parallelism over ALL ranks (must equal --gpus): ONE sample per step, head shards for attention and the "
+                         "TTT layer, token shards for the token-wise work (apply_tp layout 'full', reference parallelisms.py:106-152); "
+                         "parameters replicated, no FSDP; the line's scaling is then 'strong'")
     ap.add_argument("--remat-keep", default="attn,scan",
                     help="kernel outputs a re-materialised layer keeps instead of recomputing them (comma list of attn, scan; 'none' = "
                          "the reference's behaviour: the whole layer is recomputed) - ttt_amd/infra/remat_cache.py")
@@ -105,7 +109,7 @@ def parse():
     return ap.parse_args()
 
 
-TEXT_LEN = {"3sec": 498, "9sec": 502, "18sec": 500, "30sec": 497, "63sec": 458}   # configs/eval/ttt-mlp/*.toml:16 (L % 64 == 0)
+TEXT_LEN = {"3sec": 498, "9sec": 502, "18sec": 471, "30sec": 497, "63sec": 458}   # configs/eval/ttt-mlp/*.toml:16 (L % 64 == 0)
 
 
 class KernelTimer:
@@ -256,10 +260,20 @@ def size_warm_and_time(step, hk, remat_free_layers, warmup, steps, world):
         # layers in the second probe step: 4 at the 3 s geometry (2.7 GB of activations per layer and sample), 1 for the long
         # videos, whose layers are 3 - 20 x larger; an out-of-memory error in the probe means "none fit"
         probe = hk.probe_layers
-        hk.reset_peak()
-        hk.set_free_layers(0)
-        step()
-        hk.synchronize()
+        # first probe step: every layer re-materialised.  If even that does not fit - the kernel outputs the re-materialised
+        # layers KEEP (remat_keep) are 5 GB per layer at 30 s - the keeping policy is reduced kind by kind (one GPU; on several
+        # ranks an out-of-memory error inside a step's collectives is not recoverable: state --remat-keep explicitly there)
+        while True:
+            hk.reset_peak()
+            hk.set_free_layers(0)
+            try:
+                step()
+                hk.synchronize()
+                break
+            except hk.oom:
+                if world > 1 or not hk.reduce_keep():
+                    raise
+                hk.release()
         peak0 = hk.max_allocated()
         n_free = 0
         if probe:
@@ -365,6 +379,14 @@ def main():
     if args.adapter == "auto":
         args.adapter = "sft" if args.video_length == "3sec" else "qkvo"      # configs/train/ttt-mlp/{3s,9s,...}.toml
     mode = "off" if args.no_fsdp else args.fsdp
+    if args.tp > 1:
+        assert args.tp == world, "--tp N shards ONE sample over all N ranks (launch with torch.distributed.run --nproc-per-node N)"
+        line = _run(args, world, rank, local_rank, dev, no_fsdp=True, tp=True)
+        if rank == 0 and line is not None:
+            print(json.dumps(line), flush=True)
+        dist.barrier(device_ids=[local_rank])
+        dist.destroy_process_group()
+        return
     assert not (mode == "off" and world > 1), "--fsdp off is the one-GPU replica path"
     import gc
     line = None
@@ -415,7 +437,7 @@ def main():
     dist.destroy_process_group()
 
 
-def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False):
+def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False, tp=False):
     import test_time_training as ext
     from ttt_amd.infra.parallelisms import (ReplicaMixedPrecision, apply_fsdp, enable_tuned_gemms, get_dp_mesh, init_distributed,
                                             init_model_parameters)
@@ -440,7 +462,7 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False):
     assert L % cfg.mini_batch_size == 0
 
     with torch.device("meta"):
-        model = CogVideoX(cfg, effective_rank=rank, effective_world_size=world)
+        model = CogVideoX(cfg, effective_rank=0 if tp else rank, effective_world_size=1 if tp else world)   # (a TP group is ONE data-parallel rank)
     if not no_fsdp:
         apply_fsdp(model, get_dp_mesh(), reshard_after_forward=args.reshard_after_forward)   # reference parallelisms.py:155-175
     model.to_empty(device=dev)
@@ -448,12 +470,15 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False):
     with torch.no_grad():
         init_model_parameters(model)
         model.init_ssm_weights()
-    model.setup_generator(seed=rank, device=dev)
+    model.setup_generator(seed=0 if tp else rank, device=dev)       # (a TP group works on ONE sample: same draws on every rank)
+    if tp:
+        from ttt_amd.infra.parallelisms import apply_tp, tp_sync_gradients
+        apply_tp(model, dist.group.WORLD, layout="full")
     replica = ReplicaMixedPrecision(model.dit) if no_fsdp else None
     train_params = replica.master_parameters() if replica else [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.AdamW(train_params, lr=1e-5, weight_decay=1e-4, fused=True)
 
-    g = torch.Generator(device=dev).manual_seed(100 + rank)
+    g = torch.Generator(device=dev).manual_seed(100 + (0 if tp else rank))
     LB = args.local_batch
     vid = torch.randn(LB, frames, 16, 60, 90, device=dev, generator=g)
     text = torch.randn(LB, scenes, text_len, cfg.text_dim, device=dev, generator=g)
@@ -465,6 +490,8 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False):
         opt.zero_grad(set_to_none=True)
         loss = model(vid, text).mean()
         loss.backward()
+        if tp:
+            tp_sync_gradients(model)                # partial parameter gradients (a rank's tokens / heads) summed over the group
         if replica:
             replica.collect_grads()                 # bf16 gradients -> fp32 gradients of the masters (what FSDP's reduce does)
         torch.nn.utils.clip_grad_norm_(train_params, 1.0)
@@ -505,6 +532,15 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False):
             if replica:
                 replica.zero_grad()
             torch.cuda.empty_cache()
+
+        @staticmethod
+        def reduce_keep():
+            """drop the most expensive kind of kept kernel outputs ("scan" 1.3 GB per layer at 9 s, then "attn" 0.34 GB)"""
+            if not dit.remat_keep:
+                return False
+            dit.remat_keep = tuple(dit.remat_keep)[:-1] if "scan" not in dit.remat_keep else tuple(k for k in dit.remat_keep if k != "scan")
+            log(f"out of memory with every layer re-materialised: keeping {list(dit.remat_keep) or 'nothing'} instead")
+            return True
 
         @staticmethod
         def all_reduce_min(v):
@@ -554,7 +590,7 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False):
 
     if rank == 0:
         ms_per_step = 1e3 * dt / args.steps
-        video_tokens = world * LB * frames * TOKENS_PER_FRAME
+        video_tokens = (1 if tp else world) * LB * frames * TOKENS_PER_FRAME
         value = video_tokens / (dt / args.steps)
         ks = timer.summary()
         # ---- roofline of the dominant hand-written kernel ---------------------------------
@@ -608,13 +644,13 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False):
                     "attention_share_of_step": sum(v["total_ms"] for k, v in ks.items() if k.startswith("attn")) / (1e3 * dt)}
         line = {"metric": "DiT+TTT fwd/bwd video-tokens/sec", "value": value, "unit": "video-tokens/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                "scaling": "strong" if tp else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                 "config": {"workload": f"CogVideoX-5B+{args.ssm_layer} {args.video_length} training step (fwd+bwd+AdamW), "
                                        f"{cfg.num_layers} layers, L={L} tokens/sample, adapter={args.adapter}",
-                           "global_batch": world * LB, "seq_len": L, "parallelism": "replica1" if no_fsdp else f"fsdp{world}", "ttt_impl": args.impl,
-                           "remat_free_layers": n_free, "remat_keep": list(cfg.remat_keep), "fsdp_reshard_after_forward": bool(args.reshard_after_forward), "tuned_gemm_selections": bool(tuned),
+                           "global_batch": (1 if tp else world) * LB, "seq_len": L, "parallelism": f"tp{world}" if tp else ("replica1" if no_fsdp else f"fsdp{world}"), "ttt_impl": args.impl,
+                           "remat_free_layers": n_free, "remat_keep": list(dit.remat_keep), "fsdp_reshard_after_forward": bool(args.reshard_after_forward), "tuned_gemm_selections": bool(tuned),
                            "sweep_error": sweep_err, "valid": args.layers is None and sweep_err == 0},
-                "roofline": roof, "loss": loss_val, "peak_mem_gib": peak_mem, "peak_reserved_gib": torch.cuda.max_memory_reserved() / 2 ** 30, "total_tokens_per_s": world * L / (dt / args.steps)}
+                "roofline": roof, "loss": loss_val, "peak_mem_gib": peak_mem, "peak_reserved_gib": torch.cuda.max_memory_reserved() / 2 ** 30, "total_tokens_per_s": (1 if tp else world) * L / (dt / args.steps)}
         return line
     return None
 

@@ -44,6 +44,7 @@ class FakeDevice:
         self.peak = max(self.peak, need)
         return torch.tensor(1.0)
 
+    def reduce_keep(self): return False
     def set_free_layers(self, n): self.n_free = n
     def reset_peak(self): self.peak = 0
     def max_allocated(self): return self.peak
@@ -122,6 +123,31 @@ def test_single_rank_backs_off_and_times_again():
     hk = FakeDevice(1, 288 * GB, 60 * GB, 5 * GB, timed_oom_at=10)
     with pytest.raises(FakeOOM):
         bench.size_warm_and_time(hk.step, hk, "10", 1, 3, 1)
+
+
+def test_keeping_policy_is_reduced_when_even_full_rematerialisation_does_not_fit():
+    """30 s geometry: with every layer re-materialised, the kept kernel outputs alone exceed the device; the policy drops them
+    kind by kind before giving up (one GPU)."""
+    import bench
+    GB = 1 << 30
+
+    class Dev(FakeDevice):
+        keep = ["attn", "scan"]
+
+        def step(self):
+            if not self.in_timed and self.keep == ["attn", "scan"]:
+                raise FakeOOM("kept scan outputs do not fit")
+            return super().step()
+
+        def reduce_keep(self):
+            if not self.keep:
+                return False
+            self.keep = self.keep[:-1]
+            return True
+
+    hk = Dev(1, 288 * GB, 200 * GB, 20 * GB)
+    n, dt, loss = bench.size_warm_and_time(hk.step, hk, "auto", 1, 2, 1)
+    assert hk.keep == ["attn"] and n == 2 and hk.timed_regions == 1        # (253.4 - 200) / 20 = 2 remat-free layers
 
 
 def test_timed_region_oom_on_a_multi_rank_run_is_fatal_on_that_rank():

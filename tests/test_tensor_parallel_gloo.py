@@ -1,7 +1,8 @@
-"""Head-sharded tensor parallelism of the TTT layer (``TTTBase.init_device_mesh`` / ``apply_tp``, the reference surface of
-``ttt/models/ssm/ttt_layer.py``:114-131 and ``ttt/infra/parallelisms.py``:106-152) on CPU over gloo: world size 2, a 1-D
-DeviceMesh as the reference passes it.  Every rank runs its heads' scans over the full sequence, head outputs are all-gathered;
-outputs and - after ``tp_sync_gradients`` - every gradient must equal the single-process DiT.  Dual-form scan and kernel plumbing
+"""Tensor parallelism through the reference's API surface (``apply_tp(model, tp_mesh)`` / ``TTTBase.init_device_mesh``:
+``ttt/infra/parallelisms.py``:106-152, ``ttt/models/ssm/ttt_layer.py``:114-131) on CPU over gloo: world size 2, a 1-D DeviceMesh as
+the reference passes it.  Two layouts: ``"full"`` - the reference's whole plan (head shards for local attention and the TTT layer,
+token shards for AdaLN / output projections / norms / gates / MLP / final layer) - and ``"ttt_heads"`` (round 2: only the TTT
+layer sharded).  Outputs and - after ``tp_sync_gradients`` - every gradient must equal the single-process DiT.  Dual-form scan and kernel plumbing
 (HIP extension replaced by the oracle-backed stand-in), single- and multi-scene."""
 import os
 import socket
@@ -42,7 +43,7 @@ def _build(case):
     return m, (torch.randn(1, frames, 16, 8, 8, generator=g), torch.randn(1, scenes, 16, 32, generator=g), torch.tensor([412]))
 
 
-def _worker(rank, world, port, case, out_dir):
+def _worker(rank, world, port, case, out_dir, layout="ttt_heads"):
     for p in (ROOT, os.path.join(ROOT, "ttt-video-dit_amd")):
         sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -53,7 +54,7 @@ def _worker(rank, world, port, case, out_dir):
     cpu_ext.install()
     init_distributed("gloo")
     m, inputs = _build(case)
-    apply_tp(m, init_device_mesh("cpu", (world,), mesh_dim_names=("tp",)))
+    apply_tp(m, init_device_mesh("cpu", (world,), mesh_dim_names=("tp",)), layout=layout)
     out = m(*inputs)
     out.square().mean().backward()
     tp_sync_gradients(m)
@@ -64,9 +65,10 @@ def _worker(rank, world, port, case, out_dir):
 
 
 @pytest.mark.timeout(600)
+@pytest.mark.parametrize("layout", ["full", "ttt_heads"])
 @pytest.mark.parametrize("case", sorted(CASES))
-def test_head_sharded_tp_matches_single_process(case, tmp_path):
-    mp.spawn(_worker, args=(2, _free_port(), case, str(tmp_path)), nprocs=2, join=True)
+def test_head_sharded_tp_matches_single_process(case, layout, tmp_path):
+    mp.spawn(_worker, args=(2, _free_port(), case, str(tmp_path), layout), nprocs=2, join=True)
     from oracle import cpu_ext
     cpu_ext.install()
     try:
@@ -79,8 +81,12 @@ def test_head_sharded_tp_matches_single_process(case, tmp_path):
     rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-30))
     assert rel(got["out"], out.detach()) < 1e-5
     ref = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
-    assert set(got["grads"]) == set(ref)
-    bad = {k: rel(got["grads"][k], v) for k, v in ref.items() if not rel(got["grads"][k], v) < 2e-4}
+    # (a parameter that cannot influence the loss - the text gates of the last layer - has an all-zero gradient in the
+    # single-process graph and none in the token-sharded one, whose last layer never forms the text rows)
+    assert set(got["grads"]) <= set(ref)
+    for k in set(ref) - set(got["grads"]):
+        assert float(ref[k].abs().max()) == 0.0, k
+    bad = {k: rel(got["grads"][k], ref[k]) for k in got["grads"] if float(ref[k].norm()) > 0 and not rel(got["grads"][k], ref[k]) < 2e-4}
     assert not bad, bad
 
 

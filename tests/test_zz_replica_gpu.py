@@ -91,3 +91,80 @@ def test_replica_equals_fsdp2_on_one_gpu(tmp_path):
     r = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, env=env, timeout=580)
     print(r.stdout[-2000:], r.stderr[-2000:])
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+TP_SCRIPT = r'''
+import os, sys
+ROOT = sys.argv[1]
+for p in (ROOT, os.path.join(ROOT, "ttt-video-dit_amd")):
+    sys.path.insert(0, p)
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29673", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+import torch
+import torch.distributed as dist
+import test_time_training as ext
+from ttt_amd.infra.parallelisms import apply_tp, end_distributed, init_distributed, tp_sync_gradients
+from ttt_amd.models.cogvideo.dit import DiffusionTransformer
+from ttt_amd.models.configs import ModelConfig
+ext.load_library()
+init_distributed("nccl")
+dev = torch.device("cuda", 0)
+cfg = ModelConfig(model_dim=512, num_heads=8, num_layers=2, mini_batch_size=64, latent_height=8, latent_width=16, compressed_num_frames=5,
+                  ssm_layer="ttt_mlp", adapter_method="sft", time_embed_dim=512, text_dim=64, attn_length=2, prefix_temporal_length=1,
+                  remat_free_layers=2)
+
+def build():
+    torch.manual_seed(0)
+    m = DiffusionTransformer(cfg)
+    with torch.no_grad():
+        for _, p in m.named_parameters():
+            if p.ndim >= 2:
+                p.normal_(0, 0.02)
+    m = m.to(dev).to(torch.bfloat16)
+    for mod in m.modules():
+        if hasattr(mod, "init_freqs"):
+            mod.init_freqs()
+    return m
+
+g = torch.Generator(device=dev).manual_seed(5)
+vid = torch.randn(1, 5, 16, 16, 32, device=dev, generator=g).bfloat16()      # 5 frames x 128 tokens, 2 scenes
+text = torch.randn(1, 2, 64, 64, device=dev, generator=g).bfloat16()         # + 2 x 64 text tokens = 768 = 12 mini-batches
+ts = torch.tensor([300], device=dev)
+res = {}
+for layout in (None, "full", "ttt_heads"):
+    m = build()
+    if layout:
+        apply_tp(m, dist.group.WORLD, layout=layout)
+    out = m(vid, text, ts)
+    out.float().square().mean().backward()
+    if layout:
+        tp_sync_gradients(m)
+    torch.cuda.synchronize()
+    res[layout] = (out.detach().float(), {k: p.grad.float() for k, p in m.named_parameters() if p.grad is not None})
+rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-30))
+ref_out, ref_g = res[None]
+for layout in ("full", "ttt_heads"):
+    o, g = res[layout]
+    e_out = rel(o, ref_out)
+    errs = {k: rel(g[k], ref_g[k]) for k in g if float(ref_g[k].norm()) > 0}
+    worst = max(errs.items(), key=lambda kv: kv[1])
+    print("LAYOUT", layout, "out", e_out, "worst grad", worst)
+    assert e_out < 2e-2, (layout, e_out)
+    assert worst[1] < 8e-2, (layout, worst)
+    assert set(g) <= set(ref_g)
+end_distributed()
+'''
+
+
+@pytest.mark.timeout(600)
+def test_tensor_parallel_layouts_on_one_gpu(tmp_path):
+    """``apply_tp`` through the reference's API over a ONE-rank RCCL group on the device: the token-sharded / head-sharded code
+    path of the "full" layout (non-fused AdaLN and gates, per-head-slice attention and scans on the HIP kernels, RCCL all-gather /
+    all-to-all with one participant) and the "ttt_heads" layout against the plain bf16 HIP model - the first time these paths run
+    on hardware (no multi-GPU box is available to gpurun; world size 2 is covered over gloo, tests/test_tensor_parallel_gloo.py).
+    Different glue kernels, same arithmetic: bf16 tolerances (2e-2 / 8e-2)."""
+    script = tmp_path / "tp_one_rank.py"
+    script.write_text(TP_SCRIPT)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", TORCHDYNAMO_DISABLE="1")
+    r = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, env=env, timeout=580)
+    print(r.stdout[-2000:], r.stderr[-2000:])
+    assert r.returncode == 0, r.stderr[-3000:]

@@ -63,22 +63,58 @@ def apply_fsdp(model, dp_mesh, param_dtype=torch.bfloat16, reduce_dtype=torch.fl
     return model
 
 
-def apply_tp(model, tp_mesh):
-    """Tensor parallelism over ``tp_mesh`` (reference ``apply_tp`` :106-152, restricted to what it shards by HEAD: the TTT layer's
-    q / k / v projections, RoPE, scan and per-head parameters).  The reference's other placements (sequence-parallel norms and
-    MLP, column-parallel attention projections) exist to fit 30 - 63 s activations into 80-GB GPUs; on 288-GB MI355X they are
-    served by ``ttt_amd.infra.sequence_parallel`` (explicit collectives) when latency, not memory, asks for them.  Call
-    ``tp_sync_gradients(model)`` after backward."""
+def apply_tp(model, tp_mesh, layout: str = "full"):
+    """Tensor parallelism over ``tp_mesh`` (a 1-D ``DeviceMesh`` or a process group): ONE sample is worked on by the ranks of the
+    group, as in the reference's ``apply_tp`` (``ttt/infra/parallelisms.py``:106-152; the TP ranks of a reference job see the same
+    batch).  ``layout``:
+
+      * ``"full"`` (default) - the reference's whole plan in its MI355X form: sequence-mixing work on a rank's HEAD shard over
+        the full sequence (local-attention ``q / k / v`` projections + ``q_norm / k_norm`` + RoPE + attention: reference
+        ``ColwiseParallel`` q/k/v, ``:109-113``; the TTT layer's ``wq / wk / wv``, per-head parameters, scan and backward:
+        ``:118-120``, ``ttt_layer.py``:114-131, ``mlp_tk.py``:297-343), token-wise work on a rank's TOKEN shard (AdaLN,
+        ``o`` / ``wo`` output projections, ``post_norm``, gates, the MLP: reference ``SequenceParallel`` norms ``:116-121`` and
+        the sequence-sharded MLP, ``dit.py``:56-72,370-374; the final norm / AdaLN / projection, ``:125-127``).  Implemented by
+        ``ttt_amd.infra.sequence_parallel`` with explicit differentiable RCCL collectives instead of DTensor redistribution
+        (all-gather of the token shards in front of a sequence-mixing op, all-to-all heads -> tokens behind it);
+      * ``"ttt_heads"`` - only the TTT layer is head-sharded (round 2's form; the rest of the block runs replicated).
+
+    What is NOT mirrored, on purpose: parameters stay whole on every rank (the reference shards their storage through DTensor
+    placements to fit 80-GB GPUs; 14.5 GB of bf16 weights are no constraint on 288 GB), so every rank holds PARTIAL parameter
+    gradients - its tokens' share of the token-wise parameters, its heads' slices of the per-head ones - and
+    ``tp_sync_gradients(model)`` must be called once per optimizer step after backward; and this explicit-collective form does
+    not compose with FSDP2 (it refuses DTensor gradients): a TP group here is a group of replicas of the parameters, the
+    reference's ``tp x dp_shard`` 2-D mesh is served by FSDP-only on 8 x 288 GB.  ``reference
+    shard_transformer_inputs`` (layer-group inputs kept sharded between checkpoints, ``dit.py``:494-498) is what the "full"
+    layout does by construction: between sequence-mixing ops the activations only exist as token shards."""
+    import torch.distributed as dist
+    from ttt_amd.infra.sequence_parallel import SeqParallel
+
     dit = model.dit if hasattr(model, "dit") else model
-    for layer in dit.layers:
-        layer.seq_modeling_block.ssm.ttt.init_device_mesh(tp_mesh)
+    if layout == "ttt_heads":
+        for layer in dit.layers:
+            layer.seq_modeling_block.ssm.ttt.init_device_mesh(tp_mesh)
+    elif layout == "full":
+        group = tp_mesh if (tp_mesh is None or isinstance(tp_mesh, dist.ProcessGroup)) else tp_mesh.get_group()
+        dit.sequence_parallel = SeqParallel(group)
+    else:
+        raise ValueError(f"apply_tp: unknown layout {layout!r}")
+    dit._tp_layout = layout
     return tp_mesh
 
 
 def tp_sync_gradients(model):
+    """After backward, once per optimizer step: sum the ranks' partial parameter gradients over the TP group."""
     dit = model.dit if hasattr(model, "dit") else model
-    for layer in dit.layers:
-        layer.seq_modeling_block.ssm.ttt.tp_sync_gradients()
+    layout = getattr(dit, "_tp_layout", None)
+    if layout == "full":
+        for p in dit.parameters():
+            if p.grad is not None and type(p.grad) is not torch.Tensor:
+                raise RuntimeError("tp_sync_gradients: FSDP-sharded (DTensor) gradients - this tensor parallelism keeps whole "
+                                   "parameters per rank and does not compose with FSDP2")
+        dit.sequence_parallel.sum_gradients(dit)
+    elif layout == "ttt_heads":
+        for layer in dit.layers:
+            layer.seq_modeling_block.ssm.ttt.tp_sync_gradients()
 
 
 def enable_tuned_gemms(path: str | None = None) -> bool:
