@@ -78,10 +78,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     # debugging knobs: anything that shrinks the workload marks the result invalid
-    ap.add_argument("--tp", type=int, default=1,
+    ap.add_argument("--tp", type=int, default=0,
                     help="tensor parallelism over ALL ranks (must equal --gpus): ONE sample per step, head shards for attention and the "
                          "TTT layer, token shards for the token-wise work (apply_tp layout 'full', reference parallelisms.py:106-152); "
-                         "parameters replicated, no FSDP; the line's scaling is then 'strong'")
+                         "parameters replicated, no FSDP; the line's scaling is then 'strong'.  --tp 1 on one GPU runs the same code path over a "
+                         "one-rank group (what the layout's unfused glue costs); 0 = off")
     ap.add_argument("--remat-keep", default="attn,scan",
                     help="kernel outputs a re-materialised layer keeps instead of recomputing them (comma list of attn, scan; 'none' = "
                          "the reference's behaviour: the whole layer is recomputed) - ttt_amd/infra/remat_cache.py")
@@ -379,7 +380,7 @@ def main():
     if args.adapter == "auto":
         args.adapter = "sft" if args.video_length == "3sec" else "qkvo"      # configs/train/ttt-mlp/{3s,9s,...}.toml
     mode = "off" if args.no_fsdp else args.fsdp
-    if args.tp > 1:
+    if args.tp >= 1:
         assert args.tp == world, "--tp N shards ONE sample over all N ranks (launch with torch.distributed.run --nproc-per-node N)"
         line = _run(args, world, rank, local_rank, dev, no_fsdp=True, tp=True)
         if rank == 0 and line is not None:
@@ -447,6 +448,11 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False, tp=False):
     ext.load_library()
     ext.set_impl(args.impl)
     init_distributed("nccl")
+    # RCCL builds its communicator (and allocates ~0.5 GiB of device buffers) at the FIRST collective: do that now, while the
+    # device is empty - at 30 s the first collective used to come when the model had filled HBM and RCCL's allocation failed
+    warm = torch.zeros(1, device=dev)
+    dist.all_reduce(warm)
+    torch.cuda.synchronize()
     tuned = (not args.no_tuned_gemms) and enable_tuned_gemms()
 
     over = {}
