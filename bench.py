@@ -453,6 +453,10 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False, tp=False):
     warm = torch.zeros(1, device=dev)
     dist.all_reduce(warm)
     torch.cuda.synchronize()
+    # ... and torch's caching allocator leaves 4 % of HBM (11 GB) to everybody else - hipBLAS handles and workspaces of the
+    # autograd threads, RCCL, the HIP library's own buffers: when the 30 s sizing probe ran torch to the brim, the NEXT
+    # allocation to fail was hipblasCreate(), which is not an out-of-memory error the sizing can recover from
+    torch.cuda.set_per_process_memory_fraction(0.96, dev)
     tuned = (not args.no_tuned_gemms) and enable_tuned_gemms()
 
     over = {}
