@@ -79,9 +79,10 @@ def parse():
     ap.add_argument("--cpu-baseline-only", action="store_true")
     # debugging knobs: anything that shrinks the workload marks the result invalid
     ap.add_argument("--tp", type=int, default=0,
-                    help="tensor parallelism over ALL ranks (must equal --gpus): ONE sample per step, head shards for attention and the "
+                    help="tensor parallelism in groups of T neighbouring ranks (--gpus = dp x T): ONE sample per group and step, head shards for attention and the "
                          "TTT layer, token shards for the token-wise work (apply_tp layout 'full', reference parallelisms.py:106-152); "
-                         "parameters replicated, no FSDP; the line's scaling is then 'strong'.  --tp 1 on one GPU runs the same code path over a "
+                         "parameters, gradients and optimizer state sharded by FSDP2 over all ranks (apply_parallelisms; --fsdp off: replicas + "
+                         "a gradient all-reduce, world == T).  --tp 1 on one GPU runs the same code path over a "
                          "one-rank group (what the layout's unfused glue costs); 0 = off")
     ap.add_argument("--remat-keep", default="attn,scan",
                     help="kernel outputs a re-materialised layer keeps instead of recomputing them (comma list of attn, scan; 'none' = "
@@ -296,7 +297,7 @@ def size_warm_and_time(step, hk, remat_free_layers, warmup, steps, world):
         n_free = int(remat_free_layers)
     # warm-up with the chosen setting; if the caching allocator's fragmentation pushes it over the edge, back off and retry
     # (still untimed).  With an explicit --remat-free-layers N an out-of-memory error is fatal, as it should be.
-    refinements, fail_at = 0, None      # settings at or above `fail_at` ran out of memory in a warm-up: never tried again
+    refinements, fail_at, thrash_rounds = 0, None, 0      # settings at or above `fail_at` ran out of memory in a warm-up: never tried again
 
     def back_off():
         hk.release()
@@ -342,6 +343,7 @@ def size_warm_and_time(step, hk, remat_free_layers, warmup, steps, world):
         hk.barrier()
         hk.synchronize()
         hk.before_timed(n_free)
+        retries0 = hk.alloc_retries()
         try:
             t0 = time.perf_counter()
             for _ in range(steps):
@@ -358,6 +360,19 @@ def size_warm_and_time(step, hk, remat_free_layers, warmup, steps, world):
         hk.barrier()
         dt = time.perf_counter() - t0
         hk.after_timed()
+        # The caching allocator ran dry inside the timed region and recovered by freeing its cache and allocating again
+        # (device-synchronising hipFree / hipMalloc between kernels: call Q measured a 3 s step at 6.6 s that way, with the
+        # reserved memory at the allocator's cap): that region measures the allocator, not the step.  Automatic setting: every
+        # rank agrees (MIN all-reduce, walked by all ranks whether or not they saw retries), backs off and times again.
+        thrash = 1 if hk.alloc_retries() > retries0 else 0
+        if world > 1:
+            thrash = 1 - hk.all_reduce_min(1 - thrash)
+        if thrash and auto and n_free > 0 and thrash_rounds < 3:
+            thrash_rounds += 1
+            log(f"allocator retries inside the timed region at remat_free_layers={n_free}: backing off, timing again")
+            fail_at = n_free if fail_at is None else min(fail_at, n_free)
+            n_free = back_off()
+            continue
         return n_free, dt, loss
 
 
@@ -381,8 +396,8 @@ def main():
         args.adapter = "sft" if args.video_length == "3sec" else "qkvo"      # configs/train/ttt-mlp/{3s,9s,...}.toml
     mode = "off" if args.no_fsdp else args.fsdp
     if args.tp >= 1:
-        assert args.tp == world, "--tp N shards ONE sample over all N ranks (launch with torch.distributed.run --nproc-per-node N)"
-        line = _run(args, world, rank, local_rank, dev, no_fsdp=True, tp=True)
+        assert world % args.tp == 0, "--tp T: the ranks form world / T groups of T neighbours, each group works on ONE sample"
+        line = _run(args, world, rank, local_rank, dev, no_fsdp=(mode == "off"), tp=args.tp)
         if rank == 0 and line is not None:
             print(json.dumps(line), flush=True)
         dist.barrier(device_ids=[local_rank])
@@ -471,24 +486,30 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False, tp=False):
     L = frames * TOKENS_PER_FRAME + scenes * text_len
     assert L % cfg.mini_batch_size == 0
 
+    tp = int(tp)                                          # 0: off; T: TP groups of T neighbouring ranks, world = dp x T
+    dp, dp_rank = (world // tp, rank // tp) if tp else (world, rank)       # (the ranks of a TP group are ONE data-parallel rank)
     with torch.device("meta"):
-        model = CogVideoX(cfg, effective_rank=0 if tp else rank, effective_world_size=1 if tp else world)   # (a TP group is ONE data-parallel rank)
-    if not no_fsdp:
+        model = CogVideoX(cfg, effective_rank=dp_rank, effective_world_size=dp)
+    if tp and no_fsdp:                                    # replicas of the parameters, partial gradients summed by an all-reduce
+        from ttt_amd.infra.parallelisms import apply_tp, tp_sync_gradients
+        assert tp == world, "--tp T --fsdp off: one TP group of replicas (world == T)"
+        apply_tp(model, dist.group.WORLD, layout="full")
+    elif tp:                                              # FSDP2 over all dp x T ranks; its reduce-scatter sums the TP partials
+        from ttt_amd.infra.parallelisms import apply_parallelisms
+        apply_parallelisms(model, tp_sharding=tp, reshard_after_forward=args.reshard_after_forward, tp_layout_on_one_rank=True)   # reference parallelisms.py:92-104
+    elif not no_fsdp:
         apply_fsdp(model, get_dp_mesh(), reshard_after_forward=args.reshard_after_forward)   # reference parallelisms.py:155-175
     model.to_empty(device=dev)
     torch.manual_seed(1234)                                # same init on every rank, then sharded
     with torch.no_grad():
         init_model_parameters(model)
         model.init_ssm_weights()
-    model.setup_generator(seed=0 if tp else rank, device=dev)       # (a TP group works on ONE sample: same draws on every rank)
-    if tp:
-        from ttt_amd.infra.parallelisms import apply_tp, tp_sync_gradients
-        apply_tp(model, dist.group.WORLD, layout="full")
+    model.setup_generator(seed=dp_rank, device=dev)        # (a TP group works on ONE sample: same draws on its ranks)
     replica = ReplicaMixedPrecision(model.dit) if no_fsdp else None
     train_params = replica.master_parameters() if replica else [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.AdamW(train_params, lr=1e-5, weight_decay=1e-4, fused=True)
 
-    g = torch.Generator(device=dev).manual_seed(100 + (0 if tp else rank))
+    g = torch.Generator(device=dev).manual_seed(100 + dp_rank)
     LB = args.local_batch
     vid = torch.randn(LB, frames, 16, 60, 90, device=dev, generator=g)
     text = torch.randn(LB, scenes, text_len, cfg.text_dim, device=dev, generator=g)
@@ -500,7 +521,7 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False, tp=False):
         opt.zero_grad(set_to_none=True)
         loss = model(vid, text).mean()
         loss.backward()
-        if tp:
+        if tp and no_fsdp:
             tp_sync_gradients(model)                # partial parameter gradients (a rank's tokens / heads) summed over the group
         if replica:
             replica.collect_grads()                 # bf16 gradients -> fp32 gradients of the masters (what FSDP's reduce does)
@@ -553,6 +574,10 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False, tp=False):
             return True
 
         @staticmethod
+        def alloc_retries():
+            return int(torch.cuda.memory_stats(dev).get("num_alloc_retries", 0))
+
+        @staticmethod
         def all_reduce_min(v):
             t = torch.tensor([v], device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
@@ -600,7 +625,7 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False, tp=False):
 
     if rank == 0:
         ms_per_step = 1e3 * dt / args.steps
-        video_tokens = (1 if tp else world) * LB * frames * TOKENS_PER_FRAME
+        video_tokens = dp * LB * frames * TOKENS_PER_FRAME
         value = video_tokens / (dt / args.steps)
         ks = timer.summary()
         # ---- roofline of the dominant hand-written kernel ---------------------------------
@@ -654,13 +679,13 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False, tp=False):
                     "attention_share_of_step": sum(v["total_ms"] for k, v in ks.items() if k.startswith("attn")) / (1e3 * dt)}
         line = {"metric": "DiT+TTT fwd/bwd video-tokens/sec", "value": value, "unit": "video-tokens/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-                "scaling": "strong" if tp else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                "scaling": "strong" if (tp and dp == 1 and world > 1) else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                 "config": {"workload": f"CogVideoX-5B+{args.ssm_layer} {args.video_length} training step (fwd+bwd+AdamW), "
                                        f"{cfg.num_layers} layers, L={L} tokens/sample, adapter={args.adapter}",
-                           "global_batch": (1 if tp else world) * LB, "seq_len": L, "parallelism": f"tp{world}" if tp else ("replica1" if no_fsdp else f"fsdp{world}"), "ttt_impl": args.impl,
+                           "global_batch": dp * LB, "seq_len": L, "parallelism": (f"tp{tp}" if no_fsdp else f"fsdp{world}(dp{dp}xtp{tp})") if tp else ("replica1" if no_fsdp else f"fsdp{world}"), "ttt_impl": args.impl,
                            "remat_free_layers": n_free, "remat_keep": list(dit.remat_keep), "fsdp_reshard_after_forward": bool(args.reshard_after_forward), "tuned_gemm_selections": bool(tuned),
                            "sweep_error": sweep_err, "valid": args.layers is None and sweep_err == 0},
-                "roofline": roof, "loss": loss_val, "peak_mem_gib": peak_mem, "peak_reserved_gib": torch.cuda.max_memory_reserved() / 2 ** 30, "total_tokens_per_s": (1 if tp else world) * L / (dt / args.steps)}
+                "roofline": roof, "loss": loss_val, "peak_mem_gib": peak_mem, "peak_reserved_gib": torch.cuda.max_memory_reserved() / 2 ** 30, "alloc_retries_total": Hooks.alloc_retries(), "total_tokens_per_s": dp * L / (dt / args.steps)}
         return line
     return None
 

@@ -26,8 +26,9 @@ class FakeDevice:
     num_layers = 42
     probe_layers = 1
 
-    def __init__(self, world, total, base, per_layer, warm_oom_at=None, timed_oom_at=None):
+    def __init__(self, world, total, base, per_layer, warm_oom_at=None, timed_oom_at=None, thrash_above=None):
         self.world, self.total_memory, self.base, self.per_layer = world, total, base, per_layer
+        self.thrash_above, self.retries = thrash_above, 0       # timed steps with more free layers make the allocator retry
         self.warm_oom_at, self.timed_oom_at = warm_oom_at, timed_oom_at      # n_free values at which the allocator "fragments"
         self.n_free, self.peak, self.in_timed, self.log = 0, 0, False, []
         self.timed_regions = 0
@@ -42,8 +43,11 @@ class FakeDevice:
             self.timed_oom_at = None
             raise FakeOOM("fragmentation in the timed region")
         self.peak = max(self.peak, need)
+        if self.in_timed and self.thrash_above is not None and self.n_free > self.thrash_above:
+            self.retries += 1
         return torch.tensor(1.0)
 
+    def alloc_retries(self): return self.retries
     def reduce_keep(self): return False
     def set_free_layers(self, n): self.n_free = n
     def reset_peak(self): self.peak = 0
@@ -123,6 +127,17 @@ def test_single_rank_backs_off_and_times_again():
     hk = FakeDevice(1, 288 * GB, 60 * GB, 5 * GB, timed_oom_at=10)
     with pytest.raises(FakeOOM):
         bench.size_warm_and_time(hk.step, hk, "10", 1, 3, 1)
+
+
+def test_allocator_retries_inside_the_timed_region_cost_layers_not_the_measurement():
+    import bench
+    GB = 1 << 30
+    hk = FakeDevice(1, 288 * GB, 60 * GB, 5 * GB, thrash_above=33)      # fits 38 by the arithmetic, thrashes above 33
+    n, dt, loss = bench.size_warm_and_time(hk.step, hk, "auto", 1, 2, 1)
+    assert n <= 33 and hk.timed_regions >= 2
+    hk = FakeDevice(1, 288 * GB, 60 * GB, 5 * GB, thrash_above=33)      # an explicit setting is measured as it is
+    n, dt, loss = bench.size_warm_and_time(hk.step, hk, "36", 1, 2, 1)
+    assert n == 36 and hk.timed_regions == 1
 
 
 def test_keeping_policy_is_reduced_when_even_full_rematerialisation_does_not_fit():

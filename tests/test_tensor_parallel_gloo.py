@@ -104,3 +104,82 @@ def test_init_device_mesh_rejects_indivisible_heads():
         assert m.ttt.tp_mesh is not None
     finally:
         dist.destroy_process_group()
+
+
+def _inputs_for(dp_rank, case):
+    """sample of data-parallel rank ``dp_rank`` (the ranks of a TP group share it)"""
+    _, nh, frames, scenes, _ = CASES[case]
+    g = torch.Generator().manual_seed(100 + dp_rank)
+    return torch.randn(1, frames, 16, 8, 8, generator=g), torch.randn(1, scenes, 16, 32, generator=g), torch.tensor([412 + 97 * dp_rank])
+
+
+def _worker_2d(rank, world, port, case, out_dir, tp):
+    for p in (ROOT, os.path.join(ROOT, "ttt-video-dit_amd")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    from oracle import cpu_ext
+    from ttt_amd.infra.parallelisms import apply_parallelisms, end_distributed, init_distributed, tp_sync_gradients
+    cpu_ext.install()
+    init_distributed("gloo")
+    m, _ = _build(case)
+    m.remat_free_layers, m.remat_keep = 1, ("attn", "scan")     # layer 1 re-materialised (its collectives run again in backward)
+    mesh, dp_rank, dp = apply_parallelisms(m, tp_sharding=tp, param_dtype=torch.float32, reshard_after_forward=False)
+    assert (dp_rank, dp) == (rank // tp, world // tp) and mesh["tp"].size() == tp
+    params = [p for p in m.parameters() if p.requires_grad]
+    opt = torch.optim.SGD(params, lr=0.05)
+    losses = []
+    for _ in range(2):                       # second step: the sharded update of step one went into the next all-gather
+        opt.zero_grad(set_to_none=True)
+        loss = m(*_inputs_for(dp_rank, case)).square().mean()
+        loss.backward()
+        tp_sync_gradients(m)                 # (no-op here: the reduce-scatter did it)
+        grads = {k: p.grad.full_tensor().clone() for k, p in m.named_parameters() if p.grad is not None}
+        opt.step()
+        losses.append(float(loss))
+    final = {k: p.full_tensor().detach().clone() for k, p in m.named_parameters()}
+    if rank == world - 1:
+        torch.save({"grads": grads, "final": final}, os.path.join(out_dir, "tp2d.pt"))
+    torch.save(losses, os.path.join(out_dir, f"loss{rank}.pt"))
+    end_distributed()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world,tp", [(2, 2), (4, 2)])
+def test_tp_times_fsdp_step_matches_data_parallel_reference(world, tp, tmp_path):
+    """``apply_parallelisms`` (reference ``parallelisms.py``:92-104): "full" TP layout inside groups of ``tp`` ranks, FSDP2 over
+    ALL ranks with the divide factor ``dp`` - two SGD steps against a single-process statement of data parallelism over the
+    ``dp`` samples (gradient = mean over the samples).  fp32 policy: the comparison is about the plan, not about bf16."""
+    case = "mlp_dual_3scene"
+    mp.spawn(_worker_2d, args=(world, _free_port(), case, str(tmp_path), tp), nprocs=world, join=True)
+    dp = world // tp
+    from oracle import cpu_ext
+    cpu_ext.install()
+    try:
+        m, _ = _build(case)
+        opt = torch.optim.SGD(m.parameters(), lr=0.05)
+        ref_losses = []
+        for _ in range(2):
+            opt.zero_grad(set_to_none=True)
+            ls = []
+            for r in range(dp):
+                loss = m(*_inputs_for(r, case)).square().mean()
+                (loss / dp).backward()
+                ls.append(float(loss.detach()))
+            ref_g = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+            opt.step()
+            ref_losses.append(ls)
+    finally:
+        cpu_ext.uninstall()
+    got = torch.load(os.path.join(tmp_path, "tp2d.pt"))
+    rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-30))
+    for rank in range(world):               # every rank of a TP group reports its group's sample loss, both steps
+        ls = torch.load(os.path.join(tmp_path, f"loss{rank}.pt"))
+        for step in range(2):
+            assert abs(ls[step] - ref_losses[step][rank // tp]) <= 2e-5 * abs(ref_losses[step][rank // tp]), (rank, step, ls, ref_losses)
+    bad = {k: rel(got["grads"][k], ref_g[k]) for k in got["grads"] if k in ref_g and float(ref_g[k].norm()) > 0
+           and not rel(got["grads"][k], ref_g[k]) < 5e-4}
+    assert not bad, bad
+    ref_final = dict(m.named_parameters())
+    badp = {k: rel(v, ref_final[k].detach()) for k, v in got["final"].items() if not rel(v, ref_final[k].detach()) < 1e-4}
+    assert not badp, badp

@@ -81,9 +81,8 @@ def apply_tp(model, tp_mesh, layout: str = "full"):
     What is NOT mirrored, on purpose: parameters stay whole on every rank (the reference shards their storage through DTensor
     placements to fit 80-GB GPUs; 14.5 GB of bf16 weights are no constraint on 288 GB), so every rank holds PARTIAL parameter
     gradients - its tokens' share of the token-wise parameters, its heads' slices of the per-head ones - and
-    ``tp_sync_gradients(model)`` must be called once per optimizer step after backward; and this explicit-collective form does
-    not compose with FSDP2 (it refuses DTensor gradients): a TP group here is a group of replicas of the parameters, the
-    reference's ``tp x dp_shard`` 2-D mesh is served by FSDP-only on 8 x 288 GB.  ``reference
+    ``tp_sync_gradients(model)`` must be called once per optimizer step after backward - unless FSDP2 shards the parameters over
+    ALL ranks, TP groups included (``apply_parallelisms``: its reduce-scatter then sums the partial gradients).  ``reference
     shard_transformer_inputs`` (layer-group inputs kept sharded between checkpoints, ``dit.py``:494-498) is what the "full"
     layout does by construction: between sequence-mixing ops the activations only exist as token shards."""
     import torch.distributed as dist
@@ -102,9 +101,60 @@ def apply_tp(model, tp_mesh, layout: str = "full"):
     return tp_mesh
 
 
-def tp_sync_gradients(model):
-    """After backward, once per optimizer step: sum the ranks' partial parameter gradients over the TP group."""
+def get_world_mesh(tp_sharding: int = 1, dp_sharding: int | None = None, dp_replicate: int = 1):
+    """The job's device mesh in the reference's order ``(dp_replicate, dp_shard, tp)`` with the TP ranks innermost = neighbours
+    on the node (reference ``get_world_mesh``, ``parallelisms.py``:54-89; a dimension of size 1 is kept here, so that
+    ``mesh["tp"]`` / ``mesh["dp_shard"]`` always exist)."""
+    world = dist.get_world_size()
+    dp_sharding = dp_sharding or world // (tp_sharding * dp_replicate)
+    assert tp_sharding * dp_sharding * dp_replicate == world, \
+        "world size must be equal to the product of tp_sharding, dp_sharding, and dp_replicate"
+    dev = "cuda" if torch.cuda.is_available() else "cpu"
+    return init_device_mesh(dev, (dp_replicate, dp_sharding, tp_sharding), mesh_dim_names=("dp_replicate", "dp_shard", "tp"))
+
+
+def apply_parallelisms(model, tp_sharding: int = 1, param_dtype=torch.bfloat16, reduce_dtype=torch.float32,
+                       reshard_after_forward: bool = True, tp_layout_on_one_rank: bool = False):
+    """TP x FSDP in one call, the counterpart of the reference's ``apply_parallelisms`` (``parallelisms.py``:92-104: ``apply_tp``
+    on ``world_mesh["tp"]``, then ``apply_fsdp`` on the data-parallel dimensions).  Returns ``(world_mesh, dp_rank, dp_size)``;
+    the ranks of one TP group must be fed the SAME sample (``dp_rank`` is what seeds / shards the data).
+
+    The MI355X form of the 2-D plan: the "full" TP layout splits ACTIVATIONS (head shards / token shards) and leaves every rank
+    with partial gradients of whole parameters; FSDP2 then shards parameters, gradients and optimizer state over ALL
+    ``dp x tp`` ranks (the reference shards them over ``dp_shard`` only and adds DTensor TP placements on top, ``:106-175``).
+    One reduce-scatter per layer does both jobs at once - it sums the partial gradients of a TP group and averages over the
+    data-parallel groups: FSDP2's mean over ``W = dp x tp`` ranks is ``1 / tp`` of that, so the divide factor is set to ``dp``
+    (``set_gradient_divide_factor``).  ``tp_sync_gradients`` becomes a no-op.  Per rank: ``1 / W`` of the fp32 masters and AdamW
+    state instead of ``1 / dp``, no second gradient collective, no DTensor redistribution inside the layer."""
+    from torch.distributed.fsdp import FSDPModule
+
+    mesh = get_world_mesh(tp_sharding)
+    world = dist.get_world_size()
+    dp = world // tp_sharding
     dit = model.dit if hasattr(model, "dit") else model
+    use_tp = tp_sharding > 1 or tp_layout_on_one_rank      # (one-rank groups: the layout's code path, for measurements)
+    if use_tp:
+        apply_tp(model, mesh["tp"], layout="full")
+    dev = "cuda" if torch.cuda.is_available() else "cpu"
+    apply_fsdp(model, init_device_mesh(dev, (world,), mesh_dim_names=("dp_shard_tp",)), param_dtype=param_dtype,
+               reduce_dtype=reduce_dtype, reshard_after_forward=reshard_after_forward)
+    if use_tp:
+        for mod in dit.modules():
+            if isinstance(mod, FSDPModule):
+                mod.set_gradient_divide_factor(float(dp))
+                # plain SUM reduce-scatter + a division of the rank's shard (not the PreMulSum reduce op, which gloo does not
+                # have and RCCL has never been asked for here)
+                mod.set_force_sum_reduction_for_comms(True)
+        dit._tp_grads_by_fsdp = True
+    return mesh, dist.get_rank() // tp_sharding, dp
+
+
+def tp_sync_gradients(model):
+    """After backward, once per optimizer step: sum the ranks' partial parameter gradients over the TP group (nothing to do
+    under ``apply_parallelisms``: FSDP2's reduce-scatter over all ``dp x tp`` ranks has summed them)."""
+    dit = model.dit if hasattr(model, "dit") else model
+    if getattr(dit, "_tp_grads_by_fsdp", False):
+        return
     layout = getattr(dit, "_tp_layout", None)
     if layout == "full":
         for p in dit.parameters():

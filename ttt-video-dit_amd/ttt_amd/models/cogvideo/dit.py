@@ -384,7 +384,9 @@ class TransformerLayer(nn.Module):
         text_emb = text_emb + g_t.unsqueeze(1) * self.mlp(modulate(self.pre_mlp_layernorm(text_emb), sh_t, sc_t))
         return vid_emb, text_emb
 
-    def forward(self, vid_emb, text_emb, seq_metadata: SequenceMetadata):
+    def forward(self, vid_emb, text_emb, seq_metadata: SequenceMetadata, sp=None):
+        if sp is not None:       # token shards of one sample (through __call__: FSDP2's unshard / reshard hooks must run)
+            return self.forward_sp(vid_emb, text_emb, seq_metadata, sp)
         if self.use_fused_glue and fused_available(vid_emb, 64) and vid_emb.shape[-1] % 8 == 0 and vid_emb.shape[-1] <= 4096:
             return self._forward_fused(vid_emb, text_emb, seq_metadata)
         n_text = seq_metadata.seq_text_length
@@ -451,9 +453,9 @@ class DiffusionTransformer(nn.Module):
         self.final_layer = FinalLayer(config)
         self.sequence_parallel = None      # a ttt_amd.infra.sequence_parallel.SeqParallel: one sample over the ranks of its group
 
-    def _run_group(self, start, vid_emb, text_emb, seq_metadata):
+    def _run_group(self, start, vid_emb, text_emb, seq_metadata, sp=None):
         for layer in self.layers[start:start + self.remat_transformer_layer_group_size]:
-            vid_emb, text_emb = layer(vid_emb, text_emb, seq_metadata)
+            vid_emb, text_emb = layer(vid_emb, text_emb, seq_metadata, sp)
         return vid_emb, text_emb
 
     def forward(self, video, text, timesteps):
@@ -467,12 +469,20 @@ class DiffusionTransformer(nn.Module):
         if meta.is_multiscene:
             meta.init_multiscene_offsets()
         text_emb = text_emb.flatten(1, 2)
-        if self.sequence_parallel is not None:        # every rank got the same inputs; each keeps 1/T of the tokens
-            sp = self.sequence_parallel
-            n_vid = vid_emb.shape[1]
+        sp = self.sequence_parallel
+        if sp is not None:        # every rank got the same inputs; each keeps 1/T of the tokens: what a layer group's checkpoint
+            n_vid = vid_emb.shape[1]     # saves is a token shard (reference shard_transformer_inputs, dit.py:494-498)
             vid_emb, text_emb = sp.shard_tokens(vid_emb), sp.shard_tokens(text_emb)
-            for layer in self.layers:
-                vid_emb, text_emb = layer.forward_sp(vid_emb, text_emb, meta, sp)
+        for i in range(0, len(self.layers), self.remat_transformer_layer_group_size):
+            if torch.is_grad_enabled() and i >= self.remat_free_layers:
+                if self.remat_keep:
+                    vid_emb, text_emb = checkpoint(self._run_group, i, vid_emb, text_emb, meta, sp, use_reentrant=False,
+                                                   context_fn=remat_cache.context_fn(self.remat_keep))
+                else:
+                    vid_emb, text_emb = checkpoint(self._run_group, i, vid_emb, text_emb, meta, sp, use_reentrant=False)
+            else:
+                vid_emb, text_emb = self._run_group(i, vid_emb, text_emb, meta, sp)
+        if sp is not None:
             # final norm / AdaLN / projection are token-wise too; only the unpatchify reshape needs the whole sequence.  Every
             # rank then evaluates the same loss on the gathered output, hence replicated_consumer.
             fl = self.final_layer
@@ -480,13 +490,4 @@ class DiffusionTransformer(nn.Module):
             y = fl.linear(modulate(fl.norm(self.transformer_norm(vid_emb)), shift, scale))
             y = sp.gather_tokens(y, n_vid, replicated_consumer=True)
             return unpatchify(y, c=fl.out_channels, p=fl.patch_size, w=width // fl.patch_size, h=height // fl.patch_size)
-        for i in range(0, len(self.layers), self.remat_transformer_layer_group_size):
-            if torch.is_grad_enabled() and i >= self.remat_free_layers:
-                if self.remat_keep:
-                    vid_emb, text_emb = checkpoint(self._run_group, i, vid_emb, text_emb, meta, use_reentrant=False,
-                                                   context_fn=remat_cache.context_fn(self.remat_keep))
-                else:
-                    vid_emb, text_emb = checkpoint(self._run_group, i, vid_emb, text_emb, meta, use_reentrant=False)
-            else:
-                vid_emb, text_emb = self._run_group(i, vid_emb, text_emb, meta)
         return self.final_layer(self.transformer_norm(vid_emb), meta)
