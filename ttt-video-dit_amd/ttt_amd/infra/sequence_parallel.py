@@ -58,8 +58,9 @@ class SeqParallel:
 
     # ---- collectives (raw) -----------------------------------------------------------------------------------------------
     def _all_gather(self, x_loc: torch.Tensor) -> torch.Tensor:          # [B, n, D] -> [B, T*n, D]
+        x_loc = x_loc.contiguous()
         parts = [torch.empty_like(x_loc) for _ in range(self.size)]
-        dist.all_gather(parts, x_loc.contiguous(), group=self.group)
+        dist.all_gather(parts, x_loc, group=self.group)
         return torch.cat(parts, dim=1)
 
     def _reduce_scatter(self, g: torch.Tensor) -> torch.Tensor:          # [B, T*n, D] (differs per rank) -> sum, my [B, n, D]

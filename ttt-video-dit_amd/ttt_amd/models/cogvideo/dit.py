@@ -374,6 +374,16 @@ class TransformerLayer(nn.Module):
     def forward_sp(self, vid_emb, text_emb, seq_metadata: SequenceMetadata, sp):
         """``forward`` on token shards (sequence parallelism): AdaLN, residual gates and the MLP are token-wise."""
         t = seq_metadata.t_emb
+        if self.use_fused_glue and fused_available(vid_emb, 64) and vid_emb.shape[-1] % 8 == 0 and vid_emb.shape[-1] <= 4096:
+            # the HIP glue kernels of the fused path on this rank's [text shard | video shard] (token-wise: any row counts)
+            ln1, ln2, nt = self.pre_seq_layernorm, self.pre_mlp_layernorm, text_emb.shape[1]
+            sh_v, sc_v, g_v, sh_t, sc_t, g_t = self.pre_seq_adaLN_modulation(t).chunk(6, dim=1)
+            x = FusedAdaLN.apply(vid_emb, text_emb, ln1.weight, ln1.bias, sh_v, sc_v, sh_t, sc_t, ln1.eps)
+            v_out, t_out = self.seq_modeling_block.forward_sp(x[:, nt:], x[:, :nt], seq_metadata, sp)
+            vid_emb, text_emb = FusedResGate.apply(vid_emb, text_emb, torch.cat((t_out, v_out), dim=1), g_v, g_t)
+            sh_v, sc_v, g_v, sh_t, sc_t, g_t = self.pre_mlp_adaLN_modulation(t).chunk(6, dim=1)
+            x = FusedAdaLN.apply(vid_emb, text_emb, ln2.weight, ln2.bias, sh_v, sc_v, sh_t, sc_t, ln2.eps)
+            return FusedResGate.apply(vid_emb, text_emb, self.mlp(x), g_v, g_t)
         sh_v, sc_v, g_v, sh_t, sc_t, g_t = self.pre_seq_adaLN_modulation(t).chunk(6, dim=1)
         v_out, t_out = self.seq_modeling_block.forward_sp(modulate(self.pre_seq_layernorm(vid_emb), sh_v, sc_v),
                                                           modulate(self.pre_seq_layernorm(text_emb), sh_t, sc_t), seq_metadata, sp)
