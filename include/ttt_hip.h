@@ -264,6 +264,10 @@ int         ttt_hip_debug_option(const char* name, int value);
  * device and returns the word (0 = no hand-over has given up). */
 unsigned    ttt_hip_debug_sweep_error(void);
 void        ttt_hip_sweep_error_clear(void);
+/* DEBUG (stress tests of the cluster hand-over): enqueue on `stream` a kernel of `workgroups` workgroups that each hold
+ * `lds_bytes` of LDS (<= 160 KiB: a CU that hosts one cannot host a sweep workgroup) and do nothing for `microseconds`
+ * (<= 100 000) of wall-clock time - what a collective's kernels do to the CUs a cluster launch counts on.  Returns 0 / -1. */
+int         ttt_hip_debug_occupy_cus(int workgroups, int lds_bytes, int microseconds, void* stream);
 void        ttt_hip_debug_dump(float* device_buffer);
 
 int         ttt_hip_abi_version(void);

@@ -248,6 +248,32 @@ def test_backward_is_run_to_run_deterministic_at_the_benchmarked_head_count(over
     assert e.sweep_error() == 0
 
 
+# ---------------------------------------------------------------------------------- 3c. CUs stolen under the cluster launch
+@pytest.mark.parametrize("stolen", [96, 160])
+def test_backward_survives_stolen_cus_with_the_same_bits(stolen):
+    """What a collective's kernels do to a cluster launch at N > 1 (reduce-scatter of the previous layer beside this layer's
+    backward): another stream holds `stolen` CUs - a kernel whose workgroups keep 150 KiB of LDS each, so no sweep workgroup
+    (157 KiB) fits beside one - for 30 ms, launched ahead of a 48-head backward (192 sweep workgroups, 160 / 96 CUs free).  The
+    clusters whose fourth workgroup cannot be placed wait in their bounded polls (seconds) until the CUs come back: no
+    hand-over gives up, and the gradients are bit-identical to the undisturbed call."""
+    e = ext()
+    d = round_acts(O.make_inputs("mlp", 1, 48, 96, 64, 64, seed=997), torch.bfloat16)
+    out0, _, ref = run_mlp(e, d, 16, torch.bfloat16, impl="mfma")
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    t0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for rep in range(2):
+        t0[0].record()
+        e.debug_occupy_cus(stolen, 150 * 1024, 30000, stream=side)
+        out, _, g = run_mlp(e, d, 16, torch.bfloat16, impl="mfma")
+        t0[1].record()
+        torch.cuda.synchronize()
+        assert e.sweep_error() == 0
+        bad = [k for k, v in g.items() if not torch.equal(v, ref[k])]
+        assert not bad and torch.equal(out, out0), (rep, bad)
+    print(f"stolen={stolen}: disturbed call {t0[0].elapsed_time(t0[1]):.1f} ms")
+
+
 # ---------------------------------------------------------------------------------- 4. hand-over failure is loud
 def test_handover_timeout_poisons_outputs_and_raises():
     """A cluster workgroup whose partners never arrive (forced: the debug option makes workgroup 3 of every cluster leave before

@@ -64,6 +64,20 @@ int ttt_hip_debug_option(const char* name, int value) {
     return 0;
 }
 unsigned ttt_hip_debug_sweep_error(void) { return ttt::mfma::read_sweep_error(); }
+
+// DEBUG: a kernel that holds CUs (through its LDS allocation) for a bounded wall-clock time and does nothing
+__global__ __launch_bounds__(64) void occupy_cus_kernel(unsigned long long ticks) {
+    extern __shared__ __attribute__((aligned(16))) char occ_lds[];
+    occ_lds[threadIdx.x] = 0;
+    const unsigned long long t0 = wall_clock64();                 // constant 100 MHz counter
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+int ttt_hip_debug_occupy_cus(int workgroups, int lds_bytes, int microseconds, void* stream) {
+    if (workgroups < 1 || workgroups > 1024 || lds_bytes < 64 || lds_bytes > 160 * 1024 || microseconds < 0 || microseconds > 100000) return -1;
+    if (hipFuncSetAttribute((const void*)occupy_cus_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) return -1;
+    hipLaunchKernelGGL(occupy_cus_kernel, dim3(workgroups), dim3(64), lds_bytes, (hipStream_t)stream, 100ull * (unsigned long long)microseconds);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 void ttt_hip_sweep_error_clear(void) { ttt::mfma::clear_sweep_error(); }
 
 // A hand-over of the TTT-MLP backward that gave up has poisoned that call's gradients (NaN); it is also STICKY: every later

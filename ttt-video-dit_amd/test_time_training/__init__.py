@@ -67,7 +67,7 @@ EXPORTED_SYMBOLS = (
     "ttt_hip_mlp_forward_workspace", "ttt_hip_mlp_backward_workspace", "ttt_hip_linear_forward_workspace",
     "ttt_hip_linear_backward_workspace", "ttt_hip_mlp_forward", "ttt_hip_mlp_backward", "ttt_hip_linear_forward",
     "ttt_hip_linear_backward", "ttt_hip_resolve_impl", "ttt_hip_abi_version", "ttt_hip_last_error",
-    "ttt_hip_debug_timing", "ttt_hip_debug_groups_per_chunk", "ttt_hip_debug_dump", "ttt_hip_debug_option", "ttt_hip_debug_sweep_error", "ttt_hip_sweep_error_clear",
+    "ttt_hip_debug_timing", "ttt_hip_debug_groups_per_chunk", "ttt_hip_debug_dump", "ttt_hip_debug_option", "ttt_hip_debug_sweep_error", "ttt_hip_sweep_error_clear", "ttt_hip_debug_occupy_cus",
     "ttt_hip_pre_forward", "ttt_hip_pre_backward_partials", "ttt_hip_pre_backward", "ttt_hip_post_partials",
     "ttt_hip_post_forward", "ttt_hip_post_backward", "ttt_hip_gate_forward", "ttt_hip_gate_backward_partials",
     "ttt_hip_gate_backward", "ttt_hip_attn_forward", "ttt_hip_attn_backward",
@@ -136,6 +136,15 @@ def sweep_error() -> int:
     lib = load_library()
     lib.ttt_hip_debug_sweep_error.restype = ctypes.c_uint
     return int(lib.ttt_hip_debug_sweep_error())
+
+
+def debug_occupy_cus(workgroups: int, lds_bytes: int, microseconds: int, stream=None) -> None:
+    """DEBUG (stress tests): hold ``workgroups`` CUs' worth of LDS for ``microseconds`` on ``stream`` (default: the current one)."""
+    lib = load_library()
+    st = (stream or torch.cuda.current_stream()).cuda_stream
+    lib.ttt_hip_debug_occupy_cus.restype = ctypes.c_int
+    if lib.ttt_hip_debug_occupy_cus(int(workgroups), int(lds_bytes), int(microseconds), ctypes.c_void_p(st)) != 0:
+        raise RuntimeError("ttt_hip_debug_occupy_cus: bad arguments or launch failure")
 
 
 def sweep_error_clear() -> None:
