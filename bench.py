@@ -85,7 +85,7 @@ def parse():
                          "a gradient all-reduce, world == T).  --tp 1 on one GPU runs the same code path over a "
                          "one-rank group (what the layout's unfused glue costs); 0 = off")
     ap.add_argument("--remat-keep", default="attn,scan",
-                    help="kernel outputs a re-materialised layer keeps instead of recomputing them (comma list of attn, scan; 'none' = "
+                    help="outputs a re-materialised layer keeps instead of recomputing them (comma list of attn, scan, fc2; 'none' = "
                          "the reference's behaviour: the whole layer is recomputed) - ttt_amd/infra/remat_cache.py")
     ap.add_argument("--remat-free-layers", default="auto",
                     help="transformer layers that keep their activations instead of being re-materialised in backward: "
@@ -566,10 +566,11 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False, tp=False):
 
         @staticmethod
         def reduce_keep():
-            """drop the most expensive kind of kept kernel outputs ("scan" 1.3 GB per layer at 9 s, then "attn" 0.34 GB)"""
+            """drop the most expensive kind of kept outputs ("scan" 1.3 GB per layer at 9 s, then "fc2" 0.32 GB, then "attn" 0.34 GB)"""
             if not dit.remat_keep:
                 return False
-            dit.remat_keep = tuple(dit.remat_keep)[:-1] if "scan" not in dit.remat_keep else tuple(k for k in dit.remat_keep if k != "scan")
+            drop = next(k for k in ("scan", "fc2", "attn") if k in dit.remat_keep) if set(dit.remat_keep) & {"scan", "fc2", "attn"} else dit.remat_keep[-1]
+            dit.remat_keep = tuple(k for k in dit.remat_keep if k != drop)       # (least milliseconds per GB first)
             log(f"out of memory with every layer re-materialised: keeping {list(dit.remat_keep) or 'nothing'} instead")
             return True
 

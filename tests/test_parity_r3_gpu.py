@@ -206,7 +206,7 @@ def test_remat_keep_is_bit_identical(name):
             mod.init_freqs()
     m.remat_free_layers = 0
     res = {}
-    for keep in ((), ("attn", "scan"), ("attn",)):
+    for keep in ((), ("attn", "scan"), ("attn",), ("attn", "scan", "fc2")):
         m.remat_keep = keep
         m.zero_grad(set_to_none=True)
         out = m(g["video"].to(DEV, torch.bfloat16), g["text"].to(DEV, torch.bfloat16), g["timesteps"].to(DEV))
@@ -214,7 +214,7 @@ def test_remat_keep_is_bit_identical(name):
         torch.cuda.synchronize()
         res[keep] = (out.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
     o0, g0 = res[()]
-    for keep in (("attn", "scan"), ("attn",)):
+    for keep in (("attn", "scan"), ("attn",), ("attn", "scan", "fc2")):
         o1, g1 = res[keep]
         assert torch.equal(o0, o1)
         assert set(g0) == set(g1)

@@ -88,3 +88,45 @@ def test_nested_checkpoint_keeps_nothing_and_order_violations_are_loud():
     with rec:
         with pytest.raises(RuntimeError, match="recomputation asked"):
             remat_cache.kernel_result("scan", lambda: (torch.zeros(1),))
+
+
+def test_gelu_linear_keeps_its_output_under_the_fc2_kind(monkeypatch):
+    """``GeluLinear`` (the DiT MLP's second half, ``ttt_amd/models/cogvideo/dit.py``) inside a region that keeps ``"fc2"``: the
+    GELU + GEMM pair runs once per call instead of twice, outputs and every gradient have the same bits as the plain checkpoint
+    and as no checkpoint at all."""
+    import torch.nn.functional as F
+    from ttt_amd.models.cogvideo import dit as dit_mod
+    calls = {"n": 0}
+    real_linear = F.linear
+
+    def counting_linear(x, w, b=None):
+        calls["n"] += 1
+        return real_linear(x, w, b)
+
+    monkeypatch.setattr(dit_mod.F, "linear", counting_linear)
+    g = torch.Generator().manual_seed(1)
+    x0 = torch.randn(2, 24, 16, generator=g)
+    w1 = torch.randn(64, 16, generator=g).mul_(0.2).requires_grad_()
+    w2 = torch.randn(16, 64, generator=g).mul_(0.2).requires_grad_()
+    b2 = torch.randn(16, generator=g).requires_grad_()
+
+    def mlp(x):
+        z = x @ w1.t()
+        return dit_mod.GeluLinear.apply(z, w2, b2) + x
+
+    res = {}
+    for mode in ("plain", "ckpt", "keep"):
+        calls["n"] = 0
+        x = x0.clone().requires_grad_()
+        for p in (w1, w2, b2):
+            p.grad = None
+        if mode == "plain":
+            y = mlp(x)
+        else:
+            y = checkpoint(mlp, x, use_reentrant=False, context_fn=remat_cache.context_fn(("fc2",) if mode == "keep" else ()))
+        y.square().sum().backward()
+        res[mode] = (y.detach().clone(), x.grad.clone(), w1.grad.clone(), w2.grad.clone(), b2.grad.clone(), calls["n"])
+    assert res["plain"][5] == 1 and res["ckpt"][5] == 2 and res["keep"][5] == 1
+    for mode in ("ckpt", "keep"):
+        for a, b in zip(res[mode][:5], res["plain"][:5]):
+            assert torch.equal(a, b), mode
