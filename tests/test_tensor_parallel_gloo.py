@@ -113,7 +113,7 @@ def _inputs_for(dp_rank, case):
     return torch.randn(1, frames, 16, 8, 8, generator=g), torch.randn(1, scenes, 16, 32, generator=g), torch.tensor([412 + 97 * dp_rank])
 
 
-def _worker_2d(rank, world, port, case, out_dir, tp):
+def _worker_2d(rank, world, port, case, out_dir, tp, reshard=False):
     for p in (ROOT, os.path.join(ROOT, "ttt-video-dit_amd")):
         sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -124,7 +124,7 @@ def _worker_2d(rank, world, port, case, out_dir, tp):
     init_distributed("gloo")
     m, _ = _build(case)
     m.remat_free_layers, m.remat_keep = 1, ("attn", "scan")     # layer 1 re-materialised (its collectives run again in backward)
-    mesh, dp_rank, dp = apply_parallelisms(m, tp_sharding=tp, param_dtype=torch.float32, reshard_after_forward=False)
+    mesh, dp_rank, dp = apply_parallelisms(m, tp_sharding=tp, param_dtype=torch.float32, reshard_after_forward=reshard)
     assert (dp_rank, dp) == (rank // tp, world // tp) and mesh["tp"].size() == tp
     params = [p for p in m.parameters() if p.requires_grad]
     opt = torch.optim.SGD(params, lr=0.05)
@@ -145,13 +145,14 @@ def _worker_2d(rank, world, port, case, out_dir, tp):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("world,tp", [(2, 2), (4, 2)])
-def test_tp_times_fsdp_step_matches_data_parallel_reference(world, tp, tmp_path):
+@pytest.mark.parametrize("world,tp,reshard", [(2, 2, False), (4, 2, False), (2, 2, True)])
+def test_tp_times_fsdp_step_matches_data_parallel_reference(world, tp, reshard, tmp_path):
     """``apply_parallelisms`` (reference ``parallelisms.py``:92-104): "full" TP layout inside groups of ``tp`` ranks, FSDP2 over
     ALL ranks with the divide factor ``dp`` - two SGD steps against a single-process statement of data parallelism over the
     ``dp`` samples (gradient = mean over the samples).  fp32 policy: the comparison is about the plan, not about bf16."""
     case = "mlp_dual_3scene"
-    mp.spawn(_worker_2d, args=(world, _free_port(), case, str(tmp_path), tp), nprocs=world, join=True)
+    # (reshard = the reference's FSDP setting: parameters gathered again in backward, beside the re-materialised layer's collectives)
+    mp.spawn(_worker_2d, args=(world, _free_port(), case, str(tmp_path), tp, reshard), nprocs=world, join=True)
     dp = world // tp
     from oracle import cpu_ext
     cpu_ext.install()
