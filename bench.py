@@ -569,8 +569,8 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False, tp=False):
             """drop the most expensive kind of kept outputs ("scan" 1.3 GB per layer at 9 s, then "fc2" 0.32 GB, then "attn" 0.34 GB)"""
             if not dit.remat_keep:
                 return False
-            drop = next(k for k in ("scan", "fc2", "attn") if k in dit.remat_keep) if set(dit.remat_keep) & {"scan", "fc2", "attn"} else dit.remat_keep[-1]
-            dit.remat_keep = tuple(k for k in dit.remat_keep if k != drop)       # (least milliseconds per GB first)
+            drop = ([k for k in ("scan", "fc2", "attn") if k in dit.remat_keep] or list(dit.remat_keep))[0]      # least ms per GB first
+            dit.remat_keep = tuple(k for k in dit.remat_keep if k != drop)
             log(f"out of memory with every layer re-materialised: keeping {list(dit.remat_keep) or 'nothing'} instead")
             return True
 
