@@ -66,6 +66,18 @@ int emul_attn_dkdv_n(const attn::BwdParams* p, int variant, int nsub, char* msg,
 
 int emul_attn_dkdv(const attn::BwdParams* p, int variant, char* msg, int msg_len) { return emul_attn_dkdv_n(p, variant, 1, msg, msg_len); }
 
+// LDS bank model (wave_emul.h bank_cost) over the first workgroup of the dQ (kernel 0) or 12-wave dK / dV (kernel 1) body:
+// out[0..8] = {passes, conflict passes, instructions} of the plain reads (b128 row fragments, row scalars), the stores, and the
+// transposed reads.  Returns the number of LDS races (0).
+int emul_attn_bank_model(const attn::BwdParams* p, int kernel, long* out) {
+    emul::RaceReport r;
+    if (kernel == 0) r = emul::run_group(8, [&](emul::EmulWave& w) { attnb::dq(w, *p, 0, 0); }, true);
+    else r = emul::run_group(12, [&](emul::EmulWave& w) { attnb::dkdv<12, true>(w, *p, 0, 0); }, true);
+    const emul::BankCount* c[3] = {&r.rd, &r.wr, &r.tr};
+    for (int k = 0; k < 3; ++k) { out[3 * k] = c[k]->passes; out[3 * k + 1] = c[k]->conflicts; out[3 * k + 2] = c[k]->instructions; }
+    return r.races;
+}
+
 int emul_attn_fwd_params_size() { return (int)sizeof(attn::FwdParams); }
 int emul_attn_bwd_params_size() { return (int)sizeof(attn::BwdParams); }
 }
