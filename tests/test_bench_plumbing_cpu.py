@@ -61,3 +61,29 @@ def test_counter_summaries_reproduce_from_the_committed_csvs():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "mfma_util.py"), os.path.join(ROOT, "profiles", "r3j_op_nc804_pmc_sq.csv")],
                          capture_output=True, text=True, check=True).stdout
     assert "mlp_bwd_cluster4_kernel" in out and "mlp_scan8_kernel" in out
+
+
+def test_forward_scan_lds_model_is_near_the_device_counter():
+    """tools/lds_bank_model.py enumerates the LDS instructions of one forward-scan step (csrc/ttt_mfma2.hip) under the bank
+    model: its conflict share of the LDS passes (35.5 %) against SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of `mlp_scan8_kernel`
+    on the device (38.3 %, profiles/r3p_wait_lds_summary.txt: 19.9 of 51.8 points); the swizzled layout it proposes removes every
+    tile conflict (what remains are the owners' fp32 partial-row reads)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("lds_bank_model", os.path.join(ROOT, "tools", "lds_bank_model.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+
+    def share(lay):
+        P = C = 0
+        by = {}
+        for cls, nbytes, write, addr in m.scan_step(lay):
+            p, c = m.bank_cost(addr, nbytes, write)
+            P += p; C += c
+            by[cls] = by.get(cls, 0) + c
+        return P, C, by
+
+    P, C, by = share(m.Layout(72, False))
+    assert abs(C / P - 19.9 / 51.8) < 0.04, C / P
+    P2, C2, by2 = share(m.Layout(72, True))
+    assert P2 < 0.75 * P
+    assert all(v == 0 for k, v in by2.items() if k.startswith(("pi_read", "tr ", "st_image", "tile park")))

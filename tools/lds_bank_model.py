@@ -1,0 +1,191 @@
+"""LDS bank model of the TTT-MLP forward scan (csrc/ttt_mfma2.hip, one scan step of one workgroup) - a profiler substitute for
+layout work when no GPU is at hand.
+
+The cost function is the one of the wave emulator (tests/emul/wave_emul.h bank_cost: lane groups and banks of
+MI355X_MICROARCH.md), which reproduces the device's SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE ratio of the attention backward
+kernels to 0.3 points (tests/test_emul_attention_cpu.py).  Here the kernel is not executed: its LDS instructions are ENUMERATED,
+per wave and lane, from the address arithmetic of the source (pi_read, st_image, tr_frag_pi, write_partial2, the owners' row
+reads ...), so the numbers are as good as that enumeration; the check is the device's counter: 38.3 % of the LDS passes of
+`mlp_scan8_kernel` are conflict replays (profiles/r3p_wait_lds_summary.txt: 19.9 of 51.8 points).
+
+    python tools/lds_bank_model.py                 # the shipped layout, per access class
+    python tools/lds_bank_model.py --ts 80         # another row stride (elements) of the bf16 tiles
+    python tools/lds_bank_model.py --swizzle       # unpadded 64-element rows, 8-byte units XOR-ed by a function of the row
+"""
+import argparse
+from collections import defaultdict
+
+G128 = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+G128 += [[x + 32 for x in g] for g in G128]
+
+
+def bank_cost(addr, nbytes, write):
+    """(passes, conflict passes) of one wave-wide LDS instruction; addr[lane] = byte address or None (lane inactive)."""
+    if write:
+        nb, ng = 32, (8 if nbytes >= 16 else 4 if nbytes == 8 else 2)
+        groups = [list(range(g * (64 // ng), (g + 1) * (64 // ng))) for g in range(ng)]
+    elif nbytes >= 16:
+        nb, groups = 64, G128
+    else:
+        nb, groups = (32 if nbytes == 4 else 64), [list(range(32)), list(range(32, 64))]
+    passes = conflicts = 0
+    for g in groups:
+        banks = defaultdict(set)
+        for lane in g:
+            if addr[lane] is None:
+                continue
+            for d in range((nbytes + 3) // 4):
+                dw = addr[lane] // 4 + d
+                banks[dw % nb].add(dw)
+        if not banks:
+            continue
+        worst = max(len(v) for v in banks.values())
+        passes += worst
+        conflicts += worst - 1
+    return passes, conflicts
+
+
+class Layout:
+    """byte address of element (row, col) of a bf16 tile / image that starts at `base`"""
+
+    def __init__(self, ts=72, swizzle=False):
+        self.ts, self.swizzle = ts, swizzle
+
+    def g(self, r):
+        """4-bit XOR pattern of the 8-byte unit index (16 units per 64-element row).  bit 3 = bit 1 of the row: the 4 rows of a
+        transposed read take different 16-bank quarters; bits 0-2 = bits 2-4 of the row: the 16 rows of equal parity that a
+        ds_read_b64 group reads in one column take 16 different units; bit 2 additionally flipped by bit 0 of the row: the 16
+        CONSECUTIVE rows of a ds_write_b64 group (32 banks: row parity does not separate them) take 16 different units."""
+        return (((r >> 1) & 1) << 3) | (((r >> 2) & 7) ^ ((r & 1) << 2))
+
+    def at(self, base, r, col, nbytes=8):
+        if not self.swizzle:
+            return base + 2 * (r * self.ts + col)
+        if nbytes >= 16:       # a 16-byte access covers both units of its chunk (their order inside the chunk may be swapped)
+            return base + 2 * (r * 64) + 16 * ((col >> 3) ^ (self.g(r) >> 1))
+        unit = (col >> 2) ^ self.g(r)
+        return base + 2 * (r * 64 + 4 * unit + (col & 3))
+
+    def row_bytes(self):
+        return 2 * (64 if self.swizzle else self.ts)
+
+
+def scan_step(lay, ps=68):
+    """yield (class, nbytes, write, [64 addresses]) for every LDS instruction of one scan step, all 8 waves"""
+    tile = 64 * lay.row_bytes()
+    L_K, L_Q, L_V, L_G = 0, tile, 2 * tile, 3 * tile
+    L_X2 = 4 * tile
+    L_RED = L_X2 + 256 * lay.row_bytes()
+    L_SMALL = L_RED + 4 * 64 * ps * 4
+    etaL, b1L, b2L = L_SMALL, L_SMALL + 256, L_SMALL + 256 + 1024
+    gamL, betL = b2L + 256, b2L + 512
+    lanes = range(64)
+    H = lambda l: l >> 5
+    C = lambda l: l & 31
+
+    def pi_read(cls, base, row_of_lane, col0, s):
+        for extra in (0, 8):
+            yield cls, 8, False, [lay.at(base, row_of_lane(l), col0 + 16 * s + 4 * H(l) + extra) for l in lanes]
+
+    def tr_frag_pi(cls, base, row0, s, col0):
+        for extra in (0, 8):
+            yield cls, 8, False, [lay.at(base, row0 + 16 * s + 4 * H(l) + extra + ((l & 15) >> 2), col0 + 16 * ((l >> 4) & 1) + 4 * (l & 3)) for l in lanes]
+
+    for wv in range(8):
+        w, pp = wv >> 1, wv & 1
+        nO, nX, fO, fX = 64 * w + 32 * pp, 64 * w + 32 * (1 - pp), 32 * pp, 32 * (1 - pp)
+        tid = lambda l: 64 * wv + l
+        ot = lambda l: tid(l) >> 3
+        of0 = lambda l: 8 * (tid(l) & 7)
+        # ---- A1
+        for ti in range(2):
+            for a in range(2):
+                for s in range(2):
+                    yield from pi_read("pi_read K (A1)", L_K, lambda l: 32 * ti + C(l), 32 * a, s)
+            for s in range(2):
+                for extra in (0, 8):
+                    yield "st_image X2 (A1)", 8, True, [lay.at(L_X2, nO + C(l), 32 * ti + 16 * s + 4 * H(l) + extra) for l in lanes]
+        # ---- A2
+        for ti in range(2):
+            for s in range(2):
+                yield from tr_frag_pi("tr X2 (A2)", L_X2, nO, s, 32 * ti)
+                yield from tr_frag_pi("tr X2 (A2)", L_X2, nX, s, 32 * ti)
+            for q in range(4):
+                yield "write_partial (A2, E)", 16, True, [L_RED + 4 * ((w * 64 + 32 * ti + C(l)) * ps + 32 * pp + 8 * q + 4 * H(l)) for l in lanes]
+        yield "tile park (Q, K, V, Gs)", 16, True, [lay.at(L_Q, ot(l), of0(l), 16) for l in lanes]
+        # ---- P3 and P6 (owners): b2, four partials, tile rows, gamma / beta
+        for phase in ("P3", "P6"):
+            for k in range(2):
+                yield "owner rows small", 16, False, [b2L + 4 * (of0(l) + 4 * k) for l in lanes]
+                for ww in range(4):
+                    yield "owner partial reads", 16, False, [L_RED + 4 * ((ww * 64 + ot(l)) * ps + of0(l) + 4 * k) for l in lanes]
+                yield "owner rows small", 16, False, [gamL + 4 * (of0(l) + 4 * k) for l in lanes]
+                yield "owner rows small", 16, False, [betL + 4 * (of0(l) + 4 * k) for l in lanes]
+            if phase == "P3":
+                yield "owner tile rows", 16, False, [lay.at(L_K, ot(l), of0(l), 16) for l in lanes]
+                yield "owner tile rows", 16, False, [lay.at(L_V, ot(l), of0(l), 16) for l in lanes]
+                yield "owner rows small", 4, False, [etaL + 4 * ot(l) for l in lanes]
+                yield "tile park (Q, K, V, Gs)", 16, True, [lay.at(L_G, ot(l), of0(l), 16) for l in lanes]
+            else:
+                yield "owner tile rows", 16, False, [lay.at(L_Q, ot(l), of0(l), 16) for l in lanes]
+        # ---- C
+        if w == 0:
+            for ti in range(2):
+                for s in range(2):
+                    yield from tr_frag_pi("tr Gs (C)", L_G, 32 * ti, s, fO)
+        for ti in range(2):
+            for s in range(2):
+                yield from tr_frag_pi("tr Gs (C)", L_G, 32 * ti, s, fO)
+                yield from pi_read("pi_read X2 (C)", L_X2, lambda l: nO + C(l), 32 * ti, s)
+                yield from pi_read("pi_read X2 (C)", L_X2, lambda l: nX + C(l), 32 * ti, s)
+                yield from tr_frag_pi("tr Gs (C)", L_G, 32 * ti, s, fX)
+        for ti in range(2):
+            for s in range(2):
+                yield from pi_read("pi_read Gs (C)", L_G, lambda l: 32 * ti + C(l), fO, s)
+                yield from pi_read("pi_read Gs (C)", L_G, lambda l: 32 * ti + C(l), fX, s)
+            for s in range(2):
+                yield from tr_frag_pi("tr K (C)", L_K, 32 * ti, s, 0)
+                yield from tr_frag_pi("tr K (C)", L_K, 32 * ti, s, 32)
+        yield "owner rows small", 4, True, [b1L + 4 * (nO + C(l)) if H(l) == 0 else None for l in lanes]
+        for q in range(4):
+            yield "owner rows small", 16, False, [b1L + 4 * (nO + 8 * q + 4 * H(l)) for l in lanes]
+        # ---- f6
+        for ti in range(2):
+            for a in range(2):
+                for s in range(2):
+                    yield from pi_read("pi_read Q (f6)", L_Q, lambda l: 32 * ti + C(l), 32 * a, s)
+        # ---- exchange, E
+        for k in range(4):
+            yield "fragment exchange", 16, True, [L_X2 + ((wv * 4 + k) * 64 + l) * 16 for l in lanes]
+        for k in range(4):
+            yield "fragment exchange", 16, False, [L_X2 + (((wv ^ 1) * 4 + k) * 64 + l) * 16 for l in lanes]
+        for ti in range(2):
+            for q in range(4):
+                yield "write_partial (A2, E)", 16, True, [L_RED + 4 * ((w * 64 + 32 * ti + C(l)) * ps + 32 * pp + 8 * q + 4 * H(l)) for l in lanes]
+        yield "tile park (Q, K, V, Gs)", 16, True, [lay.at(L_K, ot(l), of0(l), 16) for l in lanes]
+        yield "tile park (Q, K, V, Gs)", 16, True, [lay.at(L_V, ot(l), of0(l), 16) for l in lanes]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ts", type=int, default=72)
+    ap.add_argument("--ps", type=int, default=68)
+    ap.add_argument("--swizzle", action="store_true")
+    a = ap.parse_args()
+    lay = Layout(a.ts, a.swizzle)
+    tot = defaultdict(lambda: [0, 0, 0])
+    for cls, nbytes, write, addr in scan_step(lay, a.ps):
+        p, c = bank_cost(addr, nbytes, write)
+        t = tot[cls]
+        t[0] += 1; t[1] += p; t[2] += c
+    P = sum(t[1] for t in tot.values())
+    Cf = sum(t[2] for t in tot.values())
+    print(f"layout: {'swizzled 64-element rows' if a.swizzle else f'row stride {a.ts} elements'}, partial stride {a.ps} floats")
+    print(f"{'access class':28s} {'instr':>6s} {'passes':>7s} {'conflict':>8s} {'x':>5s}")
+    for cls, (n, p, c) in sorted(tot.items(), key=lambda kv: -kv[1][2]):
+        print(f"{cls:28s} {n:6d} {p:7d} {c:8d} {p / (p - c):5.2f}")
+    print(f"{'one step, 8 waves':28s} {sum(t[0] for t in tot.values()):6d} {P:7d} {Cf:8d}   conflict share of the LDS passes {Cf / P:.1%}")
+
+
+if __name__ == "__main__":
+    main()
