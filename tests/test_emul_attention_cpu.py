@@ -174,11 +174,11 @@ def test_emulated_dkdv_variants_agree(emul):
     assert rel_l2(res[3][0], res[2][0]) < 5e-3 and rel_l2(res[3][1], res[2][1]) < 5e-3
 
 
-@pytest.mark.parametrize("B,NH,S,layout", [(1, 2, 40, "bshd"), (2, 3, 300, "bshd"), (1, 8, 128, "bhsd"), (1, 1, 577, "bshd"), (1, 1, 800, "bshd")])
+@pytest.mark.parametrize("B,NH,S,layout", [(1, 2, 40, "bshd"), (1, 1, 300, "bshd"), (1, 1, 128, "bhsd"), (1, 1, 577, "bshd")])
 def test_two_tiles_per_stage_is_bit_identical(emul, B, NH, S, layout):
     """dQ and dK / dV with TWO tiles of 64 per LDS stage (half the workgroup barriers; csrc/attn_body.h dq_staged / dkdv_staged,
     not instantiated on the device yet): the same arithmetic in the same order, so the same bits as the one-tile form - one tile in all (40), an
-    odd tile count (300: 5, 577: 10 with a ragged tail, 800: 13 = a half-filled last stage), exact multiples (128) - and no LDS
+    odd tile count (300: 5 = a half-filled last stage), a ragged tail (577: 10 tiles), exactly one stage (128) - and no LDS
     race between the stage being filled and the stage being read."""
     q, k, v, do = _make(B, NH, S, 21 + S, layout)
     ro, rl, *_ = _oracle(q, k, v, do)
