@@ -4,6 +4,11 @@
 #   1. the 9 s line with re-materialised layers keeping attn,scan (default) vs attn,scan,fc2 (DESIGN.md section 8, item 4:
 #      +1 % by arithmetic); adopt as the default of bench.py --remat-keep if it wins
 #   2. the full GPU suite (incl. the stolen-CU stress test, the one-rank TP layouts, remat_keep with fc2)
+#   3. (second call, after `git merge attn-staged-device` and a rebuild) the staged / swizzled attention backward kernels: first
+#      find out why their first device run aborted (AMD_LOG_LEVEL=3 shows the runtime's own message):
+#        AMD_LOG_LEVEL=3 timeout 60 python -m pytest tests/test_attention_gpu.py -x -q -m gpu -k two_tiles 2>&1 | tail -40
+#      then the interleaved A/B at the training geometry:
+#        python tools/attn_bench.py --no-sdpa --stages 1,2,3,4 --rounds 5
 cd /root/repo; mkdir -p gpurun_out/r4a; O=gpurun_out/r4a
 timeout 300 python -m pytest tests -x -q -m gpu > $O/gpu_suite.log 2>&1; echo "suite rc=$?"; tail -2 $O/gpu_suite.log
 for keep in attn,scan attn,scan,fc2; do
