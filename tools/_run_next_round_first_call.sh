@@ -9,6 +9,9 @@
 #        AMD_LOG_LEVEL=3 timeout 60 python -m pytest tests/test_attention_gpu.py -x -q -m gpu -k two_tiles 2>&1 | tail -40
 #      then the interleaved A/B at the training geometry:
 #        python tools/attn_bench.py --no-sdpa --stages 1,2,3,4 --rounds 5
+#   4. allocator fragmentation: the 30 s line reserves 275 GiB for 216 GiB allocated (9 s: 252 for 241) - every GiB of that gap
+#      is a kept kernel output or a remat-free layer that does not fit.  One try:
+#        PYTORCH_HIP_ALLOC_CONF=expandable_segments:True python bench.py --video-length 30sec --steps 1 --warmup 1 --no-cpu-baseline --no-fsdp1-compare
 cd /root/repo; mkdir -p gpurun_out/r4a; O=gpurun_out/r4a
 timeout 300 python -m pytest tests -x -q -m gpu > $O/gpu_suite.log 2>&1; echo "suite rc=$?"; tail -2 $O/gpu_suite.log
 for keep in attn,scan attn,scan,fc2; do
