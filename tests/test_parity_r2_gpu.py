@@ -205,14 +205,17 @@ def test_dit_on_hip_path_vs_reference_golden(name):
     multi = g["scenes"] > 1
     assert errs["out"] < (6e-2 if multi else 2e-2), errs
     # Gradient tolerance 8e-2 (bf16 end to end vs the reference's fp32 run); the reference's own bf16-autocast run of these
-    # models is off by up to 2.3 - 3.0e-2 (tests/golden/dit_bf16_yardstick.pt).  Exception, stated: the two learning-rate-gate
-    # parameters.  Their gradient is the token sum of d(eta), which the kernel contract returns in bf16 (mlp_tk.py:280) and whose
-    # four terms cancel: measured on an MI355X for this fixture 0.12 - 0.15 with the MFMA kernels, 0.02 - 0.03 with the fp32-
-    # arithmetic generic kernels, 0.3 - 1.2 for the reference's ops-path statements evaluated in bf16 (profiles/r2b_dit_gradient_
-    # diagnosis.txt) - so they are bounded by 0.25 here.
+    # models is off by up to 2.3 - 3.0e-2 (tests/golden/dit_bf16_yardstick.pt).  The two learning-rate-gate parameters (token
+    # sums of d(eta)): round 2 / 3 measured 0.12 - 0.15 with the MFMA kernels against 0.02 - 0.03 with the fp32-arithmetic
+    # generic kernels and bounded them by 0.25; round 4 found the cause (db2's column sums taken from a bf16 tile,
+    # tests/test_rounding_budget_cpu.py) and the TTT-MLP fixture at mini-batches of 64 is held to the common 8e-2.  The
+    # TTT-Linear fixture (mini-batches of 16, ttt_lin16_body.h) and the dual-form 3-scene fixture (a different function of the
+    # eta tile, hazard C2) keep the 0.25 bound.
     tol = 0.25 if multi else 8e-2
     lr_gate = ("learnable_ttt_lr_bias", "learnable_ttt_lr_weight")
-    bad = {k: v for k, v in errs.items() if k != "out" and not v < (0.25 if k.endswith(lr_gate) else tol)}
+    lr_tol = 8e-2 if name == "dit_mlp64_1scene.pt" else 0.25
+    print(name, "learning-rate-gate gradients:", {k.split("layers.")[1][:2] + k.rsplit("_", 1)[1]: round(v, 4) for k, v in errs.items() if k.endswith(lr_gate)})
+    bad = {k: v for k, v in errs.items() if k != "out" and not v < (lr_tol if k.endswith(lr_gate) else tol)}
     assert not bad, bad
 
 

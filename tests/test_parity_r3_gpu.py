@@ -152,12 +152,12 @@ def test_mfma_cs16_at_63s_length_vs_oracle(kind):
 def test_dit_multiscene_on_hip_path_vs_reference_lastrow():
     """The driver-benchmarked case in miniature: 3 interleaved scenes, TTT-MLP at mini-batches of 64, bf16 on the HIP path,
     against the reference's own model code run on last-row eta tiles (tests/golden/gen_golden_r2.py:
-    dit_mlp64_multiscene_lastrow_case).  2e-2 on the output, 8e-2 on every gradient; stated exception: the two
-    learning-rate-gate parameters per layer - the token sum of d(eta), four cancelling terms formed from bf16 operands, at a
-    base learning rate 10x the default (the fixture's choice, so that the inner loop matters): bounded by 3x what the
-    REFERENCE's own bf16-autocast run of this model loses on the same parameter (0.12 on the worst one,
-    dit_bf16_yardstick_r3.pt), and by 0.25 where that is smaller.  Measured on an MI355X: 0.32 on layers.1 lr_bias, < 0.25 on
-    the other three."""
+    dit_mlp64_multiscene_lastrow_case).  2e-2 on the output, 8e-2 on every gradient; the learning-rate-gate parameters (token
+    sums of d(eta) at a base learning rate 10x the default - the fixture's choice, so that the inner loop matters) are bounded
+    by what the REFERENCE's own bf16-autocast run of this model loses on the same parameter where that is more than 8e-2
+    (0.12 on layers.1 lr_bias, dit_bf16_yardstick_r3.pt) - SURVEY 8c's rule, no factor.  Round 3 measured 0.32 there and
+    carried a 3x exception; the cause was the column sum of the bf16 dZ2b tile feeding db2 (tests/test_rounding_budget_cpu.py),
+    summed in fp32 by the sweep's owner waves since round 4."""
     from ttt_amd.models.cogvideo.dit import DiffusionTransformer
     from ttt_amd.models.configs import ModelConfig
     e = ext()
@@ -178,12 +178,14 @@ def test_dit_multiscene_on_hip_path_vs_reference_lastrow():
         if params[k].grad is not None:
             errs[k] = rel_l2(params[k].grad, r)
     worst = max(((k, v) for k, v in errs.items() if k != "out"), key=lambda kv: kv[1])
-    print("3-scene bf16 HIP DiT vs reference (last-row eta):", {"out": round(errs["out"], 4), "n_grads": len(errs) - 1,
-                                                                 "worst": (worst[0], round(worst[1], 4))})
-    assert errs["out"] < 2e-2, errs
     lr_gate = ("learnable_ttt_lr_bias", "learnable_ttt_lr_weight")
+    print("3-scene bf16 HIP DiT vs reference (last-row eta):", {"out": round(errs["out"], 4), "n_grads": len(errs) - 1,
+                                                                 "worst": (worst[0], round(worst[1], 4)),
+                                                                 "lr_gate": {k.split("layers.")[1][:2] + k.rsplit("_", 1)[1]: round(v, 4)
+                                                                             for k, v in errs.items() if k.endswith(lr_gate)}})
+    assert errs["out"] < 2e-2, errs
     yard = load_golden("dit_bf16_yardstick_r3.pt")["dit_mlp64_3scene_lastrow.pt"]
-    tol = lambda k: max(0.25, 3.0 * yard.get(k, 0.0)) if k.endswith(lr_gate) else 8e-2
+    tol = lambda k: max(8e-2, yard.get(k, 0.0)) if k.endswith(lr_gate) else 8e-2
     bad = {k: (v, tol(k)) for k, v in errs.items() if k != "out" and not v < tol(k)}
     assert not bad, bad
 

@@ -1,0 +1,41 @@
+"""The bf16 rounding budget of the TTT-MLP backward sweep, on the CPU (round 4).
+
+tools/diag/lr_gate_full_emul_cpu.py restates one backward step of csrc/ttt_mfma_bwd4.hip on the fp64 oracle with every bf16
+rounding of the kernel as a named switch (MFMA operand packs of the carried state, the recorded pre-activations, the re-derived
+activation fragments, the staged gradient tiles) and drives the 3-scene kernel-contract DiT fixture through it.  It found what the
+round-3 verdict asked for: the learning-rate-gate gradients (token sums of d(eta)) were off by 0.2 - 0.3 because ONE quantity -
+the column sums of dZ2b that feed db2 - was formed from the bf16 tile; every other rounding together stays within the
+fp32-arithmetic kernels' error.  The sweep now sums those columns from the owners' fp32 values.  This test pins the finding:
+the round-4 rounding set meets the bound of tests/test_parity_r3_gpu.py, the round-3 set does not."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools", "diag"))
+from helpers import load_golden  # noqa: E402
+
+
+@pytest.fixture
+def emul():
+    import lr_gate_full_emul_cpu as E
+    from oracle import cpu_ext
+    yield E
+    cpu_ext.uninstall()
+
+
+def test_sweep_rounding_budget_lr_gate(emul):
+    torch.manual_seed(0)
+    g = load_golden("dit_mlp64_3scene_lastrow.pt")
+    yard = load_golden("dit_bf16_yardstick_r3.pt")["dit_mlp64_3scene_lastrow.pt"]
+    short = lambda k: k.split("layers.")[1].replace("seq_modeling_block.ssm.ttt.learnable_ttt_", "")
+    bound = {short(k): max(8e-2, v) for k, v in yard.items() if "ttt_lr" in k}       # no worse than the reference's own bf16 run
+    r4, worst4 = emul.run(set(emul.POINTS) - {"dZ2b_colsum"}, g)
+    assert all(v < bound[k] for k, v in r4.items()), (r4, bound)
+    assert worst4 < 8e-2
+    r3, _ = emul.run(set(emul.POINTS), g)                                            # the round-3 sweep: the finding itself
+    assert max(r3.values()) > 0.15, r3
+    only, _ = emul.run({"dZ2b_colsum"}, g)
+    assert max(only.values()) > 0.15, only

@@ -80,8 +80,9 @@ constexpr int L_A = L_Q + TILE_B;                         // dZ2b_j [t][f]
 constexpr int L_B = L_A + TILE_B;                         // dZ2_i  [t][f]
 constexpr int L_XU = L_B + TILE_B;                        // u^T exchange between the two compute waves: 2 x 4 fragments x 1 KiB
 constexpr int L_XD = L_XU + 2 * 4 * 1024;                 // dW2 block exchange: 2 x 2 fragments
-constexpr int L_SM = L_XD + 2 * 2 * 1024;                 // floats: eta[2][64], db1[64], db2[64], gamma[64], sync word
-constexpr int SM_FLOATS = 2 * 64 + 64 + 64 + 64 + 4;
+constexpr int L_SM = L_XD + 2 * 2 * 1024;                 // floats: eta[2][64], db1[64], db2[64], gamma[64], sync word, db2o[2][64]
+constexpr int SM_FLOATS = 2 * 64 + 64 + 64 + 64 + 4 + 2 * 64;
+static_assert(2 * 2 * 1024 >= 16 * 64 * 4, "the dW2 exchange region doubles as the 16 x 64 column-sum partials of dZ2b");
 // Fragment staging regions, written by the deriver waves (lane-linear fragment images: fragment f of an array at f * 1 KiB +
 // lane * 16, the layout of round 2's slot arrays) and read by the compute waves with ds_read_b128:
 //   R1  S1 operands of the step        GZ1T | D1N | XT           written for step j after Bb(i)
@@ -172,6 +173,13 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
     float* db2L = db1L + 64;
     float* gamL = db2L + 64;
     unsigned* syncw = reinterpret_cast<unsigned*>(gamL + 64);      // [0] hand-over number the owners have seen complete, [1] fast-path verdict, [2] poisoned
+    // Round 4: the OUTPUT path's share of db2 (column sums of dZ2b over the 64 tokens of a step) is summed by the owners from
+    // their fp32 dZ2b values, not by a ones-MFMA over the bf16 tile the compute waves consume: db2 enters d(eta) of every token
+    // of every earlier step, so the rounding of that tile showed up 1 : 1 in the learning-rate-gate gradients (0.32 on the
+    // 3-scene DiT fixture against 0.02 - 0.03 with this sum in fp32; tools/diag/lr_gate_full_emul_cpu.py has the ablation).
+    // A step's 16 partials per feature (4 owner waves x 4 DPP rows of 4 tokens) go through the dW2 exchange region, which is
+    // idle between Ba and the publish_state behind Bc; owner wave 2 adds them while it waits for its partners.
+    float* db2oL = reinterpret_cast<float*>(syncw + 4);            // [2][64] by iteration parity: the owners' share of db2 entering the step
 
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -254,8 +262,7 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
                     dW2t[1] = mma(xb, aX, dW2t[1]);
                     dW2Tt[0] = mma(aO, xb, dW2Tt[0]);
                     dW2Tt[1] = mma(aX, xb, dW2Tt[1]);
-                    const f32x16 acc = mma(ONES, aO, zero16());          // db2 += column sums of dZ2b
-                    db2v += acc[0];
+                    // (db2 += column sums of dZ2b: the owners' share, in fp32 - db2oL)
                 }
             }
         };
@@ -494,13 +501,14 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
                 o2[(size_t)(nO + ro) * 64 + fX + c] = dW2t[1][r] + poison;
             }
             if (h == 0) ob1[nO + c] = db1v + poison;
-            if (cq == 0 && h == 0) ob2[fO + c] = db2v + poison;
+            // (the owners' share after the last step: its last writer is ordered by the last Bc / Bd)
+            if (cq == 0 && h == 0) ob2[fO + c] = db2v + db2oL[((i0 - p.chunk_lo) & 1) * 64 + fO + c] + poison;
         }
         if (p.last) __syncthreads();           // (the owners' final reduction)
     } else if (wv != DW0 && wv != DW0 + 1) {
         // =========================================================================================================== OWNERS
-        const int ow = ((wv < DW0 ? wv - 2 : wv - 4) << 6) | (tid & 63);      // 0 .. 255 over the four owner waves
-        const int ot = ow >> 2, of0 = 16 * (ow & 3);            // token, first of this thread's 16 features
+        int ow = ((wv < DW0 ? wv - 2 : wv - 4) << 6) | (tid & 63);            // 0 .. 255 over the four owner waves
+        int ot = ow >> 2, of0 = 16 * (ow & 3);                  // token, first of this thread's 16 features
         float dgam[16], dbet[16];
         if (p.first) {
 #pragma unroll
@@ -546,7 +554,7 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
             L.rstdl = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rS, ot * 8 + 4, so + 3 * (int)SLOT_OWN_ARR, 0));
         };
         // tiles -> LDS (K, gZ2, eta into buffer `dst`, Q into Qt); backward of the output LayerNorm -> dZ2b tile (At), dgamma / dbeta
-        auto consume_step = [&](int dst, const StepLoads& L) {
+        auto consume_step = [&](int dst, const StepLoads& L, float* part) {
             __bf16* kd = Kt2 + dst * TILE_ELEMS + ot * TS + of0;
             __bf16* gd = Gt2 + dst * TILE_ELEMS + ot * TS + of0;
             __bf16* qd = Qt + ot * TS + of0;
@@ -569,17 +577,43 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) g[k] = (64.0f * g[k] - s1 - L.xl[k] * s2) * L.rstdl * (1.0f / 64.0f);
             store16_bf16(At + ot * TS + of0, g);
+            // column sums of the fp32 dZ2b: two DPP row shifts leave the sum of a row's four tokens in its lanes 12 .. 15
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                g[k] += dppq<0x114>(g[k]);                 // row_shr:4 (zero beyond the row)
+                g[k] += dppq<0x118>(g[k]);                 // row_shr:8
+            }
+            if ((tid & 12) == 12) {                        // partial (owner wave, row) x features of0 .. of0 + 16
+                float* pw = part + (ow >> 4) * 64 + of0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = {g[4 * q], g[4 * q + 1], g[4 * q + 2], g[4 * q + 3]};
+                    *reinterpret_cast<f32x4*>(pw + 4 * q) = v;
+                }
+            }
+        };
+        // owner wave 2, lane = feature: the owners' share of db2 entering the NEXT step = this one + the 16 partials (fixed order)
+        auto add_parts = [&](const float* part, const float* from, float* to) {
+            float s4 = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) s4 += part[q * 64 + (tid & 63)];
+            to[tid & 63] = (from ? from[tid & 63] : 0.f) + s4;
         };
         __syncthreads();                       // P0: gamma row, sync word visible to all owner waves
         {
             StepLoads L0;
             request_step(i0, L0);
-            consume_step(0, L0);
+            consume_step(0, L0, reinterpret_cast<float*>(exu));       // (exd is written by publish_state(i0) between P1 and P2)
         }
         owner_barrier();                       // P1
+        if (wv == 2) add_parts(reinterpret_cast<const float*>(exu), nullptr, db2oL);
         owner_barrier();                       // P2
 
         for (int i = i0; i >= p.chunk_lo; --i) {
+            // opaque owner index per step (as the compute / deriver waves do with their lane id): what derives from it - record
+            // and tile offsets, LDS rows - is re-made inside the step instead of being carried through the loop in spilled registers
+            asm volatile("" : "+v"(ow));
+            ot = ow >> 2; of0 = 16 * (ow & 3);
             const bool more = i > p.chunk_lo;
             const int cur = (i0 - i) & 1;
             const int sI = slot_off(i);
@@ -595,7 +629,7 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
             StepLoads Lj;
             if (more) request_step(i - 1, Lj);
             owner_barrier();                   // Ba (nothing of the owners is due yet: they arrive at once)
-            if (more) consume_step(cur ^ 1, Lj);
+            if (more) consume_step(cur ^ 1, Lj, reinterpret_cast<float*>(exd));
             owner_barrier();                   // Bb: this workgroup's record is complete and drained; At / Q_j / R3 visible
             unsigned long long t_o = 0;
             if (DBG && p.dbg != nullptr && blockIdx.x == 0 && ow == 0) t_o = __builtin_readcyclecounter();
@@ -609,6 +643,7 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
             if (ow == 0) __hip_atomic_store(my_flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (wv == 2) {
                 const int l = tid & 63;
+                if (more) add_parts(reinterpret_cast<const float*>(exd), db2oL + cur * 64, db2oL + (cur ^ 1) * 64);
                 if (l < 3) {
                     const unsigned* f = p.flags + ((size_t)bh * 4 + ((cq + 1 + l) & 3)) * FLAG_STRIDE;
                     // a poisoned workgroup (an earlier poll of this launch gave up) does not wait any more
@@ -685,7 +720,7 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
                     gz[k] = (64.0f * gxh[k] - s1g - xh[k] * s2g) * r * (1.0f / 64.0f);      // gZ2 (fp32)
-                    const float db2 = db2L[of0 + k];
+                    const float db2 = db2L[of0 + k] + db2oL[cur * 64 + of0 + k];
                     se += gz[k] * db2;
                     G_[k] -= eta_t * db2;                                                    // d(gZ2) complete
                     const float m = -G_[k] * r;
