@@ -3,6 +3,7 @@
 "DiT+TTT fwd/bwd video-tokens/sec".
 
     python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus N --steps K --warmup W          (no launcher: re-executes itself under torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -376,16 +377,36 @@ def size_warm_and_time(step, hk, remat_free_layers, warmup, steps, world):
         return n_free, dt, loss
 
 
+def launcher_argv(gpus, argv, port=None):
+    """The command line a bare ``python bench.py --gpus N ...`` (N > 1, no launcher environment) replaces itself with: one rank per
+    GPU of this node under torch.distributed.run, rendezvous on 127.0.0.1 (the container's hostname may not resolve) on a free
+    port - what the reference's scripts/*.sh do with torchrun.  The ranks inherit stdout: rank 0 still prints the one JSON line."""
+    if port is None:
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     args = parse()
     if args.cpu_baseline_only:
         print(json.dumps({"cpu_baseline": cpu_baseline(args.ssm_layer, args.cpu_baseline_budget)}))
         return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # started without a launcher: become one (the driver may call `python bench.py --gpus 8` exactly like `--gpus 1`)
+        cmd = launcher_argv(args.gpus, sys.argv[1:])
+        log("no launcher environment: re-executing as " + " ".join(cmd[1:9]) + " bench.py ...")
+        sys.stdout.flush()
+        os.execv(cmd[0], cmd)
+        raise AssertionError("unreachable")           # (tests replace os.execv)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus"
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
     os.environ.setdefault("RANK", "0")

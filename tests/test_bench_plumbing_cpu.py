@@ -5,6 +5,8 @@ import json
 import os
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
@@ -87,3 +89,45 @@ def test_forward_scan_lds_model_is_near_the_device_counter():
     P2, C2, by2 = share(m.Layout(72, True))
     assert P2 < 0.75 * P
     assert all(v == 0 for k, v in by2.items() if k.startswith(("pi_read", "tr ", "st_image", "tile park")))
+
+
+def test_bare_multi_gpu_invocation_relaunches_itself(monkeypatch):
+    """`python bench.py --gpus N` without a launcher environment (how the driver starts the N = 1 run) must not die on an
+    assertion for N > 1: it replaces itself with torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1, and hands
+    its own arguments through (round-3 verdict, weak #6).  Under a launcher (WORLD_SIZE set) nothing is re-executed."""
+    import bench
+    calls = []
+
+    class Stop(Exception):
+        pass
+
+    def fake_execv(path, argv):
+        calls.append((path, list(argv)))
+        raise Stop
+
+    monkeypatch.setattr(os, "execv", fake_execv)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7", "--warmup", "2"])
+    with pytest.raises(Stop):
+        bench.main()
+    (path, argv), = calls
+    assert path == sys.executable and argv[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in argv and "--nproc-per-node=4" in argv
+    assert argv[argv.index("--master-addr") + 1] == "127.0.0.1" and int(argv[argv.index("--master-port") + 1]) > 0
+    i = argv.index(os.path.abspath(bench.__file__))
+    assert argv[i + 1:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]
+    # under a launcher: no re-execution (the GPU assertion is what stops a CPU-only box here)
+    calls.clear()
+    monkeypatch.setenv("WORLD_SIZE", "4"); monkeypatch.setenv("RANK", "0")
+    if not __import__("torch").cuda.is_available():
+        with pytest.raises(AssertionError, match="needs a GPU"):
+            bench.main()
+    assert not calls
+    # one GPU: never
+    monkeypatch.delenv("WORLD_SIZE"); monkeypatch.delenv("RANK")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "1"])
+    if not __import__("torch").cuda.is_available():
+        with pytest.raises(AssertionError, match="needs a GPU"):
+            bench.main()
+    assert not calls
