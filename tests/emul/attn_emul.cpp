@@ -25,21 +25,27 @@ int emul_attn_forward(const attn::FwdParams* p, char* msg, int msg_len) {
     return races;
 }
 
-int emul_attn_dq(const attn::BwdParams* p, char* msg, int msg_len) {
+// nsub = key tiles of 64 per LDS stage (1 = the shipped form, 2 = the opt-in form with half the barriers)
+int emul_attn_dq_n(const attn::BwdParams* p, int nsub, char* msg, int msg_len) {
     const int nqb = (p->S + attnb::QB - 1) / attnb::QB, nbh = p->B * p->NH;
     int races = 0;
     for (int b = 0; b < nbh * nqb; ++b) {
         int bh, qb;
         attnb::head_of_block(b, nqb, nbh, bh, qb);
-        const emul::RaceReport r = emul::run_group(8, [&](emul::EmulWave& w) { attnb::dq(w, *p, bh, qb); });
+        const emul::RaceReport r = emul::run_group(8, [&](emul::EmulWave& w) {
+            if (nsub == 2) attnb::dq_staged<2>(w, *p, bh, qb);
+            else attnb::dq(w, *p, bh, qb);
+        });
         if (r.races && !races && msg) snprintf(msg, msg_len, "%s", r.first.c_str());
         races += r.races;
     }
     return races;
 }
 
+int emul_attn_dq(const attn::BwdParams* p, char* msg, int msg_len) { return emul_attn_dq_n(p, 1, msg, msg_len); }
+
 // variant 2 = <8 waves, revision 1's arithmetic>, 3 = <8, accumulator-initialised row scalars>, 4 = <12, ...> (attn.h)
-int emul_attn_dkdv(const attn::BwdParams* p, int variant, char* msg, int msg_len) {
+int emul_attn_dkdv_n(const attn::BwdParams* p, int variant, int nsub, char* msg, int msg_len) {
     const int nw = variant == 4 ? 12 : 8;
     const int nkb = (p->S + 32 * nw - 1) / (32 * nw), nbh = p->B * p->NH;
     int races = 0;
@@ -49,6 +55,7 @@ int emul_attn_dkdv(const attn::BwdParams* p, int variant, char* msg, int msg_len
         const emul::RaceReport r = emul::run_group(nw, [&](emul::EmulWave& w) {
             if (variant == 2) attnb::dkdv<8, false>(w, *p, bh, kvb);
             else if (variant == 3) attnb::dkdv<8, true>(w, *p, bh, kvb);
+            else if (nsub == 2) attnb::dkdv_staged<12, true, 2>(w, *p, bh, kvb);
             else attnb::dkdv<12, true>(w, *p, bh, kvb);
         });
         if (r.races && !races && msg) snprintf(msg, msg_len, "%s", r.first.c_str());
@@ -56,6 +63,8 @@ int emul_attn_dkdv(const attn::BwdParams* p, int variant, char* msg, int msg_len
     }
     return races;
 }
+
+int emul_attn_dkdv(const attn::BwdParams* p, int variant, char* msg, int msg_len) { return emul_attn_dkdv_n(p, variant, 1, msg, msg_len); }
 
 int emul_attn_fwd_params_size() { return (int)sizeof(attn::FwdParams); }
 int emul_attn_bwd_params_size() { return (int)sizeof(attn::BwdParams); }

@@ -172,3 +172,23 @@ def test_emulated_dkdv_variants_agree(emul):
         res[variant] = (dk.float().clone(), dv.float().clone())
     assert torch.equal(res[3][0], res[4][0]) and torch.equal(res[3][1], res[4][1])
     assert rel_l2(res[3][0], res[2][0]) < 5e-3 and rel_l2(res[3][1], res[2][1]) < 5e-3
+
+
+@pytest.mark.parametrize("B,NH,S,layout", [(1, 2, 40, "bshd"), (2, 3, 300, "bshd"), (1, 8, 128, "bhsd"), (1, 1, 577, "bshd"), (1, 1, 800, "bshd")])
+def test_two_tiles_per_stage_is_bit_identical(emul, B, NH, S, layout):
+    """dQ and dK / dV with TWO tiles of 64 per LDS stage (half the workgroup barriers; opt-in on the device, debug option
+    "attn_stage" = 2): the same arithmetic in the same order, so the same bits as the one-tile form - one tile in all (40), an
+    odd tile count (300: 5, 577: 10 with a ragged tail, 800: 13 = a half-filled last stage), exact multiples (128) - and no LDS
+    race between the stage being filled and the stage being read."""
+    q, k, v, do = _make(B, NH, S, 21 + S, layout)
+    ro, rl, *_ = _oracle(q, k, v, do)
+    res = {}
+    for nsub in (1, 2):
+        p, (dq, dk, dv), keep = _bwd_params(q, k, v, do, ro, rl)
+        msg = ctypes.create_string_buffer(256)
+        assert emul.emul_attn_dq_n(ctypes.byref(p), nsub, msg, 256) == 0, msg.value.decode()
+        assert emul.emul_attn_dkdv_n(ctypes.byref(p), 4, nsub, msg, 256) == 0, msg.value.decode()
+        res[nsub] = [t.float().clone() for t in (dq, dk, dv)]
+        assert not any(torch.isnan(t).any() for t in res[nsub])
+    for a, b in zip(res[1], res[2]):
+        assert torch.equal(a, b)

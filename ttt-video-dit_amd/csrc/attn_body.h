@@ -341,6 +341,104 @@ TTT_BODY_FN void dq(BK& bk, const BwdParams& p, int bh, int qb) {
     }
 }
 
+// dq() with NSUB key tiles of 64 per LDS stage, i.e. one workgroup barrier per NSUB tiles: 2 halves the number of barriers and
+// doubles the loads in flight per stage.  Same arithmetic in the same order as dq() - bit-identical (tests/test_emul_attention_cpu.py) -;
+// a separate function so that the shipped kernel's code stays byte for byte what was measured; opt-in on the device (debug option
+// "attn_stage" = 2) until it has been timed.
+template <int NSUB, class BK>
+TTT_BODY_FN void dq_staged(BK& bk, const BwdParams& p, int bh, int qb) {
+    const int tid = bk.thread(), wv = bk.wave(), l = bk.lane(), h = l >> 5, c = l & 31;
+    const int bb = bh / p.NH, hh = bh % p.NH;
+    const __bf16* Qp = p.Q + (long)bb * p.q_sb + (long)hh * p.q_sh;
+    const __bf16* Kp = p.K + (long)bb * p.k_sb + (long)hh * p.k_sh;
+    const __bf16* Vp = p.V + (long)bb * p.v_sb + (long)hh * p.v_sh;
+    const __bf16* dOp = p.dO + (long)bb * p.do_sb + (long)hh * p.do_sh;
+
+    const int qrow = qb * QB + 32 * wv + c;
+    const bool qvalid = qrow < p.S;
+    bf16x8 Qf[4], Df[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        Qf[kk] = qvalid ? *reinterpret_cast<const bf16x8*>(Qp + (long)qrow * p.q_ss + 16 * kk + 8 * h) : zero_frag();
+        Df[kk] = qvalid ? *reinterpret_cast<const bf16x8*>(dOp + (long)qrow * p.do_ss + 16 * kk + 8 * h) : zero_frag();
+    }
+    const float lse2 = qvalid ? p.LSE[(long)bh * p.S + qrow] * LOG2E : 1e30f;
+    const float delta = qvalid ? p.Delta[(long)bh * p.S + qrow] : 0.f;
+    const float sc = p.scale * LOG2E;
+    f32x16 dQ[2] = {zero16(), zero16()};       // dQ^T tiles (rows = d, lane = query)
+    const int nt = (p.S + KB - 1) / KB;        // key tiles of 64
+    const int ns = (nt + NSUB - 1) / NSUB;     // LDS stages of NSUB tiles
+    constexpr int STAGE_ELEMS = NSUB * DQ_BUF_ELEMS;
+    KVStage st;                                // ONE tile in flight, as in dq(): the loads of tile u of the next stage are issued in
+                                               // front of this stage's tile u and parked behind it (the next stage's buffer is idle)
+
+    const typename BK::tile_t lds = bk.lds_base();
+#pragma unroll
+    for (int u = 0; u < NSUB; ++u) {           // (tiles past the end of the sequence are zero-filled and never computed on)
+        kv_issue(st, Kp, Vp, p.k_ss, p.v_ss, u * KB, p.S, tid);
+        kv_park(bk, st, lds + u * DQ_BUF_ELEMS, lds + u * DQ_BUF_ELEMS + KT_ELEMS, AS, tid);
+    }
+    bk.barrier();
+    for (int j = 0; j < ns; ++j) {
+        const typename BK::tile_t stage = lds + (j & 1) * STAGE_ELEMS;
+        const typename BK::tile_t nxt = lds + ((j + 1) & 1) * STAGE_ELEMS;
+        const bool more = j + 1 < ns;
+#pragma unroll
+        for (int u = 0; u < NSUB; ++u) {
+            const int jt = j * NSUB + u;       // key tile
+            if (more) kv_issue(st, Kp, Vp, p.k_ss, p.v_ss, ((j + 1) * NSUB + u) * KB, p.S, tid);
+            if (jt < nt) {                     // (workgroup-uniform: false only in the last stage of an odd tile count)
+            const typename BK::tile_t Kt = stage + u * DQ_BUF_ELEMS, Vt = Kt + KT_ELEMS;
+            const bool ragged = jt + 1 == nt && (p.S & (KB - 1));
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                f32x16 Sc = zero16(), dP = zero16();
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    Sc = bk.mma3216(row_frag(bk, Kt, AS, 32 * kb, 16 * kk, l), Qf[kk], Sc);
+                    dP = bk.mma3216(row_frag(bk, Vt, AS, 32 * kb, 16 * kk, l), Df[kk], dP);
+                }
+                if (ragged) {                   // keys >= S (zero-filled rows of the last tile) contribute nothing: P = 0 there.
+#pragma unroll                                  // Wave-uniform and kept a real branch: exp2(-1e30) == 0 exactly
+                    for (int r = 0; r < 16; ++r) {
+                        float v = Sc[r];
+                        if (jt * KB + 32 * kb + row_of(r, h) >= p.S) v = -1e30f;
+                        TTT_PIN_IN_BRANCH(v);
+                        Sc[r] = v;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pr = bk.exp2(__builtin_fmaf(Sc[r], sc, -lse2));
+                    dP[r] = pr * (dP[r] - delta);
+                }
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const bf16x8 df = pack(dP, s);
+                    dQ[0] = bk.mma3216(tr_frag_pi(bk, Kt, AS, 32 * kb, s, 0, l), df, dQ[0]);
+                    dQ[1] = bk.mma3216(tr_frag_pi(bk, Kt, AS, 32 * kb, s, 32, l), df, dQ[1]);
+                }
+            }
+            }
+            if (more) kv_park(bk, st, nxt + u * DQ_BUF_ELEMS, nxt + u * DQ_BUF_ELEMS + KT_ELEMS, AS, tid);
+        }
+        bk.barrier();
+    }
+
+    if (qvalid) {
+        __bf16* row = p.dQ + (long)bb * p.dq_sb + (long)hh * p.dq_sh + (long)qrow * p.dq_ss;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (__bf16)(dQ[db][4 * g + e] * p.scale);
+                *reinterpret_cast<bf16x4*>(row + 32 * db + 8 * g + 4 * h) = v;
+            }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------ dK, dV
 // dV = P^T dO, dK = scale * dS^T Q for the 32 * NW keys of block kvb: each wave keeps 32 key rows of K and V as register-resident
 // B operands and its dK / dV accumulator tiles over the whole loop over query tiles of 64 (Q, dO and the per-query LSE / Delta
@@ -491,6 +589,117 @@ TTT_BODY_FN void dkdv(BK& bk, const BwdParams& p, int bh, int kvb) {
             }
         }
         if (more) qstage_park(bk, st, lds + ((j + 1) & 1) * DKV_BUF_ELEMS, tid);
+        bk.barrier();
+    }
+
+    // epilogue: lane (c,h) register r of tile db holds element [key = key0 + row_of(r,h)][d = 32 db + c]
+    __bf16* dKp = p.dK + (long)bb * p.dk_sb + (long)hh * p.dk_sh;
+    __bf16* dVp = p.dV + (long)bb * p.dv_sb + (long)hh * p.dv_sh;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = key0 + row_of(r, h);
+            if (key < p.S) {
+                dKp[(long)key * p.dk_ss + 32 * db + c] = (__bf16)(dK[db][r] * p.scale);
+                dVp[(long)key * p.dv_ss + 32 * db + c] = (__bf16)dV[db][r];
+            }
+        }
+}
+
+// dkdv() with NSUB query tiles of 64 per LDS stage (see dq_staged)
+template <int NW, bool ACC_INIT, int NSUB, class BK>
+TTT_BODY_FN void dkdv_staged(BK& bk, const BwdParams& p, int bh, int kvb) {
+    const int tid = bk.thread(), wv = bk.wave(), l = bk.lane(), h = l >> 5, c = l & 31;
+    const int bb = bh / p.NH, hh = bh % p.NH;
+    const __bf16* Qp = p.Q + (long)bb * p.q_sb + (long)hh * p.q_sh;
+    const __bf16* Kp = p.K + (long)bb * p.k_sb + (long)hh * p.k_sh;
+    const __bf16* Vp = p.V + (long)bb * p.v_sb + (long)hh * p.v_sh;
+    const __bf16* dOp = p.dO + (long)bb * p.do_sb + (long)hh * p.do_sh;
+    const float* lse = p.LSE + (long)bh * p.S;
+    const float* del = p.Delta + (long)bh * p.S;
+
+    const int key0 = kvb * (32 * NW) + 32 * wv;      // this wave's first key
+    const int krow = key0 + c;
+    bf16x8 Kf[4], Vf[4];                              // B operands: lane = key, 8 contiguous d per k-slice
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        Kf[kk] = krow < p.S ? *reinterpret_cast<const bf16x8*>(Kp + (long)krow * p.k_ss + 16 * kk + 8 * h) : zero_frag();
+        Vf[kk] = krow < p.S ? *reinterpret_cast<const bf16x8*>(Vp + (long)krow * p.v_ss + 16 * kk + 8 * h) : zero_frag();
+    }
+    f32x16 dK[2] = {zero16(), zero16()}, dV[2] = {zero16(), zero16()};   // tiles (rows = key, lane = d in block db)
+    const float sc = p.scale * LOG2E, inv_scale = 1.0f / p.scale;
+
+    const int nt = (p.S + 63) / 64;            // query tiles of 64
+    const int ns = (nt + NSUB - 1) / NSUB;     // LDS stages of NSUB tiles (NSUB = 2: half the barriers; same arithmetic and order)
+    constexpr int STAGE_ELEMS = NSUB * DKV_BUF_ELEMS;
+    const typename BK::tile_t lds = bk.lds_base();
+    QStage st;                                 // ONE tile in flight, as in dkdv() (see dq_staged)
+#pragma unroll
+    for (int u = 0; u < NSUB; ++u) {           // (query tiles past the end are zero / masked rows and never computed on)
+        qstage_issue<ACC_INIT>(st, p, Qp, dOp, lse, del, inv_scale, u * 64, tid);
+        qstage_park(bk, st, lds + u * DKV_BUF_ELEMS, tid);
+    }
+    bk.barrier();
+
+    for (int j = 0; j < ns; ++j) {
+        const typename BK::tile_t stage = lds + (j & 1) * STAGE_ELEMS;
+        const typename BK::tile_t nxt = lds + ((j + 1) & 1) * STAGE_ELEMS;
+        const bool more = j + 1 < ns;
+#pragma unroll
+        for (int u = 0; u < NSUB; ++u) {
+        if (more) qstage_issue<ACC_INIT>(st, p, Qp, dOp, lse, del, inv_scale, ((j + 1) * NSUB + u) * 64, tid);
+        if (j * NSUB + u < nt) {                         // (workgroup-uniform: false only in the last stage of an odd tile count)
+        const typename BK::tile_t buf = stage + u * DKV_BUF_ELEMS;
+        const typename BK::tile_t Qt = buf, Dt = buf + KT_ELEMS;
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            f32x16 Sc, dP;
+            if (ACC_INIT) {
+                Sc = rows_from_lds(bk, buf, 0, 32 * qb, h);      // -LSE / scale
+                dP = rows_from_lds(bk, buf, 1, 32 * qb, h);      // -Delta
+            } else {
+                Sc = zero16();
+                dP = zero16();
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                Sc = bk.mma3216(row_frag(bk, Qt, AS, 32 * qb, 16 * kk, l), Kf[kk], Sc);
+                dP = bk.mma3216(row_frag(bk, Dt, AS, 32 * qb, 16 * kk, l), Vf[kk], dP);
+            }
+            if (ACC_INIT) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float pr = bk.exp2(Sc[r] * sc);
+                    TTT_PIN_IN_BRANCH(pr);           // opaque to the SLP vectorizer, which otherwise pairs P / dS elements across the
+                    Sc[r] = pr;                      // two tiles and then needs 40 moves / 16-bit shuffles per tile to un-pair them
+                    float ds = pr * dP[r];
+                    TTT_PIN_IN_BRANCH(ds);
+                    dP[r] = ds;
+                }
+            } else {
+                const f32x16 lseR = rows_from_lds(bk, buf, 0, 32 * qb, h);
+                const f32x16 delR = rows_from_lds(bk, buf, 1, 32 * qb, h);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pr = bk.exp2(__builtin_fmaf(Sc[r], sc, -lseR[r]));
+                    Sc[r] = pr;
+                    dP[r] = pr * (dP[r] - delR[r]);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 pf = pack(Sc, s), df = pack(dP, s);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    dV[db] = bk.mma3216(pf, tr_frag_pi(bk, Dt, AS, 32 * qb, s, 32 * db, l), dV[db]);
+                    dK[db] = bk.mma3216(df, tr_frag_pi(bk, Qt, AS, 32 * qb, s, 32 * db, l), dK[db]);
+                }
+            }
+        }
+        }
+        if (more) qstage_park(bk, st, nxt + u * DKV_BUF_ELEMS, tid);
+        }
         bk.barrier();
     }
 
