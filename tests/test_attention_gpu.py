@@ -187,7 +187,7 @@ def test_attention_two_tiles_per_stage_equals_default(B, NH, S, layout):
     q, k, v, do = make(B, NH, S, 31 + S, layout)
     res = {}
     try:
-        for stage in (1, 2):
+        for stage in (1, 2, 3, 4):           # 1 shipped kernels, 2 two tiles per stage, 3 swizzled tiles, 4 both
             e.debug_option("attn_stage", stage)
             qq, kk, vv = (t.detach().clone().requires_grad_(True) for t in (q, k, v))
             SegmentAttention.apply(qq, kk, vv).backward(do)
@@ -195,6 +195,7 @@ def test_attention_two_tiles_per_stage_equals_default(B, NH, S, layout):
             res[stage] = (qq.grad.clone(), kk.grad.clone(), vv.grad.clone())
     finally:
         e.debug_option("attn_stage", 1)
-    for a, b, name in zip(res[1], res[2], ("dq", "dk", "dv")):
-        assert not torch.isnan(b.float()).any(), name
-        assert torch.equal(a, b), name
+    for stage in (2, 3, 4):
+        for a, b, name in zip(res[1], res[stage], ("dq", "dk", "dv")):
+            assert not torch.isnan(b.float()).any(), (stage, name)
+            assert torch.equal(a, b), (stage, name)

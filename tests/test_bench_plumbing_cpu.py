@@ -41,3 +41,23 @@ def test_mlp_backward_workspace_holds_two_slot_buffers():
     assert slot == 287232
     steps = 5 * 16 + 1                             # 5 checkpoint groups per chunk at 48 heads + the post-update slot
     assert 2 * 48 * steps * slot < ws < 2 * 48 * steps * slot + (64 << 20), ws
+
+
+def test_counter_summaries_reproduce_from_the_committed_csvs():
+    """tools/wait_lds.py and tools/mfma_util.py on the rocprofv3 --pmc CSVs under profiles/: the summaries quoted in DESIGN.md
+    (section 8 table, section 4 MFMA utilisation) follow from the committed counter files."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "wait_lds.py"), os.path.join(ROOT, "profiles", "r3p_op_nc804_pmc_wait_lds.csv")],
+                         capture_output=True, text=True, check=True).stdout
+    rows = {l.split()[0]: l.split() for l in out.splitlines()[1:]}
+    sweep = next(v for k, v in rows.items() if "mlp_bwd_cluster4_kernel" in k)
+    scan = next(v for k, v in rows.items() if "mlp_scan8_kernel" in k)
+    pct = lambda s: float(s.rstrip("%"))
+    assert abs(pct(sweep[3]) - 72.7) < 0.2            # parked share of the sweep's wave cycles
+    assert abs(pct(scan[-1]) - 19.9) < 0.2            # bank-conflict share of the forward scan's CU cycles
+    committed = open(os.path.join(ROOT, "profiles", "r3p_wait_lds_summary.txt")).read()
+    assert out.strip() in committed
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "mfma_util.py"), os.path.join(ROOT, "profiles", "r3j_op_nc804_pmc_sq.csv")],
+                         capture_output=True, text=True, check=True).stdout
+    assert "mlp_bwd_cluster4_kernel" in out and "mlp_scan8_kernel" in out
