@@ -252,7 +252,9 @@ void        ttt_hip_debug_groups_per_chunk(int groups);
  * backward sweep hand-over: 1 (default) = plain, L2-resident records once the four workgroups of a cluster have proven that they
  * share an XCD; 0 = write-through records always), "sweep_fast_count" (query: returns -2 - the number of cluster workgroup
  * launches that took the plain form), "sweep_fault" (fault injection for the tests of the hand-over failure path: workgroup 3 of
- * every backward cluster leaves before its first hand-over).  Returns 0, or -1 for an unknown name.  (The round-1 knobs - kernel revisions, prefetch
+ * every backward cluster leaves before its first hand-over), "attn_stage" (attention backward: 1 (default) / 2 = two tiles of 64
+ * per LDS stage in the dQ and dK / dV kernels - half the workgroup barriers, bit-identical results, opt-in until timed).
+ * Returns 0, or -1 for an unknown name.  (The round-1 knobs - kernel revisions, prefetch
  * helpers, attention / scan variants - were A/B-ed on hardware in round 2 and removed together with the losing code.) */
 int         ttt_hip_debug_option(const char* name, int value);
 /* DEBUG: device buffer (>= 120000 floats) receiving the step-0 intermediates of workgroup 0 (NULL = off). */

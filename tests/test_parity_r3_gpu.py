@@ -111,6 +111,31 @@ def test_mfma_mlp_at_30s_length_vs_oracle():
     check_per_head(f"TTT-MLP MFMA NC={NC}", out, cks, g, ro, rc, rg, 1e-2, 3e-2)
 
 
+def test_mfma_mlp_at_63s_train_length_vs_oracle():
+    """The metric's SECOND context (BASELINE.json: "at 9s & 63s"; configs/train/ttt-mlp/63s.toml, ttt/models/configs.py:71-87):
+    253 latent frames + 21 x 458 text tokens = 351 168 tokens = 5 487 mini-batches of 64, checkpoint groups of 16 (343 groups,
+    the last one of 15 steps), forward + backward, chunked like the 48-head launch (5 groups per chunk -> 69 chunks).  The
+    carried state and state gradient walk 5 487 steps: the first and the last tenth of the sequence are compared separately
+    (drift of either would show at one end)."""
+    e = ext()
+    NH, NC, G = 2, 5487, 16
+    d = round_acts(O.make_inputs("mlp", 1, NH, NC, 64, 64, seed=6000 + NC), torch.bfloat16)
+    e.debug_groups_per_chunk(5)
+    try:
+        out, cks, g = run_mlp(e, d, G, torch.bfloat16, impl="mfma")
+    finally:
+        e.debug_groups_per_chunk(0)
+    assert e.sweep_error() == 0
+    ro, rc, rg = oracle_on(d, G, "mlp")
+    check_per_head(f"TTT-MLP MFMA NC={NC}", out, cks, g, ro, rc, rg, 1e-2, 3e-2)
+    tenth = NC // 10
+    for tag, sl in (("first tenth", slice(0, tenth)), ("last tenth", slice(NC - tenth, NC))):
+        sub = lambda t: t[:, :, sl]
+        gs = {k: sub(v) for k, v in g.items() if k in ("dXQ", "dXK", "dXV", "dlast_eta")}
+        rs = {k: sub(v) for k, v in rg.items() if k in gs}
+        check_per_head(f"TTT-MLP MFMA NC={NC}, {tag}", sub(out), (), gs, sub(ro), (), rs, 1e-2, 3e-2)
+
+
 @pytest.mark.parametrize("kind", ["mlp", "linear"])
 def test_mfma_cs16_at_63s_length_vs_oracle(kind):
     """BASELINE config 5 (configs/eval/ttt-mlp/63s.toml:9,45): 253 latent frames + 21 x 458 text tokens = 351 168 tokens =

@@ -34,6 +34,9 @@ def main():
     ap.add_argument("--b", type=int, default=1)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--no-sdpa", action="store_true")
+    ap.add_argument("--stages", default="", help="comma list of attention-backward variants to A/B in interleaved rounds in THIS process "
+                    "(debug option attn_stage: 1 shipped, 2 two tiles per LDS stage, 3 swizzled tiles, 4 both), e.g. 1,2,3,4")
+    ap.add_argument("--rounds", type=int, default=5)
     a = ap.parse_args()
     import test_time_training as ext
     from ttt_amd.models.cogvideo.attention import SegmentAttention
@@ -53,6 +56,24 @@ def main():
     delta = torch.empty(B, NH, S, device=dev)
     t = timeit(lambda: ext.attn_backward(q, k, v, out, do, lse, delta, dq, dk, dv, 0.125), a.iters)
     res["hip_bwd"] = {"ms": t, "tflops": 2.5 * flops / t / 1e9}
+    if a.stages:
+        # interleaved rounds, one process (the guide's rule for perf deltas): median and minimum per variant, and bit-identity
+        stages = [int(x) for x in a.stages.split(",")]
+        times = {st: [] for st in stages}
+        ref = None
+        for rnd in range(a.rounds):
+            for st in stages:
+                ext.debug_option("attn_stage", st)
+                times[st].append(timeit(lambda: ext.attn_backward(q, k, v, out, do, lse, delta, dq, dk, dv, 0.125), a.iters))
+                if rnd == 0:
+                    torch.cuda.synchronize()
+                    cur = [x.clone() for x in (dq, dk, dv)]
+                    if ref is None:
+                        ref = cur
+                    else:
+                        res.setdefault("bit_identical_to_first", {})[st] = all(torch.equal(x, y) for x, y in zip(cur, ref))
+        ext.debug_option("attn_stage", 1)
+        res["bwd_by_stage"] = {st: {"median_ms": sorted(v)[len(v) // 2], "min_ms": min(v)} for st, v in times.items()}
     if not a.no_sdpa:
         qq, kk, vv = (x.detach().clone().requires_grad_(True) for x in (q, k, v))
         t = timeit(lambda: F.scaled_dot_product_attention(qq, kk, vv), a.iters)

@@ -53,7 +53,44 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn_dkdv2_kernel(BwdParams p) 
     attnb::dkdv<NW, ACC_INIT>(bk, p, bh, kvb);
 }
 
+// Two tiles of 64 per LDS stage (half the workgroup barriers; attn_body.h dq_staged / dkdv_staged): opt-in through the debug
+// option "attn_stage" = 2 until timed on an MI355X; bit-identical to the shipped kernels (emulator: tests/test_emul_attention_cpu.py,
+// device: tests/test_attention_gpu.py::test_attention_two_tiles_per_stage_equals_default).
+template <int W, int NSUB, bool SWZ>
+__global__ __launch_bounds__(512, W) void attn_dq2s_kernel(BwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int bh, qb;
+    attnb::head_of_block(blockIdx.x, (p.S + attnb::QB - 1) / attnb::QB, p.B * p.NH, bh, qb);
+    AttnDeviceWave bk{reinterpret_cast<__bf16*>(smem)};
+    attnb::dq_staged<NSUB, SWZ>(bk, p, bh, qb);
+}
+template <int NW, bool ACC_INIT, int MINW, int NSUB, bool SWZ>
+__global__ __launch_bounds__(64 * NW, MINW) void attn_dkdv2s_kernel(BwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int bh, kvb;
+    attnb::head_of_block(blockIdx.x, (p.S + 32 * NW - 1) / (32 * NW), p.B * p.NH, bh, kvb);
+    AttnDeviceWave bk{reinterpret_cast<__bf16*>(smem)};
+    attnb::dkdv_staged<NW, ACC_INIT, NSUB, SWZ>(bk, p, bh, kvb);
+}
+static int g_attn_stage = 1;
+void set_debug_attn_stage(int v) { g_attn_stage = (v >= 1 && v <= 4) ? v : 1; }      // 1 shipped, 2 two tiles, 3 swizzled, 4 both
+
 void launch_dq_v2(const BwdParams& p, hipStream_t s) {
+    if (g_attn_stage != 1) {
+        const int nb2 = (p.S + attnb::QB - 1) / attnb::QB;
+        const dim3 grid(p.B * p.NH * nb2);
+        static bool attr2 = false;
+        if (!attr2) {
+            (void)hipFuncSetAttribute((const void*)attn_dq2s_kernel<4, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * attnb::LDS_DQ);
+            (void)hipFuncSetAttribute((const void*)attn_dq2s_kernel<4, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, attnb::LDS_DQ);
+            (void)hipFuncSetAttribute((const void*)attn_dq2s_kernel<4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * attnb::LDS_DQ);
+            attr2 = true;
+        }
+        if (g_attn_stage == 2) hipLaunchKernelGGL((attn_dq2s_kernel<4, 2, false>), grid, dim3(512), 2 * attnb::LDS_DQ, s, p);
+        else if (g_attn_stage == 3) hipLaunchKernelGGL((attn_dq2s_kernel<4, 1, true>), grid, dim3(512), attnb::LDS_DQ, s, p);
+        else hipLaunchKernelGGL((attn_dq2s_kernel<4, 2, true>), grid, dim3(512), 2 * attnb::LDS_DQ, s, p);
+        return;
+    }
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)attn_dq2_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, attnb::LDS_DQ);
@@ -65,6 +102,21 @@ void launch_dq_v2(const BwdParams& p, hipStream_t s) {
 
 void launch_dkdv_v2(const BwdParams& p, hipStream_t s) {       // accumulator-initialised row scalars, 12 waves (3 per SIMD)
     constexpr int NW = 12;
+    if (g_attn_stage != 1) {
+        const int nb2 = (p.S + 32 * NW - 1) / (32 * NW);
+        const dim3 grid(p.B * p.NH * nb2);
+        static bool attr2 = false;
+        if (!attr2) {
+            (void)hipFuncSetAttribute((const void*)attn_dkdv2s_kernel<NW, true, 3, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * attnb::LDS_DKV);
+            (void)hipFuncSetAttribute((const void*)attn_dkdv2s_kernel<NW, true, 3, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, attnb::LDS_DKV);
+            (void)hipFuncSetAttribute((const void*)attn_dkdv2s_kernel<NW, true, 3, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * attnb::LDS_DKV);
+            attr2 = true;
+        }
+        if (g_attn_stage == 2) hipLaunchKernelGGL((attn_dkdv2s_kernel<NW, true, 3, 2, false>), grid, dim3(64 * NW), 2 * attnb::LDS_DKV, s, p);
+        else if (g_attn_stage == 3) hipLaunchKernelGGL((attn_dkdv2s_kernel<NW, true, 3, 1, true>), grid, dim3(64 * NW), attnb::LDS_DKV, s, p);
+        else hipLaunchKernelGGL((attn_dkdv2s_kernel<NW, true, 3, 2, true>), grid, dim3(64 * NW), 2 * attnb::LDS_DKV, s, p);
+        return;
+    }
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)attn_dkdv2_kernel<NW, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, attnb::LDS_DKV);
