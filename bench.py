@@ -478,6 +478,7 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False, tp=False):
     import test_time_training as ext
     from ttt_amd.infra.parallelisms import (ReplicaMixedPrecision, apply_fsdp, enable_tuned_gemms, get_dp_mesh, init_distributed,
                                             init_model_parameters)
+    from ttt_amd.infra.train_step import checked_optimizer_step
     from ttt_amd.models.cogvideo.model import CogVideoX
     from ttt_amd.models.configs import ModelConfig
 
@@ -546,8 +547,10 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False, tp=False):
             tp_sync_gradients(model)                # partial parameter gradients (a rank's tokens / heads) summed over the group
         if replica:
             replica.collect_grads()                 # bf16 gradients -> fp32 gradients of the masters (what FSDP's reduce does)
-        torch.nn.utils.clip_grad_norm_(train_params, 1.0)
-        opt.step()
+        # clip -> ONE device synchronisation (the hand-over error word of the TTT-MLP backward; a production loop needs it before
+        # optimizer.step(), so the benchmark pays for it too) -> fused AdamW
+        if checked_optimizer_step(opt, train_params, 1.0) is None:
+            raise RuntimeError("a TTT-MLP backward hand-over timed out (or the gradient norm is not finite): step skipped")
         if replica:
             replica.publish()                       # fp32 masters -> bf16 compute copies (what FSDP's all-gather does)
         return loss

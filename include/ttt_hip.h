@@ -37,7 +37,11 @@
 extern "C" {
 #endif
 
-#define TTT_HIP_ABI_VERSION 1
+/* 2 (round 4): ttt_hip_mlp_forward / _backward return -3 (sticky: an earlier backward hand-over timed out; acknowledge with
+ * ttt_hip_sweep_error_clear), -10 (fewer than 4 compute units visible), -11 (no host-mapped error word), -12 (a HIP event /
+ * stream call of the backward's two-stream schedule failed); the round-1 exports ttt_hip_debug_variant / ttt_hip_debug_helpers
+ * are gone.  1: rounds 1 - 3. */
+#define TTT_HIP_ABI_VERSION 2
 
 enum { TTT_DTYPE_BF16 = 0, TTT_DTYPE_F32 = 1 };
 /* implementation selector: AUTO picks the MFMA kernels when the geometry is supported - bf16, F=64 and
@@ -78,7 +82,9 @@ typedef struct ttt_mlp_bwd_args {
     const float* W1_checkpoints; const float* b1_checkpoints;
     const float* W2_checkpoints; const float* b2_checkpoints;
     const void*  XQW;            /* forward output (unused by the arithmetic; kept for ABI parity) */
-    /* caller-allocated re-materialisation scratch, [B,NH,G,...] (mlp_tk.py:192-210) */
+    /* caller-allocated re-materialisation scratch, [B,NH,G,...] (mlp_tk.py:192-210).  The generic kernels keep their per-step
+     * state in the four *_init_group buffers (required there); the MFMA backward works in `ws` only and accepts NULL for all
+     * sixteen; the twelve below are never touched by this implementation. */
     float* W1_init_group; float* b1_init_group; float* W2_init_group; float* b2_init_group;
     void*  x_hat_ln_group;          /* bf16 [B,NH,G,CS,F]  */
     float* std_ln_group;            /* f32  [B,NH,G,CS,1]  */

@@ -12,6 +12,12 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+
+class _NoSweepError:
+    """stand-in for the extension's error word on a GPU-less box"""
+    sweep_error = staticmethod(lambda: 0)
+    sweep_error_clear = staticmethod(lambda: None)
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -100,6 +106,7 @@ def _replica_worker(rank, world, port, out_dir):
     torch.set_num_threads(2)
     from oracle import cpu_ext
     from ttt_amd.infra.parallelisms import ReplicaMixedPrecision, apply_fsdp, end_distributed, get_dp_mesh, init_distributed
+    from ttt_amd.infra.train_step import checked_optimizer_step
     cpu_ext.install()
     init_distributed("gloo")
     out = {}
@@ -119,8 +126,9 @@ def _replica_worker(rank, world, port, out_dir):
             loss.backward()
             if rep:
                 rep.collect_grads()
-            norm = torch.nn.utils.clip_grad_norm_(params, 1.0)
-            opt.step()
+            # the gated end of a step (ttt_amd/infra/train_step.py): DTensor norm under FSDP2, the flag all-reduced over the ranks
+            norm = checked_optimizer_step(opt, params, 1.0, extension=_NoSweepError)
+            assert norm is not None
             if rep:
                 rep.publish()
             trace.append((float(loss.detach()), float(norm.full_tensor() if hasattr(norm, "full_tensor") else norm)))

@@ -1,0 +1,54 @@
+"""checked_optimizer_step (ttt_amd/infra/train_step.py): a backward whose cluster hand-over timed out must never reach
+optimizer.step() - the round-3 advisor finding (poisoned gradients were only caught by the NEXT extension call)."""
+import torch
+
+from ttt_amd.infra.train_step import checked_optimizer_step
+
+
+class FakeExt:
+    def __init__(self, err=0):
+        self.err, self.cleared = err, 0
+
+    def sweep_error(self):
+        return self.err
+
+    def sweep_error_clear(self):
+        self.err, self.cleared = 0, self.cleared + 1
+
+
+def _model():
+    torch.manual_seed(0)
+    m = torch.nn.Linear(4, 3)
+    opt = torch.optim.AdamW(m.parameters(), lr=0.1)
+    return m, opt
+
+
+def test_clean_step_updates_and_returns_the_norm():
+    m, opt = _model()
+    w0 = m.weight.detach().clone()
+    m(torch.ones(2, 4)).sum().backward()
+    n = checked_optimizer_step(opt, m.parameters(), 1.0, extension=FakeExt(0))
+    assert n is not None and float(n) > 0 and not torch.equal(m.weight, w0)
+
+
+def test_timed_out_handover_skips_the_step_and_acknowledges():
+    m, opt = _model()
+    w0 = m.weight.detach().clone()
+    m(torch.ones(2, 4)).sum().backward()
+    m.weight.grad.fill_(float("nan"))                     # what the poisoned sweep leaves behind
+    e = FakeExt(1 + 17)
+    assert checked_optimizer_step(opt, m.parameters(), 1.0, extension=e) is None
+    assert torch.equal(m.weight, w0) and m.weight.grad is None and e.cleared == 1 and len(opt.state) == 0
+    # the batch can be run again
+    m(torch.ones(2, 4)).sum().backward()
+    assert checked_optimizer_step(opt, m.parameters(), 1.0, extension=e) is not None
+
+
+def test_non_finite_norm_without_an_error_word_also_skips():
+    m, opt = _model()
+    w0 = m.weight.detach().clone()
+    m(torch.ones(2, 4)).sum().backward()
+    m.bias.grad[0] = float("inf")
+    e = FakeExt(0)
+    assert checked_optimizer_step(opt, m.parameters(), 1.0, extension=e) is None
+    assert torch.equal(m.weight, w0) and e.cleared == 0

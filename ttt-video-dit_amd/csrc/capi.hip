@@ -131,7 +131,6 @@ int ttt_hip_mlp_backward(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws,
     if (!a) return fail("ttt_hip: null args");
     NEED(XQ); NEED(XK); NEED(XV); NEED(last_eta); NEED(ttt_norm_weight); NEED(ttt_norm_bias);
     NEED(W1_checkpoints); NEED(b1_checkpoints); NEED(W2_checkpoints); NEED(b2_checkpoints);
-    NEED(W1_init_group); NEED(b1_init_group); NEED(W2_init_group); NEED(b2_init_group);
     NEED(grad_L_W1_last); NEED(grad_L_b1_last); NEED(grad_L_W2_last); NEED(grad_L_b2_last); NEED(grad_L_XQW);
     NEED(grad_L_ttt_norm_weight); NEED(grad_L_ttt_norm_bias); NEED(grad_L_W1_init); NEED(grad_L_b1_init);
     NEED(grad_L_W2_init); NEED(grad_L_b2_init); NEED(grad_L_last_eta); NEED(grad_L_XQ); NEED(grad_L_XK); NEED(grad_L_XV);
@@ -139,9 +138,13 @@ int ttt_hip_mlp_backward(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws,
     if (r < 0) return fail("ttt_hip: mlp_backward: unsupported geometry/dtype for the requested impl");
     if (wsb < ws_bytes(d, true, true) || (ws_bytes(d, true, true) && !ws)) return fail("ttt_hip: mlp_backward: workspace too small");
     if (check_sweep_error("mlp_backward")) return -3;
+    // the caller-allocated re-materialisation scratch of the reference contract: only the generic kernels keep their per-step
+    // state in the four *_init_group buffers; the MFMA backward works in `ws` and accepts NULL for all sixteen
+    if (r != TTT_IMPL_MFMA) { NEED(W1_init_group); NEED(b1_init_group); NEED(W2_init_group); NEED(b2_init_group); }
     if (r == TTT_IMPL_MFMA) {
         const int rc = ttt::mfma::mlp_backward(d, a, ws, (hipStream_t)stream);
         if (rc == -10) return fail("ttt_hip: mlp_backward: the MFMA backward needs at least 4 visible compute units (four co-resident workgroups per (b,h))");
+        if (rc == -12) return fail("ttt_hip: mlp_backward: a HIP event / stream call of the two-stream schedule failed; the gradients of this call are not valid");
         if (rc) return fail("ttt_hip: mlp_backward: could not allocate the host-mapped error word");
     } else ttt::generic::mlp_backward(d, a, ws, (hipStream_t)stream);
     return post_launch("mlp_backward");

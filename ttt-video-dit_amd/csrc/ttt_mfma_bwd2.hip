@@ -21,6 +21,7 @@
 #include "ttt_mfma_int.h"
 #include "ttt_mfma_bwd_dev.h"
 #include "ttt_bwd4_dev.h"
+#include <mutex>
 
 namespace ttt {
 namespace mfma {
@@ -45,10 +46,12 @@ void set_debug_sweep_fault(int v) { g_sweep_fault = v; }
 
 // Compute units of the current device (cached per device): the cluster sweep needs its four workgroups co-resident, one per
 // CU (157 KiB of LDS each), so a launch carries at most n_cu / 4 clusters.
+static std::mutex g_dev_mutex;         // guards the per-device caches below (two autograd threads may enter with one device each - or the same)
 static int device_cus() {
     static int cus[16] = {0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
+    std::lock_guard<std::mutex> lock(g_dev_mutex);
     if (!cus[dev]) {
         int n = 0;
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
@@ -95,6 +98,7 @@ static OverlapRes* overlap_resources() {
     static OverlapRes res[16];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    std::lock_guard<std::mutex> lock(g_dev_mutex);
     OverlapRes& r = res[dev];
     if (r.state == 0) {
         bool ok = hipStreamCreateWithFlags(&r.side, hipStreamNonBlocking) == hipSuccess;
@@ -158,6 +162,8 @@ static int mlp_backward4(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws,
     bp.err = err_word; bp.fault = g_sweep_fault;
     bp.W1c = a->W1_checkpoints; bp.W2c = a->W2_checkpoints; bp.wfinal = wfinal; bp.park = park; bp.G = G; bp.K = K; bp.prefetch = g_sweep_prefetch;
 
+    int rc = 0;                               // a failed event / stream call leaves the two streams unordered: the call fails (-12)
+    auto chk = [&](hipError_t e) { if (e != hipSuccess) rc = -12; };
     const int nchunks = (K + gpc - 1) / gpc;
     OverlapRes* ov = (g_overlap && nchunks > 1) ? overlap_resources() : nullptr;
     const int free_cus = device_cus() - 4 * (nbh < per_launch ? nbh : per_launch);
@@ -182,7 +188,7 @@ static int mlp_backward4(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws,
         bp.first = (ch == nchunks - 1);
         bp.last = (ch == 0);
         bp.dbg = get_debug_timing();
-        (void)hipMemsetAsync(flags, 0, flag_bytes, s);        // hand-over flags restart at 0 for every launch
+        chk(hipMemsetAsync(flags, 0, flag_bytes, s));         // hand-over flags restart at 0 for every launch
         for (int bh0 = 0; bh0 < nbh; bh0 += per_launch) {
             bp.bh0 = bh0;
             bp.nbh = nbh - bh0 < per_launch ? nbh - bh0 : per_launch;
@@ -190,8 +196,8 @@ static int mlp_backward4(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws,
         }
     };
     if (ov) {           // the side stream starts after everything queued on `s` before this call (the inputs), not after A(n-1)
-        (void)hipEventRecord(ov->entry, s);
-        (void)hipStreamWaitEvent(ov->side, ov->entry, 0);
+        chk(hipEventRecord(ov->entry, s));
+        chk(hipStreamWaitEvent(ov->side, ov->entry, 0));
     }
     recompute(nchunks - 1, 0, s);
     if (!ov) {          // one stream: A(c) B(c) C(c) per chunk (chunk c in slot buffer c & 1)
@@ -200,7 +206,7 @@ static int mlp_backward4(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws,
             if (ch > 0) recompute(ch - 1, 0, s);
             tail(ch, s);
         }
-        return 0;
+        return rc;
     }
     if (g_overlap == 1) {
         // Tail beside the next sweep only (round 2's schedule): stream s: A(n-1) B(n-1) A(n-2) B(n-2) ... ; side: C(c) beside B(c-1).
@@ -209,16 +215,16 @@ static int mlp_backward4(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws,
             const int buf = ch & 1;
             sweep(ch);
             if (ch > 0) {
-                if (ch + 1 < nchunks) (void)hipStreamWaitEvent(s, ov->tail_done[buf ^ 1], 0);
+                if (ch + 1 < nchunks) chk(hipStreamWaitEvent(s, ov->tail_done[buf ^ 1], 0));
                 recompute(ch - 1, 0, s);
             }
-            (void)hipEventRecord(ov->ready[buf], s);
-            (void)hipStreamWaitEvent(ov->side, ov->ready[buf], 0);
+            chk(hipEventRecord(ov->ready[buf], s));
+            chk(hipStreamWaitEvent(ov->side, ov->ready[buf], 0));
             tail(ch, ov->side);
-            (void)hipEventRecord(ov->tail_done[buf], ov->side);
+            chk(hipEventRecord(ov->tail_done[buf], ov->side));
         }
-        (void)hipStreamWaitEvent(s, ov->tail_done[0], 0);
-        return 0;
+        chk(hipStreamWaitEvent(s, ov->tail_done[0], 0));
+        return rc;
     }
     // Two streams.  The sweep B(c) occupies 4 nbh CUs with latency-bound work; everything else of the backward runs BESIDE it on
     // the CUs it leaves free: the tail C(c+1) of the chunk before, then the recompute A(c-1) of the chunk after - in launches
@@ -233,23 +239,23 @@ static int mlp_backward4(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws,
     // "A of the chunk in buffer k is complete".
     for (int ch = nchunks - 1; ch >= 0; --ch) {
         const int buf = ch & 1;
-        if (ch != nchunks - 1) (void)hipStreamWaitEvent(s, ov->tail_done[buf], 0);          // A(ch) ran on the side stream
+        if (ch != nchunks - 1) chk(hipStreamWaitEvent(s, ov->tail_done[buf], 0));          // A(ch) ran on the side stream
         sweep(ch);
-        (void)hipEventRecord(ov->ready[buf], s);
+        chk(hipEventRecord(ov->ready[buf], s));
         if (ch + 1 <= nchunks - 1) {
-            (void)hipStreamWaitEvent(ov->side, ov->ready[buf ^ 1], 0);                         // B(ch+1) complete
+            chk(hipStreamWaitEvent(ov->side, ov->ready[buf ^ 1], 0));                         // B(ch+1) complete
             tail(ch + 1, ov->side);
         }
         if (ch - 1 >= 0) {
             recompute(ch - 1, free_cus, ov->side);
-            (void)hipEventRecord(ov->tail_done[buf ^ 1], ov->side);
+            chk(hipEventRecord(ov->tail_done[buf ^ 1], ov->side));
         }
     }
-    (void)hipStreamWaitEvent(ov->side, ov->ready[0], 0);
+    chk(hipStreamWaitEvent(ov->side, ov->ready[0], 0));
     tail(0, ov->side);
-    (void)hipEventRecord(ov->tail_done[0], ov->side);
-    (void)hipStreamWaitEvent(s, ov->tail_done[0], 0);              // the caller's stream joins the side stream
-    return 0;
+    chk(hipEventRecord(ov->tail_done[0], ov->side));
+    chk(hipStreamWaitEvent(s, ov->tail_done[0], 0));              // the caller's stream joins the side stream
+    return rc;
 }
 
 int mlp_backward(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hipStream_t s) {

@@ -57,6 +57,7 @@
 #include "ttt_bwd4_dev.h"
 #define TTT_WV_FN __device__ __forceinline__
 #include "ttt_bwd4_aux_body.h"
+#include <mutex>
 
 namespace ttt {
 namespace mfma {
@@ -646,11 +647,19 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
                 if (more) add_parts(reinterpret_cast<const float*>(exd), db2oL + cur * 64, db2oL + (cur ^ 1) * 64);
                 if (l < 3) {
                     const unsigned* f = p.flags + ((size_t)bh * 4 + ((cq + 1 + l) & 3)) * FLAG_STRIDE;
-                    // a poisoned workgroup (an earlier poll of this launch gave up) does not wait any more
-                    unsigned spins = syncw[2] != 0u ? (1u << 22) : 0u;      // (a poisoned workgroup does not wait at all)
+                    // A partner that is not running: give up LOUDLY instead of hanging the GPU - after a WALL-CLOCK time (the
+                    // constant 100-MHz counter, looked at every 256 polls), not after a number of polls: how long a poll takes
+                    // depends on what else the chip is doing (a profiler, RCCL kernels on the CUs a partner is waiting for).
+                    // 2 s is 5 orders above a step; fault injection: 2 ms.  A poisoned workgroup (an earlier poll of this
+                    // launch gave up) does not wait at all.
+                    const unsigned long long t_poll = wall_clock64();
+                    const unsigned long long t_lim = p.fault ? 200000ull : 200000000ull;
+                    unsigned spins = 0u;
+                    bool give_up = syncw[2] != 0u;
                     while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
                         __builtin_amdgcn_s_sleep(1);
-                        if (++spins > (p.fault ? (1u << 16) : (1u << 22))) {        // a partner is not running: give up LOUDLY instead of hanging the GPU (fault injection: sooner)
+                        if ((++spins & 255u) == 0u && wall_clock64() - t_poll > t_lim) give_up = true;
+                        if (give_up) {
                             __hip_atomic_store(p.err, 1u + (unsigned)bh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                             __hip_atomic_store(syncw + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             break;
@@ -673,11 +682,9 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
                 }
                 if (l == 0) __hip_atomic_store(syncw, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             } else {
-                unsigned spins = 0;
-                while (__hip_atomic_load(syncw, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < epoch) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > (1u << 24)) break;
-                }
+                // (no bound of its own: wave 2 of this workgroup always arrives - its poll above is bounded by the wall clock -, and
+                // a bound counted in polls here could expire BEFORE that one and let these waves go on with stale records)
+                while (__hip_atomic_load(syncw, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < epoch) __builtin_amdgcn_s_sleep(1);
             }
             TTT_OSTAMP(0)                      // flag + poll
             float G_[16];
@@ -1028,19 +1035,27 @@ __global__ __launch_bounds__(NT) void mlp_bwd_tail4_kernel(TailParams4 p) {
 // The error word lives in host-mapped memory: the kernels store to it with system scope, the host reads it without a copy -
 // at the entry of every TTT-MLP call without synchronising (a hand-over that gave up makes the NEXT call fail), or after a
 // device synchronisation when a test / bench asks.
+// One word for the process (a time-out on ANY device makes the next call fail), mapped into every device that asks: the host
+// allocation is portable, the device pointer is looked up per device.
 static unsigned* g_err_host = nullptr;
-static unsigned* g_err_dev = nullptr;
+static unsigned* g_err_dev[16] = {nullptr};
+static std::mutex g_err_mutex;
 unsigned* sweep_error_word() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    std::lock_guard<std::mutex> lock(g_err_mutex);
     if (!g_err_host) {
         void* h = nullptr;
-        if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess) return nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) return nullptr;
         *(volatile unsigned*)h = 0u;
-        void* d = nullptr;
-        if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipHostFree(h); return nullptr; }
         g_err_host = (unsigned*)h;
-        g_err_dev = (unsigned*)d;
     }
-    return g_err_dev;
+    if (!g_err_dev[dev]) {
+        void* d = nullptr;
+        if (hipHostGetDevicePointer(&d, g_err_host, 0) != hipSuccess) return nullptr;
+        g_err_dev[dev] = (unsigned*)d;
+    }
+    return g_err_dev[dev];
 }
 unsigned peek_sweep_error() { return g_err_host ? *(volatile unsigned*)g_err_host : 0u; }
 unsigned read_sweep_error() {
@@ -1060,12 +1075,17 @@ unsigned read_sweep_fast_count() {      // DEBUG statistic: cluster workgroup la
 namespace s4 {
 
 void launch_sweep_cluster4(const SweepParams4& bp, int nbh, hipStream_t s) {
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)b4::mlp_bwd_cluster4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, b4::LDS_CL);
-        (void)hipFuncSetAttribute((const void*)b4::mlp_bwd_cluster4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, b4::LDS_CL);
-        (void)hipFuncSetAttribute((const void*)b4::mlp_bwd_tail4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, b4::LDS_TAIL4);
-        attr = true;
+    static bool attr[16] = {false};           // per device: a function attribute is a property of the function ON a device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+        std::lock_guard<std::mutex> lock(g_err_mutex);
+        if (dev >= 0 && dev < 16 && !attr[dev]) {
+            (void)hipFuncSetAttribute((const void*)b4::mlp_bwd_cluster4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, b4::LDS_CL);
+            (void)hipFuncSetAttribute((const void*)b4::mlp_bwd_cluster4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, b4::LDS_CL);
+            (void)hipFuncSetAttribute((const void*)b4::mlp_bwd_tail4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, b4::LDS_TAIL4);
+            attr[dev] = true;
+        }
     }
     const dim3 grid(nbh * 4), blk(b4::NTC);
     if (bp.dbg) hipLaunchKernelGGL((b4::mlp_bwd_cluster4_kernel<true>), grid, blk, b4::LDS_CL, s, bp);

@@ -1,0 +1,40 @@
+"""The end of a training step on the HIP path: gradient clipping and the optimizer step, GATED on the backward having been whole.
+
+Why a helper: the TTT-MLP backward's cluster sweep (csrc/ttt_mfma_bwd4.hip) gives up LOUDLY when a partner workgroup is never
+scheduled - it poisons that call's gradients with NaN and sets a host-mapped error word that makes the NEXT extension call
+raise.  The host enqueues far ahead of the GPU, so by the time that next call is reached, ``clip_grad_norm_`` and
+``optimizer.step()`` of the poisoned step are already queued: AdamW would run on NaN gradients and every parameter and moment
+would be lost before the error surfaces (round-3 advisor finding).  Callers of the extension therefore MUST look at the word
+after the backward and before ``optimizer.step()``; this function is that look: one device synchronisation per step, placed
+where the reference's loop synchronises anyway (train.py reads ``loss.item()`` / the gradient norm for its log line).
+
+Reference call sequence mirrored: train.py's ``clip_grad_norm_`` -> ``optimizer.step()`` -> ``optimizer.zero_grad()``.
+"""
+from typing import Iterable, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def checked_optimizer_step(optimizer: torch.optim.Optimizer, parameters: Iterable[torch.nn.Parameter], max_norm: float,
+                           process_group: Optional[dist.ProcessGroup] = None, extension=None) -> Optional[torch.Tensor]:
+    """Clip, verify, step.  Returns the total gradient norm, or ``None`` when the step was SKIPPED because a backward
+    hand-over timed out on some rank (or the norm is not finite): the gradients are dropped (``zero_grad``), the error word is
+    acknowledged on every rank, parameters and optimizer state are untouched, and the caller may run the batch again.
+    Every rank takes the same decision (MAX all-reduce of the flag when a process group is initialised)."""
+    if extension is None:
+        import test_time_training as extension
+    params = [p for p in parameters if p.grad is not None]
+    total = torch.nn.utils.clip_grad_norm_(params, max_norm) if params else torch.zeros(())
+    err = int(extension.sweep_error())                      # synchronises the device: everything the backward enqueued has run
+    norm = total.full_tensor() if hasattr(total, "full_tensor") else total      # (FSDP2: the norm of sharded gradients is a DTensor)
+    bad = torch.tensor([1 if (err != 0 or not bool(torch.isfinite(norm))) else 0], device=norm.device, dtype=torch.int32)
+    if dist.is_available() and dist.is_initialized():
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=process_group)
+    if int(bad):
+        optimizer.zero_grad(set_to_none=True)
+        if err:
+            extension.sweep_error_clear()
+        return None
+    optimizer.step()
+    return total

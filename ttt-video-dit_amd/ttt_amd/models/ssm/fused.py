@@ -170,11 +170,13 @@ class FusedPreScanMLP(torch.autograd.Function):
         e16 = lambda *s: torch.empty(*s, device=dev, dtype=_BF16)
         up = (z32(B, NH, Fh, H), z32(B, NH, 1, H), z32(B, NH, H, Fh), z32(B, NH, 1, Fh))
         g_out = grad_out.to(_BF16).contiguous()
-        remat = (e32(B, NH, G, Fh, H), e32(B, NH, G, 1, H), e32(B, NH, G, H, Fh), e32(B, NH, G, 1, Fh),
-                 e16(B, NH, G, CS, Fh), e32(B, NH, G, CS, 1),
-                 e16(B, NH, G, CS, H), e16(B, NH, G, CS, H), e16(B, NH, G, CS, H), e16(B, NH, G, CS, H),
-                 e16(B, NH, G, CS, Fh), e16(B, NH, G, CS, H), e16(B, NH, G, CS, Fh), e16(B, NH, G, CS, Fh), e16(B, NH, G, CS, Fh),
-                 e32(B, NH, G, CS, 1))
+        # the reference's sixteen caller-allocated re-materialisation buffers (mlp_tk.py:192-210): the MFMA backward touches none
+        # of them (0.55 GB per call at 48 heads that nobody reads - round-3 verdict), the generic kernels four; the reference-
+        # shaped wrapper (mlp_tk.py here) keeps allocating all of them, as the ABI it mirrors demands
+        if ext.resolved_impl(B, NH, NC, CS, Fh, G, _BF16, mlp=True, backward=True) == "generic":
+            remat = (e32(B, NH, G, Fh, H), e32(B, NH, G, 1, H), e32(B, NH, G, H, Fh), e32(B, NH, G, 1, Fh)) + (None,) * 12
+        else:
+            remat = (None,) * 16
         d_lnw, d_lnb = e32(B, NH, 1, Fh), e32(B, NH, 1, Fh)
         d_state = (e32(B, NH, Fh, H), e32(B, NH, 1, H), e32(B, NH, H, Fh), e32(B, NH, 1, Fh))
         d_eta = torch.empty(B, NH, NC, CS, 1, device=dev, dtype=_BF16)
