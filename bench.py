@@ -239,10 +239,20 @@ def cpu_baseline(ssm_layer, budget_s=25.0):
     finally:
         TL.ttt_mlp, TL.ttt_linear = saved
     tok_s = n_vid / (dt * 42)
+    # How much the short sample flatters the CPU: the REFERENCE's own TransformerLayer (ttt/models/cogvideo/dit.py, ops path) timed
+    # in the build container on these very samples and on the whole 13-frame attention segment (tools/ref_cpu_layer_baseline.py,
+    # BASELINE.md section 2, 8 vCPU): seconds per video token and layer relative to the full segment (L = 18 048).
+    REF_FULL_SEGMENT_RATIO = {1: 2.78, 4: 1.56, 13: 1.0}
+    ratio = REF_FULL_SEGMENT_RATIO.get(frames)
     return {"value": tok_s, "unit": "video-tokens/s", "cores": threads, "kind": "port", "dtype": "f32",
+            "full_segment_ratio": ratio, "value_at_full_segment": (tok_s / ratio) if ratio else None,
+            "reference_measured": {"where": "build container, 8 vCPU Xeon 2.1 GHz, BASELINE.md section 2", "video_tok_s_42_layers": {"L=1408": 7.76, "L=5440": 4.36, "L=18048": 2.79}},
             "sample": f"1 of 42 TransformerLayers (5B geometry, {ssm_layer}) fwd+bwd, fp32 eager, scan = oracle dual form (reference ops "
                       f"path restated, checkpoint groups of 16), one scene of {frames} latent frame(s) + {L - n_vid} text tokens "
-                      f"(L={L}; the 3 s segment is 13 frames, L=18048): {dt:.2f} s on {threads} threads; scaled by 42 layers"}
+                      f"(L={L}; the 3 s segment is 13 frames, L=18048): {dt:.2f} s on {threads} threads; scaled by 42 layers.  `value` is "
+                      f"that sample; per video token the reference's own layer costs {ratio} x more at the full segment than on this "
+                      f"sample (measured with the reference's code, BASELINE.md section 2), so the bench workload's CPU rate is "
+                      f"value / {ratio} = `value_at_full_segment`"}
 
 
 def size_warm_and_time(step, hk, remat_free_layers, warmup, steps, world):

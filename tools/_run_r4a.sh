@@ -1,0 +1,26 @@
+#!/bin/bash
+# Round 4, call A: (1) does the library with the staged attention kernels merged in still run its default path?  (2) the parity
+# items of the round-3 verdict on the device: lr-gate gradients without the exception, the 63 s training length against the oracle,
+# the reference's TkMLP argument lists replayed; (3) the 9 s line (no regression from the owners' fp32 column sums / the gated
+# optimizer step); (4) the FIRST 63 s training step on one GPU; (5) the staged / swizzled attention backward: diagnosis + A/B.
+cd /root/repo; mkdir -p gpurun_out/r4a; O=gpurun_out/r4a
+export TMPDIR=/tmp
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; rc=$?; echo "smoke rc=$rc"; tail -3 $O/smoke.log | cut -c1-300
+if [ $rc -ne 0 ]; then
+  echo "default path broken with the staged kernels in the library: runtime log, then falling back to the library without them"
+  AMD_LOG_LEVEL=3 timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke_amdlog.log 2>&1; tail -60 $O/smoke_amdlog.log | cut -c1-250
+  cp ttt-video-dit_amd/lib/alt/libttt_hip_nostaged.so ttt-video-dit_amd/lib/libttt_hip.so
+fi
+timeout 900 python -m pytest tests/test_parity_r4_gpu.py tests/test_parity_r3_gpu.py tests/test_parity_r2_gpu.py -q -m gpu -s -x > $O/parity.log 2>&1; echo "parity rc=$?"
+grep -h "lr_gate\|learning-rate-gate\|argument lists\|passed\|failed\|NC=5487" $O/parity.log | cut -c1-400 | tail -20
+timeout 420 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fsdp1-compare > $O/bench_9s.json 2> $O/bench_9s.err; echo "bench 9s rc=$?"
+grep -h "^{" $O/bench_9s.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print(d['value'], d['ms_per_step'], d['config']['remat_free_layers'], d['peak_mem_gib'], 'bwd ms', r['avg_launch_ms'], {k: round(v['avg_ms'],2) for k,v in r['other'].items()})"
+timeout 1200 python bench.py --video-length 63sec --steps 1 --warmup 1 --remat-free-layers 0 --remat-keep none --no-cpu-baseline --no-fsdp1-compare > $O/bench_63s.json 2> $O/bench_63s.err; echo "bench 63s rc=$?"
+tail -5 $O/bench_63s.err | cut -c1-300
+grep -h "^{" $O/bench_63s.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print(d['value'], d['ms_per_step'], d['peak_mem_gib'], 'bwd ms', r['avg_launch_ms'], {k: round(v['avg_ms'],2) for k,v in r['other'].items()})"
+if [ $rc -eq 0 ]; then
+  AMD_LOG_LEVEL=3 timeout 120 python -m pytest tests/test_attention_gpu.py -x -q -m gpu -k two_tiles > $O/attn_stage_amdlog.log 2>&1; echo "attn two_tiles rc=$?"
+  grep -v "^:3:\|^:4:" $O/attn_stage_amdlog.log | tail -15 | cut -c1-300; grep -n "rror\|abort\|fault" $O/attn_stage_amdlog.log | head -20 | cut -c1-300
+  timeout 300 python tools/attn_bench.py --no-sdpa --stages 1,2,3,4 --rounds 5 > $O/attn_bench_stages.log 2>&1; echo "attn_bench rc=$?"; tail -12 $O/attn_bench_stages.log | cut -c1-250
+fi
+timeout 600 python -m pytest tests -q -m gpu -x --deselect tests/test_parity_r3_gpu.py --deselect tests/test_parity_r2_gpu.py --deselect tests/test_parity_r4_gpu.py > $O/gpu_suite_rest.log 2>&1; echo "rest of suite rc=$?"; tail -3 $O/gpu_suite_rest.log | cut -c1-300
