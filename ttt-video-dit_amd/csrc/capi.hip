@@ -60,6 +60,7 @@ int ttt_hip_debug_option(const char* name, int value) {
     else if (!strcmp(name, "rc_nt")) ttt::mfma::set_debug_rc_nt(value);
     else if (!strcmp(name, "sweep_prefetch")) ttt::mfma::set_debug_sweep_prefetch(value);      // revision-4 sweep: L2 prefetch touches (1 default / 0)
     else if (!strcmp(name, "attn_stage")) ttt::attn::set_debug_attn_stage(value);               // attention backward: tiles of 64 per LDS stage, 1 (default) / 2
+    else if (!strcmp(name, "sweep_owner_overlap")) ttt::mfma::set_debug_sweep_owner_overlap(value);      // owners' partner-independent math under the record loads (1 default / 0: round-3 order)
     else if (!strcmp(name, "sweep_fault")) ttt::mfma::set_debug_sweep_fault(value);              // fault injection: workgroup 3 of every sweep cluster leaves early
     else return -1;
     return 0;

@@ -159,7 +159,15 @@ struct DeriverBackend {
     __device__ __forceinline__ void store_stream(char* p, bf16x8 v) const { __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(p)); }
 };
 
-template <bool DBG>
+#define TTT_PIN_RECORDS(dep)                                                                                                              \
+    asm volatile("; records consumed from here"                                                                                           \
+                 : "+v"(pa[0][0]), "+v"(pa[0][1]), "+v"(pa[0][2]), "+v"(pa[0][3]), "+v"(pa[1][0]), "+v"(pa[1][1]), "+v"(pa[1][2]), "+v"(pa[1][3]), \
+                   "+v"(pa[2][0]), "+v"(pa[2][1]), "+v"(pa[2][2]), "+v"(pa[2][3]), "+v"(pa[3][0]), "+v"(pa[3][1]), "+v"(pa[3][2]), "+v"(pa[3][3]) \
+                 : "v"(dep))
+
+// OVL (round 4, debug option "sweep_owner_overlap", default on): the owners' partner-independent arithmetic runs while the partner
+// records are in flight; off = the round-3 order (wait for the records, then all the arithmetic), kept for the A/B.
+template <bool DBG, bool OVL>
 __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __bf16* Kt2 = reinterpret_cast<__bf16*>(smem + L_K);
@@ -689,10 +697,10 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
             TTT_OSTAMP(0)                      // flag + poll
             float G_[16];
             float dep[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            // all four records - this workgroup's own included - come back through memory with sc1 loads: no branch on cq,
+            // and the same summation order q = 0..3 on all four workgroups -> bit-identical dZ2 everywhere
+            f32x4 pa[4][4];
             {
-                // all four records - this workgroup's own included - come back through memory with sc1 loads: no branch on cq,
-                // and the same summation order q = 0..3 on all four workgroups -> bit-identical dZ2 everywhere
-                f32x4 pa[4][4];
                 const int vo = (ot * PS + of0) * 4;
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq)
@@ -706,15 +714,13 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
                             dep[2 * qq + u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, XCH_PART_BYTES + (u * 64 + ot) * 4,
                                                                                                         xrec + qq * XCH_REC_BYTES, 16));
                 }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const f32x4 v = ((pa[0][u] + pa[1][u]) + pa[2][u]) + pa[3][u];
-                    G_[4 * u] = v[0]; G_[4 * u + 1] = v[1]; G_[4 * u + 2] = v[2]; G_[4 * u + 3] = v[3];
-                }
             }
-            TTT_OSTAMP(1)                      // the four records have arrived
             {
+                // ---- what needs no partner - gZ2 of this step in fp32 and its row statistics, the db2 term of d(eta) - runs while
+                // the records are in flight (round 4: the ISA used to wait for all sixteen loads first and start this arithmetic
+                // afterwards; the asm statement below pins the order)
                 const float eta_t = etaL2[cur * 64 + ot];
+                if constexpr (!OVL) TTT_PIN_RECORDS(eta_t);
                 float gxh[16], gz[16];
                 float s1g = 0.f, s2g = 0.f;
 #pragma unroll
@@ -724,16 +730,31 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
                 }
                 s1g = sum4(s1g); s2g = sum4(s2g);
                 float se = 0.f, s1 = 0.f, s2 = 0.f;
+                float edb[16];
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
                     gz[k] = (64.0f * gxh[k] - s1g - xh[k] * s2g) * r * (1.0f / 64.0f);      // gZ2 (fp32)
                     const float db2 = db2L[of0 + k] + db2oL[cur * 64 + of0 + k];
                     se += gz[k] * db2;
-                    G_[k] -= eta_t * db2;                                                    // d(gZ2) complete
+                    edb[k] = eta_t * db2;
+                }
+                se = sum4(se);
+                // the records are "produced" here as far as the compiler can tell: their sums cannot be scheduled (and waited
+                // for) above the arithmetic that `se` depends on
+                if constexpr (OVL) TTT_PIN_RECORDS(se);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const f32x4 v = ((pa[0][u] + pa[1][u]) + pa[2][u]) + pa[3][u];
+                    G_[4 * u] = v[0]; G_[4 * u + 1] = v[1]; G_[4 * u + 2] = v[2]; G_[4 * u + 3] = v[3];
+                }
+                TTT_OSTAMP(1)                  // the four records have arrived
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    G_[k] -= edb[k];                                                         // d(gZ2) complete
                     const float m = -G_[k] * r;
                     s1 += m; s2 += m * xh[k];
                 }
-                se = sum4(se); s1 = sum4(s1); s2 = sum4(s2);
+                s1 = sum4(s1); s2 = sum4(s2);
                 float a1 = 0.f, a2 = 0.f, dxh[16];
                 bf16x8 dv0, dv1;
 #pragma unroll
@@ -1072,6 +1093,9 @@ unsigned read_sweep_fast_count() {      // DEBUG statistic: cluster workgroup la
     return v;
 }
 
+static int g_owner_overlap = 1;
+void set_debug_sweep_owner_overlap(int v) { g_owner_overlap = v; }
+
 namespace s4 {
 
 void launch_sweep_cluster4(const SweepParams4& bp, int nbh, hipStream_t s) {
@@ -1081,15 +1105,22 @@ void launch_sweep_cluster4(const SweepParams4& bp, int nbh, hipStream_t s) {
     {
         std::lock_guard<std::mutex> lock(g_err_mutex);
         if (dev >= 0 && dev < 16 && !attr[dev]) {
-            (void)hipFuncSetAttribute((const void*)b4::mlp_bwd_cluster4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, b4::LDS_CL);
-            (void)hipFuncSetAttribute((const void*)b4::mlp_bwd_cluster4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, b4::LDS_CL);
+            (void)hipFuncSetAttribute((const void*)b4::mlp_bwd_cluster4_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, b4::LDS_CL);
+            (void)hipFuncSetAttribute((const void*)b4::mlp_bwd_cluster4_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, b4::LDS_CL);
+            (void)hipFuncSetAttribute((const void*)b4::mlp_bwd_cluster4_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, b4::LDS_CL);
+            (void)hipFuncSetAttribute((const void*)b4::mlp_bwd_cluster4_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, b4::LDS_CL);
             (void)hipFuncSetAttribute((const void*)b4::mlp_bwd_tail4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, b4::LDS_TAIL4);
             attr[dev] = true;
         }
     }
     const dim3 grid(nbh * 4), blk(b4::NTC);
-    if (bp.dbg) hipLaunchKernelGGL((b4::mlp_bwd_cluster4_kernel<true>), grid, blk, b4::LDS_CL, s, bp);
-    else hipLaunchKernelGGL((b4::mlp_bwd_cluster4_kernel<false>), grid, blk, b4::LDS_CL, s, bp);
+    if (g_owner_overlap) {
+        if (bp.dbg) hipLaunchKernelGGL((b4::mlp_bwd_cluster4_kernel<true, true>), grid, blk, b4::LDS_CL, s, bp);
+        else hipLaunchKernelGGL((b4::mlp_bwd_cluster4_kernel<false, true>), grid, blk, b4::LDS_CL, s, bp);
+    } else {
+        if (bp.dbg) hipLaunchKernelGGL((b4::mlp_bwd_cluster4_kernel<true, false>), grid, blk, b4::LDS_CL, s, bp);
+        else hipLaunchKernelGGL((b4::mlp_bwd_cluster4_kernel<false, false>), grid, blk, b4::LDS_CL, s, bp);
+    }
 }
 
 void launch_tail4(const __bf16* dOut, const __bf16* eta, const __bf16* dXV, char* slots, size_t slot_stride_bh, __bf16* dXQ, __bf16* dXK,
