@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--write-through-records", action="store_true", help="DEBUG A/B: the backward sweep's hand-over records always write-through (sc1), never plain")
     ap.add_argument("--rc-nt", type=int, default=1, help="A/B: revision-4 recompute, non-temporal stores of the step records")
     ap.add_argument("--prefetch", type=int, default=1, help="A/B: revision-4 sweep, L2 prefetch touches two steps ahead (1 default, 0 off)")
+    ap.add_argument("--owner-overlap", type=int, default=1, help="A/B: revision-4 sweep, owners' partner-independent arithmetic under the record loads (1 default, 0 = round-3 order)")
+    ap.add_argument("--ab", default=None, metavar="OPTION", help="interleaved A/B inside one process: the named debug option alternates 0 / 1 from iteration to iteration; the backward's average is reported per value (same box, same clocks)")
     ap.add_argument("--phases", action="store_true", help="also print per-phase cycle totals of workgroup 0")
     a = ap.parse_args()
     import test_time_training as ext
@@ -43,6 +45,7 @@ def main():
     ext.set_impl(a.impl)
     ext.debug_option("fast_records", 0 if a.write_through_records else 1)
     ext.debug_option("sweep_prefetch", a.prefetch)
+    ext.debug_option("sweep_owner_overlap", a.owner_overlap)
     ext.debug_option("rc_nt", a.rc_nt)
     ext.debug_option("overlap_tail", a.overlap)
     ext.debug_option("groups_per_chunk", a.gpc)
@@ -81,14 +84,22 @@ def main():
             times[_k].append((s, e))
         setattr(ext, name, wrapped)
 
+    ab = {0: [], 1: []}
     for it in range(a.iters + 2):
         if it == 2:
             torch.cuda.synchronize()
             times = {"fwd": [], "bwd": []}
+        if a.ab:
+            ext.debug_option(a.ab, it & 1)
+        n0 = len(times["bwd"])
         out = fwd()
         if not a.fwd_only:
             out.backward(dOut)
+        if a.ab and it >= 2:
+            ab[it & 1] += times["bwd"][n0:]
     torch.cuda.synchronize()
+    if a.ab:
+        ext.debug_option(a.ab, 1)
     g = 2.0 * CS * F * H
     nfl = {"fwd": (7 if a.kind == "mlp" else 3) * g, "bwd": (14 if a.kind == "mlp" else 6) * g}
     res = {"kind": a.kind, "impl_requested": a.impl, "shape": [B, NH, NC, CS, F], "G": G}
@@ -101,6 +112,8 @@ def main():
         res[k] = {"impl": ext.resolved_impl(B, NH, NC, CS, F, G, torch.bfloat16, a.kind == "mlp", k == "bwd"),
                   "avg_ms": avg, "min_ms": ms[0], "us_per_step": 1e3 * avg / NC, "tflops": fl / (avg * 1e-3) / 1e12,
                   "frac_mfma_peak": fl / (avg * 1e-3) / 2.5e15, "frac_occupied_cu_peak": fl / (avg * 1e-3) / (2.5e15 * min(B * NH, 256) / 256)}
+    if a.ab:
+        res["ab"] = {"option": a.ab, **{str(v): {"bwd_avg_ms": sum(s.elapsed_time(e) for s, e in ev) / max(1, len(ev)), "n": len(ev)} for v, ev in ab.items()}}
     if a.phases:
         buf = torch.zeros(32, dtype=torch.int64, device=dev)
         ext.debug_timing(buf)
