@@ -80,6 +80,14 @@ TTT_WV_FN f32x4 rowsum64(BK& bk, const f32x4 (&v)[4]) {
     for (int r = 0; r < 4; ++r) s[r] = bk.sum16(s[r]);
     return s;
 }
+// column sums over the 16 tokens of a (rows = t, lane = f) tile, in fp32: the lane's four rows, then the four row groups (lanes
+// l ^ 16, l ^ 32) - replicated over the row groups like the first row of a ones-MFMA product.  Round 4: the bias gradients
+// db1 are summed from the fp32 tiles instead of by a ones-MFMA over their bf16 packs (the same finding as in the TTT-MLP sweep,
+// tests/test_rounding_budget_cpu.py: db enters d(eta) of every token of every earlier step).
+template <class BK>
+TTT_WV_FN float colsum16(BK& bk, const f32x4& v) {
+    return bk.xor_add(bk.xor_add((v[0] + v[1]) + (v[2] + v[3]), 16), 32);
+}
 // (rows = t, lane = f) tiles -> [16 t][64 f] bf16 in global memory, 8 bytes per lane and feature block, through the [f][t]
 // image `img_off`
 template <class BK>
@@ -529,12 +537,15 @@ TTT_WV_FN void backward(BK& bk, const Lin16Params& p, int bh) {
                 const f32x4 u1 = rowsum64(bk, dxl), u2 = rowsum64(bk, t2);
                 const f32x4 sc = rstdl * (1.0f / 64.0f);
 #pragma unroll
-                for (int fb = 0; fb < 4; ++fb) dZbp[fb] = pack4((64.0f * dxl[fb] - u1 - y[fb] * u2) * sc);
+                for (int fb = 0; fb < 4; ++fb) {
+                    const f32x4 dzb = (64.0f * dxl[fb] - u1 - y[fb] * u2) * sc;
+                    dZbp[fb] = pack4(dzb);
+                    db[fb] += colsum16(bk, dzb);                                                        // db1n += colsum dZ1b (fp32)
+                }
             }
             // ---- (3) dW1n += Q^T dZ1b ; db1n += colsum dZ1b ------------------------------------------------------------------------------
 #pragma unroll
             for (int fb = 0; fb < 4; ++fb) {
-                db[fb] += bk.mma16(ONES, dZbp[fb], zero4())[0];
 #pragma unroll
                 for (int fa = 0; fa < 4; ++fa) dWt[fa][fb] = bk.mma16(qT[fa], dZbp[fb], dWt[fa][fb]);
             }
@@ -585,6 +596,7 @@ TTT_WV_FN void backward(BK& bk, const Lin16Params& p, int bh) {
             bk.lds_fence();
             // ---- (6) dgZ1 = -eta (K dW1n + db1n) ; (8) backward of the fused LN / L2 gradient -> dZ1, dt, dgamma, dbeta -----------------
             bf16x4 dZ1p[4];
+            float dbz[4];                        // colsum dZ1 (fp32), added to db1 in (10) - d(eta) in (7) needs db1n
             f32x4 dk[4];                     // starts as -dt (dt = gradient w.r.t. the target V - K = dV)
             {
                 f32x4 dgz[4], mGr[4], t2[4];
@@ -613,7 +625,11 @@ TTT_WV_FN void backward(BK& bk, const Lin16Params& p, int bh) {
                 }
                 const f32x4 v1 = rowsum64(bk, dxh) * (1.0f / 64.0f), v2 = rowsum64(bk, dstd) * (1.0f / 64.0f);
 #pragma unroll
-                for (int fb = 0; fb < 4; ++fb) dZ1p[fb] = pack4((dxh[fb] - v1) * ig.rstd + ig.xh[fb] * v2);
+                for (int fb = 0; fb < 4; ++fb) {
+                    const f32x4 dz1 = (dxh[fb] - v1) * ig.rstd + ig.xh[fb] * v2;
+                    dZ1p[fb] = pack4(dz1);
+                    dbz[fb] = colsum16(bk, dz1);
+                }
                 f32x4 dv[4];
 #pragma unroll
                 for (int fb = 0; fb < 4; ++fb) dv[fb] = -dk[fb];
@@ -656,7 +672,7 @@ TTT_WV_FN void backward(BK& bk, const Lin16Params& p, int bh) {
             // ---- (10) dW1 = dW1n + K^T dZ1 ; db1 = db1n + colsum dZ1 --------------------------------------------------------------------------------
 #pragma unroll
             for (int fb = 0; fb < 4; ++fb) {
-                db[fb] += bk.mma16(ONES, dZ1p[fb], zero4())[0];
+                db[fb] += dbz[fb];
 #pragma unroll
                 for (int fa = 0; fa < 4; ++fa) dWt[fa][fb] = bk.mma16(kT[fa], dZ1p[fb], dWt[fa][fb]);
             }
