@@ -58,6 +58,7 @@ int emul_attn_dkdv_n(const attn::BwdParams* p, int variant, int nsub, char* msg,
             if (variant == 2) attnb::dkdv<8, false>(w, *p, bh, kvb);
             else if (variant == 3) attnb::dkdv<8, true>(w, *p, bh, kvb);
             else if (nsub == 2) attnb::dkdv_staged<12, true, 2>(w, *p, bh, kvb);
+            else if (nsub == 3) attnb::dkdv_staged<12, true, 3>(w, *p, bh, kvb);
             else if (nsub == 4) attnb::dkdv_staged<12, true, 4>(w, *p, bh, kvb);
             else if (nsub == -1) attnb::dkdv_staged<12, true, 1, true>(w, *p, bh, kvb);
             else if (nsub == -2) attnb::dkdv_staged<12, true, 2, true>(w, *p, bh, kvb);

@@ -193,6 +193,13 @@ def test_two_tiles_per_stage_is_bit_identical(emul, B, NH, S, layout):
     for nsub in (2, -1, -2):
         for a, b in zip(res[1], res[nsub]):
             assert torch.equal(a, b), nsub
+    # dK / dV with three and four tiles per stage (one workgroup per CU: up to 148 KiB of LDS; round-4 A/B candidates)
+    for nsub in (3, 4):
+        p, (dq, dk, dv), keep = _bwd_params(q, k, v, do, ro, rl)
+        msg = ctypes.create_string_buffer(256)
+        assert emul.emul_attn_dkdv_n(ctypes.byref(p), 4, nsub, msg, 256) == 0, msg.value.decode()
+        for a, b in zip(res[1][1:], (dk.float(), dv.float())):
+            assert torch.equal(a, b), nsub
 
 
 def test_lds_bank_model_of_the_backward_bodies(emul):

@@ -208,12 +208,12 @@ def test_dit_on_hip_path_vs_reference_golden(name):
     # models is off by up to 2.3 - 3.0e-2 (tests/golden/dit_bf16_yardstick.pt).  The two learning-rate-gate parameters (token
     # sums of d(eta)): round 2 / 3 measured 0.12 - 0.15 with the MFMA kernels against 0.02 - 0.03 with the fp32-arithmetic
     # generic kernels and bounded them by 0.25; round 4 found the cause (db2's column sums taken from a bf16 tile,
-    # tests/test_rounding_budget_cpu.py) and the TTT-MLP fixture at mini-batches of 64 is held to the common 8e-2.  The
-    # TTT-Linear fixture (mini-batches of 16, ttt_lin16_body.h) and the dual-form 3-scene fixture (a different function of the
-    # eta tile, hazard C2) keep the 0.25 bound.
+    # tests/test_rounding_budget_cpu.py; the TTT-Linear backward had the same path for db1) and the single-scene fixtures are held
+    # to the common 8e-2 (measured: TTT-MLP <= 3.0e-2, TTT-Linear <= 7.6e-3, profiles/r4a_parity_tests.log).  The dual-form
+    # 3-scene fixture is a different function of the eta tile (hazard C2) and keeps the 0.25 bound (measured 2.0e-2).
     tol = 0.25 if multi else 8e-2
     lr_gate = ("learnable_ttt_lr_bias", "learnable_ttt_lr_weight")
-    lr_tol = 8e-2 if name == "dit_mlp64_1scene.pt" else 0.25
+    lr_tol = 0.25 if multi else 8e-2
     print(name, "learning-rate-gate gradients:", {k.split("layers.")[1][:2] + k.rsplit("_", 1)[1]: round(v, 4) for k, v in errs.items() if k.endswith(lr_gate)})
     bad = {k: v for k, v in errs.items() if k != "out" and not v < (lr_tol if k.endswith(lr_gate) else tol)}
     assert not bad, bad

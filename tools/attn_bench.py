@@ -34,8 +34,8 @@ def main():
     ap.add_argument("--b", type=int, default=1)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--no-sdpa", action="store_true")
-    ap.add_argument("--stages", default="", help="comma list of attention-backward variants to A/B in interleaved rounds in THIS process "
-                    "(debug option attn_stage: 1 shipped, 2 two tiles per LDS stage, 3 swizzled tiles, 4 both), e.g. 1,2,3,4")
+    ap.add_argument("--stages", default="", help="comma list of attention-backward variants to A/B in interleaved rounds in THIS process: "
+                    "DQ:DKDV = tiles of 64 per LDS stage in the dQ (1 / 2) and the dK / dV kernel (1 .. 4), e.g. 1:1,2:2,2:3,2:4,1:2")
     ap.add_argument("--rounds", type=int, default=5)
     a = ap.parse_args()
     import test_time_training as ext
@@ -58,12 +58,13 @@ def main():
     res["hip_bwd"] = {"ms": t, "tflops": 2.5 * flops / t / 1e9}
     if a.stages:
         # interleaved rounds, one process (the guide's rule for perf deltas): median and minimum per variant, and bit-identity
-        stages = [int(x) for x in a.stages.split(",")]
+        stages = [x if ":" in x else f"{x}:{x}" for x in a.stages.split(",")]
         times = {st: [] for st in stages}
         ref = None
         for rnd in range(a.rounds):
             for st in stages:
-                ext.debug_option("attn_stage", st)
+                ext.debug_option("attn_stage_dq", int(st.split(":")[0]))
+                ext.debug_option("attn_stage_dkdv", int(st.split(":")[1]))
                 times[st].append(timeit(lambda: ext.attn_backward(q, k, v, out, do, lse, delta, dq, dk, dv, 0.125), a.iters))
                 if rnd == 0:
                     torch.cuda.synchronize()
@@ -72,7 +73,7 @@ def main():
                         ref = cur
                     else:
                         res.setdefault("bit_identical_to_first", {})[st] = all(torch.equal(x, y) for x, y in zip(cur, ref))
-        ext.debug_option("attn_stage", 1)
+        ext.debug_option("attn_stage", 2)
         res["bwd_by_stage"] = {st: {"median_ms": sorted(v)[len(v) // 2], "min_ms": min(v)} for st, v in times.items()}
     if not a.no_sdpa:
         qq, kk, vv = (x.detach().clone().requires_grad_(True) for x in (q, k, v))

@@ -53,44 +53,49 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn_dkdv2_kernel(BwdParams p) 
     attnb::dkdv<NW, ACC_INIT>(bk, p, bh, kvb);
 }
 
-// Two tiles of 64 per LDS stage (half the workgroup barriers; attn_body.h dq_staged / dkdv_staged): opt-in through the debug
-// option "attn_stage" = 2 until timed on an MI355X; bit-identical to the shipped kernels (emulator: tests/test_emul_attention_cpu.py,
-// device: tests/test_attention_gpu.py::test_attention_two_tiles_per_stage_equals_default).
-template <int W, int NSUB, bool SWZ>
+// SEVERAL tiles of 64 per LDS stage (attn_body.h dq_staged / dkdv_staged): one workgroup barrier per NSUB tiles instead of one per
+// tile, the same arithmetic in the same order - bit-identical to the one-tile kernels (emulator: tests/test_emul_attention_cpu.py,
+// device: tests/test_attention_gpu.py::test_attention_tiles_per_stage_equal_the_one_tile_kernels).  Round 4, one MI355X,
+// 48 heads x S = 18 048 (profiles/r4a_attn_backward_stages_ab.log): two tiles per stage 13.51 ms per backward against 14.17 ms
+// (one tile); the XOR-swizzled unpadded tiles of round 3 - conflict-free under the bank model - LOST on the device (15.08 ms
+// alone, 15.02 ms with two tiles: the extra address arithmetic costs more than the replays it removes) and their device
+// instantiations are gone (the body keeps the template parameter for the emulator's bank-model tests).
+template <int W, int NSUB>
 __global__ __launch_bounds__(512, W) void attn_dq2s_kernel(BwdParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int bh, qb;
     attnb::head_of_block(blockIdx.x, (p.S + attnb::QB - 1) / attnb::QB, p.B * p.NH, bh, qb);
     AttnDeviceWave bk{reinterpret_cast<__bf16*>(smem)};
-    attnb::dq_staged<NSUB, SWZ>(bk, p, bh, qb);
+    attnb::dq_staged<NSUB, false>(bk, p, bh, qb);
 }
-template <int NW, bool ACC_INIT, int MINW, int NSUB, bool SWZ>
+template <int NW, bool ACC_INIT, int MINW, int NSUB>
 __global__ __launch_bounds__(64 * NW, MINW) void attn_dkdv2s_kernel(BwdParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int bh, kvb;
     attnb::head_of_block(blockIdx.x, (p.S + 32 * NW - 1) / (32 * NW), p.B * p.NH, bh, kvb);
     AttnDeviceWave bk{reinterpret_cast<__bf16*>(smem)};
-    attnb::dkdv_staged<NW, ACC_INIT, NSUB, SWZ>(bk, p, bh, kvb);
+    attnb::dkdv_staged<NW, ACC_INIT, NSUB, false>(bk, p, bh, kvb);
 }
-static int g_attn_stage = 1;
-void set_debug_attn_stage(int v) { g_attn_stage = (v >= 1 && v <= 4) ? v : 1; }      // 1 shipped, 2 two tiles, 3 swizzled, 4 both
+// tiles of 64 per LDS stage: dQ 1 / 2 (two workgroups of 73 KiB share a CU), dK / dV 1 .. 4 (one workgroup of 768 threads per CU:
+// up to 148 KiB).  Debug option "attn_stage" sets both, "attn_stage_dq" / "attn_stage_dkdv" one of them (A/B).
+static int g_stage_dq = 2, g_stage_dkdv = 2;
+void set_debug_attn_stage(int which, int v) {
+    if (which != 2) g_stage_dq = (v >= 1 && v <= 2) ? v : 2;
+    if (which != 1) g_stage_dkdv = (v >= 1 && v <= 4) ? v : 2;
+}
 
-void launch_dq_v2(const BwdParams& p, hipStream_t s) {
-    if (g_attn_stage != 1) {
-        const int nb2 = (p.S + attnb::QB - 1) / attnb::QB;
-        const dim3 grid(p.B * p.NH * nb2);
-        static bool attr2 = false;
-        if (!attr2) {
-            (void)hipFuncSetAttribute((const void*)attn_dq2s_kernel<4, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * attnb::LDS_DQ);
-            (void)hipFuncSetAttribute((const void*)attn_dq2s_kernel<4, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, attnb::LDS_DQ);
-            (void)hipFuncSetAttribute((const void*)attn_dq2s_kernel<4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * attnb::LDS_DQ);
-            attr2 = true;
-        }
-        if (g_attn_stage == 2) hipLaunchKernelGGL((attn_dq2s_kernel<4, 2, false>), grid, dim3(512), 2 * attnb::LDS_DQ, s, p);
-        else if (g_attn_stage == 3) hipLaunchKernelGGL((attn_dq2s_kernel<4, 1, true>), grid, dim3(512), attnb::LDS_DQ, s, p);
-        else hipLaunchKernelGGL((attn_dq2s_kernel<4, 2, true>), grid, dim3(512), 2 * attnb::LDS_DQ, s, p);
-        return;
+template <int NSUB>
+static void launch_dq_staged(const BwdParams& p, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)attn_dq2s_kernel<4, NSUB>, hipFuncAttributeMaxDynamicSharedMemorySize, NSUB * attnb::LDS_DQ);
+        attr = true;
     }
+    const int nb = (p.S + attnb::QB - 1) / attnb::QB;
+    hipLaunchKernelGGL((attn_dq2s_kernel<4, NSUB>), dim3(p.B * p.NH * nb), dim3(512), NSUB * attnb::LDS_DQ, s, p);
+}
+void launch_dq_v2(const BwdParams& p, hipStream_t s) {
+    if (g_stage_dq == 2) return launch_dq_staged<2>(p, s);
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)attn_dq2_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, attnb::LDS_DQ);
@@ -100,23 +105,23 @@ void launch_dq_v2(const BwdParams& p, hipStream_t s) {
     hipLaunchKernelGGL(attn_dq2_kernel<4>, dim3(p.B * p.NH * nb), dim3(512), attnb::LDS_DQ, s, p);
 }
 
+template <int NSUB>
+static void launch_dkdv_staged(const BwdParams& p, hipStream_t s) {
+    constexpr int NW = 12;
+    static_assert(NSUB * attnb::LDS_DKV <= 160 * 1024, "LDS budget");
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)attn_dkdv2s_kernel<NW, true, 3, NSUB>, hipFuncAttributeMaxDynamicSharedMemorySize, NSUB * attnb::LDS_DKV);
+        attr = true;
+    }
+    const int nb = (p.S + 32 * NW - 1) / (32 * NW);
+    hipLaunchKernelGGL((attn_dkdv2s_kernel<NW, true, 3, NSUB>), dim3(p.B * p.NH * nb), dim3(64 * NW), NSUB * attnb::LDS_DKV, s, p);
+}
 void launch_dkdv_v2(const BwdParams& p, hipStream_t s) {       // accumulator-initialised row scalars, 12 waves (3 per SIMD)
     constexpr int NW = 12;
-    if (g_attn_stage != 1) {
-        const int nb2 = (p.S + 32 * NW - 1) / (32 * NW);
-        const dim3 grid(p.B * p.NH * nb2);
-        static bool attr2 = false;
-        if (!attr2) {
-            (void)hipFuncSetAttribute((const void*)attn_dkdv2s_kernel<NW, true, 3, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * attnb::LDS_DKV);
-            (void)hipFuncSetAttribute((const void*)attn_dkdv2s_kernel<NW, true, 3, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, attnb::LDS_DKV);
-            (void)hipFuncSetAttribute((const void*)attn_dkdv2s_kernel<NW, true, 3, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * attnb::LDS_DKV);
-            attr2 = true;
-        }
-        if (g_attn_stage == 2) hipLaunchKernelGGL((attn_dkdv2s_kernel<NW, true, 3, 2, false>), grid, dim3(64 * NW), 2 * attnb::LDS_DKV, s, p);
-        else if (g_attn_stage == 3) hipLaunchKernelGGL((attn_dkdv2s_kernel<NW, true, 3, 1, true>), grid, dim3(64 * NW), attnb::LDS_DKV, s, p);
-        else hipLaunchKernelGGL((attn_dkdv2s_kernel<NW, true, 3, 2, true>), grid, dim3(64 * NW), 2 * attnb::LDS_DKV, s, p);
-        return;
-    }
+    if (g_stage_dkdv == 2) return launch_dkdv_staged<2>(p, s);
+    if (g_stage_dkdv == 3) return launch_dkdv_staged<3>(p, s);
+    if (g_stage_dkdv == 4) return launch_dkdv_staged<4>(p, s);
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)attn_dkdv2_kernel<NW, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, attnb::LDS_DKV);

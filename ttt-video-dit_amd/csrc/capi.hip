@@ -59,7 +59,9 @@ int ttt_hip_debug_option(const char* name, int value) {
     else if (!strcmp(name, "groups_per_chunk")) ttt::mfma::set_debug_groups_per_chunk(value);
     else if (!strcmp(name, "rc_nt")) ttt::mfma::set_debug_rc_nt(value);
     else if (!strcmp(name, "sweep_prefetch")) ttt::mfma::set_debug_sweep_prefetch(value);      // revision-4 sweep: L2 prefetch touches (1 default / 0)
-    else if (!strcmp(name, "attn_stage")) ttt::attn::set_debug_attn_stage(value);               // attention backward: tiles of 64 per LDS stage, 1 (default) / 2
+    else if (!strcmp(name, "attn_stage")) ttt::attn::set_debug_attn_stage(0, value);            // attention backward: tiles of 64 per LDS stage (default 2; 1 = round-3 kernels)
+    else if (!strcmp(name, "attn_stage_dq")) ttt::attn::set_debug_attn_stage(1, value);         //   dQ kernel only (1 / 2)
+    else if (!strcmp(name, "attn_stage_dkdv")) ttt::attn::set_debug_attn_stage(2, value);       //   dK / dV kernel only (1 .. 4)
     else if (!strcmp(name, "sweep_owner_overlap")) ttt::mfma::set_debug_sweep_owner_overlap(value);      // owners' partner-independent math under the record loads (1 default / 0: round-3 order)
     else if (!strcmp(name, "sweep_fault")) ttt::mfma::set_debug_sweep_fault(value);              // fault injection: workgroup 3 of every sweep cluster leaves early
     else return -1;
