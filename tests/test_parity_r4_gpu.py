@@ -56,3 +56,42 @@ def test_reference_tkmlp_argument_lists_replayed_on_the_device():
     assert errs["out"] < 1e-2, errs
     bad = {k: v for k, v in errs.items() if k != "out" and not v < 3e-2}
     assert not bad, (bad, errs)
+
+
+def _run_sweep_variant(e, d, G, **opts):
+    from test_kernels_gpu import run_mlp
+    for k, v in opts.items():
+        e.debug_option(k, v)
+    e.debug_groups_per_chunk(2)
+    try:
+        return run_mlp(e, d, G, torch.bfloat16, impl="mfma")
+    finally:
+        e.debug_groups_per_chunk(0)
+        e.debug_option("sweep_owner_overlap", 1)
+        e.debug_option("sweep_records_bf16", 0)
+
+
+def test_sweep_schedule_and_record_variants():
+    """Round-4 variants of the TTT-MLP backward sweep (csrc/ttt_mfma_bwd4.hip): (a) the owners' partner-independent arithmetic
+    ordered under the record loads (default) against the round-3 order - the same arithmetic, so the same bits; (b) hand-over
+    records that carry the partial d(gZ2) tiles as bf16 (debug option "sweep_records_bf16") - another rounding, so compared
+    with the fp64 oracle at the usual tolerances, head by head, and required to be run-to-run deterministic."""
+    from oracle import ttt_oracle as O
+    from test_kernels_gpu import oracle_on, round_acts
+    from test_parity_r2_gpu import check_per_head
+    e = ext()
+    NH, NC, G = 8, 70, 16
+    d = round_acts(O.make_inputs("mlp", 1, NH, NC, 64, 64, seed=8100), torch.bfloat16)
+    out1, cks1, g1 = _run_sweep_variant(e, d, G, sweep_owner_overlap=1)
+    out0, cks0, g0 = _run_sweep_variant(e, d, G, sweep_owner_overlap=0)
+    assert e.sweep_error() == 0
+    for k in g1:
+        assert torch.equal(g1[k], g0[k]), f"owner-overlap order changed the bits of {k}"
+    ro, rc, rg = oracle_on(d, G, "mlp")
+    check_per_head("TTT-MLP MFMA backward, default sweep", out1, cks1, g1, ro, rc, rg, 1e-2, 3e-2)
+    outb, cksb, gb = _run_sweep_variant(e, d, G, sweep_records_bf16=1)
+    outc, cksc, gc = _run_sweep_variant(e, d, G, sweep_records_bf16=1)
+    assert e.sweep_error() == 0
+    check_per_head("TTT-MLP MFMA backward, bf16 hand-over records", outb, cksb, gb, ro, rc, rg, 1e-2, 3e-2)
+    for k in gb:
+        assert torch.equal(gb[k], gc[k]), f"bf16 records: {k} differs between two identical calls"
