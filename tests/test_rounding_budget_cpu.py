@@ -35,6 +35,9 @@ def test_sweep_rounding_budget_lr_gate(emul):
     r4, worst4 = emul.run(set(emul.POINTS) - {"dZ2b_colsum"}, g)
     assert all(v < bound[k] for k, v in r4.items()), (r4, bound)
     assert worst4 < 8e-2
+    # the bf16 hand-over records (debug option "sweep_records_bf16") stay inside the same budget
+    r16, worst16 = emul.run(set(emul.POINTS) - {"dZ2b_colsum"} | {"P_rec"}, g)
+    assert all(v < bound[k] for k, v in r16.items()) and worst16 < 8e-2, (r16, worst16)
     r3, _ = emul.run(set(emul.POINTS), g)                                            # the round-3 sweep: the finding itself
     assert max(r3.values()) > 0.15, r3
     only, _ = emul.run({"dZ2b_colsum"}, g)

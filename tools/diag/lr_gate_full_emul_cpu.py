@@ -48,7 +48,12 @@ def step_bwd(st_in, Q, K, V, eta, gam, bet, dOut, dst, on):
     deta = -((gZ1 * e1).sum(-1, keepdim=True) + (X2 * a2).sum(-1, keepdim=True) + (s["gZ2"] * db2n).sum(-1, keepdim=True))
     deta = r("deta_out", deta)
     u = r("u", -eta * e1 * D1)
-    dgZ2 = -eta * (X2 @ d2p) + u @ W2m - eta * db2n
+    if "P_rec" in on:       # option "sweep_records_bf16": the four hidden slices' partial d(gZ2) tiles rounded to bf16 before they are summed
+        parts = [bf(-eta * (X2[..., :, 64 * q:64 * q + 64] @ d2p[..., 64 * q:64 * q + 64, :]) + u[..., :, 64 * q:64 * q + 64] @ W2m[..., 64 * q:64 * q + 64, :])
+                 for q in range(4)]
+        dgZ2 = ((parts[0] + parts[1]) + parts[2]) + parts[3] - eta * db2n
+    else:
+        dgZ2 = -eta * (X2 @ d2p) + u @ W2m - eta * db2n
     dZ2, dgam2, dbet2, dt = O._ln_l2_bwd_bwd(dgZ2, s["xh"], s["std"], s["go"], s["gxh"], s["gZ2"], gam, Fd)
     dgam = dgam + dgam2.sum(-2, keepdim=True)
     dbet = dbet + dbet2.sum(-2, keepdim=True)
@@ -124,6 +129,7 @@ if __name__ == "__main__":
     print("none                         ", *run(set(), g), flush=True)
     print("ALL (round 3 sweep)          ", *run(set(POINTS), g), flush=True)
     print("all but dZ2b_colsum (round 4)", *run(set(POINTS) - {"dZ2b_colsum"}, g), flush=True)
+    print("round 4 + bf16 records       ", *run(set(POINTS) - {"dZ2b_colsum"} | {"P_rec"}, g), flush=True)
     if len(sys.argv) > 1 and sys.argv[1] == "quick":
         sys.exit(0)
     for pnt in POINTS:
