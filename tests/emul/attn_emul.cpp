@@ -46,6 +46,23 @@ int emul_attn_dq_n(const attn::BwdParams* p, int nsub, char* msg, int msg_len) {
 
 int emul_attn_dq(const attn::BwdParams* p, char* msg, int msg_len) { return emul_attn_dq_n(p, 1, msg, msg_len); }
 
+// dq_wide: NQ = 2 blocks of 32 query rows per wave (a workgroup covers 512 rows), nsub tiles of 64 keys per LDS stage
+int emul_attn_dq_wide(const attn::BwdParams* p, int nsub, char* msg, int msg_len) {
+    const int nqb = (p->S + 2 * attnb::QB - 1) / (2 * attnb::QB), nbh = p->B * p->NH;
+    int races = 0;
+    for (int b = 0; b < nbh * nqb; ++b) {
+        int bh, qb;
+        attnb::head_of_block(b, nqb, nbh, bh, qb);
+        const emul::RaceReport r = emul::run_group(8, [&](emul::EmulWave& w) {
+            if (nsub == 2) attnb::dq_wide<2, 2>(w, *p, bh, qb);
+            else attnb::dq_wide<1, 2>(w, *p, bh, qb);
+        });
+        if (r.races && !races && msg) snprintf(msg, msg_len, "%s", r.first.c_str());
+        races += r.races;
+    }
+    return races;
+}
+
 // variant 2 = <8 waves, revision 1's arithmetic>, 3 = <8, accumulator-initialised row scalars>, 4 = <12, ...> (attn.h)
 int emul_attn_dkdv_n(const attn::BwdParams* p, int variant, int nsub, char* msg, int msg_len) {
     const int nw = variant == 4 ? 12 : 8;

@@ -237,3 +237,22 @@ def test_swizzled_tiles_are_conflict_free_both_ways(emul):
         assert emul.emul_attn_bank_model(ctypes.byref(p), kernel, out) == 0
         print("kernel", kernel, list(out))
         assert out[1] == 0 and out[4] == 0 and out[7] == 0
+
+
+@pytest.mark.parametrize("B,NH,S,layout", [(1, 2, 40, "bshd"), (1, 1, 300, "bshd"), (1, 1, 577, "bhsd"), (1, 1, 700, "bshd")])
+def test_dq_with_64_query_rows_per_wave_is_bit_identical(emul, B, NH, S, layout):
+    """dq_wide<NSUB, 2> (csrc/attn_body.h, round 4): a wave owns TWO blocks of 32 query rows, so every K / V fragment read from LDS
+    feeds two MFMAs (half the LDS bytes per MFMA); a workgroup covers 512 rows.  A query row's arithmetic and its order over the
+    keys are dq()'s: same bits - one partly filled workgroup (40, 300), a ragged key tail inside the second workgroup (577), rows
+    of the second query block past the end (700) - and no LDS race, with one and with two key tiles per stage."""
+    q, k, v, do = _make(B, NH, S, 77 + S, layout)
+    ro, rl, *_ = _oracle(q, k, v, do)
+    p, (dq, dk, dv), keep = _bwd_params(q, k, v, do, ro, rl)
+    msg = ctypes.create_string_buffer(256)
+    assert emul.emul_attn_dq_n(ctypes.byref(p), 1, msg, 256) == 0, msg.value.decode()
+    ref = dq.float().clone()
+    for nsub in (1, 2):
+        p, (dq, dk, dv), keep = _bwd_params(q, k, v, do, ro, rl)
+        assert emul.emul_attn_dq_wide(ctypes.byref(p), nsub, msg, 256) == 0, msg.value.decode()
+        assert not torch.isnan(dq.float()).any()
+        assert torch.equal(dq.float(), ref), nsub

@@ -473,6 +473,130 @@ TTT_BODY_FN void dq_staged(BK& bk, const BwdParams& p, int bh, int qb) {
     }
 }
 
+// dq_staged() with NQ blocks of 32 query rows per wave (round 4).  Why: every attention loop here feeds each MFMA with ONE 1-KiB
+// fragment read from LDS - 32 cycles of the CU's LDS bandwidth share per SIMD for 32 cycles of MFMA pipe -, so the LDS array and the
+// MFMA pipe are loaded equally and neither gets past ~40 % (profiles/r3p_wait_lds_summary.txt: LDS busy 29 - 42 % of the CU cycles
+// with 3 - 4 waves per SIMD, MFMA busy 37 - 40 %).  A wave that owns 64 query rows uses every K / V fragment (row and transposed)
+// for TWO MFMAs: half the LDS bytes per MFMA, at 2 waves of <= 256 registers per SIMD instead of 4 of 128.  The arithmetic of a
+// query row and its order over the keys are those of dq(): bit-identical (tests/test_emul_attention_cpu.py).
+// Workgroup = 8 waves = 256 * NQ query rows (block qb).
+template <int NSUB, int NQ, class BK>
+TTT_BODY_FN void dq_wide(BK& bk, const BwdParams& p, int bh, int qb) {
+    const int tid = bk.thread(), wv = bk.wave(), l = bk.lane(), h = l >> 5, c = l & 31;
+    const int bb = bh / p.NH, hh = bh % p.NH;
+    const __bf16* Qp = p.Q + (long)bb * p.q_sb + (long)hh * p.q_sh;
+    const __bf16* Kp = p.K + (long)bb * p.k_sb + (long)hh * p.k_sh;
+    const __bf16* Vp = p.V + (long)bb * p.v_sb + (long)hh * p.v_sh;
+    const __bf16* dOp = p.dO + (long)bb * p.do_sb + (long)hh * p.do_sh;
+
+    int qrow[NQ];
+    bool qvalid[NQ];
+    bf16x8 Qf[NQ][4], Df[NQ][4];
+    float lse2[NQ], delta[NQ];
+    f32x16 dQ[NQ][2];                           // dQ^T tiles (rows = d, lane = query)
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) {
+        qrow[qi] = qb * (QB * NQ) + 32 * NQ * wv + 32 * qi + c;
+        qvalid[qi] = qrow[qi] < p.S;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            Qf[qi][kk] = qvalid[qi] ? *reinterpret_cast<const bf16x8*>(Qp + (long)qrow[qi] * p.q_ss + 16 * kk + 8 * h) : zero_frag();
+            Df[qi][kk] = qvalid[qi] ? *reinterpret_cast<const bf16x8*>(dOp + (long)qrow[qi] * p.do_ss + 16 * kk + 8 * h) : zero_frag();
+        }
+        lse2[qi] = qvalid[qi] ? p.LSE[(long)bh * p.S + qrow[qi]] * LOG2E : 1e30f;
+        delta[qi] = qvalid[qi] ? p.Delta[(long)bh * p.S + qrow[qi]] : 0.f;
+        dQ[qi][0] = zero16();
+        dQ[qi][1] = zero16();
+    }
+    const float sc = p.scale * LOG2E;
+    const int nt = (p.S + KB - 1) / KB;        // key tiles of 64
+    const int ns = (nt + NSUB - 1) / NSUB;     // LDS stages of NSUB tiles
+    constexpr int STAGE_ELEMS = NSUB * DQ_BUF_ELEMS;
+    KVStage st;
+
+    const typename BK::tile_t lds = bk.lds_base();
+#pragma unroll
+    for (int u = 0; u < NSUB; ++u) {
+        kv_issue(st, Kp, Vp, p.k_ss, p.v_ss, u * KB, p.S, tid);
+        kv_park_s<false>(bk, st, lds + u * DQ_BUF_ELEMS, lds + u * DQ_BUF_ELEMS + KT_ELEMS, tid);
+    }
+    bk.barrier();
+    for (int j = 0; j < ns; ++j) {
+        const typename BK::tile_t stage = lds + (j & 1) * STAGE_ELEMS;
+        const typename BK::tile_t nxt = lds + ((j + 1) & 1) * STAGE_ELEMS;
+        const bool more = j + 1 < ns;
+#pragma unroll
+        for (int u = 0; u < NSUB; ++u) {
+            const int jt = j * NSUB + u;       // key tile
+            if (more) kv_issue(st, Kp, Vp, p.k_ss, p.v_ss, ((j + 1) * NSUB + u) * KB, p.S, tid);
+            if (jt < nt) {
+            const typename BK::tile_t Kt = stage + u * DQ_BUF_ELEMS, Vt = Kt + KT_ELEMS;
+            const bool ragged = jt + 1 == nt && (p.S & (KB - 1));
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                f32x16 Sc[NQ], dP[NQ];
+#pragma unroll
+                for (int qi = 0; qi < NQ; ++qi) { Sc[qi] = zero16(); dP[qi] = zero16(); }
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const bf16x8 kf = row_frag_s<false>(bk, Kt, 32 * kb, 16 * kk, l), vf = row_frag_s<false>(bk, Vt, 32 * kb, 16 * kk, l);
+#pragma unroll
+                    for (int qi = 0; qi < NQ; ++qi) {
+                        Sc[qi] = bk.mma3216(kf, Qf[qi][kk], Sc[qi]);
+                        dP[qi] = bk.mma3216(vf, Df[qi][kk], dP[qi]);
+                    }
+                }
+                if (ragged) {
+#pragma unroll
+                    for (int qi = 0; qi < NQ; ++qi)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            float v = Sc[qi][r];
+                            if (jt * KB + 32 * kb + row_of(r, h) >= p.S) v = -1e30f;
+                            TTT_PIN_IN_BRANCH(v);
+                            Sc[qi][r] = v;
+                        }
+                }
+#pragma unroll
+                for (int qi = 0; qi < NQ; ++qi)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float pr = bk.exp2(__builtin_fmaf(Sc[qi][r], sc, -lse2[qi]));
+                        dP[qi][r] = pr * (dP[qi][r] - delta[qi]);
+                    }
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const bf16x8 k0 = tr_frag_pi_s<false>(bk, Kt, 32 * kb, s, 0, l), k1 = tr_frag_pi_s<false>(bk, Kt, 32 * kb, s, 32, l);
+#pragma unroll
+                    for (int qi = 0; qi < NQ; ++qi) {
+                        const bf16x8 df = pack(dP[qi], s);
+                        dQ[qi][0] = bk.mma3216(k0, df, dQ[qi][0]);
+                        dQ[qi][1] = bk.mma3216(k1, df, dQ[qi][1]);
+                    }
+                }
+            }
+            }
+            if (more) kv_park_s<false>(bk, st, nxt + u * DQ_BUF_ELEMS, nxt + u * DQ_BUF_ELEMS + KT_ELEMS, tid);
+        }
+        bk.barrier();
+    }
+
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi)
+        if (qvalid[qi]) {
+            __bf16* row = p.dQ + (long)bb * p.dq_sb + (long)hh * p.dq_sh + (long)qrow[qi] * p.dq_ss;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bf16x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (__bf16)(dQ[qi][db][4 * g + e] * p.scale);
+                    *reinterpret_cast<bf16x4*>(row + 32 * db + 8 * g + 4 * h) = v;
+                }
+        }
+}
+
 // ------------------------------------------------------------------------------------------------------------------ dK, dV
 // dV = P^T dO, dK = scale * dS^T Q for the 32 * NW keys of block kvb: each wave keeps 32 key rows of K and V as register-resident
 // B operands and its dK / dV accumulator tiles over the whole loop over query tiles of 64 (Q, dO and the per-query LSE / Delta

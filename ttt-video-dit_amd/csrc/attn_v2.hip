@@ -76,6 +76,29 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn_dkdv2s_kernel(BwdParams p)
     AttnDeviceWave bk{reinterpret_cast<__bf16*>(smem)};
     attnb::dkdv_staged<NW, ACC_INIT, NSUB, false>(bk, p, bh, kvb);
 }
+// dQ with 64 query rows per wave (attn_body.h dq_wide: every K / V fragment read from LDS feeds two MFMAs; 2 waves of <= 256
+// registers per SIMD, one 8-wave workgroup of 512 rows per CU), NSUB key tiles per stage.  Debug option "attn_dq_wide".
+template <int NSUB>
+__global__ __launch_bounds__(512, 2) void attn_dq_wide_kernel(BwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int bh, qb;
+    attnb::head_of_block(blockIdx.x, (p.S + 2 * attnb::QB - 1) / (2 * attnb::QB), p.B * p.NH, bh, qb);
+    AttnDeviceWave bk{reinterpret_cast<__bf16*>(smem)};
+    attnb::dq_wide<NSUB, 2>(bk, p, bh, qb);
+}
+static int g_dq_wide = 0;
+void set_debug_attn_dq_wide(int v) { g_dq_wide = v; }
+template <int NSUB>
+static void launch_dq_wide(const BwdParams& p, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)attn_dq_wide_kernel<NSUB>, hipFuncAttributeMaxDynamicSharedMemorySize, NSUB * attnb::LDS_DQ);
+        attr = true;
+    }
+    const int nb = (p.S + 2 * attnb::QB - 1) / (2 * attnb::QB);
+    hipLaunchKernelGGL((attn_dq_wide_kernel<NSUB>), dim3(p.B * p.NH * nb), dim3(512), NSUB * attnb::LDS_DQ, s, p);
+}
+
 // tiles of 64 per LDS stage: dQ 1 / 2 (two workgroups of 73 KiB share a CU), dK / dV 1 .. 4 (one workgroup of 768 threads per CU:
 // up to 148 KiB).  Debug option "attn_stage" sets both, "attn_stage_dq" / "attn_stage_dkdv" one of them (A/B).
 static int g_stage_dq = 2, g_stage_dkdv = 2;
@@ -95,6 +118,7 @@ static void launch_dq_staged(const BwdParams& p, hipStream_t s) {
     hipLaunchKernelGGL((attn_dq2s_kernel<4, NSUB>), dim3(p.B * p.NH * nb), dim3(512), NSUB * attnb::LDS_DQ, s, p);
 }
 void launch_dq_v2(const BwdParams& p, hipStream_t s) {
+    if (g_dq_wide) return g_stage_dq == 2 ? launch_dq_wide<2>(p, s) : launch_dq_wide<1>(p, s);
     if (g_stage_dq == 2) return launch_dq_staged<2>(p, s);
     static bool attr = false;
     if (!attr) {

@@ -72,7 +72,9 @@ constexpr int NTC = 512;                                  // 2 compute waves + 4
 // deriver waves DW0, DW0 + 1 = 4, 5 share SIMDs 0 / 1 - the compute waves idle there during the hand-over, which is when the
 // derivers do most of their (VALU-heavy) work -, the owner waves 2, 3, 6, 7 have SIMDs 2 / 3 to themselves: their hand-over
 // chain (poll, record reads, LayerNorm backward-of-backward) is the critical path of a step.
-constexpr int DW0 = 4;
+// (round 4: DW0 is a template parameter of the kernel - 4 as above, or 2: the derivers on SIMDs 2 / 3 beside two of the owner
+// waves, the other two owner waves beside the compute waves - the stage stamps of profiles/r4b show the Bb .. Bc phase bounded by
+// the derivers' reverse_step (12.5 k cycles) with the owners finished after 8.2 k and the compute waves after 5.1 k)
 constexpr int TILE_B = TILE_ELEMS * 2;                    // 9216 bytes: one padded [64][64] bf16 tile
 constexpr int L_K = 0;                                    // K   [2][t][f]  (by step parity)
 constexpr int L_G = L_K + 2 * TILE_B;                     // gZ2 [2][t][f]
@@ -178,8 +180,9 @@ struct DeriverBackend {
 // the other roundings (worst 3.0e-2 -> 3.6e-2 / 2.6e-2 -> 2.5e-2).  [t][PS16] bf16 inside the fp32 tile's area of the record.
 constexpr int PS16 = 72;
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-template <bool DBG, bool OVL, bool R16>
+template <bool DBG, bool OVL, bool R16, int DW0>
 __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
+    constexpr int OW0 = DW0 == 2 ? 4 : 2;                        // first owner wave (it polls the partner flags)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __bf16* Kt2 = reinterpret_cast<__bf16*>(smem + L_K);
     __bf16* Gt2 = reinterpret_cast<__bf16*>(smem + L_G);
@@ -543,7 +546,7 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
         if (p.last) __syncthreads();           // (the owners' final reduction)
     } else if (wv != DW0 && wv != DW0 + 1) {
         // =========================================================================================================== OWNERS
-        int ow = ((wv < DW0 ? wv - 2 : wv - 4) << 6) | (tid & 63);            // 0 .. 255 over the four owner waves
+        int ow = ((DW0 == 2 ? wv - 4 : (wv < DW0 ? wv - 2 : wv - 4)) << 6) | (tid & 63);      // 0 .. 255 over the four owner waves
         int ot = ow >> 2, of0 = 16 * (ow & 3);                  // token, first of this thread's 16 features
         float dgam[16], dbet[16];
         if (p.first) {
@@ -642,7 +645,7 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
             consume_step(0, L0, reinterpret_cast<float*>(exu));       // (exd is written by publish_state(i0) between P1 and P2)
         }
         owner_barrier();                       // P1
-        if (wv == 2) add_parts(reinterpret_cast<const float*>(exu), nullptr, db2oL);
+        if (wv == OW0) add_parts(reinterpret_cast<const float*>(exu), nullptr, db2oL);
         owner_barrier();                       // P2
 
         for (int i = i0; i >= p.chunk_lo; --i) {
@@ -677,7 +680,7 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
             }
             // ---- O-C: hand-over ------------------------------------------------------------------------------------------------
             if (ow == 0) __hip_atomic_store(my_flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (wv == 2) {
+            if (wv == OW0) {
                 const int l = tid & 63;
                 if (more) add_parts(reinterpret_cast<const float*>(exd), db2oL + cur * 64, db2oL + (cur ^ 1) * 64);
                 if (l < 3) {
@@ -757,6 +760,7 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
                 // afterwards; the asm statement below pins the order)
                 const float eta_t = etaL2[cur * 64 + ot];
                 if constexpr (!OVL && !R16) TTT_PIN_RECORDS(eta_t);
+                if constexpr (!OVL && R16) TTT_PIN_RECORDS16(eta_t);
                 float gxh[16], gz[16];
                 float s1g = 0.f, s2g = 0.f;
 #pragma unroll
@@ -778,7 +782,7 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
                 // the records are "produced" here as far as the compiler can tell: their sums cannot be scheduled (and waited
                 // for) above the arithmetic that `se` depends on
                 if constexpr (R16) {
-                    TTT_PIN_RECORDS16(se);
+                    if constexpr (OVL) TTT_PIN_RECORDS16(se);
                     // bf16 pair (lo, hi) of dword w = features 2w, 2w + 1: the same four partials in the same order on all four CUs
                     auto lo = [](unsigned w) { return __builtin_bit_cast(float, w << 16); };
                     auto hi = [](unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); };
@@ -1143,9 +1147,11 @@ unsigned read_sweep_fast_count() {      // DEBUG statistic: cluster workgroup la
     return v;
 }
 
-static int g_owner_overlap = 1;
+static int g_owner_overlap = 0;           // round 4, one box: 14.15 ms per backward with it against 13.44 without (NC = 804): off
 void set_debug_sweep_owner_overlap(int v) { g_owner_overlap = v; }
-static int g_records_bf16 = 0;            // opt-in until the A/B on the device is in
+static int g_deriver_wave0 = 4;           // 4: derivers = waves 4, 5 (SIMDs 0 / 1, beside the compute waves); 2: waves 2, 3 (beside two owner waves)
+void set_debug_sweep_deriver_wave0(int v) { g_deriver_wave0 = v == 2 ? 2 : 4; }
+static int g_records_bf16 = 1;            // round 4, one box: 11.82 against 14.16 ms per backward at NC = 804, 4.24 against 5.11 at NC = 282
 void set_debug_sweep_records_bf16(int v) { g_records_bf16 = v; }
 
 namespace s4 {
@@ -1154,29 +1160,37 @@ void launch_sweep_cluster4(const SweepParams4& bp, int nbh, hipStream_t s) {
     static bool attr[16] = {false};           // per device: a function attribute is a property of the function ON a device
     int dev = 0;
     (void)hipGetDevice(&dev);
+    const dim3 grid(nbh * 4), blk(b4::NTC);
+    const bool first = dev >= 0 && dev < 16 && !attr[dev];
+    auto go = [&](auto kern) {
+        if (first) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, b4::LDS_CL);
+        hipLaunchKernelGGL(kern, grid, blk, b4::LDS_CL, s, bp);
+    };
     {
         std::lock_guard<std::mutex> lock(g_err_mutex);
-        if (dev >= 0 && dev < 16 && !attr[dev]) {
-            (void)hipFuncSetAttribute((const void*)b4::mlp_bwd_cluster4_kernel<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, b4::LDS_CL);
-            (void)hipFuncSetAttribute((const void*)b4::mlp_bwd_cluster4_kernel<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, b4::LDS_CL);
-            (void)hipFuncSetAttribute((const void*)b4::mlp_bwd_cluster4_kernel<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, b4::LDS_CL);
-            (void)hipFuncSetAttribute((const void*)b4::mlp_bwd_cluster4_kernel<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, b4::LDS_CL);
-            (void)hipFuncSetAttribute((const void*)b4::mlp_bwd_cluster4_kernel<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, b4::LDS_CL);
-            (void)hipFuncSetAttribute((const void*)b4::mlp_bwd_cluster4_kernel<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, b4::LDS_CL);
+        if (first) {
+            // every instantiation a later call may select gets its attribute on this device now
+            auto set = [&](auto kern) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, b4::LDS_CL); };
+            set(b4::mlp_bwd_cluster4_kernel<false, false, false, 4>); set(b4::mlp_bwd_cluster4_kernel<true, false, false, 4>);
+            set(b4::mlp_bwd_cluster4_kernel<false, true, false, 4>);  set(b4::mlp_bwd_cluster4_kernel<true, true, false, 4>);
+            set(b4::mlp_bwd_cluster4_kernel<false, false, true, 4>);  set(b4::mlp_bwd_cluster4_kernel<true, false, true, 4>);
+            set(b4::mlp_bwd_cluster4_kernel<false, true, true, 4>);   set(b4::mlp_bwd_cluster4_kernel<true, true, true, 4>);
+            set(b4::mlp_bwd_cluster4_kernel<false, false, true, 2>);  set(b4::mlp_bwd_cluster4_kernel<true, false, true, 2>);
+            set(b4::mlp_bwd_cluster4_kernel<false, true, true, 2>);   set(b4::mlp_bwd_cluster4_kernel<true, true, true, 2>);
             (void)hipFuncSetAttribute((const void*)b4::mlp_bwd_tail4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, b4::LDS_TAIL4);
             attr[dev] = true;
         }
     }
-    const dim3 grid(nbh * 4), blk(b4::NTC);
-    if (g_records_bf16) {               // (bf16 records imply the overlapped owner order)
-        if (bp.dbg) hipLaunchKernelGGL((b4::mlp_bwd_cluster4_kernel<true, true, true>), grid, blk, b4::LDS_CL, s, bp);
-        else hipLaunchKernelGGL((b4::mlp_bwd_cluster4_kernel<false, true, true>), grid, blk, b4::LDS_CL, s, bp);
-    } else if (g_owner_overlap) {
-        if (bp.dbg) hipLaunchKernelGGL((b4::mlp_bwd_cluster4_kernel<true, true, false>), grid, blk, b4::LDS_CL, s, bp);
-        else hipLaunchKernelGGL((b4::mlp_bwd_cluster4_kernel<false, true, false>), grid, blk, b4::LDS_CL, s, bp);
+    const bool dbg = bp.dbg != nullptr, ovl = g_owner_overlap != 0, r16 = g_records_bf16 != 0, dw2 = g_deriver_wave0 == 2 && r16;
+    if (dw2) {
+        if (ovl) { if (dbg) go(b4::mlp_bwd_cluster4_kernel<true, true, true, 2>); else go(b4::mlp_bwd_cluster4_kernel<false, true, true, 2>); }
+        else     { if (dbg) go(b4::mlp_bwd_cluster4_kernel<true, false, true, 2>); else go(b4::mlp_bwd_cluster4_kernel<false, false, true, 2>); }
+    } else if (r16) {
+        if (ovl) { if (dbg) go(b4::mlp_bwd_cluster4_kernel<true, true, true, 4>); else go(b4::mlp_bwd_cluster4_kernel<false, true, true, 4>); }
+        else     { if (dbg) go(b4::mlp_bwd_cluster4_kernel<true, false, true, 4>); else go(b4::mlp_bwd_cluster4_kernel<false, false, true, 4>); }
     } else {
-        if (bp.dbg) hipLaunchKernelGGL((b4::mlp_bwd_cluster4_kernel<true, false, false>), grid, blk, b4::LDS_CL, s, bp);
-        else hipLaunchKernelGGL((b4::mlp_bwd_cluster4_kernel<false, false, false>), grid, blk, b4::LDS_CL, s, bp);
+        if (ovl) { if (dbg) go(b4::mlp_bwd_cluster4_kernel<true, true, false, 4>); else go(b4::mlp_bwd_cluster4_kernel<false, true, false, 4>); }
+        else     { if (dbg) go(b4::mlp_bwd_cluster4_kernel<true, false, false, 4>); else go(b4::mlp_bwd_cluster4_kernel<false, false, false, 4>); }
     }
 }
 
