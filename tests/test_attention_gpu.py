@@ -201,3 +201,28 @@ def test_attention_tiles_per_stage_equal_the_one_tile_kernels(B, NH, S, layout):
         for a, b, name in zip(res[(1, 1)], res[key], ("dq", "dk", "dv")):
             assert not torch.isnan(b.float()).any(), (key, name)
             assert torch.equal(a, b), (key, name)
+
+
+@pytest.mark.parametrize("B,NH,S,layout", [(2, 3, 300, "bshd"), (1, 8, 1024, "bhsd"), (1, 2, 40, "bshd"), (1, 16, 833, "bshd")])
+def test_attention_dq_wide_equals_default(B, NH, S, layout):
+    """dQ with 64 query rows per wave (csrc/attn_body.h dq_wide, debug option "attn_dq_wide"): every K / V fragment read from LDS
+    feeds two MFMAs; a query row's arithmetic and its order over the keys are unchanged, so dQ must have the same bits as the
+    default kernel's - with one and with two key tiles per LDS stage."""
+    e = ext()
+    from ttt_amd.models.cogvideo.attention import SegmentAttention
+    q, k, v, do = make(B, NH, S, 57 + S, layout)
+    res = {}
+    try:
+        for wide, st in ((0, 2), (1, 2), (1, 1)):
+            e.debug_option("attn_dq_wide", wide)
+            e.debug_option("attn_stage_dq", st)
+            qq, kk, vv = (t.detach().clone().requires_grad_(True) for t in (q, k, v))
+            SegmentAttention.apply(qq, kk, vv).backward(do)
+            torch.cuda.synchronize()
+            res[(wide, st)] = qq.grad.clone()
+    finally:
+        e.debug_option("attn_dq_wide", 0)
+        e.debug_option("attn_stage", 2)
+    for key in ((1, 2), (1, 1)):
+        assert not torch.isnan(res[key].float()).any(), key
+        assert torch.equal(res[(0, 2)], res[key]), key

@@ -8,4 +8,6 @@ for k in ("fwd", "bwd"):
 ph = d.get("phase_cycles_per_step")
 if ph:
     out += ["| sweep stages", str(ph[16:24]), "| owner hand-over", str(ph[24:28]), "| deriver (stage, z1b, reverse, barriers)", str(ph[28:32])]
+    if len(ph) >= 36:
+        out += ["| owners before Bb (Bd..Ba arrival, wait Ba, consume_step, wait Bb)", str(ph[32:36])]
 print(" ".join(out))

@@ -63,7 +63,8 @@ def main():
         ref = None
         for rnd in range(a.rounds):
             for st in stages:
-                ext.debug_option("attn_stage_dq", int(st.split(":")[0]))
+                ext.debug_option("attn_dq_wide", 1 if st.split(":")[0].endswith("w") else 0)      # "2w:2" = dQ with 64 query rows per wave
+                ext.debug_option("attn_stage_dq", int(st.split(":")[0].rstrip("w")))
                 ext.debug_option("attn_stage_dkdv", int(st.split(":")[1]))
                 times[st].append(timeit(lambda: ext.attn_backward(q, k, v, out, do, lse, delta, dq, dk, dv, 0.125), a.iters))
                 if rnd == 0:
@@ -74,6 +75,7 @@ def main():
                     else:
                         res.setdefault("bit_identical_to_first", {})[st] = all(torch.equal(x, y) for x, y in zip(cur, ref))
         ext.debug_option("attn_stage", 2)
+        ext.debug_option("attn_dq_wide", 0)
         res["bwd_by_stage"] = {st: {"median_ms": sorted(v)[len(v) // 2], "min_ms": min(v)} for st, v in times.items()}
     if not a.no_sdpa:
         qq, kk, vv = (x.detach().clone().requires_grad_(True) for x in (q, k, v))

@@ -648,6 +648,7 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
         if (wv == OW0) add_parts(reinterpret_cast<const float*>(exu), nullptr, db2oL);
         owner_barrier();                       // P2
 
+        unsigned long long t_prev = 0;
         for (int i = i0; i >= p.chunk_lo; --i) {
             // opaque owner index per step (as the compute / deriver waves do with their lane id): what derives from it - record
             // and tile offsets, LDS rows - is re-made inside the step instead of being carried through the loop in spilled registers
@@ -667,10 +668,21 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
             const float r = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rS, ot * 8, so + 3 * (int)SLOT_OWN_ARR, 0));
             StepLoads Lj;
             if (more) request_step(i - 1, Lj);
-            owner_barrier();                   // Ba (nothing of the owners is due yet: they arrive at once)
-            if (more) consume_step(cur ^ 1, Lj, reinterpret_cast<float*>(exd));
-            owner_barrier();                   // Bb: this workgroup's record is complete and drained; At / Q_j / R3 visible
+            // DEBUG stamps 32 .. 35 (owner wave 0 of workgroup 0): Bd .. Ba arrival, wait at Ba, consume_step, wait at Bb
             unsigned long long t_o = 0;
+#define TTT_OSTAMP2(k)                                                           \
+            if (DBG && p.dbg != nullptr && blockIdx.x == 0 && ow == 0) {         \
+                const unsigned long long _t = __builtin_readcyclecounter();      \
+                if (t_prev) p.dbg[32 + (k)] += _t - t_prev;                      \
+                t_prev = _t;                                                     \
+            }
+            TTT_OSTAMP2(0)
+            owner_barrier();                   // Ba (nothing of the owners is due yet: they arrive at once)
+            TTT_OSTAMP2(1)
+            if (more) consume_step(cur ^ 1, Lj, reinterpret_cast<float*>(exd));
+            TTT_OSTAMP2(2)
+            owner_barrier();                   // Bb: this workgroup's record is complete and drained; At / Q_j / R3 visible
+            TTT_OSTAMP2(3)
             if (DBG && p.dbg != nullptr && blockIdx.x == 0 && ow == 0) t_o = __builtin_readcyclecounter();
 #define TTT_OSTAMP(k)                                                            \
             if (DBG && p.dbg != nullptr && blockIdx.x == 0 && ow == 0) {         \
@@ -866,6 +878,7 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
             }
             owner_barrier();                   // Bd
             asm volatile("" :: "v"(touch));    // (keeps the prefetch loads alive; they landed long ago)
+            if (DBG && p.dbg != nullptr && blockIdx.x == 0 && ow == 0) t_prev = __builtin_readcyclecounter();
         }
 
         // ---- dgamma / dbeta: to the next chunk, or reduced over the 64 tokens ----------------------------------------------------
@@ -1150,7 +1163,7 @@ unsigned read_sweep_fast_count() {      // DEBUG statistic: cluster workgroup la
 static int g_owner_overlap = 0;           // round 4, one box: 14.15 ms per backward with it against 13.44 without (NC = 804): off
 void set_debug_sweep_owner_overlap(int v) { g_owner_overlap = v; }
 static int g_deriver_wave0 = 4;           // 4: derivers = waves 4, 5 (SIMDs 0 / 1, beside the compute waves); 2: waves 2, 3 (beside two owner waves)
-void set_debug_sweep_deriver_wave0(int v) { g_deriver_wave0 = v == 2 ? 2 : 4; }
+void set_debug_sweep_deriver_wave0(int v) { g_deriver_wave0 = (v == 2 || v == 1) ? 2 : 4; }      // (1 = 2: the 0 / 1 toggle of op_bench --ab)
 static int g_records_bf16 = 1;            // round 4, one box: 11.82 against 14.16 ms per backward at NC = 804, 4.24 against 5.11 at NC = 282
 void set_debug_sweep_records_bf16(int v) { g_records_bf16 = v; }
 
