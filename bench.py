@@ -85,7 +85,7 @@ def parse():
                          "parameters, gradients and optimizer state sharded by FSDP2 over all ranks (apply_parallelisms; --fsdp off: replicas + "
                          "a gradient all-reduce, world == T).  --tp 1 on one GPU runs the same code path over a "
                          "one-rank group (what the layout's unfused glue costs); 0 = off")
-    ap.add_argument("--remat-keep", default="attn,scan",
+    ap.add_argument("--remat-keep", default="attn,scan,fc2",
                     help="outputs a re-materialised layer keeps instead of recomputing them (comma list of attn, scan, fc2; 'none' = "
                          "the reference's behaviour: the whole layer is recomputed) - ttt_amd/infra/remat_cache.py")
     ap.add_argument("--remat-free-layers", default="auto",

@@ -176,6 +176,13 @@ def test_fused_attention_node_equals_two_nodes():
         assert torch.equal(a, b)
 
 
+def _attn_defaults(e):
+    """the library's defaults of the attention-backward debug options (csrc/attn_v2.hip)"""
+    e.debug_option("attn_dq_wide", 1)
+    e.debug_option("attn_stage_dq", 1)
+    e.debug_option("attn_stage_dkdv", 2)
+
+
 @pytest.mark.parametrize("B,NH,S,layout", [(2, 3, 300, "bshd"), (1, 8, 1024, "bhsd"), (1, 2, 40, "bshd"), (1, 16, 833, "bshd")])
 def test_attention_tiles_per_stage_equal_the_one_tile_kernels(B, NH, S, layout):
     """The backward kernels with SEVERAL tiles of 64 per LDS stage (csrc/attn_body.h dq_staged / dkdv_staged; the default since
@@ -188,6 +195,7 @@ def test_attention_tiles_per_stage_equal_the_one_tile_kernels(B, NH, S, layout):
     q, k, v, do = make(B, NH, S, 31 + S, layout)
     res = {}
     try:
+        e.debug_option("attn_dq_wide", 0)
         for dq_st, dkdv_st in ((1, 1), (2, 2), (2, 3), (1, 4)):
             e.debug_option("attn_stage_dq", dq_st)
             e.debug_option("attn_stage_dkdv", dkdv_st)
@@ -196,7 +204,7 @@ def test_attention_tiles_per_stage_equal_the_one_tile_kernels(B, NH, S, layout):
             torch.cuda.synchronize()
             res[(dq_st, dkdv_st)] = (qq.grad.clone(), kk.grad.clone(), vv.grad.clone())
     finally:
-        e.debug_option("attn_stage", 2)
+        _attn_defaults(e)
     for key in ((2, 2), (2, 3), (1, 4)):
         for a, b, name in zip(res[(1, 1)], res[key], ("dq", "dk", "dv")):
             assert not torch.isnan(b.float()).any(), (key, name)
@@ -221,8 +229,7 @@ def test_attention_dq_wide_equals_default(B, NH, S, layout):
             torch.cuda.synchronize()
             res[(wide, st)] = qq.grad.clone()
     finally:
-        e.debug_option("attn_dq_wide", 0)
-        e.debug_option("attn_stage", 2)
+        _attn_defaults(e)
     for key in ((1, 2), (1, 1)):
         assert not torch.isnan(res[key].float()).any(), key
         assert torch.equal(res[(0, 2)], res[key]), key

@@ -67,7 +67,7 @@ def _run_sweep_variant(e, d, G, **opts):
         return run_mlp(e, d, G, torch.bfloat16, impl="mfma")
     finally:
         e.debug_groups_per_chunk(0)
-        e.debug_option("sweep_owner_overlap", 0)
+        e.debug_option("sweep_owner_overlap", 1)       # library defaults (csrc/ttt_mfma_bwd4.hip)
         e.debug_option("sweep_records_bf16", 1)
         e.debug_option("sweep_deriver_wave0", 4)
 

@@ -74,8 +74,9 @@ def main():
                         ref = cur
                     else:
                         res.setdefault("bit_identical_to_first", {})[st] = all(torch.equal(x, y) for x, y in zip(cur, ref))
-        ext.debug_option("attn_stage", 2)
-        ext.debug_option("attn_dq_wide", 0)
+        ext.debug_option("attn_dq_wide", 1)          # library defaults (csrc/attn_v2.hip)
+        ext.debug_option("attn_stage_dq", 1)
+        ext.debug_option("attn_stage_dkdv", 2)
         res["bwd_by_stage"] = {st: {"median_ms": sorted(v)[len(v) // 2], "min_ms": min(v)} for st, v in times.items()}
     if not a.no_sdpa:
         qq, kk, vv = (x.detach().clone().requires_grad_(True) for x in (q, k, v))

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(512, 2) void attn_dq_wide_kernel(BwdParams p) {
     AttnDeviceWave bk{reinterpret_cast<__bf16*>(smem)};
     attnb::dq_wide<NSUB, 2>(bk, p, bh, qb);
 }
-static int g_dq_wide = 0;
+static int g_dq_wide = 1;                // round 4, one box (profiles/r4c_attn_dq_wide_ab.log): 13.26 - 13.44 ms per backward against 13.79
 void set_debug_attn_dq_wide(int v) { g_dq_wide = v; }
 template <int NSUB>
 static void launch_dq_wide(const BwdParams& p, hipStream_t s) {
@@ -101,9 +101,9 @@ static void launch_dq_wide(const BwdParams& p, hipStream_t s) {
 
 // tiles of 64 per LDS stage: dQ 1 / 2 (two workgroups of 73 KiB share a CU), dK / dV 1 .. 4 (one workgroup of 768 threads per CU:
 // up to 148 KiB).  Debug option "attn_stage" sets both, "attn_stage_dq" / "attn_stage_dkdv" one of them (A/B).
-static int g_stage_dq = 2, g_stage_dkdv = 2;
+static int g_stage_dq = 1, g_stage_dkdv = 2;      // (dQ: the wide kernel holds one workgroup per CU; one tile per stage measured best there)
 void set_debug_attn_stage(int which, int v) {
-    if (which != 2) g_stage_dq = (v >= 1 && v <= 2) ? v : 2;
+    if (which != 2) g_stage_dq = (v >= 1 && v <= 2) ? v : 1;
     if (which != 1) g_stage_dkdv = (v >= 1 && v <= 4) ? v : 2;
 }
 

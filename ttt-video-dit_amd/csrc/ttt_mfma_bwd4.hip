@@ -1160,7 +1160,7 @@ unsigned read_sweep_fast_count() {      // DEBUG statistic: cluster workgroup la
     return v;
 }
 
-static int g_owner_overlap = 0;           // round 4, one box: 14.15 ms per backward with it against 13.44 without (NC = 804): off
+static int g_owner_overlap = 1;           // round 4, one box, NC = 804: with fp32 records 14.15 ms per backward against 13.44 without; with bf16 records 11.76 against 12.71: on
 void set_debug_sweep_owner_overlap(int v) { g_owner_overlap = v; }
 static int g_deriver_wave0 = 4;           // 4: derivers = waves 4, 5 (SIMDs 0 / 1, beside the compute waves); 2: waves 2, 3 (beside two owner waves)
 void set_debug_sweep_deriver_wave0(int v) { g_deriver_wave0 = (v == 2 || v == 1) ? 2 : 4; }      // (1 = 2: the 0 / 1 toggle of op_bench --ab)
