@@ -34,7 +34,6 @@ def main():
     ap.add_argument("--write-through-records", action="store_true", help="DEBUG A/B: the backward sweep's hand-over records always write-through (sc1), never plain")
     ap.add_argument("--rc-nt", type=int, default=1, help="A/B: revision-4 recompute, non-temporal stores of the step records")
     ap.add_argument("--prefetch", type=int, default=1, help="A/B: revision-4 sweep, L2 prefetch touches two steps ahead (1 default, 0 off)")
-    ap.add_argument("--owner-overlap", type=int, default=None, help="A/B: revision-4 sweep, owners' partner-independent arithmetic under the record loads (library default: 0 = round-3 order)")
     ap.add_argument("--ab", default=None, metavar="OPTION", help="interleaved A/B inside one process: the named debug option alternates 0 / 1 from iteration to iteration; the backward's average is reported per value (same box, same clocks)")
     ap.add_argument("--ab-fixed", default=None, metavar="OPTION=VALUE", help="set one more debug option for the whole run")
     ap.add_argument("--phases", action="store_true", help="also print per-phase cycle totals of workgroup 0")
@@ -46,8 +45,6 @@ def main():
     ext.set_impl(a.impl)
     ext.debug_option("fast_records", 0 if a.write_through_records else 1)
     ext.debug_option("sweep_prefetch", a.prefetch)
-    if a.owner_overlap is not None:
-        ext.debug_option("sweep_owner_overlap", a.owner_overlap)
     if a.ab_fixed:
         ext.debug_option(a.ab_fixed.split("=")[0], int(a.ab_fixed.split("=")[1]))
     ext.debug_option("rc_nt", a.rc_nt)
