@@ -104,9 +104,10 @@ int emul_bwd4_aux_step_pre(float* W1, float* W2, const unsigned short* z1, const
                 st.W2t[a][r] = W2[(32 * pp + ro) * 64 + 32 * a + c];
             }
         }
-        bwd4::Frags4 X2;
-        bwd4::load_parked_x2(w, park + pp * bwd4::PARK_BYTES, X2);
-        bwd4::reverse_step_pre(w, st, pp, L_K, L_G, L_ETA, X2, L_R1, L_R2, gslice, 0, 8 * 1024, park + pp * bwd4::PARK_BYTES);
+        bwd4::Frags4 D1, D2, X2;
+        bwd4::load_parked(w, park + pp * bwd4::PARK_BYTES, D1, D2, X2);
+        bwd4::stage_r1_static(w, pp, D1, X2, L_R1);
+        bwd4::reverse_step_pre(w, st, pp, L_K, L_G, L_ETA, D1, D2, X2, L_R1, L_R2, gslice, 0, 8 * 1024, park + pp * bwd4::PARK_BYTES);
         bwd4::stage_r4(w, pp, L_R4, park + pp * bwd4::PARK_BYTES);
         bwd4::stage_w2t(w, st, pp, L_R3 + 16 * 1024);
         for (int r = 0; r < 16; ++r) {

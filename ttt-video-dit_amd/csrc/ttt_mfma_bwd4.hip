@@ -861,8 +861,38 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
                 }
             }
             TTT_OSTAMP(2)                      // owner math, dZ2 / dV / d(eta) stores
+            // ---- PRE (round 4): the elementwise GELU work of step i - 2 is the OWNERS' - they are through with their chain 8 k
+            // cycles before the derivers reach Bc, and idle through Bc .. Bd -: owner wave w takes fragments 2 w, 2 w + 1 of the
+            // slice's eight Z1 ([ti][pp][s]) fragments -> D1 | D2 | X2 into the parking buffer (step parity) of deriver wave pp;
+            // behind Bc (R3's D1B / X2B arrays are free then: their reader, the output path of step i - 1, is done) the same two
+            // fragments of Z1b -> gelu'(Z1b) | X2b in R3.
+            bf16x8 zb_ahead[2];
+            const bool ahead = PRE && i - 2 >= p.chunk_lo;
+            if (PRE && ahead) {
+                DeriverBackend obk{smem, (int)(threadIdx.x & 63)};
+                const int l = obk.lane();
+                const int sA = slot_off(i - 2) + WREG;
+                bf16x8 z[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    z[k] = bld8(rS, l * 16, sA + fro4(A_Z1, 2 * (ow >> 6) + k));
+                    zb_ahead[k] = bld8(rS, l * 16, sA + fro4(A_Z1B, 2 * (ow >> 6) + k));
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int f = 2 * (ow >> 6) + k, ti = f >> 2, ppd = (f >> 1) & 1, s = f & 1;
+                    char* pk = p.park + ((((size_t)(bh * 4 + cq) * 2 + ppd) * 2) + ((i - 2) & 1)) * bwd4::PARK_BYTES;
+                    bwd4::prederive_frag(obk, z[k], ti, s, pk);
+                }
+            }
             owner_barrier();                   // Bc: dZ2_i visible to the compute waves
             TTT_OSTAMP(3)                      // wait for the compute waves at Bc
+            if (PRE && ahead) {
+                DeriverBackend obk{smem, (int)(threadIdx.x & 63)};
+#pragma unroll
+                for (int k = 0; k < 2; ++k) bwd4::derive_z1b_frag(obk, zb_ahead[k], 2 * (ow >> 6) + k, L_R3, L_R3 + FRK);
+                asm volatile("s_waitcnt vmcnt(0) ; the parked fragments are in memory before Bd" ::: "memory");
+            }
             // ---- L2 prefetch, two steps ahead: one dword per 128-byte line of what the owners of this CU will request for step
             // i - 2 (owner rows, gZ2 tile: 452 lines; K, Q, dOut tiles: 192 lines).  Issued HERE, behind Bc: the owners idle
             // during S4a, and the issue of an instruction whose 64 lanes miss 64 different lines blocks the wave for a while
@@ -958,9 +988,41 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
         }
         if constexpr (PRE) {
         // ------------------------------------------------------------------------------------------ two-part reverse step (round 4)
-        bwd4::Frags4 Z1, Z1B, X2;
+        bwd4::Frags4 Z1, Z1B, D1f, D2f, X2;
         char* const park0 = p.park + ((size_t)(bh * 4 + cq) * 2 + pp) * 2 * bwd4::PARK_BYTES;      // two parking buffers, by step parity
         auto parkof = [&](int step) { return park0 + (step & 1) * bwd4::PARK_BYTES; };
+        // The parked D1 | D2 | X2 of a step are written by the OWNER waves of this workgroup (below, one iteration ahead): read
+        // them back with sc1 loads, which are never served by this CU's vector L1 (a line of the same parking buffer may still
+        // sit there from two steps ago), like the hand-over records.
+        const __amdgpu_buffer_rsrc_t rP = make_srd(park0, 2 * bwd4::PARK_BYTES);
+        auto ld_park = [&](int step, int arr, int ti, int s_) {
+            return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rP, (step & 1) * (int)bwd4::PARK_BYTES + bwd4::park_off(arr, ti, s_) + l * 16, 0, 16));
+        };
+        auto load_parked_sc1 = [&](int step) {
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int s_ = 0; s_ < 2; ++s_) {
+                    D1f.f[ti][s_] = ld_park(step, 0, ti, s_);
+                    D2f.f[ti][s_] = ld_park(step, 1, ti, s_);
+                    X2.f[ti][s_] = ld_park(step, 2, ti, s_);
+                }
+        };
+        auto stage_r4_sc1 = [&](int step) {        // bwd4::stage_r4 with the loads above
+            bf16x8 v[12];
+#pragma unroll
+            for (int arr = 0; arr < 3; ++arr)
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                    for (int s_ = 0; s_ < 2; ++s_) v[(arr * 2 + ti) * 2 + s_] = ld_park(step, arr, ti, s_);
+#pragma unroll
+            for (int arr = 0; arr < 3; ++arr)
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                    for (int s_ = 0; s_ < 2; ++s_) bwd4::st_frag(bk, L_R4 + arr * FRK, fr_idx(ti, pp, s_), v[(arr * 2 + ti) * 2 + s_]);
+        };
         load_frags(i0, A_Z1, Z1);
         load_frags(i0, A_Z1B, Z1B);
         owner_barrier();                       // P0
@@ -968,9 +1030,10 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
         bwd4::derive_z1b(bk, Z1B, pp, L_R3, L_R3 + FRK);
         bwd4::prederive(bk, Z1, parkof(i0));
         asm volatile("s_waitcnt vmcnt(0) ; the parked fragments are in memory before this wave reads them back" ::: "memory");
-        bwd4::load_parked_x2(bk, parkof(i0), X2);
+        load_parked_sc1(i0);
+        bwd4::stage_r1_static(bk, pp, D1f, X2, L_R1);
         owner_barrier();                       // P1: the tiles of step i0 (K, gZ2, eta) are visible
-        bwd4::reverse_step_pre(bk, st, pp, L_K, L_G, L_SM, X2, L_R1, L_R2, slots + (size_t)slot_off(i0) + WREG,
+        bwd4::reverse_step_pre(bk, st, pp, L_K, L_G, L_SM, D1f, D2f, X2, L_R1, L_R2, slots + (size_t)slot_off(i0) + WREG,
                                fro4(A_GZ1T, 0), fro4(A_W1, 0), parkof(i0));
         if (i0 - 1 >= p.chunk_lo) {            // what the first iteration's reverse step loads
             load_frags(i0 - 1, A_Z1, Z1);
@@ -990,7 +1053,7 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
             const bool more = i > p.chunk_lo;
             const int nxt = ((i0 - i) & 1) ^ 1;                 // tile buffer of step j = i - 1
             bk.refresh();
-            bwd4::stage_r4(bk, pp, L_R4, parkof(i));            // of step i: S4a of the step before is behind Bd / P2
+            stage_r4_sc1(i);                                    // of step i: S4a of the step before is behind Bd / P2
             bwd4::stage_w2t(bk, st, pp, L_R3 + 2 * FRK);        // W2_i^T: S4a of step i, output path of step j
             if (more && i == i0) load_frags(i - 1, A_Z1B, Z1B); // (first iteration only: later ones derive Z1b in the window below)
             TTT_DSTAMP_P(28)
@@ -999,30 +1062,21 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
             if (more && i == i0) bwd4::derive_z1b(bk, Z1B, pp, L_R3, L_R3 + FRK);
             if (more) {
                 asm volatile("s_waitcnt vmcnt(0) ; the fragments parked a phase ago are in memory" ::: "memory");
-                bwd4::load_parked_x2(bk, parkof(i - 1), X2);    // in flight across Bb
+                load_parked_sc1(i - 1);
+                bwd4::stage_r1_static(bk, pp, D1f, X2, L_R1);   // (S1 of step i left R1 behind Ba)
             }
             TTT_DSTAMP_P(29)
             owner_barrier();                   // Bb: K_j, gZ2_j, eta_j staged by the owners are visible
             TTT_DSTAMP_P(31)
             if (more) {
                 if (i % p.G == 0) load_anchor(i);               // group boundary: the exact state entering step i
-                bwd4::reverse_step_pre(bk, st, pp, L_K + nxt * TILE_B, L_G + nxt * TILE_B, L_SM + nxt * 64 * 4, X2, L_R1, L_R2,
+                bwd4::reverse_step_pre(bk, st, pp, L_K + nxt * TILE_B, L_G + nxt * TILE_B, L_SM + nxt * 64 * 4, D1f, D2f, X2, L_R1, L_R2,
                                        slots + (size_t)slot_off(i - 1) + WREG, fro4(A_GZ1T, 0), fro4(A_W1, 0), parkof(i - 1));
-            }
-            const bool ahead = i - 2 >= p.chunk_lo;
-            if (ahead) {                       // requested here, consumed behind Bc
-                load_frags(i - 2, A_Z1B, Z1B);
-                load_frags(i - 2, A_Z1, Z1);
             }
             TTT_DSTAMP_P(30)
             owner_barrier();                   // Bc
             TTT_DSTAMP_P(31)
-            // ---- the window the derivers used to idle through: step i - 2, which needs nothing but its stored pre-activations.
-            // R3's D1B / X2B arrays are free (their reader, the output path of step i - 1, finished in front of Bc).
-            if (ahead) {
-                bwd4::derive_z1b(bk, Z1B, pp, L_R3, L_R3 + FRK);
-                bwd4::prederive(bk, Z1, parkof(i - 2));
-            }
+            // (step i - 2's GELU family and Z1b derivation: the OWNER waves, see there)
             unsigned touch = 0u;               // L2 prefetch of this wave's share of the Z1 / Z1b fragments of step i - 4
             if (p.prefetch && i - 4 >= p.chunk_lo)
                 touch = __builtin_amdgcn_raw_buffer_load_b32(rS, (pp * 64 + l) * 128, slot_off(i - 4) + WREG + fro4(A_Z1, 0), 0);
