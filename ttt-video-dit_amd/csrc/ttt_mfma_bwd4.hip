@@ -866,29 +866,28 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
             // slice's eight Z1 ([ti][pp][s]) fragments -> D1 | D2 | X2 into the parking buffer (step parity) of deriver wave pp;
             // behind Bc (R3's D1B / X2B arrays are free then: their reader, the output path of step i - 1, is done) the same two
             // fragments of Z1b -> gelu'(Z1b) | X2b in R3.
-            bf16x8 zb_ahead[2];
+            // (requested here: in flight while the owners wait at Bc; ALL of the work sits behind Bc - the first cut had the parking
+            // half in front of it and made the owners the last to arrive there, profiles/r4e_*)
+            bf16x8 z_ahead[2], zb_ahead[2];
             const bool ahead = PRE && i - 2 >= p.chunk_lo;
             if (PRE && ahead) {
-                DeriverBackend obk{smem, (int)(threadIdx.x & 63)};
-                const int l = obk.lane();
-                const int sA = slot_off(i - 2) + WREG;
-                bf16x8 z[2];
+                const int l = (int)(threadIdx.x & 63), sA = slot_off(i - 2) + WREG;
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
-                    z[k] = bld8(rS, l * 16, sA + fro4(A_Z1, 2 * (ow >> 6) + k));
+                    z_ahead[k] = bld8(rS, l * 16, sA + fro4(A_Z1, 2 * (ow >> 6) + k));
                     zb_ahead[k] = bld8(rS, l * 16, sA + fro4(A_Z1B, 2 * (ow >> 6) + k));
-                }
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const int f = 2 * (ow >> 6) + k, ti = f >> 2, ppd = (f >> 1) & 1, s = f & 1;
-                    char* pk = p.park + ((((size_t)(bh * 4 + cq) * 2 + ppd) * 2) + ((i - 2) & 1)) * bwd4::PARK_BYTES;
-                    bwd4::prederive_frag(obk, z[k], ti, s, pk);
                 }
             }
             owner_barrier();                   // Bc: dZ2_i visible to the compute waves
             TTT_OSTAMP(3)                      // wait for the compute waves at Bc
             if (PRE && ahead) {
                 DeriverBackend obk{smem, (int)(threadIdx.x & 63)};
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int f = 2 * (ow >> 6) + k, ti = f >> 2, ppd = (f >> 1) & 1, s = f & 1;
+                    char* pk = p.park + ((((size_t)(bh * 4 + cq) * 2 + ppd) * 2) + ((i - 2) & 1)) * bwd4::PARK_BYTES;
+                    bwd4::prederive_frag(obk, z_ahead[k], ti, s, pk);
+                }
 #pragma unroll
                 for (int k = 0; k < 2; ++k) bwd4::derive_z1b_frag(obk, zb_ahead[k], 2 * (ow >> 6) + k, L_R3, L_R3 + FRK);
                 asm volatile("s_waitcnt vmcnt(0) ; the parked fragments are in memory before Bd" ::: "memory");
