@@ -71,57 +71,5 @@ int emul_bwd4_aux_step(float* W1, float* W2, const unsigned short* z1, const uns
     if (rep.races && msg) snprintf(msg, msg_len, "%s", rep.first.c_str());
     return rep.races;
 }
-// the same step through the two-part form of round 4: prederive() (+ derive_z1b) "one phase early", then reverse_step_pre()
-int emul_bwd4_aux_step_pre(float* W1, float* W2, const unsigned short* z1, const unsigned short* z1b, const unsigned short* K,
-                           const unsigned short* G, const float* eta, char* lds_out, char* gslice, char* msg, int msg_len) {
-    static char park[2 * bwd4::PARK_BYTES];
-    const emul::RaceReport rep = emul::run_group(2, [&](emul::EmulWave& w) {
-        const int pp = w.wave(), l = w.lane(), h = l >> 5, c = l & 31;
-        bwd4::Frags4 Z1, Z1B;
-        for (int ti = 0; ti < 2; ++ti)
-            for (int s = 0; s < 2; ++s) {
-                std::memcpy(&Z1.f[ti][s], z1 + ((size_t)bwd4::fr_idx(ti, pp, s) * 64 + l) * 8, 16);
-                std::memcpy(&Z1B.f[ti][s], z1b + ((size_t)bwd4::fr_idx(ti, pp, s) * 64 + l) * 8, 16);
-            }
-        // "Bc .. Bd of the iteration before": needs the stored pre-activations only
-        bwd4::derive_z1b(w, Z1B, pp, L_R3, L_R3 + 8 * 1024);
-        bwd4::prederive(w, Z1, park + pp * bwd4::PARK_BYTES);
-        if (pp == 0) {
-            for (int t = l; t < 64; t += 64) {
-                for (int f = 0; f < 64; ++f) {
-                    *reinterpret_cast<unsigned short*>(w.lds_ptr(L_K + (t * bwd4::TS + f) * 2)) = K[t * 64 + f];
-                    *reinterpret_cast<unsigned short*>(w.lds_ptr(L_G + (t * bwd4::TS + f) * 2)) = G[t * 64 + f];
-                }
-                *reinterpret_cast<float*>(w.lds_ptr(L_ETA + t * 4)) = eta[t];
-            }
-        }
-        w.barrier();
-        bwd4::AuxState st;
-        for (int r = 0; r < 16; ++r) {
-            const int ro = (r & 3) + 8 * (r >> 2) + 4 * h;
-            for (int a = 0; a < 2; ++a) {
-                st.W1t[a][r] = W1[(32 * a + ro) * 64 + 32 * pp + c];
-                st.W2t[a][r] = W2[(32 * pp + ro) * 64 + 32 * a + c];
-            }
-        }
-        bwd4::Frags4 D1, D2, X2;
-        bwd4::load_parked(w, park + pp * bwd4::PARK_BYTES, D1, D2, X2);
-        bwd4::stage_r1_static(w, pp, D1, X2, L_R1);
-        bwd4::reverse_step_pre(w, st, pp, L_K, L_G, L_ETA, D1, D2, X2, L_R1, L_R2, gslice, 0, 8 * 1024, park + pp * bwd4::PARK_BYTES);
-        bwd4::stage_r4(w, pp, L_R4, park + pp * bwd4::PARK_BYTES);
-        bwd4::stage_w2t(w, st, pp, L_R3 + 16 * 1024);
-        for (int r = 0; r < 16; ++r) {
-            const int ro = (r & 3) + 8 * (r >> 2) + 4 * h;
-            for (int a = 0; a < 2; ++a) {
-                W1[(32 * a + ro) * 64 + 32 * pp + c] = st.W1t[a][r];
-                W2[(32 * pp + ro) * 64 + 32 * a + c] = st.W2t[a][r];
-            }
-        }
-        w.barrier();
-        if (pp == 0 && l == 0) std::memcpy(lds_out, w.lds_ptr(L_R1), L_END - L_R1);
-    });
-    if (rep.races && msg) snprintf(msg, msg_len, "%s", rep.first.c_str());
-    return rep.races;
-}
 int emul_bwd4_lds_bytes() { return L_END - L_R1; }
 }

@@ -67,28 +67,19 @@ def _run_sweep_variant(e, d, G, **opts):
         return run_mlp(e, d, G, torch.bfloat16, impl="mfma")
     finally:
         e.debug_groups_per_chunk(0)
-        _sweep_defaults(e)
+        e.debug_option("sweep_owner_overlap", 1)       # library defaults (csrc/ttt_mfma_bwd4.hip)
+        e.debug_option("sweep_records_bf16", 1)
+        e.debug_option("sweep_deriver_wave0", 2)
 
 
-def _sweep_defaults(e):
-    """the library's defaults of the sweep's debug options (csrc/ttt_mfma_bwd4.hip)"""
-    e.debug_option("sweep_records_bf16", 1)
-    e.debug_option("sweep_deriver_wave0", 4)
-    e.debug_option("sweep_prederive", SWEEP_PREDERIVE_DEFAULT)
-
-
-SWEEP_PREDERIVE_DEFAULT = 0
-
-
-@pytest.mark.parametrize("bf16_records,deriver_wave0,prederive", [(1, 4, 0), (0, 4, 0), (1, 2, 0), (1, 4, 1), (1, 2, 1)])
-def test_sweep_schedule_and_record_variants(bf16_records, deriver_wave0, prederive):
+@pytest.mark.parametrize("overlap,bf16_records,deriver_wave0", [(0, 1, 4), (0, 0, 4), (1, 1, 4), (1, 0, 4), (0, 1, 2), (1, 1, 2)])
+def test_sweep_schedule_and_record_variants(overlap, bf16_records, deriver_wave0):
     """Round-4 variants of the TTT-MLP backward sweep (csrc/ttt_mfma_bwd4.hip), each against the fp64 oracle head by head at the
     usual tolerances and required to be run-to-run deterministic: hand-over records that carry the partial d(gZ2) tiles as
-    bf16 with the owners' partner-independent arithmetic under the record loads (debug option "sweep_records_bf16", the default
-    since the round-4 A/B: 11.8 against 13.4 ms per backward at NC = 804) or the round-3 sweep (0); the deriver role on waves
-    4, 5 (beside the compute waves on SIMDs 0 / 1) or 2, 3 ("sweep_deriver_wave0"); the derivers' reverse step in one part or
-    with the GELU family evaluated one phase early ("sweep_prederive").  NC = 70 with checkpoint groups of 16 and two groups
-    per chunk: three chunks, the last of them short.  (No bit-equality ACROSS variants: separate instantiations, and the
+    bf16 (debug option "sweep_records_bf16", the default since the round-4 A/B: 11.8 against 14.2 ms per backward at NC = 804)
+    or as fp32, and the owners' partner-independent arithmetic ordered under the record loads ("sweep_owner_overlap", lost its
+    A/B: 14.15 against 13.44 ms) or behind them, the deriver role on waves 4, 5 (beside the compute waves on SIMDs 0 / 1) or on waves
+    2, 3 (beside two owner waves, "sweep_deriver_wave0").  (No bit-equality ACROSS variants: they are separate instantiations and the
     compiler contracts their multiply-adds differently - measured on dln_w.)"""
     from oracle import ttt_oracle as O
     from test_kernels_gpu import oracle_on, round_acts
@@ -97,32 +88,10 @@ def test_sweep_schedule_and_record_variants(bf16_records, deriver_wave0, prederi
     NH, NC, G = 8, 70, 16
     d = round_acts(O.make_inputs("mlp", 1, NH, NC, 64, 64, seed=8100), torch.bfloat16)
     ro, rc, rg = oracle_on(d, G, "mlp")
-    opts = dict(sweep_records_bf16=bf16_records, sweep_deriver_wave0=deriver_wave0, sweep_prederive=prederive)
+    opts = dict(sweep_owner_overlap=overlap, sweep_records_bf16=bf16_records, sweep_deriver_wave0=deriver_wave0)
     out1, cks1, g1 = _run_sweep_variant(e, d, G, **opts)
     out2, cks2, g2 = _run_sweep_variant(e, d, G, **opts)
     assert e.sweep_error() == 0
-    check_per_head(f"TTT-MLP MFMA backward, bf16 records={bf16_records} derivers on waves {deriver_wave0}, {deriver_wave0 + 1} prederive={prederive}",
-                   out1, cks1, g1, ro, rc, rg, 1e-2, 3e-2)
+    check_per_head(f"TTT-MLP MFMA backward, overlap={overlap} bf16 records={bf16_records} derivers on waves {deriver_wave0}, {deriver_wave0 + 1}", out1, cks1, g1, ro, rc, rg, 1e-2, 3e-2)
     for k in g1:
         assert torch.equal(g1[k], g2[k]), f"{k} differs between two identical calls"
-
-
-@pytest.mark.parametrize("NC,G,gpc", [(5, 16, 0), (17, 16, 1), (33, 4, 3), (2, 1, 1)])
-def test_prederive_sweep_at_chunk_and_group_edges(NC, G, gpc):
-    """The two-part reverse step looks TWO steps ahead (it pre-derives step i - 2 while step i is swept): chunks of one and two
-    steps, a chunk boundary inside the look-ahead, checkpoint groups of one step - against the oracle."""
-    from oracle import ttt_oracle as O
-    from test_kernels_gpu import oracle_on, round_acts, run_mlp
-    from test_parity_r2_gpu import check_per_head
-    e = ext()
-    d = round_acts(O.make_inputs("mlp", 1, 8, NC, 64, 64, seed=8200 + NC), torch.bfloat16)
-    ro, rc, rg = oracle_on(d, G, "mlp")
-    e.debug_option("sweep_prederive", 1)
-    e.debug_groups_per_chunk(gpc)
-    try:
-        out, cks, g = run_mlp(e, d, G, torch.bfloat16, impl="mfma")
-    finally:
-        e.debug_groups_per_chunk(0)
-        _sweep_defaults(e)
-    assert e.sweep_error() == 0
-    check_per_head(f"two-part reverse step, NC={NC} G={G} groups per chunk={gpc}", out, cks, g, ro, rc, rg, 1e-2, 3e-2)

@@ -121,27 +121,23 @@ struct Frags4 {
 };
 
 // Z1b fragments -> X2b, gelu'(Z1b) fragments, written to their staging arrays (FR_D1B | FR_X2B order of the round-2 sweep)
-// one fragment (index idx of the slice's [ti][pp][s] arrays) - the form the sweep's OWNER waves call in round 4's two-part schedule,
-// where the elementwise GELU work is theirs (any wave can do it: fragment images in, fragment images out)
-template <class BK>
-TTT_WV_FN void derive_z1b_frag(BK& bk, bf16x8 z, int idx, int off_d1b, int off_x2b) {
-    bf16x8 x, d;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        float y, dy;
-        gelu2(bk, (float)z[e], y, dy);
-        x[e] = (__bf16)y;
-        d[e] = (__bf16)dy;
-    }
-    st_frag(bk, off_d1b, idx, d);
-    st_frag(bk, off_x2b, idx, x);
-}
 template <class BK>
 TTT_WV_FN void derive_z1b(BK& bk, const Frags4& z1b, int pp, int off_d1b, int off_x2b) {
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) derive_z1b_frag(bk, z1b.f[ti][s], fr_idx(ti, pp, s), off_d1b, off_x2b);
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 x, d;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float y, dy;
+                gelu2(bk, (float)z1b.f[ti][s][e], y, dy);
+                x[e] = (__bf16)y;
+                d[e] = (__bf16)dy;
+            }
+            st_frag(bk, off_d1b, fr_idx(ti, pp, s), d);
+            st_frag(bk, off_x2b, fr_idx(ti, pp, s), x);
+        }
 }
 // W2^T fragments (rows = f in 32 b .., lane = n) of the current state -> staging array in FR_W2T order [fj][ni][s]
 template <class BK>
@@ -268,145 +264,6 @@ TTT_WV_FN void reverse_step(BK& bk, AuxState& st, int pp, int tile_k, int tile_g
         }
     }
     // (7) packed W1_i for the tail (FR_W1 order [fi][nj][s])
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) bk.store_stream(g_slice + off_w1 + fr_idx(a, pp, s) * FRAG + l * 16, pack(st.W1t[a], s));
-}
-
-// ---- round 4: the reverse step in two parts ------------------------------------------------------------------------------------
-// Stage stamps (profiles/r4c_op_phases_*.json) show the sweep's Bb .. Bc phase bounded by reverse_step() - 12 k of the step's 28 k
-// cycles, two thirds of them the three evaluations of the tanh-GELU family per element, which need nothing but the stored
-// pre-activation Z1 -, while the deriver waves idle through the Bc .. Bd phase.  So the evaluations move there, one step ahead:
-//   prederive(Z1_k)       (Bc .. Bd of the iteration before the step's own reverse step) -> D1 | D2 | X2 of step k as bf16 T
-//                         fragments in the wave's parking buffer of that step's parity;
-//   reverse_step_pre(k)   (Bb .. Bc) = reverse_step() with those fragments loaded instead of evaluated; it overwrites D2 with
-//                         M = gX2 * D2, after which the buffer holds what stage_r4() expects.
-// Same values as reverse_step() everywhere except M, which sees gelu'' rounded to bf16 first (one more rounding at the precision M
-// is stored in anyway).  The parked fragments arrive as arguments: the caller loads them (load_parked) and writes the tile-free
-// part of R1 (stage_r1_static) ahead of the barrier in front of the reverse step.
-// one fragment [ti][s] of a deriver wave's 32 hidden units -> that wave's parking buffer `park` (also called by the owner waves)
-template <class BK>
-TTT_WV_FN void prederive_frag(BK& bk, bf16x8 z, int ti, int s, char* park) {
-    const int l = bk.lane();
-    bf16x8 x, d, d2;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        float y, dy, d2y;
-        gelu3(bk, (float)z[e], y, dy, d2y);
-        x[e] = (__bf16)y;
-        d[e] = (__bf16)dy;
-        d2[e] = (__bf16)d2y;
-    }
-    *reinterpret_cast<bf16x8*>(park + park_off(0, ti, s) + l * 16) = d;
-    *reinterpret_cast<bf16x8*>(park + park_off(1, ti, s) + l * 16) = d2;
-    *reinterpret_cast<bf16x8*>(park + park_off(2, ti, s) + l * 16) = x;
-}
-template <class BK>
-TTT_WV_FN void prederive(BK& bk, const Frags4& Z1, char* park) {
-#pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) prederive_frag(bk, Z1.f[ti][s], ti, s, park);
-}
-// the parked D1 | D2 | X2 of a step: twelve 16-byte loads per lane, issued together ahead of the barrier in front of the reverse step
-template <class BK>
-TTT_WV_FN void load_parked(BK& bk, const char* park, Frags4& D1, Frags4& D2, Frags4& X2) {
-    const int l = bk.lane();
-#pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            D1.f[ti][s] = *reinterpret_cast<const bf16x8*>(park + park_off(0, ti, s) + l * 16);
-            D2.f[ti][s] = *reinterpret_cast<const bf16x8*>(park + park_off(1, ti, s) + l * 16);
-            X2.f[ti][s] = *reinterpret_cast<const bf16x8*>(park + park_off(2, ti, s) + l * 16);
-        }
-}
-// the part of R1 that needs no tile of the step: gelu'(Z1)^T | X2^T (N orientation), FR_D1N | FR_XT order [nj][ti][s] - written as
-// soon as the parked fragments have arrived, i.e. in front of the barrier too (S1 of the step before has left R1 behind Ba)
-template <class BK>
-TTT_WV_FN void stage_r1_static(BK& bk, int pp, const Frags4& D1, const Frags4& X2, int off_r1) {
-    const int l = bk.lane(), h = l >> 5, c = l & 31;
-    constexpr int FRK = 8 * FRAG;
-    const bf16x8 I0 = ident_pi(0, h, c), I1 = ident_pi(1, h, c);
-#pragma unroll
-    for (int ti = 0; ti < 2; ++ti) {
-        {
-            const f32x16 t = transpose_tile(bk, D1.f[ti][0], D1.f[ti][1], I0, I1);
-#pragma unroll
-            for (int s = 0; s < 2; ++s) st_frag(bk, off_r1 + FRK, fr_idx(pp, ti, s), pack(t, s));
-        }
-        {
-            const f32x16 t = transpose_tile(bk, X2.f[ti][0], X2.f[ti][1], I0, I1);
-#pragma unroll
-            for (int s = 0; s < 2; ++s) st_frag(bk, off_r1 + 2 * FRK, fr_idx(pp, ti, s), pack(t, s));
-        }
-    }
-}
-template <class BK>
-TTT_WV_FN void reverse_step_pre(BK& bk, AuxState& st, int pp, int tile_k, int tile_g, int vec_eta, const Frags4& D1, const Frags4& D2,
-                                const Frags4& X2, int off_r1, int off_r2, char* g_slice, int off_gz1t, int off_w1, char* park) {
-    const int l = bk.lane(), h = l >> 5, c = l & 31;
-    constexpr int FRK = 8 * FRAG;
-    // (2)  W2_i = W2_{i+1} + (eta X2)^T gZ2
-#pragma unroll
-    for (int ti = 0; ti < 2; ++ti) {
-        const f32x16 etaR = rows_from_lds(bk, vec_eta, 32 * ti, h);
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            bf16x8 xs;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) xs[e] = (__bf16)((float)X2.f[ti][s][e] * etaR[8 * s + e]);
-#pragma unroll
-            for (int b = 0; b < 2; ++b) st.W2t[b] = bk.mma3216(xs, tr_pi(bk, tile_g, 32 * ti, s, 32 * b), st.W2t[b]);
-        }
-    }
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) st_frag(bk, off_r2, fr_idx(pp, b, s), pack(st.W2t[b], s));
-    // (3), (4), (5) per token tile
-#pragma unroll
-    for (int ti = 0; ti < 2; ++ti) {
-        const bf16x8 I0 = ident_pi(0, h, c), I1 = ident_pi(1, h, c);
-        f32x16 gx = zero16();                                     // gX2 = gZ2 W2^T   (rows = t, lane = n)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const f32x16 t = transpose_tile(bk, pack(st.W2t[b], 0), pack(st.W2t[b], 1), I0, I1);
-#pragma unroll
-            for (int s = 0; s < 2; ++s) gx = bk.mma3216(pi_row(bk, tile_g, 32 * ti + c, 32 * b, s, h), pack(t, s), gx);
-        }
-        bf16x8 g1p[2], g1sp[2];
-        {
-            const f32x16 etaR = rows_from_lds(bk, vec_eta, 32 * ti, h);
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                bf16x8 m;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float g1 = gx[8 * s + e] * (float)D1.f[ti][s][e];
-                    g1p[s][e] = (__bf16)g1;
-                    g1sp[s][e] = (__bf16)(g1 * etaR[8 * s + e]);
-                    m[e] = (__bf16)(gx[8 * s + e] * (float)D2.f[ti][s][e]);
-                }
-                *reinterpret_cast<bf16x8*>(park + park_off(1, ti, s) + l * 16) = m;
-            }
-        }
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int a = 0; a < 2; ++a) st.W1t[a] = bk.mma3216(tr_pi(bk, tile_k, 32 * ti, s, 32 * a), g1sp[s], st.W1t[a]);
-        {
-            const f32x16 t = transpose_tile(bk, g1p[0], g1p[1], I0, I1);
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bf16x8 v = pack(t, s);
-                st_frag(bk, off_r1, fr_idx(pp, ti, s), v);
-                bk.store_stream(g_slice + off_gz1t + fr_idx(pp, ti, s) * FRAG + l * 16, v);
-            }
-        }
-        // (gelu'(Z1)^T and X2^T: stage_r1_static())
-    }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll

@@ -85,7 +85,7 @@ size_t workspace_bytes(const ttt_dims* d, bool mlp, bool backward) {
     // two record buffers + carried state gradient + exchange records and flag lines of the cluster sweep + the state after the
     // last step + the derivers' parking areas
     return nbh * (2 * slots * s4::SLOT4_BYTES + b2::CARRY_FLOATS2 * sizeof(float)) + align128(nbh * 64) +
-           nbh * (b2::XCH_BH_BYTES + 4 * b2::FLAG_STRIDE * sizeof(unsigned)) + nbh * (s4::FINAL_FLOATS * sizeof(float) + 16 * s4::PARK4_BYTES);      // (two parking buffers per deriver wave)
+           nbh * (b2::XCH_BH_BYTES + 4 * b2::FLAG_STRIDE * sizeof(unsigned)) + nbh * (s4::FINAL_FLOATS * sizeof(float) + 8 * s4::PARK4_BYTES);
 }
 
 // Side stream and the events of the two-buffer hand-over, one set per device, created on first use.

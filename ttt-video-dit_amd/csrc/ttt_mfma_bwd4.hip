@@ -180,10 +180,7 @@ struct DeriverBackend {
 // the other roundings (worst 3.0e-2 -> 3.6e-2 / 2.6e-2 -> 2.5e-2).  [t][PS16] bf16 inside the fp32 tile's area of the record.
 constexpr int PS16 = 72;
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-// PRE (round 4, debug option "sweep_prederive"): the derivers evaluate a step's GELU family one phase EARLY - in the Bc .. Bd
-// phase of the iteration before, which they used to idle through - and park it (ttt_bwd4_aux_body.h prederive / reverse_step_pre);
-// the Bb .. Bc phase, which reverse_step() bounded with 12 k of the step's 28 k cycles, keeps only what needs the step's tiles.
-template <bool DBG, bool OVL, bool R16, int DW0, bool PRE>
+template <bool DBG, bool OVL, bool R16, int DW0>
 __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
     constexpr int OW0 = DW0 == 2 ? 4 : 2;                        // first owner wave (it polls the partner flags)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -861,37 +858,8 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
                 }
             }
             TTT_OSTAMP(2)                      // owner math, dZ2 / dV / d(eta) stores
-            // ---- PRE (round 4): the elementwise GELU work of step i - 2 is the OWNERS' - they are through with their chain 8 k
-            // cycles before the derivers reach Bc, and idle through Bc .. Bd -: owner wave w takes fragments 2 w, 2 w + 1 of the
-            // slice's eight Z1 ([ti][pp][s]) fragments -> D1 | D2 | X2 into the parking buffer (step parity) of deriver wave pp;
-            // behind Bc (R3's D1B / X2B arrays are free then: their reader, the output path of step i - 1, is done) the same two
-            // fragments of Z1b -> gelu'(Z1b) | X2b in R3.
-            // (requested here: in flight while the owners wait at Bc; ALL of the work sits behind Bc - the first cut had the parking
-            // half in front of it and made the owners the last to arrive there, profiles/r4e_*)
-            bf16x8 z_ahead[2], zb_ahead[2];
-            const bool ahead = PRE && i - 2 >= p.chunk_lo;
-            if (PRE && ahead) {
-                const int l = (int)(threadIdx.x & 63), sA = slot_off(i - 2) + WREG;
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    z_ahead[k] = bld8(rS, l * 16, sA + fro4(A_Z1, 2 * (ow >> 6) + k));
-                    zb_ahead[k] = bld8(rS, l * 16, sA + fro4(A_Z1B, 2 * (ow >> 6) + k));
-                }
-            }
             owner_barrier();                   // Bc: dZ2_i visible to the compute waves
             TTT_OSTAMP(3)                      // wait for the compute waves at Bc
-            if (PRE && ahead) {
-                DeriverBackend obk{smem, (int)(threadIdx.x & 63)};
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const int f = 2 * (ow >> 6) + k, ti = f >> 2, ppd = (f >> 1) & 1, s = f & 1;
-                    char* pk = p.park + ((((size_t)(bh * 4 + cq) * 2 + ppd) * 2) + ((i - 2) & 1)) * bwd4::PARK_BYTES;
-                    bwd4::prederive_frag(obk, z_ahead[k], ti, s, pk);
-                }
-#pragma unroll
-                for (int k = 0; k < 2; ++k) bwd4::derive_z1b_frag(obk, zb_ahead[k], 2 * (ow >> 6) + k, L_R3, L_R3 + FRK);
-                asm volatile("s_waitcnt vmcnt(0) ; the parked fragments are in memory before Bd" ::: "memory");
-            }
             // ---- L2 prefetch, two steps ahead: one dword per 128-byte line of what the owners of this CU will request for step
             // i - 2 (owner rows, gZ2 tile: 452 lines; K, Q, dOut tiles: 192 lines).  Issued HERE, behind Bc: the owners idle
             // during S4a, and the issue of an instruction whose 64 lanes miss 64 different lines blocks the wave for a while
@@ -985,108 +953,8 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
 #pragma unroll
                 for (int s = 0; s < 2; ++s) *reinterpret_cast<bf16x8*>(sl + fro4(A_W1, fr_idx(a, pp, s)) + l * 16) = pack(st.W1t[a], s);
         }
-        if constexpr (PRE) {
-        // ------------------------------------------------------------------------------------------ two-part reverse step (round 4)
-        bwd4::Frags4 Z1, Z1B, D1f, D2f, X2;
-        char* const park0 = p.park + ((size_t)(bh * 4 + cq) * 2 + pp) * 2 * bwd4::PARK_BYTES;      // two parking buffers, by step parity
-        auto parkof = [&](int step) { return park0 + (step & 1) * bwd4::PARK_BYTES; };
-        // The parked D1 | D2 | X2 of a step are written by the OWNER waves of this workgroup (below, one iteration ahead): read
-        // them back with sc1 loads, which are never served by this CU's vector L1 (a line of the same parking buffer may still
-        // sit there from two steps ago), like the hand-over records.
-        const __amdgpu_buffer_rsrc_t rP = make_srd(park0, 2 * bwd4::PARK_BYTES);
-        auto ld_park = [&](int step, int arr, int ti, int s_) {
-            return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rP, (step & 1) * (int)bwd4::PARK_BYTES + bwd4::park_off(arr, ti, s_) + l * 16, 0, 16));
-        };
-        auto load_parked_sc1 = [&](int step) {
-#pragma unroll
-            for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-                for (int s_ = 0; s_ < 2; ++s_) {
-                    D1f.f[ti][s_] = ld_park(step, 0, ti, s_);
-                    D2f.f[ti][s_] = ld_park(step, 1, ti, s_);
-                    X2.f[ti][s_] = ld_park(step, 2, ti, s_);
-                }
-        };
-        auto stage_r4_sc1 = [&](int step) {        // bwd4::stage_r4 with the loads above
-            bf16x8 v[12];
-#pragma unroll
-            for (int arr = 0; arr < 3; ++arr)
-#pragma unroll
-                for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-                    for (int s_ = 0; s_ < 2; ++s_) v[(arr * 2 + ti) * 2 + s_] = ld_park(step, arr, ti, s_);
-#pragma unroll
-            for (int arr = 0; arr < 3; ++arr)
-#pragma unroll
-                for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-                    for (int s_ = 0; s_ < 2; ++s_) bwd4::st_frag(bk, L_R4 + arr * FRK, fr_idx(ti, pp, s_), v[(arr * 2 + ti) * 2 + s_]);
-        };
-        load_frags(i0, A_Z1, Z1);
-        load_frags(i0, A_Z1B, Z1B);
-        owner_barrier();                       // P0
-        bwd4::stage_w2t(bk, st, pp, L_R3 + 2 * FRK);
-        bwd4::derive_z1b(bk, Z1B, pp, L_R3, L_R3 + FRK);
-        bwd4::prederive(bk, Z1, parkof(i0));
-        asm volatile("s_waitcnt vmcnt(0) ; the parked fragments are in memory before this wave reads them back" ::: "memory");
-        load_parked_sc1(i0);
-        bwd4::stage_r1_static(bk, pp, D1f, X2, L_R1);
-        owner_barrier();                       // P1: the tiles of step i0 (K, gZ2, eta) are visible
-        bwd4::reverse_step_pre(bk, st, pp, L_K, L_G, L_SM, D1f, D2f, X2, L_R1, L_R2, slots + (size_t)slot_off(i0) + WREG,
-                               fro4(A_GZ1T, 0), fro4(A_W1, 0), parkof(i0));
-        if (i0 - 1 >= p.chunk_lo) {            // what the first iteration's reverse step loads
-            load_frags(i0 - 1, A_Z1, Z1);
-            bwd4::prederive(bk, Z1, parkof(i0 - 1));
-        }
-        owner_barrier();                       // P2
-
-        unsigned long long t_d = 0;
-        if (DBG && p.dbg != nullptr && blockIdx.x == 0 && tid == 64 * DW0) t_d = __builtin_readcyclecounter();
-#define TTT_DSTAMP_P(k)                                                              \
-        if (DBG && p.dbg != nullptr && blockIdx.x == 0 && tid == 64 * DW0) {         \
-            const unsigned long long _t = __builtin_readcyclecounter();              \
-            p.dbg[(k)] += _t - t_d;                                                  \
-            t_d = _t;                                                                \
-        }
-        for (int i = i0; i >= p.chunk_lo; --i) {
-            const bool more = i > p.chunk_lo;
-            const int nxt = ((i0 - i) & 1) ^ 1;                 // tile buffer of step j = i - 1
-            bk.refresh();
-            stage_r4_sc1(i);                                    // of step i: S4a of the step before is behind Bd / P2
-            bwd4::stage_w2t(bk, st, pp, L_R3 + 2 * FRK);        // W2_i^T: S4a of step i, output path of step j
-            if (more && i == i0) load_frags(i - 1, A_Z1B, Z1B); // (first iteration only: later ones derive Z1b in the window below)
-            TTT_DSTAMP_P(28)
-            owner_barrier();                   // Ba
-            TTT_DSTAMP_P(31)
-            if (more && i == i0) bwd4::derive_z1b(bk, Z1B, pp, L_R3, L_R3 + FRK);
-            if (more) {
-                asm volatile("s_waitcnt vmcnt(0) ; the fragments parked a phase ago are in memory" ::: "memory");
-                load_parked_sc1(i - 1);
-                bwd4::stage_r1_static(bk, pp, D1f, X2, L_R1);   // (S1 of step i left R1 behind Ba)
-            }
-            TTT_DSTAMP_P(29)
-            owner_barrier();                   // Bb: K_j, gZ2_j, eta_j staged by the owners are visible
-            TTT_DSTAMP_P(31)
-            if (more) {
-                if (i % p.G == 0) load_anchor(i);               // group boundary: the exact state entering step i
-                bwd4::reverse_step_pre(bk, st, pp, L_K + nxt * TILE_B, L_G + nxt * TILE_B, L_SM + nxt * 64 * 4, D1f, D2f, X2, L_R1, L_R2,
-                                       slots + (size_t)slot_off(i - 1) + WREG, fro4(A_GZ1T, 0), fro4(A_W1, 0), parkof(i - 1));
-            }
-            TTT_DSTAMP_P(30)
-            owner_barrier();                   // Bc
-            TTT_DSTAMP_P(31)
-            // (step i - 2's GELU family and Z1b derivation: the OWNER waves, see there)
-            unsigned touch = 0u;               // L2 prefetch of this wave's share of the Z1 / Z1b fragments of step i - 4
-            if (p.prefetch && i - 4 >= p.chunk_lo)
-                touch = __builtin_amdgcn_raw_buffer_load_b32(rS, (pp * 64 + l) * 128, slot_off(i - 4) + WREG + fro4(A_Z1, 0), 0);
-            TTT_DSTAMP_P(36)
-            owner_barrier();                   // Bd
-            asm volatile("" :: "v"(touch));
-            TTT_DSTAMP_P(31)
-        }
-        } else {
         bwd4::Frags4 Z1, Z1B;
-        char* const park = p.park + ((size_t)(bh * 4 + cq) * 2 + pp) * 2 * bwd4::PARK_BYTES;  // this wave's R4 parking area (L2-resident; two buffers, the second for PRE)
+        char* const park = p.park + ((size_t)(bh * 4 + cq) * 2 + pp) * bwd4::PARK_BYTES;     // this wave's R4 parking area (L2-resident)
         load_frags(i0, A_Z1, Z1);
         load_frags(i0, A_Z1B, Z1B);
         owner_barrier();                       // P0
@@ -1137,7 +1005,6 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
             owner_barrier();                   // Bd
             asm volatile("" :: "v"(touch));
             TTT_DSTAMP(3)
-        }
         }
         if (p.last) owner_barrier();           // (the owners' final reduction)
     }
@@ -1293,12 +1160,11 @@ unsigned read_sweep_fast_count() {      // DEBUG statistic: cluster workgroup la
     return v;
 }
 
-// (the owners' partner-independent arithmetic under the record loads - template parameter OVL: one box, NC = 804: with fp32
-// records 14.15 ms per backward against 13.44 without, with bf16 records 11.76 against 12.71 - goes with the bf16 records)
-static int g_prederive = 0;               // two-part reverse step (template parameter PRE): opt-in until timed
-void set_debug_sweep_prederive(int v) { g_prederive = v; }
-static int g_deriver_wave0 = 4;           // 4: derivers = waves 4, 5 (SIMDs 0 / 1, beside the compute waves); 2: waves 2, 3 (beside two owner waves)
-void set_debug_sweep_deriver_wave0(int v) { g_deriver_wave0 = (v == 2 || v == 1) ? 2 : 4; }      // (1 = 2: the 0 / 1 toggle of op_bench --ab)
+static int g_owner_overlap = 1;           // round 4, one box, NC = 804: with fp32 records 14.15 ms per backward against 13.44 without; with bf16 records 11.76 against 12.71: on
+void set_debug_sweep_owner_overlap(int v) { g_owner_overlap = v; }
+static int g_deriver_wave0 = 2;           // 4: derivers = waves 4, 5 (SIMDs 0 / 1, beside the compute waves); 2: waves 2, 3 (beside two owner waves) - the
+                                          // default since round 4: 11.48 - 11.62 ms per backward against 11.79 - 11.94 in three interleaved A/Bs (profiles/r4d - r4f)
+void set_debug_sweep_deriver_wave0(int v) { g_deriver_wave0 = (v == 4 || v == 0) ? 4 : 2; }      // (0 = 4, 1 = 2: the 0 / 1 toggle of op_bench --ab)
 static int g_records_bf16 = 1;            // round 4, one box: 11.82 against 14.16 ms per backward at NC = 804, 4.24 against 5.11 at NC = 282
 void set_debug_sweep_records_bf16(int v) { g_records_bf16 = v; }
 
@@ -1309,29 +1175,37 @@ void launch_sweep_cluster4(const SweepParams4& bp, int nbh, hipStream_t s) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     const dim3 grid(nbh * 4), blk(b4::NTC);
+    const bool first = dev >= 0 && dev < 16 && !attr[dev];
+    auto go = [&](auto kern) {
+        if (first) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, b4::LDS_CL);
+        hipLaunchKernelGGL(kern, grid, blk, b4::LDS_CL, s, bp);
+    };
     {
         std::lock_guard<std::mutex> lock(g_err_mutex);
-        if (dev >= 0 && dev < 16 && !attr[dev]) {
+        if (first) {
             // every instantiation a later call may select gets its attribute on this device now
             auto set = [&](auto kern) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, b4::LDS_CL); };
-            set(b4::mlp_bwd_cluster4_kernel<false, false, false, 4, false>); set(b4::mlp_bwd_cluster4_kernel<true, false, false, 4, false>);
-            set(b4::mlp_bwd_cluster4_kernel<false, true, true, 4, false>);   set(b4::mlp_bwd_cluster4_kernel<true, true, true, 4, false>);
-            set(b4::mlp_bwd_cluster4_kernel<false, true, true, 2, false>);   set(b4::mlp_bwd_cluster4_kernel<true, true, true, 2, false>);
-            set(b4::mlp_bwd_cluster4_kernel<false, true, true, 4, true>);    set(b4::mlp_bwd_cluster4_kernel<true, true, true, 4, true>);
-            set(b4::mlp_bwd_cluster4_kernel<false, true, true, 2, true>);    set(b4::mlp_bwd_cluster4_kernel<true, true, true, 2, true>);
+            set(b4::mlp_bwd_cluster4_kernel<false, false, false, 4>); set(b4::mlp_bwd_cluster4_kernel<true, false, false, 4>);
+            set(b4::mlp_bwd_cluster4_kernel<false, true, false, 4>);  set(b4::mlp_bwd_cluster4_kernel<true, true, false, 4>);
+            set(b4::mlp_bwd_cluster4_kernel<false, false, true, 4>);  set(b4::mlp_bwd_cluster4_kernel<true, false, true, 4>);
+            set(b4::mlp_bwd_cluster4_kernel<false, true, true, 4>);   set(b4::mlp_bwd_cluster4_kernel<true, true, true, 4>);
+            set(b4::mlp_bwd_cluster4_kernel<false, false, true, 2>);  set(b4::mlp_bwd_cluster4_kernel<true, false, true, 2>);
+            set(b4::mlp_bwd_cluster4_kernel<false, true, true, 2>);   set(b4::mlp_bwd_cluster4_kernel<true, true, true, 2>);
             (void)hipFuncSetAttribute((const void*)b4::mlp_bwd_tail4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, b4::LDS_TAIL4);
             attr[dev] = true;
         }
     }
-    auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, blk, b4::LDS_CL, s, bp); };
-    const bool dbg = bp.dbg != nullptr, r16 = g_records_bf16 != 0, dw2 = g_deriver_wave0 == 2, pre = g_prederive != 0;
-    // variants kept for the A/Bs of round 4: the round-3 sweep (fp32 records, round-3 owner order), and with bf16 records +
-    // owner overlap: deriver waves 4, 5 / 2, 3 x one-part / two-part reverse step
-    if (!r16) { if (dbg) go(b4::mlp_bwd_cluster4_kernel<true, false, false, 4, false>); else go(b4::mlp_bwd_cluster4_kernel<false, false, false, 4, false>); }
-    else if (!pre && !dw2) { if (dbg) go(b4::mlp_bwd_cluster4_kernel<true, true, true, 4, false>); else go(b4::mlp_bwd_cluster4_kernel<false, true, true, 4, false>); }
-    else if (!pre) { if (dbg) go(b4::mlp_bwd_cluster4_kernel<true, true, true, 2, false>); else go(b4::mlp_bwd_cluster4_kernel<false, true, true, 2, false>); }
-    else if (!dw2) { if (dbg) go(b4::mlp_bwd_cluster4_kernel<true, true, true, 4, true>); else go(b4::mlp_bwd_cluster4_kernel<false, true, true, 4, true>); }
-    else { if (dbg) go(b4::mlp_bwd_cluster4_kernel<true, true, true, 2, true>); else go(b4::mlp_bwd_cluster4_kernel<false, true, true, 2, true>); }
+    const bool dbg = bp.dbg != nullptr, ovl = g_owner_overlap != 0, r16 = g_records_bf16 != 0, dw2 = g_deriver_wave0 == 2 && r16;
+    if (dw2) {
+        if (ovl) { if (dbg) go(b4::mlp_bwd_cluster4_kernel<true, true, true, 2>); else go(b4::mlp_bwd_cluster4_kernel<false, true, true, 2>); }
+        else     { if (dbg) go(b4::mlp_bwd_cluster4_kernel<true, false, true, 2>); else go(b4::mlp_bwd_cluster4_kernel<false, false, true, 2>); }
+    } else if (r16) {
+        if (ovl) { if (dbg) go(b4::mlp_bwd_cluster4_kernel<true, true, true, 4>); else go(b4::mlp_bwd_cluster4_kernel<false, true, true, 4>); }
+        else     { if (dbg) go(b4::mlp_bwd_cluster4_kernel<true, false, true, 4>); else go(b4::mlp_bwd_cluster4_kernel<false, false, true, 4>); }
+    } else {
+        if (ovl) { if (dbg) go(b4::mlp_bwd_cluster4_kernel<true, true, false, 4>); else go(b4::mlp_bwd_cluster4_kernel<false, true, false, 4>); }
+        else     { if (dbg) go(b4::mlp_bwd_cluster4_kernel<true, false, false, 4>); else go(b4::mlp_bwd_cluster4_kernel<false, false, false, 4>); }
+    }
 }
 
 void launch_tail4(const __bf16* dOut, const __bf16* eta, const __bf16* dXV, char* slots, size_t slot_stride_bh, __bf16* dXQ, __bf16* dXK,
