@@ -258,8 +258,10 @@ void        ttt_hip_debug_groups_per_chunk(int groups);
  * backward sweep hand-over: 1 (default) = plain, L2-resident records once the four workgroups of a cluster have proven that they
  * share an XCD; 0 = write-through records always), "sweep_fast_count" (query: returns -2 - the number of cluster workgroup
  * launches that took the plain form), "sweep_fault" (fault injection for the tests of the hand-over failure path: workgroup 3 of
- * every backward cluster leaves before its first hand-over), "sweep_owner_overlap" (1 default / 0: the sweep's owner waves do
- * their partner-independent arithmetic under the record loads), "attn_stage" (attention backward: tiles of 64 per LDS stage in
+ * every backward cluster leaves before its first hand-over), "sweep_records_bf16" (1 default / 0: the sweep's hand-over records
+ * carry the partial d(gZ2) tiles as bf16 and the owner waves do their partner-independent arithmetic under the record loads; 0 =
+ * the round-3 sweep), "sweep_deriver_wave0" (2 default / 4: which waves take the deriver role), "own_bf16" (the inner
+ * LayerNorm's owner rows of the backward's step record as bf16), "attn_stage" (attention backward: tiles of 64 per LDS stage in
  * the dQ and dK / dV kernels, default 2 - half the workgroup barriers of 1, the round-3 kernels; bit-identical results),
  * "attn_stage_dq" (1 / 2) and "attn_stage_dkdv" (1 .. 4) for one kernel only.
  * Returns 0, or -1 for an unknown name.  (The round-1 knobs - kernel revisions, prefetch

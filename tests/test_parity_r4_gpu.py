@@ -67,20 +67,27 @@ def _run_sweep_variant(e, d, G, **opts):
         return run_mlp(e, d, G, torch.bfloat16, impl="mfma")
     finally:
         e.debug_groups_per_chunk(0)
-        e.debug_option("sweep_owner_overlap", 1)       # library defaults (csrc/ttt_mfma_bwd4.hip)
-        e.debug_option("sweep_records_bf16", 1)
-        e.debug_option("sweep_deriver_wave0", 2)
+        sweep_defaults(e)
 
 
-@pytest.mark.parametrize("overlap,bf16_records,deriver_wave0", [(0, 1, 4), (0, 0, 4), (1, 1, 4), (1, 0, 4), (0, 1, 2), (1, 1, 2)])
-def test_sweep_schedule_and_record_variants(overlap, bf16_records, deriver_wave0):
+SWEEP_DEFAULTS = dict(sweep_records_bf16=1, sweep_deriver_wave0=2, own_bf16=0)      # the library's (csrc/ttt_mfma_bwd4.hip, ttt_mfma_bwd2.hip)
+
+
+def sweep_defaults(e):
+    for k, v in SWEEP_DEFAULTS.items():
+        e.debug_option(k, v)
+
+
+@pytest.mark.parametrize("bf16_records,deriver_wave0,own_bf16", [(1, 2, 0), (0, 4, 0), (1, 4, 0), (1, 2, 1)])
+def test_sweep_schedule_and_record_variants(bf16_records, deriver_wave0, own_bf16):
     """Round-4 variants of the TTT-MLP backward sweep (csrc/ttt_mfma_bwd4.hip), each against the fp64 oracle head by head at the
     usual tolerances and required to be run-to-run deterministic: hand-over records that carry the partial d(gZ2) tiles as
-    bf16 (debug option "sweep_records_bf16", the default since the round-4 A/B: 11.8 against 14.2 ms per backward at NC = 804)
-    or as fp32, and the owners' partner-independent arithmetic ordered under the record loads ("sweep_owner_overlap", lost its
-    A/B: 14.15 against 13.44 ms) or behind them, the deriver role on waves 4, 5 (beside the compute waves on SIMDs 0 / 1) or on waves
-    2, 3 (beside two owner waves, "sweep_deriver_wave0").  (No bit-equality ACROSS variants: they are separate instantiations and the
-    compiler contracts their multiply-adds differently - measured on dln_w.)"""
+    bf16 with the owners' partner-independent arithmetic under the record loads (debug option "sweep_records_bf16", the default
+    since the round-4 A/B: 11.8 against 13.4 ms per backward at NC = 804) or the round-3 sweep (0); the deriver role on waves
+    2, 3 (default: -2.5 % in three A/Bs) or 4, 5 ("sweep_deriver_wave0"); the inner LayerNorm's owner rows of the step record
+    as bf16 ("own_bf16").  NC = 70 with checkpoint groups of 16 and two groups per chunk: three chunks, the last of them short.
+    (No bit-equality ACROSS variants: separate instantiations, and the compiler contracts their multiply-adds differently -
+    measured on dln_w.)"""
     from oracle import ttt_oracle as O
     from test_kernels_gpu import oracle_on, round_acts
     from test_parity_r2_gpu import check_per_head
@@ -88,10 +95,11 @@ def test_sweep_schedule_and_record_variants(overlap, bf16_records, deriver_wave0
     NH, NC, G = 8, 70, 16
     d = round_acts(O.make_inputs("mlp", 1, NH, NC, 64, 64, seed=8100), torch.bfloat16)
     ro, rc, rg = oracle_on(d, G, "mlp")
-    opts = dict(sweep_owner_overlap=overlap, sweep_records_bf16=bf16_records, sweep_deriver_wave0=deriver_wave0)
+    opts = dict(sweep_records_bf16=bf16_records, sweep_deriver_wave0=deriver_wave0, own_bf16=own_bf16)
     out1, cks1, g1 = _run_sweep_variant(e, d, G, **opts)
     out2, cks2, g2 = _run_sweep_variant(e, d, G, **opts)
     assert e.sweep_error() == 0
-    check_per_head(f"TTT-MLP MFMA backward, overlap={overlap} bf16 records={bf16_records} derivers on waves {deriver_wave0}, {deriver_wave0 + 1}", out1, cks1, g1, ro, rc, rg, 1e-2, 3e-2)
+    check_per_head(f"TTT-MLP MFMA backward, bf16 records={bf16_records} derivers on waves {deriver_wave0}, {deriver_wave0 + 1} bf16 owner rows={own_bf16}",
+                   out1, cks1, g1, ro, rc, rg, 1e-2, 3e-2)
     for k in g1:
         assert torch.equal(g1[k], g2[k]), f"{k} differs between two identical calls"

@@ -30,9 +30,10 @@ def step_bwd(st_in, Q, K, V, eta, gam, bet, dOut, dst, on):
     gZ1 = r("gZ1", gX2 * D1)
     M = r("M", gX2 * O.gelu_bwd2(Z1))
     # output path
-    dgam = (dOut * s["xhl"]).sum(-2, keepdim=True)
+    xhl_r = r("own_xl", s["xhl"])
+    dgam = (dOut * xhl_r).sum(-2, keepdim=True)
     dbet = dOut.sum(-2, keepdim=True)
-    dZ2b = O._ln_bwd(dOut, s["xhl"], s["stdl"], gam, Fd)
+    dZ2b = O._ln_bwd(dOut, xhl_r, s["stdl"], gam, Fd)
     dW2n = dW2n + T(X2b) @ r("dZ2b", dZ2b)
     # "dZ2b_colsum": db2 += column sums of the bf16 tile (a ones-MFMA; round 3) instead of the owners' fp32 values (round 4)
     db2n = db2n + r("dZ2b_colsum", dZ2b).sum(-2, keepdim=True)
@@ -54,7 +55,12 @@ def step_bwd(st_in, Q, K, V, eta, gam, bet, dOut, dst, on):
         dgZ2 = ((parts[0] + parts[1]) + parts[2]) + parts[3] - eta * db2n
     else:
         dgZ2 = -eta * (X2 @ d2p) + u @ W2m - eta * db2n
-    dZ2, dgam2, dbet2, dt = O._ln_l2_bwd_bwd(dgZ2, s["xh"], s["std"], s["go"], s["gxh"], s["gZ2"], gam, Fd)
+    # option "own_bf16": the inner LayerNorm's owner rows of the step record (x_hat, y - target) as bf16; "own_xl" = the OUTPUT
+    # LayerNorm's x_hat too - which is NOT affordable (it feeds dZ2b and through it db2: lr-gate gradients off by 0.3)
+    xh_r, go_r = r("own_xh", s["xh"]), r("own_go", s["go"])
+    gxh_r = go_r * gam
+    gZ2_own = (Fd * gxh_r - gxh_r.sum(-1, keepdim=True) - xh_r * (gxh_r * xh_r).sum(-1, keepdim=True)) / (Fd * s["std"])
+    dZ2, dgam2, dbet2, dt = O._ln_l2_bwd_bwd(dgZ2, xh_r, s["std"], go_r, gxh_r, gZ2_own, gam, Fd)
     dgam = dgam + dgam2.sum(-2, keepdim=True)
     dbet = dbet + dbet2.sum(-2, keepdim=True)
     dV = dt
@@ -130,6 +136,8 @@ if __name__ == "__main__":
     print("ALL (round 3 sweep)          ", *run(set(POINTS), g), flush=True)
     print("all but dZ2b_colsum (round 4)", *run(set(POINTS) - {"dZ2b_colsum"}, g), flush=True)
     print("round 4 + bf16 records       ", *run(set(POINTS) - {"dZ2b_colsum"} | {"P_rec"}, g), flush=True)
+    print("  + bf16 inner owner rows    ", *run(set(POINTS) - {"dZ2b_colsum"} | {"P_rec", "own_xh", "own_go"}, g), flush=True)
+    print("  + bf16 OUTPUT-LN x_hat too ", *run(set(POINTS) - {"dZ2b_colsum"} | {"P_rec", "own_xh", "own_go", "own_xl"}, g), flush=True)
     if len(sys.argv) > 1 and sys.argv[1] == "quick":
         sys.exit(0)
     for pnt in POINTS:

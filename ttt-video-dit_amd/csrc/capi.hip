@@ -63,9 +63,9 @@ int ttt_hip_debug_option(const char* name, int value) {
     else if (!strcmp(name, "attn_dq_wide")) ttt::attn::set_debug_attn_dq_wide(value);           //   dQ kernel with 64 query rows per wave (A/B)
     else if (!strcmp(name, "attn_stage_dq")) ttt::attn::set_debug_attn_stage(1, value);         //   dQ kernel only (1 / 2)
     else if (!strcmp(name, "attn_stage_dkdv")) ttt::attn::set_debug_attn_stage(2, value);       //   dK / dV kernel only (1 .. 4)
-    else if (!strcmp(name, "sweep_owner_overlap")) ttt::mfma::set_debug_sweep_owner_overlap(value);      // owners' partner-independent math under the record loads (1 default / 0: round-3 order)
     else if (!strcmp(name, "sweep_records_bf16")) ttt::mfma::set_debug_sweep_records_bf16(value);        // partial d(gZ2) tiles of the hand-over records as bf16 (A/B)
     else if (!strcmp(name, "sweep_deriver_wave0")) ttt::mfma::set_debug_sweep_deriver_wave0(value);      // 4 (default) / 2: which waves take the deriver role (A/B of the SIMD placement)
+    else if (!strcmp(name, "own_bf16")) ttt::mfma::set_debug_own_bf16(value);                          // step record: inner-LayerNorm owner rows as bf16 (A/B)
     else if (!strcmp(name, "sweep_fault")) ttt::mfma::set_debug_sweep_fault(value);              // fault injection: workgroup 3 of every sweep cluster leaves early
     else return -1;
     return 0;

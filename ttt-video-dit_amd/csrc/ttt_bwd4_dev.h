@@ -49,6 +49,7 @@ struct RecomputeParams {
     int NH, NC, G, K;
     int chunk_group0, chunk_groups, chunk_lo;
     int nt;                                // 1: non-temporal stores of the step records
+    int own16;                             // 1: the owner rows x_hat and y - target of the INNER LayerNorm as bf16 (first half of their fp32 arrays' space)
     int item0;                             // (set by the launcher) first work item of this launch; item = item0 + blockIdx.x
     float eps;
 };
@@ -63,6 +64,7 @@ struct SweepParams4 : b2::SweepParams2 {
     char* park;                            // [B NH][4 workgroups][2 deriver waves][PARK4_BYTES]: R4 fragments between derivation and staging
     int G, K;
     int prefetch;                          // 1: owners / derivers touch the records of step i - 2 (L2 prefetch); 0: off (A/B)
+    int own16;                             // as RecomputeParams::own16 (both kernels of a backward call agree)
 };
 constexpr size_t PARK4_BYTES = 12 * FRAG_BYTES;
 void launch_sweep_cluster4(const SweepParams4& bp, int nbh, hipStream_t s);

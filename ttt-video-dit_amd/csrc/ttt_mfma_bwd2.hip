@@ -39,6 +39,8 @@ static int g_fast_records = 1;        // cluster hand-over: plain (L2-resident) 
 void set_debug_fast_records(int v) { g_fast_records = v; }
 static int g_rc_nt = 1;               // revision-4 recompute: 1 (default) = non-temporal stores of the step records (they are read a launch later, from HBM: keep them out of the sweep's L2 working set), 0 = plain (A/B)
 void set_debug_rc_nt(int v) { g_rc_nt = v; }
+static int g_own16 = 0;               // round 4: inner-LayerNorm owner rows of the step record as bf16 (A/B; opt-in until timed)
+void set_debug_own_bf16(int v) { g_own16 = v; }
 static int g_sweep_prefetch = 1;      // revision-4 sweep: L2 prefetch touches two steps ahead (0 = off, A/B)
 void set_debug_sweep_prefetch(int v) { g_sweep_prefetch = v; }
 static int g_sweep_fault = 0;         // DEBUG fault injection (tests of the hand-over failure path)
@@ -147,7 +149,7 @@ static int mlp_backward4(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws,
     rp.ln_w = a->ttt_norm_weight; rp.ln_b = a->ttt_norm_bias;
     rp.W1c = a->W1_checkpoints; rp.b1c = a->b1_checkpoints; rp.W2c = a->W2_checkpoints; rp.b2c = a->b2_checkpoints;
     rp.slot_stride_bh = slot_stride; rp.wfinal = wfinal;
-    rp.NH = d->NH; rp.NC = NC; rp.G = G; rp.K = K; rp.eps = d->eps; rp.nt = g_rc_nt;
+    rp.NH = d->NH; rp.NC = NC; rp.G = G; rp.K = K; rp.eps = d->eps; rp.nt = g_rc_nt; rp.own16 = g_own16 && sweep_supports_own16();
 
     s4::SweepParams4 bp = {};
     bp.XQ = (const __bf16*)a->XQ; bp.XK = (const __bf16*)a->XK; bp.dOut = (const __bf16*)a->grad_L_XQW; bp.eta = (const __bf16*)a->last_eta;
@@ -160,7 +162,7 @@ static int mlp_backward4(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws,
     bp.NH = d->NH; bp.NC = NC;
     bp.xch = xch; bp.flags = flags; bp.fast_records = g_fast_records;
     bp.err = err_word; bp.fault = g_sweep_fault;
-    bp.W1c = a->W1_checkpoints; bp.W2c = a->W2_checkpoints; bp.wfinal = wfinal; bp.park = park; bp.G = G; bp.K = K; bp.prefetch = g_sweep_prefetch;
+    bp.W1c = a->W1_checkpoints; bp.W2c = a->W2_checkpoints; bp.wfinal = wfinal; bp.park = park; bp.G = G; bp.K = K; bp.prefetch = g_sweep_prefetch; bp.own16 = g_own16 && sweep_supports_own16();
 
     int rc = 0;                               // a failed event / stream call leaves the two streams unordered: the call fails (-12)
     auto chk = [&](hipError_t e) { if (e != hipSuccess) rc = -12; };

@@ -180,7 +180,8 @@ struct DeriverBackend {
 // the other roundings (worst 3.0e-2 -> 3.6e-2 / 2.6e-2 -> 2.5e-2).  [t][PS16] bf16 inside the fp32 tile's area of the record.
 constexpr int PS16 = 72;
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-template <bool DBG, bool OVL, bool R16, int DW0>
+// OWN16 (round 4, debug option "own_bf16"): the inner LayerNorm's owner rows of the step record (x_hat, y - target) are bf16
+template <bool DBG, bool OVL, bool R16, int DW0, bool OWN16>
 __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
     constexpr int OW0 = DW0 == 2 ? 4 : 2;                        // first owner wave (it polls the partner flags)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -662,9 +663,18 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
             // ---- requests of this iteration: the owner inputs of step i, the tiles / output-LayerNorm inputs of step j - all in
             //      flight across Ba ------------------------------------------------------------------------------------------------
             float xh[16], go[16];
+            u32x4 xg16[4];                     // own16: the two rows as bf16, 2 x 16 bytes each, converted behind Bb
             const int so = sI + (int)SLOT4_FR;
-            ld16f(rS, ow * 64, so, xh);
-            ld16f(rS, ow * 64, so + (int)SLOT_OWN_ARR, go);
+            if constexpr (OWN16) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    xg16[u] = __builtin_amdgcn_raw_buffer_load_b128(rS, ow * 32 + 16 * u, so, 0);
+                    xg16[2 + u] = __builtin_amdgcn_raw_buffer_load_b128(rS, ow * 32 + 16 * u, so + (int)SLOT_OWN_ARR, 0);
+                }
+            } else {
+                ld16f(rS, ow * 64, so, xh);
+                ld16f(rS, ow * 64, so + (int)SLOT_OWN_ARR, go);
+            }
             const float r = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rS, ot * 8, so + 3 * (int)SLOT_OWN_ARR, 0));
             StepLoads Lj;
             if (more) request_step(i - 1, Lj);
@@ -692,6 +702,17 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
             }
             // ---- O-C: hand-over ------------------------------------------------------------------------------------------------
             if (ow == 0) __hip_atomic_store(my_flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if constexpr (OWN16) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        xh[8 * u + 2 * w] = __builtin_bit_cast(float, xg16[u][w] << 16);
+                        xh[8 * u + 2 * w + 1] = __builtin_bit_cast(float, xg16[u][w] & 0xffff0000u);
+                        go[8 * u + 2 * w] = __builtin_bit_cast(float, xg16[2 + u][w] << 16);
+                        go[8 * u + 2 * w + 1] = __builtin_bit_cast(float, xg16[2 + u][w] & 0xffff0000u);
+                    }
+            }
             if (wv == OW0) {
                 const int l = tid & 63;
                 if (more) add_parts(reinterpret_cast<const float*>(exd), db2oL + cur * 64, db2oL + (cur ^ 1) * 64);
@@ -869,7 +890,7 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
             unsigned touch = 0u;
             if (p.prefetch && i - 2 >= p.chunk_lo) {
                 const int s2 = slot_off(i - 2) + (int)SLOT4_FR;
-                touch = __builtin_amdgcn_raw_buffer_load_b32(rS, ow * 128, s2, 0);
+                if (!(OWN16 && (ow & 64))) touch = __builtin_amdgcn_raw_buffer_load_b32(rS, ow * 128, s2, 0);      // (own16: the second halves of the first two arrays are unused)
                 if (ow < 452 - 256) touch += __builtin_amdgcn_raw_buffer_load_b32(rS, (256 + ow) * 128, s2, 0);
                 if (ow < 192) {
                     const __amdgpu_buffer_rsrc_t rT = ow < 64 ? rK : ow < 128 ? rQ : rO;
@@ -1160,13 +1181,16 @@ unsigned read_sweep_fast_count() {      // DEBUG statistic: cluster workgroup la
     return v;
 }
 
-static int g_owner_overlap = 1;           // round 4, one box, NC = 804: with fp32 records 14.15 ms per backward against 13.44 without; with bf16 records 11.76 against 12.71: on
-void set_debug_sweep_owner_overlap(int v) { g_owner_overlap = v; }
+// (the owners' partner-independent arithmetic under the record loads - template parameter OVL; one box, NC = 804: with fp32 records
+// 14.15 ms per backward against 13.44 without, with bf16 records 11.76 against 12.71 - goes with the bf16 records)
+bool sweep_supports_own16() ;
 static int g_deriver_wave0 = 2;           // 4: derivers = waves 4, 5 (SIMDs 0 / 1, beside the compute waves); 2: waves 2, 3 (beside two owner waves) - the
                                           // default since round 4: 11.48 - 11.62 ms per backward against 11.79 - 11.94 in three interleaved A/Bs (profiles/r4d - r4f)
 void set_debug_sweep_deriver_wave0(int v) { g_deriver_wave0 = (v == 4 || v == 0) ? 4 : 2; }      // (0 = 4, 1 = 2: the 0 / 1 toggle of op_bench --ab)
 static int g_records_bf16 = 1;            // round 4, one box: 11.82 against 14.16 ms per backward at NC = 804, 4.24 against 5.11 at NC = 282
 void set_debug_sweep_records_bf16(int v) { g_records_bf16 = v; }
+
+bool sweep_supports_own16() { return g_records_bf16 != 0 && g_deriver_wave0 == 2; }
 
 namespace s4 {
 
@@ -1175,37 +1199,28 @@ void launch_sweep_cluster4(const SweepParams4& bp, int nbh, hipStream_t s) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     const dim3 grid(nbh * 4), blk(b4::NTC);
-    const bool first = dev >= 0 && dev < 16 && !attr[dev];
-    auto go = [&](auto kern) {
-        if (first) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, b4::LDS_CL);
-        hipLaunchKernelGGL(kern, grid, blk, b4::LDS_CL, s, bp);
-    };
     {
         std::lock_guard<std::mutex> lock(g_err_mutex);
-        if (first) {
+        if (dev >= 0 && dev < 16 && !attr[dev]) {
             // every instantiation a later call may select gets its attribute on this device now
             auto set = [&](auto kern) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, b4::LDS_CL); };
-            set(b4::mlp_bwd_cluster4_kernel<false, false, false, 4>); set(b4::mlp_bwd_cluster4_kernel<true, false, false, 4>);
-            set(b4::mlp_bwd_cluster4_kernel<false, true, false, 4>);  set(b4::mlp_bwd_cluster4_kernel<true, true, false, 4>);
-            set(b4::mlp_bwd_cluster4_kernel<false, false, true, 4>);  set(b4::mlp_bwd_cluster4_kernel<true, false, true, 4>);
-            set(b4::mlp_bwd_cluster4_kernel<false, true, true, 4>);   set(b4::mlp_bwd_cluster4_kernel<true, true, true, 4>);
-            set(b4::mlp_bwd_cluster4_kernel<false, false, true, 2>);  set(b4::mlp_bwd_cluster4_kernel<true, false, true, 2>);
-            set(b4::mlp_bwd_cluster4_kernel<false, true, true, 2>);   set(b4::mlp_bwd_cluster4_kernel<true, true, true, 2>);
+            set(b4::mlp_bwd_cluster4_kernel<false, false, false, 4, false>); set(b4::mlp_bwd_cluster4_kernel<true, false, false, 4, false>);
+            set(b4::mlp_bwd_cluster4_kernel<false, true, true, 4, false>);   set(b4::mlp_bwd_cluster4_kernel<true, true, true, 4, false>);
+            set(b4::mlp_bwd_cluster4_kernel<false, true, true, 2, false>);   set(b4::mlp_bwd_cluster4_kernel<true, true, true, 2, false>);
+            set(b4::mlp_bwd_cluster4_kernel<false, true, true, 2, true>);    set(b4::mlp_bwd_cluster4_kernel<true, true, true, 2, true>);
             (void)hipFuncSetAttribute((const void*)b4::mlp_bwd_tail4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, b4::LDS_TAIL4);
             attr[dev] = true;
         }
     }
-    const bool dbg = bp.dbg != nullptr, ovl = g_owner_overlap != 0, r16 = g_records_bf16 != 0, dw2 = g_deriver_wave0 == 2 && r16;
-    if (dw2) {
-        if (ovl) { if (dbg) go(b4::mlp_bwd_cluster4_kernel<true, true, true, 2>); else go(b4::mlp_bwd_cluster4_kernel<false, true, true, 2>); }
-        else     { if (dbg) go(b4::mlp_bwd_cluster4_kernel<true, false, true, 2>); else go(b4::mlp_bwd_cluster4_kernel<false, false, true, 2>); }
-    } else if (r16) {
-        if (ovl) { if (dbg) go(b4::mlp_bwd_cluster4_kernel<true, true, true, 4>); else go(b4::mlp_bwd_cluster4_kernel<false, true, true, 4>); }
-        else     { if (dbg) go(b4::mlp_bwd_cluster4_kernel<true, false, true, 4>); else go(b4::mlp_bwd_cluster4_kernel<false, false, true, 4>); }
-    } else {
-        if (ovl) { if (dbg) go(b4::mlp_bwd_cluster4_kernel<true, true, false, 4>); else go(b4::mlp_bwd_cluster4_kernel<false, true, false, 4>); }
-        else     { if (dbg) go(b4::mlp_bwd_cluster4_kernel<true, false, false, 4>); else go(b4::mlp_bwd_cluster4_kernel<false, false, false, 4>); }
-    }
+    auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, blk, b4::LDS_CL, s, bp); };
+    const bool dbg = bp.dbg != nullptr, r16 = g_records_bf16 != 0, dw2 = g_deriver_wave0 == 2;
+    // variants kept for the A/Bs of round 4: the round-3 sweep (fp32 records, round-3 owner order); bf16 records + owner overlap
+    // with the derivers on waves 4, 5 or 2, 3; the latter with bf16 inner-LayerNorm owner rows (bp.own16, set by the caller for
+    // both kernels of the backward)
+    if (!r16) { if (dbg) go(b4::mlp_bwd_cluster4_kernel<true, false, false, 4, false>); else go(b4::mlp_bwd_cluster4_kernel<false, false, false, 4, false>); }
+    else if (!dw2) { if (dbg) go(b4::mlp_bwd_cluster4_kernel<true, true, true, 4, false>); else go(b4::mlp_bwd_cluster4_kernel<false, true, true, 4, false>); }
+    else if (!bp.own16) { if (dbg) go(b4::mlp_bwd_cluster4_kernel<true, true, true, 2, false>); else go(b4::mlp_bwd_cluster4_kernel<false, true, true, 2, false>); }
+    else { if (dbg) go(b4::mlp_bwd_cluster4_kernel<true, true, true, 2, true>); else go(b4::mlp_bwd_cluster4_kernel<false, true, true, 2, true>); }
 }
 
 void launch_tail4(const __bf16* dOut, const __bf16* eta, const __bf16* dXV, char* slots, size_t slot_stride_bh, __bf16* dXQ, __bf16* dXK,

@@ -41,7 +41,8 @@ void set_debug_rc_nt(int v);           // revision-4 recompute: non-temporal sto
 void set_debug_sweep_prefetch(int v);  // revision-4 sweep: 1 (default) L2 prefetch touches two steps ahead, 0 off
 void set_debug_sweep_records_bf16(int v);   // revision-4 sweep: hand-over records carry the partial d(gZ2) tiles as bf16 (0 default until timed)
 void set_debug_sweep_deriver_wave0(int v);  // revision-4 sweep: deriver role on waves 4, 5 (default) or 2, 3 (A/B of the SIMD placement)
-void set_debug_sweep_owner_overlap(int v);  // revision-4 sweep: 1 (default) the owners' partner-independent arithmetic runs under the record loads, 0 = round-3 order
+bool sweep_supports_own16();                // (the instantiation the current options select reads bf16 owner rows)
+void set_debug_own_bf16(int v);             // revision-4 backward: inner-LayerNorm owner rows of the step record as bf16
 unsigned read_sweep_fast_count();   // DEBUG statistic (synchronises)
 
 }  // namespace mfma

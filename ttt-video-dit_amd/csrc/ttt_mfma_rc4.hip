@@ -245,8 +245,16 @@ __global__ __launch_bounds__(NT8) void mlp_recompute8_kernel(RecomputeParams p) 
             }
             *reinterpret_cast<bf16x8*>(Gs + ot * TS + of0) = o;
             st16<NTS>(reinterpret_cast<__bf16*>(slot + SLOT4_FR + SLOT4_OWN) + ot * 64 + of0, __builtin_bit_cast(u32x4v, gu));
-            st_rows<NTS, 8>(own, 0, ot, of0, z);
-            st_rows<NTS, 8>(own, 1, ot, of0, go);
+            if (p.own16) {      // round 4: these two arrays as bf16 (the sweep's owners read half the bytes; precision budget: tools/diag/
+                bf16x8 zb, gb;  // lr_gate_full_emul_cpu.py points own_xh / own_go - no gradient moves; the OUTPUT LayerNorm's x_hat must stay fp32)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { zb[j] = (__bf16)z[j]; gb[j] = (__bf16)go[j]; }
+                st16<NTS>(reinterpret_cast<__bf16*>(own) + ot * 64 + of0, __builtin_bit_cast(u32x4v, zb));
+                st16<NTS>(reinterpret_cast<__bf16*>(own + SLOT_OWN_ARR) + ot * 64 + of0, __builtin_bit_cast(u32x4v, gb));
+            } else {
+                st_rows<NTS, 8>(own, 0, ot, of0, z);
+                st_rows<NTS, 8>(own, 1, ot, of0, go);
+            }
             if ((tid & 7) == 0) own_stats(own, ot)[0] = rstd;
         }
         __syncthreads();              // B2: Gs visible
