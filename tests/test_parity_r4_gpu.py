@@ -70,7 +70,7 @@ def _run_sweep_variant(e, d, G, **opts):
         sweep_defaults(e)
 
 
-SWEEP_DEFAULTS = dict(sweep_records_bf16=1, sweep_deriver_wave0=2, own_bf16=0)      # the library's (csrc/ttt_mfma_bwd4.hip, ttt_mfma_bwd2.hip)
+SWEEP_DEFAULTS = dict(sweep_records_bf16=1, sweep_deriver_wave0=2, own_bf16=1)      # the library's (csrc/ttt_mfma_bwd4.hip, ttt_mfma_bwd2.hip)
 
 
 def sweep_defaults(e):

@@ -39,7 +39,7 @@ static int g_fast_records = 1;        // cluster hand-over: plain (L2-resident) 
 void set_debug_fast_records(int v) { g_fast_records = v; }
 static int g_rc_nt = 1;               // revision-4 recompute: 1 (default) = non-temporal stores of the step records (they are read a launch later, from HBM: keep them out of the sweep's L2 working set), 0 = plain (A/B)
 void set_debug_rc_nt(int v) { g_rc_nt = v; }
-static int g_own16 = 0;               // round 4: inner-LayerNorm owner rows of the step record as bf16 (A/B; opt-in until timed)
+static int g_own16 = 1;               // round 4: inner-LayerNorm owner rows of the step record as bf16: 11.35 against 11.63 ms per backward at NC = 804, 4.09 against 4.21 at NC = 282 (profiles/r4g_*)
 void set_debug_own_bf16(int v) { g_own16 = v; }
 static int g_sweep_prefetch = 1;      // revision-4 sweep: L2 prefetch touches two steps ahead (0 = off, A/B)
 void set_debug_sweep_prefetch(int v) { g_sweep_prefetch = v; }
