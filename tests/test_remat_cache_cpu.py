@@ -130,3 +130,42 @@ def test_gelu_linear_keeps_its_output_under_the_fc2_kind(monkeypatch):
     for mode in ("ckpt", "keep"):
         for a, b in zip(res[mode][:5], res["plain"][:5]):
             assert torch.equal(a, b), mode
+
+
+def test_a_second_backward_over_a_keeping_region_finds_its_outputs_again():
+    """retain_graph=True / two backward passes over the same checkpointed graph: the recomputation contexts are entered twice.
+    (Round-3 advisor finding: single-use generator contexts and a queue drained by the first recomputation made the second
+    backward fail with an opaque AttributeError / IndexError.)"""
+    for k in LAUNCHES:
+        LAUNCHES[k] = 0
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(5, 8, generator=g, requires_grad=True)
+    w1 = torch.randn(8, 8, generator=g, requires_grad=True)
+    w2 = torch.randn(8, 8, generator=g, requires_grad=True)
+    y = checkpoint(block, x, w1, w2, use_reentrant=False, context_fn=remat_cache.context_fn(("attn", "scan")))
+    y.sum().backward(retain_graph=True)
+    g1 = [t.grad.clone() for t in (x, w1, w2)]
+    for t in (x, w1, w2):
+        t.grad = None
+    y.sum().backward()
+    assert all(torch.equal(a, t.grad) for a, t in zip(g1, (x, w1, w2)))
+    assert LAUNCHES == {"attn": 1, "scan": 1}                          # kept once, handed back in both recomputations
+
+
+def test_in_place_write_into_a_kept_output_is_caught():
+    """The kept copies alias the forward pass's outputs: a later in-place op on such an output would silently corrupt what the
+    recomputation is handed; the version counter of the kept alias gives it away."""
+    import pytest
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(5, 8, generator=g, requires_grad=True)
+    w = torch.randn(8, 8, generator=g, requires_grad=True)
+
+    def bad_block(x, w):
+        h = Node.apply(x, w, "attn")
+        with torch.no_grad():
+            h.mul_(2.0)                      # writes into the kernel's output
+        return h * x
+
+    y = checkpoint(bad_block, x, w, use_reentrant=False, context_fn=remat_cache.context_fn(("attn",)))
+    with pytest.raises(RuntimeError, match="modified in place"):
+        y.sum().backward()

@@ -16,44 +16,54 @@ behaviour)."""
 from __future__ import annotations
 
 import threading
-from collections import deque
-from contextlib import contextmanager
 
 _state = threading.local()
 
 
 class _Region:
-    __slots__ = ("kinds", "queue")
+    """The kept kernel outputs of ONE ``checkpoint`` call, in call order.  Entries stay until the region is freed with its
+    checkpoint frame (they share storage with what the recomputed graph saves anyway), so a second recomputation of the same
+    region - ``retain_graph=True``, or a double backward through it - finds them again instead of an empty queue."""
+    __slots__ = ("kinds", "entries", "cursor")
 
     def __init__(self, kinds):
-        self.kinds, self.queue = frozenset(kinds), deque()
+        self.kinds, self.entries, self.cursor = frozenset(kinds), [], 0
 
 
-@contextmanager
-def _scope(region, mode):
-    prev = getattr(_state, "cur", None)
-    _state.cur = None if region is None else (region, mode)
-    try:
-        yield
-    finally:
-        _state.cur = prev
+class _Scope:
+    """Re-usable context manager (``torch.utils.checkpoint`` may enter the contexts it was handed more than once)."""
+
+    def __init__(self, region, mode):
+        self.region, self.mode, self._prev = region, mode, []
+
+    def __enter__(self):
+        self._prev.append(getattr(_state, "cur", None))
+        _state.cur = None if self.region is None else (self.region, self.mode)
+        if self.region is not None and self.mode == "recompute":
+            self.region.cursor = 0                 # every recomputation walks the region's calls from the start
+        return self
+
+    def __exit__(self, *exc):
+        _state.cur = self._prev.pop()
+        return False
 
 
 def context_fn(kinds):
     """``context_fn`` for ``torch.utils.checkpoint.checkpoint(..., use_reentrant=False)``: one region per checkpoint call."""
     region = _Region(kinds)
-    return lambda: (_scope(region, "forward"), _scope(region, "recompute"))
+    return lambda: (_Scope(region, "forward"), _Scope(region, "recompute"))
 
 
 def suspended():
     """Context in which nothing is kept (nested checkpoints recompute in an order of their own)."""
-    return _scope(None, None)
+    return _Scope(None, None)
 
 
 def kernel_result(kind: str, compute):
     """``compute() -> tuple of tensors`` (the kernel's outputs).  Outside a keeping region: just ``compute()``.  In the forward
     pass of a region that keeps ``kind``: compute and remember.  In its recomputation: hand the remembered tuple back (the
-    calls of a region recur in the same order; the kind is checked)."""
+    calls of a region recur in the same order; the kind is checked, and so is that nobody wrote into a kept tensor in between:
+    the kept copies alias the forward pass's outputs)."""
     cur = getattr(_state, "cur", None)
     if cur is None or kind not in cur[0].kinds:
         return compute()
@@ -62,9 +72,17 @@ def kernel_result(kind: str, compute):
     #  and the recomputation's node must not be handed an object that already carries the forward pass's)
     if mode == "forward":
         out = compute()
-        region.queue.append((kind, tuple(t.detach() for t in out)))
+        kept = tuple(t.detach() for t in out)
+        region.entries.append((kind, kept, tuple(t._version for t in kept)))
         return out
-    got, out = region.queue.popleft()
+    if region.cursor >= len(region.entries):
+        raise RuntimeError(f"remat_cache: the recomputation asks for a {kind!r} result the forward pass of this region did not produce "
+                           f"({len(region.entries)} kept): the region's calls must recur in the same order")
+    got, out, versions = region.entries[region.cursor]
+    region.cursor += 1
     if got != kind:
         raise RuntimeError(f"remat_cache: recomputation asked for {kind!r} where the forward pass produced {got!r}")
+    if any(t._version != v for t, v in zip(out, versions)):
+        raise RuntimeError(f"remat_cache: a kept {kind!r} output was modified in place after the forward pass (the kept copy aliases it); "
+                           "clone before writing into a kernel output inside a region that keeps it")
     return tuple(t.detach() for t in out)

@@ -150,6 +150,7 @@ class FusedPreScanMLP(torch.autograd.Function):
         out, *cks = kernel_result("scan", run)
         ctx.save_for_backward(q, k, v, w32, b32, rope, src, pos, last_eta, *cks)
         ctx.meta = (NH, G, tuple(eta.shape), ln_w.dtype, W1.dtype, eta.dtype)
+        ctx.n_pos = getattr(pos, "_ttt_max_pos", None) if pos is not None else None      # (the backward's pre_forward must not fall into the binding's synchronising pos.max())
         return out
 
     @staticmethod
@@ -163,7 +164,7 @@ class FusedPreScanMLP(torch.autograd.Function):
         NC = L // CS
         H, dev = 4 * Fh, q.device
         XQ, XK, XV = (torch.empty(B, NH, L, Fh, device=dev, dtype=_BF16) for _ in range(3))
-        ext.pre_forward(q, k, v, rope, src, pos, w32, b32, XQ, XK, XV, NH)              # re-derive the scan inputs
+        ext.pre_forward(q, k, v, rope, src, pos, w32, b32, XQ, XK, XV, NH, n_pos=ctx.n_pos)      # re-derive the scan inputs
         mb = lambda t: t.view(B, NH, NC, CS, Fh)
         z32 = lambda *s: torch.zeros(*s, device=dev, dtype=_F32)
         e32 = lambda *s: torch.empty(*s, device=dev, dtype=_F32)
