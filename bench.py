@@ -99,11 +99,13 @@ def parse():
     ap.add_argument("--local-batch", type=int, default=1,
                     help="samples per GPU (default 1 = the reference's training setting).  The TTT scans of a second sample run "
                          "beside the first at no extra wall time (one workgroup per head, 48 of 256 CUs at batch 1)")
-    ap.add_argument("--fsdp", default="auto", choices=["auto", "on", "off"],
-                    help="off (one GPU only): fp32 masters + bf16 compute copies kept by ttt_amd.infra.parallelisms.ReplicaMixedPrecision "
-                         "(three multi-tensor launches per step) instead of FSDP2 over a one-rank mesh (~3000 per-parameter cast / copy "
-                         "kernels, 190 ms of a 3.26 s step); same arithmetic, bit-identical updates (tests/test_fsdp_gloo.py).  auto = off "
-                         "on one GPU (falling back to FSDP2 should the replica path fail), FSDP2 on several; on = FSDP2 always")
+    ap.add_argument("--fsdp", default="auto", choices=["auto", "flat", "on", "off"],
+                    help="how parameters / gradients / optimizer state are kept.  flat = ttt_amd.infra.flat_fsdp.FlatFSDP: the reference's "
+                         "FSDP partitioning (one unit per TransformerLayer + root, fp32 masters and AdamW state sharded over the ranks, bf16 "
+                         "compute parameters, fp32 gradient reduction) on flat buffers - one in-place all-gather and one reduce-scatter per unit "
+                         "and step on a side stream, frozen parameters replicated (round 4: FSDP2's per-parameter copies cost 7 %% of the step on "
+                         "one rank, profiles/r4i_*).  on = the reference's own FSDP2 wrapping (apply_fsdp).  off (one GPU only): "
+                         "ReplicaMixedPrecision, the same arithmetic without any sharding machinery.  auto = off on one GPU, flat on several")
     ap.add_argument("--no-fsdp", action="store_true", help="same as --fsdp off")
     ap.add_argument("--layers", type=int, default=None, help="DEBUG: fewer layers (result flagged invalid)")
     ap.add_argument("--torch-profile", default=None, metavar="FILE",
@@ -435,6 +437,7 @@ def main():
         dist.destroy_process_group()
         return
     assert not (mode == "off" and world > 1), "--fsdp off is the one-GPU replica path"
+    multi = {"auto": "flat", "flat": "flat", "on": "fsdp2"}.get(mode, "flat")           # the sharded implementation of this run
     import gc
     line = None
     if world == 1 and mode in ("auto", "off"):
@@ -444,28 +447,29 @@ def main():
         except Exception as ex:      # an untested corner of the replica path must not cost the measurement
             if mode == "off":
                 raise
-            print(f"bench.py: replica path failed ({ex!r}); falling back to FSDP2 over a one-rank mesh", file=sys.stderr, flush=True)
+            print(f"bench.py: replica path failed ({ex!r}); falling back to the flat FSDP path over a one-rank group", file=sys.stderr, flush=True)
         gc.collect()
         torch.cuda.empty_cache()
         if line is None:
-            line = _run(args, world, rank, local_rank, dev, no_fsdp=False)
+            line = _run(args, world, rank, local_rank, dev, no_fsdp=False, sharded=multi)
         elif not args.no_fsdp1_compare and mode == "auto":
-            # the same step through FSDP2 over a one-rank mesh = the code path of N > 1 (like-for-like point of a 1 -> N curve)
+            # the same step through the sharded path over a one-rank group WITH its collectives (RCCL all-gather / reduce-scatter
+            # of one rank) = the code path of N > 1 (like-for-like point of a 1 -> N curve)
             try:
                 log(f"main line done: {line['value']:.1f} video-tok/s, {line['ms_per_step']:.0f} ms/step; fsdp1 comparison run")
                 import copy
                 a2 = copy.copy(args)
                 a2.steps, a2.warmup = max(1, args.fsdp1_steps), 1
                 a2.remat_free_layers = str(max(0, line["config"]["remat_free_layers"] - 1))
-                f = _run(a2, world, rank, local_rank, dev, no_fsdp=False, quiet=True)
-                line["fsdp1"] = {"value": f["value"], "ms_per_step": f["ms_per_step"], "steps": a2.steps,
+                f = _run(a2, world, rank, local_rank, dev, no_fsdp=False, quiet=True, sharded=multi)
+                line["fsdp1"] = {"impl": multi, "value": f["value"], "ms_per_step": f["ms_per_step"], "steps": a2.steps,
                                  "remat_free_layers": f["config"]["remat_free_layers"], "peak_mem_gib": f["peak_mem_gib"]}
             except Exception as ex:
                 line["fsdp1"] = {"error": repr(ex)[:300]}
             gc.collect()
             torch.cuda.empty_cache()
     else:
-        line = _run(args, world, rank, local_rank, dev, no_fsdp=False)
+        line = _run(args, world, rank, local_rank, dev, no_fsdp=False, sharded=multi)
     if rank == 0 and line is not None:
         if world == 1 and not args.no_cpu_baseline:
             # the CPU leg runs in a child process with a wall-clock limit: whatever happens to it (host out-of-memory kill,
@@ -484,7 +488,7 @@ def main():
     dist.destroy_process_group()
 
 
-def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False, tp=False):
+def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False, tp=False, sharded="fsdp2"):
     import test_time_training as ext
     from ttt_amd.infra.parallelisms import (ReplicaMixedPrecision, apply_fsdp, enable_tuned_gemms, get_dp_mesh, init_distributed,
                                             init_model_parameters)
@@ -529,7 +533,7 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False, tp=False):
     elif tp:                                              # FSDP2 over all dp x T ranks; its reduce-scatter sums the TP partials
         from ttt_amd.infra.parallelisms import apply_parallelisms
         apply_parallelisms(model, tp_sharding=tp, reshard_after_forward=args.reshard_after_forward, tp_layout_on_one_rank=True)   # reference parallelisms.py:92-104
-    elif not no_fsdp:
+    elif not no_fsdp and sharded == "fsdp2":
         apply_fsdp(model, get_dp_mesh(), reshard_after_forward=args.reshard_after_forward)   # reference parallelisms.py:155-175
     model.to_empty(device=dev)
     torch.manual_seed(1234)                                # same init on every rank, then sharded
@@ -538,7 +542,11 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False, tp=False):
         model.init_ssm_weights()
     model.setup_generator(seed=dp_rank, device=dev)        # (a TP group works on ONE sample: same draws on its ranks)
     replica = ReplicaMixedPrecision(model.dit) if no_fsdp else None
-    train_params = replica.master_parameters() if replica else [p for p in model.parameters() if p.requires_grad]
+    flat = None
+    if not no_fsdp and not tp and sharded == "flat":      # the same partitioning on flat buffers (ttt_amd/infra/flat_fsdp.py)
+        from ttt_amd.infra.flat_fsdp import FlatFSDP
+        flat = FlatFSDP(model.dit, always_communicate=True)
+    train_params = replica.master_parameters() if replica else flat.master_parameters() if flat else [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.AdamW(train_params, lr=1e-5, weight_decay=1e-4, fused=True)
 
     g = torch.Generator(device=dev).manual_seed(100 + dp_rank)
@@ -557,12 +565,16 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False, tp=False):
             tp_sync_gradients(model)                # partial parameter gradients (a rank's tokens / heads) summed over the group
         if replica:
             replica.collect_grads()                 # bf16 gradients -> fp32 gradients of the masters (what FSDP's reduce does)
+        if flat:
+            flat.finish_backward()                  # (the units' reduce-scatters were queued by their last gradients' hooks)
         # clip -> ONE device synchronisation (the hand-over error word of the TTT-MLP backward; a production loop needs it before
         # optimizer.step(), so the benchmark pays for it too) -> fused AdamW
-        if checked_optimizer_step(opt, train_params, 1.0) is None:
+        if checked_optimizer_step(opt, train_params, 1.0, clip_fn=flat.clip_grad_norm_ if flat else None) is None:
             raise RuntimeError("a TTT-MLP backward hand-over timed out (or the gradient norm is not finite): step skipped")
         if replica:
             replica.publish()                       # fp32 masters -> bf16 compute copies (what FSDP's all-gather does)
+        if flat:
+            flat.publish()                          # masters -> bf16 shards, one in-place all-gather per unit on the side stream
         return loss
 
     # ---- activation re-materialisation sized for this GPU (untimed), warm-up, timed region: size_warm_and_time() ------------
@@ -596,6 +608,8 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False, tp=False):
             opt.zero_grad(set_to_none=True)
             if replica:
                 replica.zero_grad()
+            if flat:
+                flat.zero_grad()
             torch.cuda.empty_cache()
 
         @staticmethod
@@ -717,7 +731,7 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False, tp=False):
                 "scaling": "strong" if (tp and dp == 1 and world > 1) else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                 "config": {"workload": f"CogVideoX-5B+{args.ssm_layer} {args.video_length} training step (fwd+bwd+AdamW), "
                                        f"{cfg.num_layers} layers, L={L} tokens/sample, adapter={args.adapter}",
-                           "global_batch": dp * LB, "seq_len": L, "parallelism": (f"tp{tp}" if no_fsdp else f"fsdp{world}(dp{dp}xtp{tp})") if tp else ("replica1" if no_fsdp else f"fsdp{world}"), "ttt_impl": args.impl,
+                           "global_batch": dp * LB, "seq_len": L, "parallelism": (f"tp{tp}" if no_fsdp else f"fsdp{world}(dp{dp}xtp{tp})") if tp else ("replica1" if no_fsdp else f"flat_fsdp{world}" if flat else f"fsdp2_{world}"), "ttt_impl": args.impl,
                            "remat_free_layers": n_free, "remat_keep": list(dit.remat_keep), "fsdp_reshard_after_forward": bool(args.reshard_after_forward), "tuned_gemm_selections": bool(tuned),
                            "sweep_error": sweep_err, "valid": args.layers is None and sweep_err == 0},
                 "roofline": roof, "loss": loss_val, "peak_mem_gib": peak_mem, "peak_reserved_gib": torch.cuda.max_memory_reserved() / 2 ** 30, "alloc_retries_total": Hooks.alloc_retries(), "total_tokens_per_s": dp * L / (dt / args.steps)}

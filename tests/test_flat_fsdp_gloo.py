@@ -1,0 +1,172 @@
+"""FlatFSDP (ttt_amd/infra/flat_fsdp.py) - the flat-buffer form of the reference's FSDP wrapping - on gloo ranks (CPU) against a
+single process doing the same data-parallel arithmetic by hand (ReplicaMixedPrecision: bf16 compute copies of fp32 masters, the
+ranks' bf16 gradients widened to fp32 and averaged, one clip, one AdamW step): per-rank losses and the clipped norm of two steps,
+the reduced gradients of the first step, the parameters after the second.  World 2 with everything trainable ("sft"), world 3
+(a shard size that needs padding) with the "qkvo" adapter (frozen parameters are replicated and never communicated), and a
+one-process instance (no process group: what bench.py's N = 1 line would run)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from test_fsdp_gloo import ROOT, _free_port, _inputs
+
+
+def _build(adapter):
+    from ttt_amd.models.cogvideo.dit import DiffusionTransformer
+    from ttt_amd.models.configs import ModelConfig
+    torch.manual_seed(0)
+    cfg = ModelConfig(model_dim=128, num_heads=2, num_layers=2, mini_batch_size=16, latent_height=8, latent_width=8,
+                      compressed_num_frames=3, ssm_layer="ttt_linear", text_dim=32, time_embed_dim=64, attn_length=2,
+                      prefix_temporal_length=1, adapter_method=adapter, scan_checkpoint_group_size=2)
+    m = DiffusionTransformer(cfg)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if p.ndim >= 2:
+                p.normal_(0, 0.02)
+    return m
+
+
+def _loss(m, rank):
+    v, t, ts = _inputs(rank)
+    return m(v, t, ts).square().mean()
+
+
+def _steps(m, fs, opt, rank, n_steps=2):
+    trace, grads0 = [], None
+    for it in range(n_steps):
+        opt.zero_grad(set_to_none=True)
+        fs.zero_grad()
+        loss = _loss(m, rank)
+        loss.backward()
+        fs.finish_backward()
+        if it == 0:
+            grads0 = fs.full_parameters("grad")
+        norm = fs.clip_grad_norm_(1.0)
+        opt.step()
+        fs.publish()
+        trace.append((float(loss.detach()), float(norm)))
+    return trace, grads0
+
+
+def _worker(rank, world, port, out_dir, adapter):
+    for p in (ROOT, os.path.join(ROOT, "ttt-video-dit_amd")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    from oracle import cpu_ext
+    from ttt_amd.infra.flat_fsdp import FlatFSDP
+    cpu_ext.install()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = _build(adapter)
+    m.remat_free_layers = 1
+    fs = FlatFSDP(m)
+    assert all(p.dtype == torch.bfloat16 for p in m.parameters())
+    assert sum(u.shard for u in fs.units) * world >= sum(p.numel() for p in m.parameters() if p.requires_grad)
+    opt = torch.optim.AdamW(fs.master_parameters(), lr=1e-3, weight_decay=1e-4)
+    trace, grads0 = _steps(m, fs, opt, rank)
+    final = fs.full_parameters("param")
+    # every rank holds the same gathered bf16 parameters after publish()
+    chk = torch.cat([u.gathered.float().reshape(-1) for u in fs.units])
+    ref = chk.clone()
+    dist.broadcast(ref, 0)
+    assert torch.equal(chk, ref)
+    if rank == 0:
+        torch.save({"grads0": grads0, "final": final}, os.path.join(out_dir, "flat.pt"))
+    torch.save({"trace": trace}, os.path.join(out_dir, f"flat_trace{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def _reference(world, adapter):
+    from oracle import cpu_ext
+    from ttt_amd.infra.parallelisms import ReplicaMixedPrecision
+    cpu_ext.install()
+    try:
+        m = _build(adapter)
+        m.remat_free_layers = 0
+        rep = ReplicaMixedPrecision(m)
+        masters = rep.master_parameters()
+        opt = torch.optim.AdamW(masters, lr=1e-3, weight_decay=1e-4)
+        names = [k for k, p in m.named_parameters()]
+        tr, norms, grads0 = [[] for _ in range(world)], [], None
+        for it in range(2):
+            opt.zero_grad(set_to_none=True)
+            rep.zero_grad()
+            for r in range(world):
+                loss = _loss(m, r)
+                loss.backward()
+                rep.collect_grads()
+                tr[r].append(float(loss.detach()))
+            for p in masters:
+                p.grad.mul_(1.0 / world)
+            if it == 0:
+                grads0 = {k: x.grad.clone() for k, x in zip(names, rep._master) if x.grad is not None}
+            norms.append(float(torch.nn.utils.clip_grad_norm_(masters, 1.0)))
+            opt.step()
+            rep.publish()
+        final = {k: x.data.clone() for k, x in zip(names, rep._master) if x.requires_grad}
+    finally:
+        cpu_ext.uninstall()
+    return tr, norms, grads0, final
+
+
+def _compare(tmp_path, world, adapter):
+    ref_tr, ref_norms, ref_g0, ref_final = _reference(world, adapter)
+    got = torch.load(os.path.join(tmp_path, "flat.pt"))
+    for r in range(world):
+        tr = torch.load(os.path.join(tmp_path, f"flat_trace{r}.pt"))["trace"]
+        for it, ((l_got, n_got), l_ref) in enumerate(zip(tr, ref_tr[r])):
+            assert abs(l_got - l_ref) <= 2e-3 * abs(l_ref), (r, it, l_got, l_ref)
+            assert abs(n_got - ref_norms[it]) <= (1e-4 if it == 0 else 5e-2) * ref_norms[it], (it, n_got, ref_norms[it])
+    assert set(got["grads0"]) == set(ref_g0)
+    for k, v in ref_g0.items():
+        err = float((got["grads0"][k] - v).norm() / v.norm().clamp_min(1e-20))
+        assert err < 5e-2, (k, err)
+    assert set(got["final"]) == set(ref_final)
+    # after two AdamW steps (lr 1e-3): the normalised update turns a rounding-level difference of a near-zero gradient into a
+    # step of up to lr for THAT element, so: isolated elements may differ by up to the two steps (2e-3), the mean difference
+    # must stay two orders below a step (a missing / doubled / mis-scaled update moves every element by ~1e-3)
+    # (k_norm.bias shifts every key of a head by the same vector, which softmax cannot see: its true gradient is zero, what both
+    # sides compute for it is rounding noise, and AdamW turns noise into full steps)
+    for k, v in ref_final.items():
+        if k.endswith("k_norm.bias"):
+            continue
+        d = (got["final"][k] - v).abs()
+        assert float(d.max()) < 2.5e-3 and float(d.mean()) < 2e-5, (k, float(d.max()), float(d.mean()))
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world,adapter", [(2, "sft"), (3, "qkvo")])
+def test_flat_fsdp_matches_data_parallel_reference(tmp_path, world, adapter):
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), adapter), nprocs=world, join=True)
+    _compare(tmp_path, world, adapter)
+
+
+def test_flat_fsdp_without_a_process_group_is_the_replica_path():
+    """One process, no process group: the collectives are skipped and what remains is ReplicaMixedPrecision's arithmetic - the
+    first step's gradients and the parameters after two steps agree to fp32 rounding."""
+    from oracle import cpu_ext
+    from ttt_amd.infra.flat_fsdp import FlatFSDP
+    cpu_ext.install()
+    try:
+        m = _build("qkvo")
+        m.remat_free_layers = 0
+        frozen_before = {n: p.detach().clone() for n, p in m.named_parameters() if not p.requires_grad}
+        fs = FlatFSDP(m)
+        opt = torch.optim.AdamW(fs.master_parameters(), lr=1e-3, weight_decay=1e-4)
+        trace, g0 = _steps(m, fs, opt, 0)
+        final = fs.full_parameters("param")
+        for n, p in m.named_parameters():
+            if not p.requires_grad:
+                assert torch.equal(p.float(), frozen_before[n].to(torch.bfloat16).float()), n       # frozen: cast once, never touched
+    finally:
+        cpu_ext.uninstall()
+    ref_tr, ref_norms, ref_g0, ref_final = _reference(1, "qkvo")
+    assert abs(trace[0][0] - ref_tr[0][0]) <= 1e-6 * abs(ref_tr[0][0]) and abs(trace[0][1] - ref_norms[0]) <= 1e-5 * ref_norms[0]
+    for k, v in ref_g0.items():
+        assert torch.allclose(g0[k], v, rtol=1e-5, atol=1e-8), k
+    for k, v in ref_final.items():
+        assert torch.allclose(final[k], v, rtol=1e-4, atol=1e-7), k

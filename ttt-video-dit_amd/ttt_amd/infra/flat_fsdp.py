@@ -1,0 +1,234 @@
+"""Flat-buffer FSDP for the DiT: the MI355X-first form of ``apply_fsdp`` (reference ``ttt/infra/parallelisms.py``:155-175).
+
+Same partitioning and arithmetic as the reference's FSDP2 wrapping - one unit per ``TransformerLayer`` plus the DiT root, fp32
+master parameters and optimizer state sharded over the data-parallel ranks, bf16 compute parameters, gradients reduced in fp32 and
+averaged over the ranks - with the data movement laid out for few, large RCCL collectives over xGMI instead of FSDP2's
+per-parameter bookkeeping:
+
+  * a unit's TRAINABLE parameters live in ONE flat bf16 buffer (the parameters are views of it).  Per step and unit: one cast of
+    the rank's fp32 master shard into its slice of that buffer, ONE in-place ``all_gather_into_tensor`` (no copy-in, no copy-out:
+    the gathered buffer IS the parameters), after the unit's backward one multi-tensor cast of its bf16 gradients into a flat fp32
+    buffer and ONE ``reduce_scatter_tensor`` into the rank's fp32 gradient shard.  The gathered parameters stay resident between
+    forward and backward (288 GB: ``reshard_after_forward=False`` of ``apply_fsdp``), so there is one all-gather per unit and step;
+  * FROZEN parameters (adapter "qkvo" freezes 4.0 of the 7.2 B parameters) are replicated in bf16 and never communicated (FSDP2
+    shards, casts and re-gathers them every step: 8 GB of bf16 weights are no constraint on 288 GB);
+  * collectives run on a side stream: the all-gathers of all units are queued after the optimizer step and a unit's forward waits
+    for its own; a unit's reduce-scatter is queued when the last of its gradients has been accumulated and runs beside the
+    backward of the units in front of it (the TTT backward never blocks its stream).
+
+Why (round-4 measurement, ``profiles/r4i_*``): over a one-rank mesh FSDP2 costs 7 % of the 9 s step against the same arithmetic
+without it - 195 ms of per-parameter ``copy_`` kernels (8 914 launches) and a cluster sweep that runs 0.95 instead of 0.82 ms beside
+them.  With one rank this class does what ``ReplicaMixedPrecision`` does (the collectives are skipped), so the N = 1 line and
+the N > 1 path are the same code.
+
+    fs = FlatFSDP(model.dit)                                  # after init; parameters become bf16 views
+    opt = torch.optim.AdamW(fs.master_parameters(), ...)
+    loss.backward(); fs.finish_backward(); norm = fs.clip_grad_norm_(1.0); opt.step(); fs.publish()
+
+Covered on the CPU by ``tests/test_flat_fsdp_gloo.py`` (world 2 and 3, gloo) against a hand-written data-parallel reference.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+
+_ALIGN = 64          # elements: every parameter starts on a 128-byte boundary of the flat bf16 buffer
+
+
+class _Unit:
+    __slots__ = ("module", "params", "names", "offsets", "numel", "padded", "shard", "gathered", "shard_view", "master", "pending",
+                 "ready", "held")
+
+
+class FlatFSDP:
+    def __init__(self, dit: torch.nn.Module, process_group: Optional[dist.ProcessGroup] = None, param_dtype=torch.bfloat16,
+                 reduce_dtype=torch.float32, gradient_divide_factor: Optional[float] = None, always_communicate: bool = False):
+        self.dit, self.param_dtype, self.reduce_dtype = dit, param_dtype, reduce_dtype
+        self.group = process_group
+        on = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(process_group) if on else 1
+        self.rank = dist.get_rank(process_group) if on else 0
+        self.divide = float(gradient_divide_factor if gradient_divide_factor is not None else self.world)
+        # with one rank the collectives are skipped - unless asked for (bench.py's `fsdp1` point: the code path of N > 1 on one GPU)
+        self._communicate = self.world > 1 or (always_communicate and on)
+        self.units: List[_Unit] = []
+        self._cuda = next(dit.parameters()).is_cuda
+        self._comm = torch.cuda.Stream() if self._cuda else None
+        self._hooks = []
+        names = {id(p): n for n, p in dit.named_parameters()}
+        seen = set()
+        for mod in list(getattr(dit, "layers", [])) + [dit]:
+            train = []
+            for p in mod.parameters():
+                if id(p) in seen or not p.is_floating_point():
+                    continue
+                seen.add(id(p))
+                if p.requires_grad:
+                    train.append(p)
+                else:
+                    p.data = p.data.to(param_dtype)            # frozen: replicated compute copy, nothing to communicate
+            if train:
+                self.units.append(self._build_unit(mod, train, names))
+        self._root_hook = dit.register_forward_pre_hook(self._cast_inputs, with_kwargs=True)
+        self._published = True                                # the gathered buffers were filled from the full initial values
+
+    # ------------------------------------------------------------------------------------------------------------ construction
+    def _build_unit(self, mod, train, names) -> _Unit:
+        u = _Unit()
+        u.module, u.params, u.names = mod, train, [names[id(p)] for p in train]
+        u.offsets, off = [], 0
+        for p in train:
+            u.offsets.append(off)
+            off += -(-p.numel() // _ALIGN) * _ALIGN
+        u.numel = off
+        q = self.world * _ALIGN
+        u.padded = -(-off // q) * q
+        u.shard = u.padded // self.world
+        dev = train[0].device
+        full32 = torch.zeros(u.padded, dtype=torch.float32, device=dev)
+        for p, o in zip(train, u.offsets):
+            full32[o:o + p.numel()].copy_(p.detach().reshape(-1))
+        lo = self.rank * u.shard
+        u.master = torch.nn.Parameter(full32[lo:lo + u.shard].clone(), requires_grad=True)
+        u.gathered = full32.to(self.param_dtype)
+        u.shard_view = u.gathered[lo:lo + u.shard]
+        for p, o in zip(train, u.offsets):
+            p.data = u.gathered[o:o + p.numel()].view(p.shape)
+        u.pending, u.ready, u.held = len(train), None, []
+        for p in train:
+            self._hooks.append(p.register_post_accumulate_grad_hook(lambda _p, _u=u: self._on_grad(_u)))
+        if self._cuda:
+            self._hooks.append(mod.register_forward_pre_hook(lambda _m, _a, _u=u: self._wait_ready(_u)))
+        return u
+
+    def _cast_inputs(self, module, args, kwargs):
+        cast = lambda t: t.to(self.param_dtype) if isinstance(t, torch.Tensor) and t.is_floating_point() else t
+        return tuple(cast(a) for a in args), {k: cast(v) for k, v in kwargs.items()}
+
+    def master_parameters(self) -> List[torch.nn.Parameter]:
+        """The rank's fp32 shards (one flat parameter per unit): what the optimizer steps."""
+        return [u.master for u in self.units]
+
+    # ---------------------------------------------------------------------------------------------------------------- forward
+    def _wait_ready(self, u: _Unit):
+        if u.ready is not None:
+            torch.cuda.current_stream().wait_event(u.ready)
+
+    def publish(self):
+        """After the optimizer step: masters -> bf16 compute parameters on every rank (one cast for all units, one in-place
+        all-gather per unit on the side stream; a unit's forward waits for its own)."""
+        with torch.no_grad():
+            ctx = torch.cuda.stream(self._comm) if self._cuda else _null()
+            if self._cuda:
+                self._comm.wait_stream(torch.cuda.current_stream())       # the step's reads of the old parameters are queued in front
+            with ctx:
+                torch._foreach_copy_([u.shard_view for u in self.units], [u.master.data for u in self.units])
+                for u in self.units:
+                    if self._communicate:
+                        dist.all_gather_into_tensor(u.gathered, u.shard_view, group=self.group)
+                    if self._cuda:
+                        u.ready = torch.cuda.Event()
+                        u.ready.record(self._comm)
+        self._published = True
+
+    # --------------------------------------------------------------------------------------------------------------- backward
+    def _on_grad(self, u: _Unit):
+        u.pending -= 1
+        if u.pending == 0:
+            self._reduce(u)
+
+    def _reduce(self, u: _Unit):
+        grads = [p.grad for p in u.params]
+        if all(g is None for g in grads):
+            u.pending = len(u.params)
+            return
+        with torch.no_grad():
+            if self._cuda:
+                self._comm.wait_stream(torch.cuda.current_stream())       # the gradients are complete when the side stream starts
+            with (torch.cuda.stream(self._comm) if self._cuda else _null()):
+                flat = torch.empty(u.padded, dtype=self.reduce_dtype, device=u.master.device)
+                if u.padded > u.numel or any(g is None for g in grads) or any(p.numel() % _ALIGN for p in u.params):
+                    flat.zero_()                                          # padding between / behind the parameters, unused parameters
+                dst = [flat[o:o + p.numel()].view(p.shape) for p, o, g in zip(u.params, u.offsets, grads) if g is not None]
+                torch._foreach_copy_(dst, [g for g in grads if g is not None])            # bf16 -> fp32, one multi-tensor launch
+                if self._communicate:
+                    shard = torch.empty(u.shard, dtype=self.reduce_dtype, device=flat.device)
+                    dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM, group=self.group)
+                    if self.divide != 1.0:
+                        shard.div_(self.divide)
+                else:
+                    shard = flat if self.divide == 1.0 else flat.div_(self.divide)
+                if u.master.grad is None:
+                    u.master.grad = shard
+                else:
+                    u.master.grad.add_(shard)                             # gradient accumulation over micro-batches
+        u.held.append(grads)                                              # (alive until the side stream has read them: finish_backward)
+        for p in u.params:
+            p.grad = None
+        u.pending = len(u.params)
+
+    def finish_backward(self):
+        """Once per backward, before clipping / the optimizer: reduces units whose parameters did not all receive a gradient
+        (a unit is normally reduced by the hook of its last gradient) and joins the side stream."""
+        for u in self.units:
+            if u.pending != len(u.params) or any(p.grad is not None for p in u.params):
+                self._reduce(u)
+        if self._cuda:
+            torch.cuda.current_stream().wait_stream(self._comm)
+        for u in self.units:
+            u.held.clear()
+
+    def zero_grad(self):
+        for u in self.units:
+            u.master.grad = None
+            u.held.clear()
+            u.pending = len(u.params)
+            for p in u.params:
+                p.grad = None
+
+    def clip_grad_norm_(self, max_norm: float) -> torch.Tensor:
+        """Global 2-norm over all ranks' shards (one scalar all-reduce), gradients scaled in place like
+        ``torch.nn.utils.clip_grad_norm_``; returns the norm."""
+        grads = [u.master.grad for u in self.units if u.master.grad is not None]
+        if not grads:
+            return torch.zeros((), device=self.units[0].master.device)
+        sq = torch.stack([n * n for n in torch._foreach_norm(grads)]).sum()
+        if self.world > 1:
+            dist.all_reduce(sq, op=dist.ReduceOp.SUM, group=self.group)
+        total = sq.sqrt()
+        coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+        torch._foreach_mul_(grads, coef)
+        return total
+
+    # ------------------------------------------------------------------------------------------------------------ inspection
+    def full_parameters(self, what: str = "param") -> Dict[str, torch.Tensor]:
+        """{name: fp32 tensor} of the masters (``what="param"``) or of their gradients (``"grad"``), gathered from all ranks -
+        for tests and checkpoints; collective."""
+        out = {}
+        for u in self.units:
+            src = u.master.data if what == "param" else u.master.grad
+            if src is None:
+                continue
+            full = torch.empty(u.padded, dtype=src.dtype, device=src.device)
+            if self.world > 1:
+                dist.all_gather_into_tensor(full, src.contiguous(), group=self.group)
+            else:
+                full.copy_(src)
+            for n, p, o in zip(u.names, u.params, u.offsets):
+                out[n] = full[o:o + p.numel()].view(p.shape).clone()
+        return out
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._root_hook.remove()
+
+
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False

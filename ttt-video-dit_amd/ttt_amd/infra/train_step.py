@@ -17,15 +17,19 @@ import torch.distributed as dist
 
 
 def checked_optimizer_step(optimizer: torch.optim.Optimizer, parameters: Iterable[torch.nn.Parameter], max_norm: float,
-                           process_group: Optional[dist.ProcessGroup] = None, extension=None) -> Optional[torch.Tensor]:
+                           process_group: Optional[dist.ProcessGroup] = None, extension=None, clip_fn=None) -> Optional[torch.Tensor]:
     """Clip, verify, step.  Returns the total gradient norm, or ``None`` when the step was SKIPPED because a backward
     hand-over timed out on some rank (or the norm is not finite): the gradients are dropped (``zero_grad``), the error word is
     acknowledged on every rank, parameters and optimizer state are untouched, and the caller may run the batch again.
-    Every rank takes the same decision (MAX all-reduce of the flag when a process group is initialised)."""
+    Every rank takes the same decision (MAX all-reduce of the flag when a process group is initialised).  ``clip_fn(max_norm) ->
+    norm`` replaces ``torch.nn.utils.clip_grad_norm_`` where the gradients are shards of a flat buffer (``FlatFSDP``)."""
     if extension is None:
         import test_time_training as extension
     params = [p for p in parameters if p.grad is not None]
-    total = torch.nn.utils.clip_grad_norm_(params, max_norm) if params else torch.zeros(())
+    if clip_fn is not None:                                  # e.g. FlatFSDP.clip_grad_norm_: the norm over all ranks' shards
+        total = clip_fn(max_norm)
+    else:
+        total = torch.nn.utils.clip_grad_norm_(params, max_norm) if params else torch.zeros(())
     err = int(extension.sweep_error())                      # synchronises the device: everything the backward enqueued has run
     norm = total.full_tensor() if hasattr(total, "full_tensor") else total      # (FSDP2: the norm of sharded gradients is a DTensor)
     bad = torch.tensor([1 if (err != 0 or not bool(torch.isfinite(norm))) else 0], device=norm.device, dtype=torch.int32)
