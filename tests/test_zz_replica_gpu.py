@@ -171,3 +171,92 @@ def test_tensor_parallel_layouts_on_one_gpu(tmp_path):
     r = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, env=env, timeout=580)
     print(r.stdout[-2000:], r.stderr[-2000:])
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+FLAT_SCRIPT = r'''
+import os, sys
+ROOT = sys.argv[1]
+for p in (ROOT, os.path.join(ROOT, "ttt-video-dit_amd")):
+    sys.path.insert(0, p)
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29677", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+import torch
+import test_time_training as ext
+from ttt_amd.infra.flat_fsdp import FlatFSDP
+from ttt_amd.infra.parallelisms import ReplicaMixedPrecision, end_distributed, init_distributed
+from ttt_amd.models.cogvideo.dit import DiffusionTransformer
+from ttt_amd.models.configs import ModelConfig
+ext.load_library()
+init_distributed("nccl")
+dev = torch.device("cuda", 0)
+
+def build(adapter):
+    cfg = ModelConfig(model_dim=512, num_heads=8, num_layers=2, mini_batch_size=64, latent_height=8, latent_width=16, compressed_num_frames=4,
+                      ssm_layer="ttt_mlp", adapter_method=adapter, time_embed_dim=512, text_dim=64, remat_free_layers=1)
+    torch.manual_seed(0)
+    m = DiffusionTransformer(cfg)
+    with torch.no_grad():
+        for _, p in m.named_parameters():
+            if p.ndim >= 2:
+                p.normal_(0, 0.02)
+    m = m.to(dev)
+    for mod in m.modules():
+        if hasattr(mod, "init_freqs"):
+            mod.init_freqs()
+    return m
+
+g = torch.Generator(device=dev).manual_seed(5)
+vid = torch.randn(1, 4, 16, 16, 32, device=dev, generator=g)
+text = torch.randn(1, 1, 64, 64, device=dev, generator=g)
+ts = torch.tensor([300], device=dev)
+for adapter in ("sft", "qkvo"):
+    out = {}
+    for mode in ("flat", "replica"):
+        m = build(adapter)
+        if mode == "flat":
+            fs, rep = FlatFSDP(m, always_communicate=True), None          # RCCL all-gather / reduce-scatter over the one rank
+            params = fs.master_parameters()
+        else:
+            fs, rep = None, ReplicaMixedPrecision(m)
+            params = rep.master_parameters()
+        opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=1e-4, fused=True)
+        trace = []
+        for _ in range(3):
+            opt.zero_grad(set_to_none=True)
+            loss = m(vid, text, ts).float().square().mean()
+            loss.backward()
+            if rep:
+                rep.collect_grads()
+                norm = torch.nn.utils.clip_grad_norm_(params, 1.0)
+            else:
+                fs.finish_backward()
+                norm = fs.clip_grad_norm_(1.0)
+            opt.step()
+            (rep or fs).publish()
+            trace.append((float(loss.detach()), float(norm)))
+        if rep:
+            names = [k for k, _ in m.named_parameters()]
+            final = {k: x.data.float() for k, x in zip(names, rep._master) if x.requires_grad}
+        else:
+            final = fs.full_parameters("param")
+        out[mode] = (trace, final)
+    worst = max(float((out["replica"][1][k] - v).norm() / (v.norm() + 1e-12)) for k, v in out["flat"][1].items())
+    print(adapter, "TRACE", out["flat"][0], out["replica"][0], "WORST", worst)
+    assert set(out["flat"][1]) == set(out["replica"][1])
+    assert all(abs(a[0] - b[0]) <= 1e-5 * abs(a[0]) and abs(a[1] - b[1]) <= 1e-4 * abs(a[1]) for a, b in zip(out["flat"][0], out["replica"][0]))
+    assert worst < 1e-5, worst
+end_distributed()
+'''
+
+
+@pytest.mark.timeout(600)
+def test_flat_fsdp_with_its_collectives_equals_replica_on_one_gpu(tmp_path):
+    """FlatFSDP (ttt_amd/infra/flat_fsdp.py) over a one-rank RCCL group WITH its collectives - the in-place all-gather of the flat
+    bf16 buffers and the reduce-scatter of the flat fp32 gradients on the side stream, the units' hooks, the events a unit's
+    forward waits for - against ReplicaMixedPrecision on the same small DiT with the HIP kernels underneath: three AdamW steps,
+    losses / clipped norms to 1e-5 / 1e-4, parameters to 1e-5; everything trainable and the "qkvo" adapter (frozen parameters)."""
+    script = tmp_path / "flat_vs_replica.py"
+    script.write_text(FLAT_SCRIPT)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", TORCHDYNAMO_DISABLE="1")
+    r = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, env=env, timeout=580)
+    print(r.stdout[-2000:], r.stderr[-2000:])
+    assert r.returncode == 0, r.stderr[-3000:]
