@@ -441,17 +441,24 @@ def main():
     import gc
     line = None
     if world == 1 and mode in ("auto", "off"):
+        # one GPU: the sharded path's own code with nothing to communicate (FlatFSDP over one rank skips its collectives and is
+        # then ReplicaMixedPrecision's arithmetic, bit for bit - tests/test_zz_replica_gpu.py - without fp32 masters of FROZEN
+        # parameters: 16 GB at 5B / qkvo that go to remat-free layers); --fsdp off = ReplicaMixedPrecision itself
         try:
-            log("replica path (one GPU)")
-            line = _run(args, world, rank, local_rank, dev, no_fsdp=True)
-        except Exception as ex:      # an untested corner of the replica path must not cost the measurement
+            if mode == "off":
+                log("replica path (one GPU)")
+                line = _run(args, world, rank, local_rank, dev, no_fsdp=True)
+            else:
+                log("flat FSDP path over one rank, collectives skipped (one GPU)")
+                line = _run(args, world, rank, local_rank, dev, no_fsdp=False, sharded="flat", communicate=False)
+        except Exception as ex:      # an untested corner must not cost the measurement
             if mode == "off":
                 raise
-            print(f"bench.py: replica path failed ({ex!r}); falling back to the flat FSDP path over a one-rank group", file=sys.stderr, flush=True)
+            print(f"bench.py: flat path failed ({ex!r}); falling back to ReplicaMixedPrecision", file=sys.stderr, flush=True)
         gc.collect()
         torch.cuda.empty_cache()
         if line is None:
-            line = _run(args, world, rank, local_rank, dev, no_fsdp=False, sharded=multi)
+            line = _run(args, world, rank, local_rank, dev, no_fsdp=True)
         elif not args.no_fsdp1_compare and mode == "auto":
             # the same step through the sharded path over a one-rank group WITH its collectives (RCCL all-gather / reduce-scatter
             # of one rank) = the code path of N > 1 (like-for-like point of a 1 -> N curve)
@@ -488,7 +495,7 @@ def main():
     dist.destroy_process_group()
 
 
-def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False, tp=False, sharded="fsdp2"):
+def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False, tp=False, sharded="fsdp2", communicate=True):
     import test_time_training as ext
     from ttt_amd.infra.parallelisms import (ReplicaMixedPrecision, apply_fsdp, enable_tuned_gemms, get_dp_mesh, init_distributed,
                                             init_model_parameters)
@@ -545,7 +552,7 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False, tp=False, sha
     flat = None
     if not no_fsdp and not tp and sharded == "flat":      # the same partitioning on flat buffers (ttt_amd/infra/flat_fsdp.py)
         from ttt_amd.infra.flat_fsdp import FlatFSDP
-        flat = FlatFSDP(model.dit, always_communicate=True)
+        flat = FlatFSDP(model.dit, always_communicate=communicate)
     train_params = replica.master_parameters() if replica else flat.master_parameters() if flat else [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.AdamW(train_params, lr=1e-5, weight_decay=1e-4, fused=True)
 
@@ -731,7 +738,7 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False, tp=False, sha
                 "scaling": "strong" if (tp and dp == 1 and world > 1) else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                 "config": {"workload": f"CogVideoX-5B+{args.ssm_layer} {args.video_length} training step (fwd+bwd+AdamW), "
                                        f"{cfg.num_layers} layers, L={L} tokens/sample, adapter={args.adapter}",
-                           "global_batch": dp * LB, "seq_len": L, "parallelism": (f"tp{tp}" if no_fsdp else f"fsdp{world}(dp{dp}xtp{tp})") if tp else ("replica1" if no_fsdp else f"flat_fsdp{world}" if flat else f"fsdp2_{world}"), "ttt_impl": args.impl,
+                           "global_batch": dp * LB, "seq_len": L, "parallelism": (f"tp{tp}" if no_fsdp else f"fsdp{world}(dp{dp}xtp{tp})") if tp else ("replica1" if no_fsdp else (f"flat_fsdp{world}" if (communicate or world > 1) else "flat1") if flat else f"fsdp2_{world}"), "ttt_impl": args.impl,
                            "remat_free_layers": n_free, "remat_keep": list(dit.remat_keep), "fsdp_reshard_after_forward": bool(args.reshard_after_forward), "tuned_gemm_selections": bool(tuned),
                            "sweep_error": sweep_err, "valid": args.layers is None and sweep_err == 0},
                 "roofline": roof, "loss": loss_val, "peak_mem_gib": peak_mem, "peak_reserved_gib": torch.cuda.max_memory_reserved() / 2 ** 30, "alloc_retries_total": Hooks.alloc_retries(), "total_tokens_per_s": dp * L / (dt / args.steps)}
