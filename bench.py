@@ -742,7 +742,11 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False, tp=False, sha
                            "remat_free_layers": n_free, "remat_keep": list(dit.remat_keep), "fsdp_reshard_after_forward": bool(args.reshard_after_forward), "tuned_gemm_selections": bool(tuned),
                            "sweep_error": sweep_err, "valid": args.layers is None and sweep_err == 0},
                 "roofline": roof, "loss": loss_val, "peak_mem_gib": peak_mem, "peak_reserved_gib": torch.cuda.max_memory_reserved() / 2 ** 30, "alloc_retries_total": Hooks.alloc_retries(), "total_tokens_per_s": dp * L / (dt / args.steps)}
+        if flat:
+            flat.remove()
         return line
+    if flat:
+        flat.remove()
     return None
 
 

@@ -221,9 +221,16 @@ class FlatFSDP:
         return out
 
     def remove(self):
+        """Detach from the module (hooks removed, buffers released): the parameters keep their last bf16 values as views of
+        nothing shared any more.  bench.py calls it between its runs so that the first model's memory is returned."""
         for h in self._hooks:
             h.remove()
+        self._hooks.clear()
         self._root_hook.remove()
+        for u in self.units:
+            u.held.clear()
+            u.master.grad = None
+        self.units.clear()
 
 
 class _null:
