@@ -441,24 +441,20 @@ def main():
     import gc
     line = None
     if world == 1 and mode in ("auto", "off"):
-        # one GPU: the sharded path's own code with nothing to communicate (FlatFSDP over one rank skips its collectives and is
-        # then ReplicaMixedPrecision's arithmetic, bit for bit - tests/test_zz_replica_gpu.py - without fp32 masters of FROZEN
-        # parameters: 16 GB at 5B / qkvo that go to remat-free layers); --fsdp off = ReplicaMixedPrecision itself
+        # one GPU: ReplicaMixedPrecision - the sharded path's arithmetic with nothing to shard.  (Round 4 measured the flat FSDP path
+        # with its collectives skipped in this place on one box: 6 638 against 6 505 ms per step at equal re-materialisation - the
+        # per-unit gradient casts it queues beside the backward cost more than the one pass at the end; profiles/r4l_*.)
         try:
-            if mode == "off":
-                log("replica path (one GPU)")
-                line = _run(args, world, rank, local_rank, dev, no_fsdp=True)
-            else:
-                log("flat FSDP path over one rank, collectives skipped (one GPU)")
-                line = _run(args, world, rank, local_rank, dev, no_fsdp=False, sharded="flat", communicate=False)
-        except Exception as ex:      # an untested corner must not cost the measurement
+            log("replica path (one GPU)")
+            line = _run(args, world, rank, local_rank, dev, no_fsdp=True)
+        except Exception as ex:      # an untested corner of the replica path must not cost the measurement
             if mode == "off":
                 raise
-            print(f"bench.py: flat path failed ({ex!r}); falling back to ReplicaMixedPrecision", file=sys.stderr, flush=True)
+            print(f"bench.py: replica path failed ({ex!r}); falling back to the flat FSDP path over a one-rank group", file=sys.stderr, flush=True)
         gc.collect()
         torch.cuda.empty_cache()
         if line is None:
-            line = _run(args, world, rank, local_rank, dev, no_fsdp=True)
+            line = _run(args, world, rank, local_rank, dev, no_fsdp=False, sharded=multi)
         elif not args.no_fsdp1_compare and mode == "auto":
             # the same step through the sharded path over a one-rank group WITH its collectives (RCCL all-gather / reduce-scatter
             # of one rank) = the code path of N > 1 (like-for-like point of a 1 -> N curve)

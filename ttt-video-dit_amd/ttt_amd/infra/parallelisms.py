@@ -231,8 +231,14 @@ class ReplicaMixedPrecision:
             if id(p) in seen or not p.is_floating_point():
                 continue
             seen[id(p)] = True
-            master = torch.nn.Parameter(p.detach().to(torch.float32, copy=True), requires_grad=p.requires_grad)
-            p.data = p.detach().to(param_dtype)
+            if p.requires_grad:
+                master = torch.nn.Parameter(p.detach().to(torch.float32, copy=True), requires_grad=True)
+                p.data = p.detach().to(param_dtype)
+            else:
+                # frozen (adapter "qkvo": 4.0 of 7.2 B parameters): nothing ever updates it, so no fp32 master is kept - 16 GB at
+                # 5B that go to remat-free layers (round 4); the entry keeps the two lists aligned
+                p.data = p.detach().to(param_dtype)
+                master = p
             self._compute.append(p)
             self._master.append(master)
         self._hook = module.register_forward_pre_hook(self._cast_inputs, with_kwargs=True)
@@ -268,7 +274,8 @@ class ReplicaMixedPrecision:
     def publish(self):
         """Masters -> compute copies (after the optimizer step)."""
         with torch.no_grad():
-            torch._foreach_copy_([p.data for p in self._compute], [m.data for m in self._master])
+            pairs = [(p, m) for p, m in zip(self._compute, self._master) if m is not p]
+            torch._foreach_copy_([p.data for p, _ in pairs], [m.data for _, m in pairs])
 
     def zero_grad(self):
         for m in self._master:
