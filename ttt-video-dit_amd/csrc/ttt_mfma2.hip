@@ -88,6 +88,42 @@ __device__ __forceinline__ bf16x8 tr_frag_pi(const __bf16* img, int stride, int 
     return tr_frag(img, stride, row0 + 16 * s + 4 * h, row0 + 16 * s + 8 + 4 * h, col0, l);
 }
 
+// ---- half-chunk swap (template parameter SW of the scan) ------------------------------------------------------------------
+// With the 144-byte row stride every 8-byte access that walks ROWS at a fixed column (pi_read, st_image) is a 2-way bank
+// conflict: rows r and r + 16 (reads: 32 lanes over 64 banks) or r and r + 8 (writes: 16 lanes over 32 banks) meet in the same
+// banks (tools/lds_bank_model.py: 1 280 of a step's 7 576 LDS passes).  Under SW the two 8-byte units of every 16-byte chunk
+// of a tile row are stored swapped in rows with  x(r) = bit 3 ^ bit 4 of r  = 1, which sends the colliding rows to
+// different banks.  The price is address selection only: for the row walkers x is a lane constant folded into `h`, for the
+// transposed reads it is a compile-time constant per instruction, and the 16-byte accessors (tile parking, the owners' rows)
+// swap the halves of their value in registers (4 v_cndmask).  The data are the same: SW on / off give identical bits.
+__device__ __forceinline__ int sw_x(int r) { return ((r >> 3) ^ (r >> 4)) & 1; }
+template <bool SW>
+__device__ __forceinline__ uint4 sw16(uint4 v, int x) {
+    if (!SW) return v;
+    return x ? uint4{v.z, v.w, v.x, v.y} : v;
+}
+template <bool SW>
+__device__ __forceinline__ bf16x8 tr_frag_pi_sw(const __bf16* img, int stride, int row0, int s, int col0, int l) {
+    if (!SW) return tr_frag_pi(img, stride, row0, s, col0, l);
+    // rows row0 + 16 s + 4 h + (0 | 8) + (i >> 2), row0 a multiple of 32: bit 4 = s, bit 3 = (0 | 1)  ->  x = s for the
+    // first read, s ^ 1 for the second; the lane's unit (i & 3) of its 16-column group flips its low bit when x = 1
+    const int h = l >> 5, i = l & 15, g1 = (l >> 4) & 1;
+    const int base = (i >> 2) * stride + col0 + 16 * g1;
+    const int off0 = base + 4 * (i & 3), off1 = base + 4 * ((i & 3) ^ 1);
+    const int r0 = row0 + 16 * s + 4 * h;
+    typedef __attribute__((address_space(3))) bf16x4 lds_b4;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(img + r0 * stride + ((s & 1) ? off1 : off0)));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(img + (r0 + 8) * stride + ((s & 1) ? off0 : off1)));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+template <bool SW>
+__device__ __forceinline__ void load8_bf16_sw(const __bf16* p, int x, float (&o)[8]) {
+    const uint4 raw = sw16<SW>(*reinterpret_cast<const uint4*>(p), x);
+    const bf16x8 a = __builtin_bit_cast(bf16x8, raw);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (float)a[j];
+}
+
 __device__ __forceinline__ void load8_bf16(const __bf16* p, float (&o)[8]) {
     const bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
 #pragma unroll
@@ -118,7 +154,7 @@ __device__ __forceinline__ void write_partial2(float* redw, const f32x16& P, int
         t_last = _t;                                                         \
     }
 
-template <bool DBG>
+template <bool DBG, bool SW>
 __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __bf16* Kt = reinterpret_cast<__bf16*>(smem + L_K);
@@ -189,8 +225,8 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
         pfK = *reinterpret_cast<const uint4*>(p.XK + off);
         pfV = *reinterpret_cast<const uint4*>(p.XV + off);
         if (tid < 64) pfE = (float)p.eta[tile0 * 64 + tid];
-        *reinterpret_cast<uint4*>(Kt + prow * TS + pcol) = pfK;
-        *reinterpret_cast<uint4*>(Vt + prow * TS + pcol) = pfV;
+        *reinterpret_cast<uint4*>(Kt + prow * TS + pcol) = sw16<SW>(pfK, sw_x(prow));
+        *reinterpret_cast<uint4*>(Vt + prow * TS + pcol) = sw16<SW>(pfV, sw_x(prow));
         if (tid < 64) etaL[tid] = pfE;
     }
     // packed operands of the entering state (re-made after every update, carried across steps)
@@ -215,6 +251,8 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
         const int tid = tid_op;
         const int ot = tid >> 3, of0 = 8 * (tid & 7);
         const int prow = tid >> 3, pcol = (tid & 7) * 8;
+        const int hs = SW ? (h ^ sw_x(c)) : h;                // the row walkers' half selector (rows = 32 k + c): see sw_x
+        const int xo = SW ? sw_x(ot) : 0;                     // the 16-byte accessors' swap (row ot == prow)
 
         if (i % G == 0) {   // checkpoint: state entering step i (mlp_tk.py:95-98)
             const size_t ck = (size_t)bh * p.K + i / G;
@@ -252,7 +290,7 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
-                    Z = mma(pi_read(Kt + (32 * ti + c) * TS, 32 * a, s, h), W1F[a][s], Z);
+                    Z = mma(pi_read(Kt + (32 * ti + c) * TS, 32 * a, s, hs), W1F[a][s], Z);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float y, dy;
@@ -264,13 +302,13 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
             // ~56 registers) alive across A2 / P3 instead of these 16
             asm volatile("" : "+v"(D1[ti]));
 #pragma unroll
-            for (int s = 0; s < 2; ++s) st_image(X2img + (nO + c) * TS, 32 * ti, s, h, pack(Z, s));
+            for (int s = 0; s < 2; ++s) st_image(X2img + (nO + c) * TS, 32 * ti, s, hs, pack(Z, s));
         }
         TTT_STAMP2(0)
         __syncthreads();              // B0: X2 image complete; every P6 read of step i-1 (red, Qt, b2L) is done
         TTT_STAMP2(8)
         if (DBG && p.dump && blockIdx.x == 0 && i == 0)
-            for (int e = tid; e < 256 * 64; e += NT2) p.dump[e] = (float)X2img[(e >> 6) * TS + (e & 63)];
+            for (int e = tid; e < 256 * 64; e += NT2) p.dump[e] = (float)X2img[(e >> 6) * TS + ((e & 63) ^ (SW ? 4 * sw_x(e >> 6) : 0))];
 
         // ================= A2: partial Z2^T[Fp, t] over the hidden slice ==========================
         {
@@ -284,13 +322,13 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
                 f32x16 P = zero16();
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    P = mma(W2F[0][s], tr_frag_pi(X2img, TS, nO, s, 32 * ti, l), P);
-                    P = mma(W2F[1][s], tr_frag_pi(X2img, TS, nX, s, 32 * ti, l), P);
+                    P = mma(W2F[0][s], tr_frag_pi_sw<SW>(X2img, TS, nO, s, 32 * ti, l), P);
+                    P = mma(W2F[1][s], tr_frag_pi_sw<SW>(X2img, TS, nX, s, 32 * ti, l), P);
                 }
                 write_partial2(red + (size_t)w * 64 * PS, P, ti, pp, h, c);
             }
         }
-        *reinterpret_cast<uint4*>(Qt + prow * TS + pcol) = pfQ;   // Q of this step (read only after B2)
+        *reinterpret_cast<uint4*>(Qt + prow * TS + pcol) = sw16<SW>(pfQ, xo);   // Q of this step (read only after B2)
         TTT_STAMP2(1)
         __syncthreads();              // B1: partials visible
         TTT_STAMP2(9)
@@ -315,8 +353,8 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
             for (int j = 0; j < 8; ++j) { const float d = z[j] - mu; v += d * d; }
             const float rstd = __builtin_amdgcn_rsqf(sum8(v) * (1.0f / 64.0f) + p.eps);
             if (DBG && p.dump && blockIdx.x == 0 && i == 0 && (tid & 7) == 0) { p.dump[60000 + ot] = mu; p.dump[60064 + ot] = rstd; }
-            load8_bf16(Kt + ot * TS + of0, kk);
-            load8_bf16(Vt + ot * TS + of0, vv);
+            load8_bf16_sw<SW>(Kt + ot * TS + of0, xo, kk);
+            load8_bf16_sw<SW>(Vt + ot * TS + of0, xo, vv);
             float s1 = 0.f, s2 = 0.f, gx[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -332,13 +370,13 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
             bf16x8 o;
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = (__bf16)((64.0f * gx[j] - s1 - z[j] * s2) * sc);
-            *reinterpret_cast<bf16x8*>(Gs + ot * TS + of0) = o;
+            *reinterpret_cast<uint4*>(Gs + ot * TS + of0) = sw16<SW>(__builtin_bit_cast(uint4, o), xo);
         }
         TTT_STAMP2(2)
         __syncthreads();              // B2: Gs visible
         TTT_STAMP2(10)
         if (DBG && p.dump && blockIdx.x == 0 && i == 0)
-            for (int e = tid; e < 64 * 64; e += NT2) p.dump[20480 + e] = (float)Gs[(e >> 6) * TS + (e & 63)];
+            for (int e = tid; e < 64 * 64; e += NT2) p.dump[20480 + e] = (float)Gs[(e >> 6) * TS + ((e & 63) ^ (SW ? 4 * sw_x(e >> 6) : 0))];
 
         // ================= C: state updates, f3, f4 ===============================================
         {
@@ -354,7 +392,7 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
 #pragma unroll
                 for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-                    for (int s = 0; s < 2; ++s) acc = mma(ONES, tr_frag_pi(Gs, TS, 32 * ti, s, fO, l), acc);
+                    for (int s = 0; s < 2; ++s) acc = mma(ONES, tr_frag_pi_sw<SW>(Gs, TS, 32 * ti, s, fO, l), acc);
                 b2v += acc[0];
             }
             // f5 + W2^T update.  Gs^T fragments (outer=f, k=t) by transposed reads: own half of f (also f5's B
@@ -364,12 +402,12 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
             for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    const bf16x8 gO = tr_frag_pi(Gs, TS, 32 * ti, s, fO, l);
-                    const bf16x8 xO = pi_read(X2img + (nO + c) * TS, 32 * ti, s, h);
+                    const bf16x8 gO = tr_frag_pi_sw<SW>(Gs, TS, 32 * ti, s, fO, l);
+                    const bf16x8 xO = pi_read(X2img + (nO + c) * TS, 32 * ti, s, hs);
                     W2t[0] = mma(xO, gO, W2t[0]);                                                  // f5, own hidden half
-                    W2t[1] = mma(pi_read(X2img + (nX + c) * TS, 32 * ti, s, h), gO, W2t[1]);       // f5, partner's half
+                    W2t[1] = mma(pi_read(X2img + (nX + c) * TS, 32 * ti, s, hs), gO, W2t[1]);       // f5, partner's half
                     W2Tt[0] = mma(gO, xO, W2Tt[0]);
-                    W2Tt[1] = mma(tr_frag_pi(Gs, TS, 32 * ti, s, fX, l), xO, W2Tt[1]);
+                    W2Tt[1] = mma(tr_frag_pi_sw<SW>(Gs, TS, 32 * ti, s, fX, l), xO, W2Tt[1]);
                 }
             // f3: gX2s = Gs W2^T ; gZ1s = gX2s * D1   (rows=t, lane=n) ; f4: W1[f, n in Hp] += K[:, f]^T gZ1s
             float sb = 0.f;
@@ -378,8 +416,8 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
                 f32x16 gx = zero16();
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    gx = mma(pi_read(Gs + (32 * ti + c) * TS, fO, s, h), W2TF[0][s], gx);
-                    gx = mma(pi_read(Gs + (32 * ti + c) * TS, fX, s, h), W2TF[1][s], gx);
+                    gx = mma(pi_read(Gs + (32 * ti + c) * TS, fO, s, hs), W2TF[0][s], gx);
+                    gx = mma(pi_read(Gs + (32 * ti + c) * TS, fX, s, hs), W2TF[1][s], gx);
                 }
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {      // aligned register pairs (see gelu_fwd_tile_pk)
@@ -392,8 +430,8 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const bf16x8 gz = pack(gx, s);           // (outer=n, k=t)
-                    W1t[0] = mma(tr_frag_pi(Kt, TS, 32 * ti, s, 0, l), gz, W1t[0]);
-                    W1t[1] = mma(tr_frag_pi(Kt, TS, 32 * ti, s, 32, l), gz, W1t[1]);
+                    W1t[0] = mma(tr_frag_pi_sw<SW>(Kt, TS, 32 * ti, s, 0, l), gz, W1t[0]);
+                    W1t[1] = mma(tr_frag_pi_sw<SW>(Kt, TS, 32 * ti, s, 32, l), gz, W1t[1]);
                 }
             }
             b1v += xor_add(sb, 32);   // b1' = b1 - sum_t eta gZ1
@@ -428,7 +466,7 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
                     for (int s = 0; s < 2; ++s)
-                        zb = mma(W1F[a][s], pi_read(Qt + (32 * ti + c) * TS, 32 * a, s, h), zb);
+                        zb = mma(W1F[a][s], pi_read(Qt + (32 * ti + c) * TS, 32 * a, s, hs), zb);
                 gelu_fwd_tile_pk(zb);
                 if (DBG && p.dump && blockIdx.x == 0 && i == 0)
                     for (int r = 0; r < 16; ++r) p.dump[28992 + (size_t)(nO + row_of(r, h)) * 64 + 32 * ti + c] = zb[r];
@@ -476,8 +514,8 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
             }
         }
         if (more) {                   // next step's K, V, eta (their last readers finished before B3)
-            *reinterpret_cast<uint4*>(Kt + prow * TS + pcol) = pfK;
-            *reinterpret_cast<uint4*>(Vt + prow * TS + pcol) = pfV;
+            *reinterpret_cast<uint4*>(Kt + prow * TS + pcol) = sw16<SW>(pfK, xo);
+            *reinterpret_cast<uint4*>(Vt + prow * TS + pcol) = sw16<SW>(pfV, xo);
             if (tid < 64) etaL[tid] = pfE;
         }
         TTT_STAMP2(5)
@@ -500,7 +538,7 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const float d = z[j] - mu; v += d * d; }
             const float rstd = __builtin_amdgcn_rsqf(sum8(v) * (1.0f / 64.0f) + p.eps);
-            load8_bf16(Qt + ot * TS + of0, q);
+            load8_bf16_sw<SW>(Qt + ot * TS + of0, xo, q);
             bf16x8 o;
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = (__bf16)(q[j] + gamL[of0 + j] * ((z[j] - mu) * rstd) + betL[of0 + j]);
@@ -513,8 +551,10 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
 static void set_attr_once() {
     static bool done = false;
     if (!done) {
-        (void)hipFuncSetAttribute((const void*)mlp_scan8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_V2);
-        (void)hipFuncSetAttribute((const void*)mlp_scan8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_V2);
+        (void)hipFuncSetAttribute((const void*)mlp_scan8_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_V2);
+        (void)hipFuncSetAttribute((const void*)mlp_scan8_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_V2);
+        (void)hipFuncSetAttribute((const void*)mlp_scan8_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_V2);
+        (void)hipFuncSetAttribute((const void*)mlp_scan8_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_V2);
         done = true;
     }
 }
@@ -523,13 +563,21 @@ static void set_attr_once() {
 
 static float* g_dump = nullptr;
 void set_debug_dump(float* buf) { g_dump = buf; }
+static int g_scan_swap = 0;           // forward scan: half-chunk swap of the LDS tiles (sw_x above); A/B option "scan_swap"
+void set_debug_scan_swap(int v) { g_scan_swap = v; }
 void launch_scan_forward_v2(const ScanParams& p0, int n_bh, unsigned long long* dbg, hipStream_t s) {
     ScanParams p = p0;
     p.dbg = dbg;
     p.dump = g_dump;
     v2::set_attr_once();
-    if (p.dbg || p.dump) hipLaunchKernelGGL(v2::mlp_scan8_kernel<true>, dim3(n_bh), dim3(v2::NT2), v2::LDS_V2, s, p);
-    else hipLaunchKernelGGL(v2::mlp_scan8_kernel<false>, dim3(n_bh), dim3(v2::NT2), v2::LDS_V2, s, p);
+    const bool dbg_build = p.dbg || p.dump;
+    if (g_scan_swap) {
+        if (dbg_build) hipLaunchKernelGGL((v2::mlp_scan8_kernel<true, true>), dim3(n_bh), dim3(v2::NT2), v2::LDS_V2, s, p);
+        else hipLaunchKernelGGL((v2::mlp_scan8_kernel<false, true>), dim3(n_bh), dim3(v2::NT2), v2::LDS_V2, s, p);
+    } else {
+        if (dbg_build) hipLaunchKernelGGL((v2::mlp_scan8_kernel<true, false>), dim3(n_bh), dim3(v2::NT2), v2::LDS_V2, s, p);
+        else hipLaunchKernelGGL((v2::mlp_scan8_kernel<false, false>), dim3(n_bh), dim3(v2::NT2), v2::LDS_V2, s, p);
+    }
 }
 
 }  // namespace mfma
