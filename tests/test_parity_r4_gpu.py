@@ -103,3 +103,34 @@ def test_sweep_schedule_and_record_variants(bf16_records, deriver_wave0, own_bf1
                    out1, cks1, g1, ro, rc, rg, 1e-2, 3e-2)
     for k in g1:
         assert torch.equal(g1[k], g2[k]), f"{k} differs between two identical calls"
+
+
+def test_forward_scan_half_chunk_swap_variant():
+    """Debug option "scan_swap" of the TTT-MLP forward scan (csrc/ttt_mfma2.hip, template parameter SW): the two 8-byte units of
+    every 16-byte chunk of an LDS tile row are stored swapped in rows with bit 3 ^ bit 4 set, which removes the 2-way bank
+    conflicts of the accesses that walk rows at a fixed column (tools/lds_bank_model.py --half-swap).  A pure change of
+    addresses: the variant is held to the fp64 oracle at the usual tolerances (outputs AND the checkpointed states, i.e. every
+    LDS tile of every phase was read back as it was written) and to the other variant (same data, so the same result up to
+    the contraction choices of a separate instantiation: reported, bounded far below a layout error)."""
+    from oracle import ttt_oracle as O
+    from test_kernels_gpu import oracle_on, round_acts, run_mlp
+    from test_parity_r2_gpu import check_per_head
+    e = ext()
+    NH, NC, G = 8, 70, 16
+    d = round_acts(O.make_inputs("mlp", 1, NH, NC, 64, 64, seed=8200), torch.bfloat16)
+    ro, rc, rg = oracle_on(d, G, "mlp")
+    res = {}
+    try:
+        for v in (0, 1):
+            e.debug_option("scan_swap", v)
+            res[v] = run_mlp(e, d, G, torch.bfloat16, impl="mfma")
+            check_per_head(f"TTT-MLP MFMA forward scan, scan_swap={v}", *res[v], ro, rc, rg, 1e-2, 3e-2)
+    finally:
+        e.debug_option("scan_swap", SCAN_SWAP_DEFAULT)
+    same = torch.equal(res[0][0], res[1][0]) and all(torch.equal(a, b) for a, b in zip(res[0][1], res[1][1]))
+    worst = max([rel_l2(res[1][0], res[0][0])] + [rel_l2(a, b) for a, b in zip(res[1][1], res[0][1])])
+    print(f"scan_swap 1 vs 0: outputs and checkpoints bit-identical = {same}, worst relative L2 difference {worst:.2e}")
+    assert worst < 2e-3, worst
+
+
+SCAN_SWAP_DEFAULT = 0          # the library's (csrc/ttt_mfma2.hip g_scan_swap)

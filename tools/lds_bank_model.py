@@ -11,6 +11,8 @@ reads ...), so the numbers are as good as that enumeration; the check is the dev
     python tools/lds_bank_model.py                 # the shipped layout, per access class
     python tools/lds_bank_model.py --ts 80         # another row stride (elements) of the bf16 tiles
     python tools/lds_bank_model.py --swizzle       # unpadded 64-element rows, 8-byte units XOR-ed by a function of the row
+    python tools/lds_bank_model.py --half-swap     # padded rows, the two 8-byte units of a 16-byte chunk swapped by row bits 3 ^ 4
+                                                   # (csrc/ttt_mfma2.hip, debug option "scan_swap": address selection only)
 """
 import argparse
 from collections import defaultdict
@@ -48,8 +50,8 @@ def bank_cost(addr, nbytes, write):
 class Layout:
     """byte address of element (row, col) of a bf16 tile / image that starts at `base`"""
 
-    def __init__(self, ts=72, swizzle=False):
-        self.ts, self.swizzle = ts, swizzle
+    def __init__(self, ts=72, swizzle=False, half_swap=False):
+        self.ts, self.swizzle, self.half_swap = ts, swizzle, half_swap
 
     def g(self, r):
         """4-bit XOR pattern of the 8-byte unit index (16 units per 64-element row).  bit 3 = bit 1 of the row: the 4 rows of a
@@ -59,6 +61,10 @@ class Layout:
         return (((r >> 1) & 1) << 3) | (((r >> 2) & 7) ^ ((r & 1) << 2))
 
     def at(self, base, r, col, nbytes=8):
+        if self.half_swap and nbytes < 16:
+            # csrc/ttt_mfma2.hip template parameter SW (sw_x): padded rows kept; the two 8-byte units of a 16-byte chunk swapped
+            # in rows with bit 3 ^ bit 4 set (a 16-byte access keeps its address and swaps its halves in registers)
+            return base + 2 * (r * self.ts + (col ^ (4 * (((r >> 3) ^ (r >> 4)) & 1))))
         if not self.swizzle:
             return base + 2 * (r * self.ts + col)
         if nbytes >= 16:       # a 16-byte access covers both units of its chunk (their order inside the chunk may be swapped)
@@ -171,8 +177,9 @@ def main():
     ap.add_argument("--ts", type=int, default=72)
     ap.add_argument("--ps", type=int, default=68)
     ap.add_argument("--swizzle", action="store_true")
+    ap.add_argument("--half-swap", action="store_true", help="the shipped A/B variant: 8-byte units of a 16-byte chunk swapped in rows with bit 3 ^ bit 4 set")
     a = ap.parse_args()
-    lay = Layout(a.ts, a.swizzle)
+    lay = Layout(a.ts, a.swizzle, a.half_swap)
     tot = defaultdict(lambda: [0, 0, 0])
     for cls, nbytes, write, addr in scan_step(lay, a.ps):
         p, c = bank_cost(addr, nbytes, write)

@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--rc-nt", type=int, default=1, help="A/B: revision-4 recompute, non-temporal stores of the step records")
     ap.add_argument("--prefetch", type=int, default=1, help="A/B: revision-4 sweep, L2 prefetch touches two steps ahead (1 default, 0 off)")
     ap.add_argument("--ab", default=None, metavar="OPTION", help="interleaved A/B inside one process: the named debug option alternates 0 / 1 from iteration to iteration; the backward's average is reported per value (same box, same clocks)")
+    ap.add_argument("--ab-restore", type=int, default=1, help="value the --ab option is left at for the --phases pass")
     ap.add_argument("--ab-fixed", default=None, metavar="OPTION=VALUE", help="set one more debug option for the whole run")
     ap.add_argument("--phases", action="store_true", help="also print per-phase cycle totals of workgroup 0")
     a = ap.parse_args()
@@ -86,21 +87,23 @@ def main():
         setattr(ext, name, wrapped)
 
     ab = {0: [], 1: []}
+    abf = {0: [], 1: []}
     for it in range(a.iters + 2):
         if it == 2:
             torch.cuda.synchronize()
             times = {"fwd": [], "bwd": []}
         if a.ab:
             ext.debug_option(a.ab, it & 1)
-        n0 = len(times["bwd"])
+        n0, f0 = len(times["bwd"]), len(times["fwd"])
         out = fwd()
         if not a.fwd_only:
             out.backward(dOut)
         if a.ab and it >= 2:
             ab[it & 1] += times["bwd"][n0:]
+            abf[it & 1] += times["fwd"][f0:]
     torch.cuda.synchronize()
     if a.ab:
-        ext.debug_option(a.ab, 1)
+        ext.debug_option(a.ab, a.ab_restore)
     g = 2.0 * CS * F * H
     nfl = {"fwd": (7 if a.kind == "mlp" else 3) * g, "bwd": (14 if a.kind == "mlp" else 6) * g}
     res = {"kind": a.kind, "impl_requested": a.impl, "shape": [B, NH, NC, CS, F], "G": G}
@@ -114,7 +117,8 @@ def main():
                   "avg_ms": avg, "min_ms": ms[0], "us_per_step": 1e3 * avg / NC, "tflops": fl / (avg * 1e-3) / 1e12,
                   "frac_mfma_peak": fl / (avg * 1e-3) / 2.5e15, "frac_occupied_cu_peak": fl / (avg * 1e-3) / (2.5e15 * min(B * NH, 256) / 256)}
     if a.ab:
-        res["ab"] = {"option": a.ab, **{str(v): {"bwd_avg_ms": sum(s.elapsed_time(e) for s, e in ev) / max(1, len(ev)), "n": len(ev)} for v, ev in ab.items()}}
+        avg = lambda ev: sum(s.elapsed_time(e) for s, e in ev) / max(1, len(ev))
+        res["ab"] = {"option": a.ab, **{str(v): {"fwd_avg_ms": avg(abf[v]), "bwd_avg_ms": avg(ab[v]), "n": len(abf[v])} for v in (0, 1)}}
     if a.phases:
         buf = torch.zeros(48, dtype=torch.int64, device=dev)
         ext.debug_timing(buf)
