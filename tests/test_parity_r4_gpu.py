@@ -134,39 +134,3 @@ def test_forward_scan_half_chunk_swap_variant():
 
 
 SCAN_SWAP_DEFAULT = 0          # the library's (csrc/ttt_mfma2.hip g_scan_swap)
-
-
-LIGHT_BARRIERS_DEFAULT = 0     # the library's (csrc/ttt_mfma2.hip g_light)
-
-
-@pytest.mark.parametrize("bits", [1, 2, 4, 7])
-def test_lds_only_barriers_same_bits(bits):
-    """Debug option "light_barriers": the step barriers of the forward scan (bit 0), of the recompute kernel (bit 1) and of the
-    sweep's compute waves (bit 2) as `s_waitcnt lgkmcnt(0) ; s_barrier` instead of __syncthreads(), whose workgroup fence drains
-    every global load and store in flight (vmcnt(0)).  No step communicates through global memory inside a kernel (the hand-over
-    records are drained explicitly in front of their flag), so the results must be IDENTICAL, bit for bit, to the fenced form -
-    outputs, checkpoints and every gradient, over three chunks with a short last one - and match the fp64 oracle."""
-    from oracle import ttt_oracle as O
-    from test_kernels_gpu import oracle_on, round_acts, run_mlp
-    from test_parity_r2_gpu import check_per_head
-    e = ext()
-    NH, NC, G = 8, 70, 16
-    d = round_acts(O.make_inputs("mlp", 1, NH, NC, 64, 64, seed=8300), torch.bfloat16)
-    ro, rc, rg = oracle_on(d, G, "mlp")
-    res = {}
-    e.debug_groups_per_chunk(2)
-    try:
-        for v in (0, bits, bits):
-            e.debug_option("light_barriers", v)
-            res.setdefault(v, []).append(run_mlp(e, d, G, torch.bfloat16, impl="mfma"))
-    finally:
-        e.debug_option("light_barriers", LIGHT_BARRIERS_DEFAULT)
-        e.debug_groups_per_chunk(0)
-    assert e.sweep_error() == 0
-    out, cks, g = res[bits][0]
-    check_per_head(f"TTT-MLP MFMA, light_barriers={bits}", out, cks, g, ro, rc, rg, 1e-2, 3e-2)
-    for other in (res[bits][1], res[0][0]):
-        assert torch.equal(out, other[0])
-        assert all(torch.equal(a, b) for a, b in zip(cks, other[1]))
-        for k in g:
-            assert torch.equal(g[k], other[2][k]), k

@@ -50,7 +50,6 @@ struct RecomputeParams {
     int chunk_group0, chunk_groups, chunk_lo;
     int nt;                                // 1: non-temporal stores of the step records
     int own16;                             // 1: the owner rows x_hat and y - target of the INNER LayerNorm as bf16 (first half of their fp32 arrays' space)
-    int light;                             // 1: LDS-only barriers inside the step (the record stores stay in flight across them)
     int item0;                             // (set by the launcher) first work item of this launch; item = item0 + blockIdx.x
     float eps;
 };
@@ -66,7 +65,6 @@ struct SweepParams4 : b2::SweepParams2 {
     int G, K;
     int prefetch;                          // 1: owners / derivers touch the records of step i - 2 (L2 prefetch); 0: off (A/B)
     int own16;                             // as RecomputeParams::own16 (both kernels of a backward call agree)
-    int light;                             // 1: the compute waves' barriers Ba / Bc / Bd wait for LDS only (their tail-array stores stay in flight)
 };
 constexpr size_t PARK4_BYTES = 12 * FRAG_BYTES;
 void launch_sweep_cluster4(const SweepParams4& bp, int nbh, hipStream_t s);

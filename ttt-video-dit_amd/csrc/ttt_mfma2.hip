@@ -147,13 +147,6 @@ __device__ __forceinline__ void write_partial2(float* redw, const f32x16& P, int
     }
 }
 
-// Barrier of the scan step.  __syncthreads() carries a workgroup-scope fence, i.e. s_waitcnt vmcnt(0): every barrier of the step
-// then waits for the global memory operations in flight - the L2 prefetch touches at B0 (HBM misses by design), the next step's
-// K / V / Q loads at B4, the output and checkpoint stores at the next B0.  Nothing in the step communicates through global
-// memory, so the light form waits for this wave's LDS operations only.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-#define SCAN_BARRIER() do { if (p.light) lds_barrier(); else __syncthreads(); } while (0)
-
 #define TTT_STAMP2(k)                                                        \
     if (DBG && p.dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {    \
         const unsigned long long _t = __builtin_readcyclecounter();          \
@@ -312,7 +305,7 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
             for (int s = 0; s < 2; ++s) st_image(X2img + (nO + c) * TS, 32 * ti, s, hs, pack(Z, s));
         }
         TTT_STAMP2(0)
-        SCAN_BARRIER();               // B0: X2 image complete; every P6 read of step i-1 (red, Qt, b2L) is done
+        __syncthreads();              // B0: X2 image complete; every P6 read of step i-1 (red, Qt, b2L) is done
         TTT_STAMP2(8)
         if (DBG && p.dump && blockIdx.x == 0 && i == 0)
             for (int e = tid; e < 256 * 64; e += NT2) p.dump[e] = (float)X2img[(e >> 6) * TS + ((e & 63) ^ (SW ? 4 * sw_x(e >> 6) : 0))];
@@ -337,7 +330,7 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
         }
         *reinterpret_cast<uint4*>(Qt + prow * TS + pcol) = sw16<SW>(pfQ, xo);   // Q of this step (read only after B2)
         TTT_STAMP2(1)
-        SCAN_BARRIER();               // B1: partials visible
+        __syncthreads();              // B1: partials visible
         TTT_STAMP2(9)
 
         // ================= P3: owners - reduce, fused LN / L2 backward -> Gs = -eta gZ2 ===========
@@ -380,7 +373,7 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
             *reinterpret_cast<uint4*>(Gs + ot * TS + of0) = sw16<SW>(__builtin_bit_cast(uint4, o), xo);
         }
         TTT_STAMP2(2)
-        SCAN_BARRIER();               // B2: Gs visible
+        __syncthreads();              // B2: Gs visible
         TTT_STAMP2(10)
         if (DBG && p.dump && blockIdx.x == 0 && i == 0)
             for (int e = tid; e < 64 * 64; e += NT2) p.dump[20480 + e] = (float)Gs[(e >> 6) * TS + ((e & 63) ^ (SW ? 4 * sw_x(e >> 6) : 0))];
@@ -482,7 +475,7 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
             }
         }
         TTT_STAMP2(4)
-        SCAN_BARRIER();               // B3: every read of the X2 image, of Kt and of Vt / etaL is done
+        __syncthreads();              // B3: every read of the X2 image, of Kt and of Vt / etaL is done
         TTT_STAMP2(11)
         asm volatile("" :: "v"(touch));
         if (more) {
@@ -498,7 +491,7 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
             for (int s = 0; s < 2; ++s)
                 *reinterpret_cast<bf16x8*>(exch + ((size_t)(wv * 4 + ti * 2 + s) * 64 + l) * 16) = X2bF[ti][s];
         if (w == 0 && h == 0) b2L[fO + c] = b2v;
-        SCAN_BARRIER();               // B4: exchange visible
+        __syncthreads();              // B4: exchange visible
         TTT_STAMP2(12)
 
         // ================= E: partial Z2b^T[Fp, t] ================================================
@@ -526,7 +519,7 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
             if (tid < 64) etaL[tid] = pfE;
         }
         TTT_STAMP2(5)
-        SCAN_BARRIER();               // B5
+        __syncthreads();              // B5
         TTT_STAMP2(13)
 
         // ================= P6: owners - reduce, LayerNorm, residual -> XQW ========================
@@ -570,14 +563,10 @@ static void set_attr_once() {
 
 static float* g_dump = nullptr;
 void set_debug_dump(float* buf) { g_dump = buf; }
-static int g_light = 0;               // bit 0 forward scan, bit 1 recompute, bit 2 sweep compute waves (A/B option "light_barriers")
-void set_debug_light_barriers(int v) { g_light = v; }
-int debug_light_barriers() { return g_light; }
 static int g_scan_swap = 0;           // forward scan: half-chunk swap of the LDS tiles (sw_x above); A/B option "scan_swap"
 void set_debug_scan_swap(int v) { g_scan_swap = v; }
 void launch_scan_forward_v2(const ScanParams& p0, int n_bh, unsigned long long* dbg, hipStream_t s) {
     ScanParams p = p0;
-    p.light = debug_light_barriers() & 1;
     p.dbg = dbg;
     p.dump = g_dump;
     v2::set_attr_once();

@@ -149,7 +149,7 @@ static int mlp_backward4(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws,
     rp.ln_w = a->ttt_norm_weight; rp.ln_b = a->ttt_norm_bias;
     rp.W1c = a->W1_checkpoints; rp.b1c = a->b1_checkpoints; rp.W2c = a->W2_checkpoints; rp.b2c = a->b2_checkpoints;
     rp.slot_stride_bh = slot_stride; rp.wfinal = wfinal;
-    rp.NH = d->NH; rp.NC = NC; rp.G = G; rp.K = K; rp.eps = d->eps; rp.nt = g_rc_nt; rp.own16 = g_own16 && sweep_supports_own16(); rp.light = (debug_light_barriers() >> 1) & 1;
+    rp.NH = d->NH; rp.NC = NC; rp.G = G; rp.K = K; rp.eps = d->eps; rp.nt = g_rc_nt; rp.own16 = g_own16 && sweep_supports_own16();
 
     s4::SweepParams4 bp = {};
     bp.XQ = (const __bf16*)a->XQ; bp.XK = (const __bf16*)a->XK; bp.dOut = (const __bf16*)a->grad_L_XQW; bp.eta = (const __bf16*)a->last_eta;
@@ -162,7 +162,7 @@ static int mlp_backward4(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws,
     bp.NH = d->NH; bp.NC = NC;
     bp.xch = xch; bp.flags = flags; bp.fast_records = g_fast_records;
     bp.err = err_word; bp.fault = g_sweep_fault;
-    bp.W1c = a->W1_checkpoints; bp.W2c = a->W2_checkpoints; bp.wfinal = wfinal; bp.park = park; bp.G = G; bp.K = K; bp.prefetch = g_sweep_prefetch; bp.own16 = g_own16 && sweep_supports_own16(); bp.light = (debug_light_barriers() >> 2) & 1;
+    bp.W1c = a->W1_checkpoints; bp.W2c = a->W2_checkpoints; bp.wfinal = wfinal; bp.park = park; bp.G = G; bp.K = K; bp.prefetch = g_sweep_prefetch; bp.own16 = g_own16 && sweep_supports_own16();
 
     int rc = 0;                               // a failed event / stream call leaves the two streams unordered: the call fails (-12)
     auto chk = [&](hipError_t e) { if (e != hipSuccess) rc = -12; };

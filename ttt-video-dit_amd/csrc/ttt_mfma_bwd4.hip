@@ -128,9 +128,6 @@ __device__ __forceinline__ bf16x8 lfr(const char* smem, int off, int idx, int l)
 }
 // owner / deriver barrier that leaves global loads in flight (a plain __syncthreads() would drain them: its fence waits vmcnt(0))
 __device__ __forceinline__ void owner_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-// compute waves, barriers Ba / Bc / Bd: their global stores (tail arrays, carried-state arrays: read by the NEXT kernel) have no
-// reader inside this kernel, so nothing has to drain there; the record stores are drained explicitly in front of Bb
-__device__ __forceinline__ void compute_barrier(int light) { if (light) owner_barrier(); else __syncthreads(); }
 
 #define TTT_STAMP4(k)                                                        \
     if (DBG && p.dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {    \
@@ -404,7 +401,7 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
                 }
             }
             TTT_STAMP4(0)
-            compute_barrier(p.light);                   // Ba: u^T fragments visible
+            __syncthreads();                   // Ba: u^T fragments visible
             TTT_STAMP4(1)
 
             // ================= S2 : second half of d(gZ2)^T partial -> LDS (own owners) + published record (partners) ======
@@ -455,7 +452,7 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
                 for (int s = 0; s < 2; ++s) { D1p[a][s] = pack(dW1t[a], s); D2p[a][s] = pack(dW2Tt[a], s); }
             if (more) add_output_path(i - 1);
             TTT_STAMP4(4)
-            compute_barrier(p.light);                   // Bc: dZ2_i (Bt) written by the owners
+            __syncthreads();                   // Bc: dZ2_i (Bt) written by the owners
             TTT_STAMP4(5)
 
             // ================= S4a : first-layer gradients and this step's state updates ====================================
@@ -522,7 +519,7 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
             }
             if (more) publish_state(i - 1);
             TTT_STAMP4(6)
-            compute_barrier(p.light);                   // Bd: every read of K_i, gZ2_i, dZ2_i, dZ2b_j, Q_j is done; state published
+            __syncthreads();                   // Bd: every read of K_i, gZ2_i, dZ2_i, dZ2b_j, Q_j is done; state published
             TTT_STAMP4(7)
         }
 

@@ -18,7 +18,6 @@ struct ScanParams {
     float eps;
     unsigned long long* dbg;               // optional per-phase cycle totals of workgroup 0
     float* dump;                           // DEBUG: intermediates of workgroup 0, step 0 (revision-2 forward)
-    int light;                             // 1: the step's barriers wait for LDS only (s_waitcnt lgkmcnt(0) ; s_barrier) - global loads / stores stay in flight
 };
 
 bool bwd_available();
@@ -40,8 +39,6 @@ unsigned* sweep_error_word();          // device pointer of the host-mapped word
 void set_debug_sweep_fault(int v);     // DEBUG fault injection: workgroup 3 of every sweep cluster leaves before its first hand-over
 void set_debug_rc_nt(int v);           // revision-4 recompute: non-temporal stores of the step records (A/B)
 void set_debug_sweep_prefetch(int v);  // revision-4 sweep: 1 (default) L2 prefetch touches two steps ahead, 0 off
-void set_debug_light_barriers(int v);  // bit 0 forward scan, bit 1 recompute, bit 2 the sweep's compute waves: barriers that leave global memory operations in flight (A/B)
-int debug_light_barriers();
 void set_debug_scan_swap(int v);       // forward scan: 1 = the two 8-byte units of a 16-byte tile chunk swapped in rows with bit 3 ^ bit 4 set (bank conflicts of the row walkers), 0 off
 void set_debug_sweep_records_bf16(int v);   // revision-4 sweep: hand-over records carry the partial d(gZ2) tiles as bf16 (0 default until timed)
 void set_debug_sweep_deriver_wave0(int v);  // revision-4 sweep: deriver role on waves 4, 5 (default) or 2, 3 (A/B of the SIMD placement)

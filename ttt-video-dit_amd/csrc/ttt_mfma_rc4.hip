@@ -63,11 +63,6 @@ __device__ __forceinline__ void st_rows(char* own, int arr, int ot, int of0, con
     }
 }
 
-// Barrier of the recompute step (see SCAN_BARRIER in ttt_mfma2.hip): the light form leaves the step-record stores (104 - 120 KiB per
-// step and workgroup) and the next step's tile loads in flight instead of draining them at each of the six barriers.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-#define RC_BARRIER() do { if (p.light) lds_barrier(); else __syncthreads(); } while (0)
-
 template <bool NTS>
 __global__ __launch_bounds__(NT8) void mlp_recompute8_kernel(RecomputeParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -189,7 +184,7 @@ __global__ __launch_bounds__(NT8) void mlp_recompute8_kernel(RecomputeParams p) 
 #pragma unroll
             for (int s = 0; s < 2; ++s) st_image(X2img + (nO + c) * TS, 32 * ti, s, h, pack(Z, s));
         }
-        RC_BARRIER();                 // B0: X2 image complete; every P6 read of step i-1 (red, b2L) is done
+        __syncthreads();              // B0: X2 image complete; every P6 read of step i-1 (red, b2L) is done
 
         // ================= A2: partial Z2^T[Fp, t] over the hidden slice ==========================
         {
@@ -210,7 +205,7 @@ __global__ __launch_bounds__(NT8) void mlp_recompute8_kernel(RecomputeParams p) 
             }
         }
         *reinterpret_cast<uint4*>(Qt + prow * TS + pcol) = pfQ;   // Q of this step (read only after B2)
-        RC_BARRIER();                 // B1: partials visible
+        __syncthreads();              // B1: partials visible
 
         // ================= P3: owners - reduce, fused LN / L2 backward -> gZ2 (stored), Gs = -eta gZ2 =======
         {
@@ -262,7 +257,7 @@ __global__ __launch_bounds__(NT8) void mlp_recompute8_kernel(RecomputeParams p) 
             }
             if ((tid & 7) == 0) own_stats(own, ot)[0] = rstd;
         }
-        RC_BARRIER();                 // B2: Gs visible
+        __syncthreads();              // B2: Gs visible
 
         // ================= C: state updates, f3, f4 ===============================================
         {
@@ -340,7 +335,7 @@ __global__ __launch_bounds__(NT8) void mlp_recompute8_kernel(RecomputeParams p) 
                 X2bF[ti][1] = pack(zb, 1);
             }
         }
-        RC_BARRIER();                 // B3: every read of the X2 image, of Kt and of Vt / etaL is done
+        __syncthreads();              // B3: every read of the X2 image, of Kt and of Vt / etaL is done
         if (more) {
             const size_t off = (tile + 1) * 4096 + (size_t)prow * 64 + pcol;
             pfK = *reinterpret_cast<const uint4*>(p.XK + off);
@@ -353,7 +348,7 @@ __global__ __launch_bounds__(NT8) void mlp_recompute8_kernel(RecomputeParams p) 
 #pragma unroll
             for (int s = 0; s < 2; ++s) st_image(X2img + (nO + c) * TS, 32 * ti, s, h, X2bF[ti][s]);      // X2b image [n][t]
         if (w == 0 && h == 0) b2L[fO + c] = b2v;
-        RC_BARRIER();                 // B4: X2b image, b2' visible
+        __syncthreads();              // B4: X2b image, b2' visible
 
         // ================= E: partial Z2b^T[Fp, t] ================================================
         {
@@ -392,7 +387,7 @@ __global__ __launch_bounds__(NT8) void mlp_recompute8_kernel(RecomputeParams p) 
             *reinterpret_cast<uint4*>(Vt + prow * TS + pcol) = pfV;
             if (tid < 64) etaL[tid] = pfE;
         }
-        RC_BARRIER();                 // B5
+        __syncthreads();              // B5
 
         // ================= P6: owners - reduce, output LayerNorm statistics -> x_hat rows (stored) ==
         {
