@@ -133,4 +133,4 @@ def test_forward_scan_half_chunk_swap_variant():
     assert worst < 2e-3, worst
 
 
-SCAN_SWAP_DEFAULT = 0          # the library's (csrc/ttt_mfma2.hip g_scan_swap)
+SCAN_SWAP_DEFAULT = 1          # the library's (csrc/ttt_mfma2.hip g_scan_swap)

@@ -219,15 +219,20 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
     const size_t tile0 = (size_t)bh * NC;
     const int prow = tid >> 3, pcol = (tid & 7) * 8;          // one 16-byte chunk per thread per tile
     uint4 pfK, pfQ, pfV;
-    float pfE = 0.f;
+    unsigned short pfE = 0;      // eta row of the next step as raw bf16 bits, every wave its own copy: converted when it is parked -
+                                 // a conversion at the load sits behind the K / V / Q loads issued with it and waits vmcnt(0) for all of them
     {
         const size_t off = tile0 * 4096 + (size_t)prow * 64 + pcol;
         pfK = *reinterpret_cast<const uint4*>(p.XK + off);
         pfV = *reinterpret_cast<const uint4*>(p.XV + off);
-        if (tid < 64) pfE = (float)p.eta[tile0 * 64 + tid];
+        pfE = reinterpret_cast<const unsigned short*>(p.eta)[tile0 * 64 + (tid & 63)];
         *reinterpret_cast<uint4*>(Kt + prow * TS + pcol) = sw16<SW>(pfK, sw_x(prow));
         *reinterpret_cast<uint4*>(Vt + prow * TS + pcol) = sw16<SW>(pfV, sw_x(prow));
-        if (tid < 64) etaL[tid] = pfE;
+        unsigned pfEu = pfE;
+        asm volatile("" : "+v"(pfEu));     // every wave consumes its load HERE (left to the compiler the conversion sinks into the branch below,
+                                          // the register stays pending in the other waves, and its pairing with b1v in A1 waits vmcnt(0) there)
+        const float pfEf = __builtin_bit_cast(float, pfEu << 16);
+        if (tid < 64) etaL[tid] = pfEf;
     }
     // packed operands of the entering state (re-made after every update, carried across steps)
     bf16x8 W1F[2][2];
@@ -483,7 +488,7 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
             pfK = *reinterpret_cast<const uint4*>(p.XK + off);
             pfV = *reinterpret_cast<const uint4*>(p.XV + off);
             pfQ = *reinterpret_cast<const uint4*>(p.XQ + off);
-            if (tid < 64) pfE = (float)p.eta[(tile + 1) * 64 + tid];
+            pfE = reinterpret_cast<const unsigned short*>(p.eta)[(tile + 1) * 64 + (tid & 63)];
         }
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti)
@@ -516,7 +521,11 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
         if (more) {                   // next step's K, V, eta (their last readers finished before B3)
             *reinterpret_cast<uint4*>(Kt + prow * TS + pcol) = sw16<SW>(pfK, xo);
             *reinterpret_cast<uint4*>(Vt + prow * TS + pcol) = sw16<SW>(pfV, xo);
-            if (tid < 64) etaL[tid] = pfE;
+            unsigned pfEu = pfE;
+            asm volatile("" : "+v"(pfEu));     // every wave consumes its load HERE (left to the compiler the conversion sinks into the branch below,
+                                              // the register stays pending in the other waves, and its pairing with b1v in A1 waits vmcnt(0) there)
+            const float pfEf = __builtin_bit_cast(float, pfEu << 16);
+            if (tid < 64) etaL[tid] = pfEf;
         }
         TTT_STAMP2(5)
         __syncthreads();              // B5
@@ -563,7 +572,7 @@ static void set_attr_once() {
 
 static float* g_dump = nullptr;
 void set_debug_dump(float* buf) { g_dump = buf; }
-static int g_scan_swap = 0;           // forward scan: half-chunk swap of the LDS tiles (sw_x above); A/B option "scan_swap"
+static int g_scan_swap = 1;           // forward scan: half-chunk swap of the LDS tiles (sw_x above): 6.06 against 6.22 ms at NC = 804, 2.14 against 2.19 at NC = 282, identical bits (profiles/r4m_*); 0 = off (A/B option "scan_swap")
 void set_debug_scan_swap(int v) { g_scan_swap = v; }
 void launch_scan_forward_v2(const ScanParams& p0, int n_bh, unsigned long long* dbg, hipStream_t s) {
     ScanParams p = p0;

@@ -126,7 +126,8 @@ typedef __attribute__((address_space(1))) void glb_void;
 __device__ __forceinline__ bf16x8 lfr(const char* smem, int off, int idx, int l) {
     return *reinterpret_cast<const bf16x8*>(smem + off + idx * 1024 + l * 16);
 }
-// owner / deriver barrier that leaves global loads in flight (a plain __syncthreads() would drain them: its fence waits vmcnt(0))
+// owner / deriver barrier: LDS operations only, global loads stay in flight.  (Round 4 checked the ISA: on ROCm 7.2 a plain
+// __syncthreads() compiles to the same pair - no vmcnt(0) - and swapping the two forms changes neither bits nor time, profiles/r4n_*.)
 __device__ __forceinline__ void owner_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 #define TTT_STAMP4(k)                                                        \

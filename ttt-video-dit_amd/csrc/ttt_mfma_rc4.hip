@@ -126,17 +126,22 @@ __global__ __launch_bounds__(NT8) void mlp_recompute8_kernel(RecomputeParams p) 
     // ---- first tiles ------------------------------------------------------------------------------
     const size_t tile0 = (size_t)bh * NC;
     uint4 pfK, pfQ, pfV;
-    float pfE = 0.f;
+    unsigned short pfE = 0;      // eta row of the next step as raw bf16 bits, every wave its own copy: converted when it is parked -
+                                 // a conversion at the load sits behind the K / V / Q loads issued with it and waits vmcnt(0) for all of them
     {
         const int prow = tid >> 3, pcol = (tid & 7) * 8;          // one 16-byte chunk per thread per tile
         const size_t off = (tile0 + i_lo) * 4096 + (size_t)prow * 64 + pcol;
         pfK = *reinterpret_cast<const uint4*>(p.XK + off);
         pfV = *reinterpret_cast<const uint4*>(p.XV + off);
         pfQ = *reinterpret_cast<const uint4*>(p.XQ + off);
-        if (tid < 64) pfE = (float)p.eta[(tile0 + i_lo) * 64 + tid];
+        pfE = reinterpret_cast<const unsigned short*>(p.eta)[(tile0 + i_lo) * 64 + (tid & 63)];
         *reinterpret_cast<uint4*>(Kt + prow * TS + pcol) = pfK;
         *reinterpret_cast<uint4*>(Vt + prow * TS + pcol) = pfV;
-        if (tid < 64) etaL[tid] = pfE;
+        unsigned pfEu = pfE;
+        asm volatile("" : "+v"(pfEu));     // every wave consumes its load HERE (left to the compiler the conversion sinks into the branch below,
+                                          // the register stays pending in the other waves, and its pairing with b1v in A1 waits vmcnt(0) there)
+        const float pfEf = __builtin_bit_cast(float, pfEu << 16);
+        if (tid < 64) etaL[tid] = pfEf;
     }
     bf16x8 W1F[2][2];
 #pragma unroll
@@ -341,7 +346,7 @@ __global__ __launch_bounds__(NT8) void mlp_recompute8_kernel(RecomputeParams p) 
             pfK = *reinterpret_cast<const uint4*>(p.XK + off);
             pfV = *reinterpret_cast<const uint4*>(p.XV + off);
             pfQ = *reinterpret_cast<const uint4*>(p.XQ + off);
-            if (tid < 64) pfE = (float)p.eta[(tile + 1) * 64 + tid];
+            pfE = reinterpret_cast<const unsigned short*>(p.eta)[(tile + 1) * 64 + (tid & 63)];
         }
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti)
@@ -385,7 +390,11 @@ __global__ __launch_bounds__(NT8) void mlp_recompute8_kernel(RecomputeParams p) 
         if (more) {                   // next step's K, V, eta (their last readers finished before B3)
             *reinterpret_cast<uint4*>(Kt + prow * TS + pcol) = pfK;
             *reinterpret_cast<uint4*>(Vt + prow * TS + pcol) = pfV;
-            if (tid < 64) etaL[tid] = pfE;
+            unsigned pfEu = pfE;
+            asm volatile("" : "+v"(pfEu));     // every wave consumes its load HERE (left to the compiler the conversion sinks into the branch below,
+                                              // the register stays pending in the other waves, and its pairing with b1v in A1 waits vmcnt(0) there)
+            const float pfEf = __builtin_bit_cast(float, pfEu << 16);
+            if (tid < 64) etaL[tid] = pfEf;
         }
         __syncthreads();              // B5
 
