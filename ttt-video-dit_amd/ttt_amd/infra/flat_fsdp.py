@@ -14,7 +14,11 @@ per-parameter bookkeeping:
     shards, casts and re-gathers them every step: 8 GB of bf16 weights are no constraint on 288 GB);
   * collectives run on a side stream: the all-gathers of all units are queued after the optimizer step and a unit's forward waits
     for its own; a unit's reduce-scatter is queued when the last of its gradients has been accumulated and runs beside the
-    backward of the units in front of it (the TTT backward never blocks its stream).
+    backward of the units in front of it (the TTT backward never blocks its stream, DESIGN.md section 5);
+  * nothing is allocated inside the backward: the reduce-scatter inputs are two persistent full-size fp32 buffers used in turn,
+    the fp32 gradient shards are kept across steps.  (Measured: a 0.3-GB allocation per unit in the middle of the backward moves
+    the TTT backward's buffers, and its cluster sweep then runs 16 % slower - ``profiles/r4q_*``, ``r4r_*``.)  Without
+    collectives (one rank, no group) there is nothing to overlap and every unit is cast in ``finish_backward``.
 
 Why (round-4 measurement, ``profiles/r4i_*``): over a one-rank mesh FSDP2 costs 7 % of the 9 s step against the same arithmetic
 without it - 195 ms of per-parameter ``copy_`` kernels (8 914 launches) and a cluster sweep that runs 0.95 instead of 0.82 ms beside
@@ -31,6 +35,8 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -39,7 +45,7 @@ _ALIGN = 64          # elements: every parameter starts on a 128-byte boundary o
 
 class _Unit:
     __slots__ = ("module", "params", "names", "offsets", "numel", "padded", "shard", "gathered", "shard_view", "master", "pending",
-                 "ready", "held")
+                 "ready", "grad_shard")
 
 
 class FlatFSDP:
@@ -55,7 +61,17 @@ class FlatFSDP:
         self._communicate = self.world > 1 or (always_communicate and on)
         self.units: List[_Unit] = []
         self._cuda = next(dit.parameters()).is_cuda
-        self._comm = torch.cuda.Stream() if self._cuda else None
+        self._comm = torch.cuda.Stream() if (self._cuda and self._communicate) else None      # no collectives: no side stream
+        # Without collectives there is nothing to overlap: every unit is reduced (= cast to fp32) in finish_backward, as the replica
+        # path does.  With them, a unit is reduced by the hook of its last gradient through PERSISTENT buffers (two rotating
+        # full-size fp32 buffers, one fp32 shard per unit): no allocation happens inside the backward.  Measured on one rank
+        # (profiles/r4q_*, r4r_*): a 0.3-GB allocation per unit in the middle of the backward moves the TTT backward's own
+        # buffers and its cluster sweep then runs 0.95 instead of 0.82 ms per launch (+120 ms per step; every other kernel
+        # unchanged, nothing concurrent) - the 2 % that separated this class from the replica path, and FSDP2's 7 % too.
+        self._defer = not self._communicate or os.environ.get("FLAT_FSDP_DEFER_REDUCE", "0") == "1"
+        self._full: List[torch.Tensor] = []                   # rotating reduce-scatter inputs (communicate mode)
+        self._full_free: List[Optional[torch.cuda.Event]] = []
+        self._turn = 0
         self._hooks = []
         names = {id(p): n for n, p in dit.named_parameters()}
         seen = set()
@@ -96,7 +112,7 @@ class FlatFSDP:
         u.shard_view = u.gathered[lo:lo + u.shard]
         for p, o in zip(train, u.offsets):
             p.data = u.gathered[o:o + p.numel()].view(p.shape)
-        u.pending, u.ready, u.held = len(train), None, []
+        u.pending, u.ready, u.grad_shard = len(train), None, None
         for p in train:
             self._hooks.append(p.register_post_accumulate_grad_hook(lambda _p, _u=u: self._on_grad(_u)))
         if self._cuda:
@@ -120,15 +136,15 @@ class FlatFSDP:
         """After the optimizer step: masters -> bf16 compute parameters on every rank (one cast for all units, one in-place
         all-gather per unit on the side stream; a unit's forward waits for its own)."""
         with torch.no_grad():
-            ctx = torch.cuda.stream(self._comm) if self._cuda else _null()
-            if self._cuda:
+            side = self._comm is not None
+            if side:
                 self._comm.wait_stream(torch.cuda.current_stream())       # the step's reads of the old parameters are queued in front
-            with ctx:
+            with (torch.cuda.stream(self._comm) if side else _null()):
                 torch._foreach_copy_([u.shard_view for u in self.units], [u.master.data for u in self.units])
                 for u in self.units:
                     if self._communicate:
                         dist.all_gather_into_tensor(u.gathered, u.shard_view, group=self.group)
-                    if self._cuda:
+                    if side:
                         u.ready = torch.cuda.Event()
                         u.ready.record(self._comm)
         self._published = True
@@ -136,8 +152,21 @@ class FlatFSDP:
     # --------------------------------------------------------------------------------------------------------------- backward
     def _on_grad(self, u: _Unit):
         u.pending -= 1
-        if u.pending == 0:
+        if u.pending == 0 and not self._defer:
             self._reduce(u)
+
+    def _flat_buffer(self, n: int) -> torch.Tensor:
+        """One of two persistent full-size fp32 buffers, in turn; the compute stream waits until the side stream has finished the
+        reduce-scatter that last read it."""
+        if not self._full:
+            big = max(u.padded for u in self.units)
+            dev = self.units[0].master.device
+            self._full = [torch.empty(big, dtype=self.reduce_dtype, device=dev) for _ in range(2)]
+            self._full_free = [None, None]
+        k = self._turn = (self._turn + 1) & 1
+        if self._full_free[k] is not None:
+            torch.cuda.current_stream().wait_event(self._full_free[k])
+        return self._full[k][:n]
 
     def _reduce(self, u: _Unit):
         grads = [p.grad for p in u.params]
@@ -145,29 +174,44 @@ class FlatFSDP:
             u.pending = len(u.params)
             return
         with torch.no_grad():
-            if self._cuda:
-                self._comm.wait_stream(torch.cuda.current_stream())       # the gradients are complete when the side stream starts
-            with (torch.cuda.stream(self._comm) if self._cuda else _null()):
-                flat = torch.empty(u.padded, dtype=self.reduce_dtype, device=u.master.device)
-                if u.padded > u.numel or any(g is None for g in grads) or any(p.numel() % _ALIGN for p in u.params):
-                    flat.zero_()                                          # padding between / behind the parameters, unused parameters
-                dst = [flat[o:o + p.numel()].view(p.shape) for p, o, g in zip(u.params, u.offsets, grads) if g is not None]
-                torch._foreach_copy_(dst, [g for g in grads if g is not None])            # bf16 -> fp32, one multi-tensor launch
-                if self._communicate:
-                    shard = torch.empty(u.shard, dtype=self.reduce_dtype, device=flat.device)
+            # the bf16 -> fp32 cast of the unit's gradients runs on the compute stream (0.1 - 0.2 ms per unit): on the side stream it
+            # would stream 0.5 GB beside the next layer's TTT backward; only the collective runs beside the backward
+            persistent = self._communicate and self._cuda
+            flat = self._flat_buffer(u.padded) if persistent else torch.empty(u.padded, dtype=self.reduce_dtype, device=u.master.device)
+            if u.padded > u.numel or any(g is None for g in grads) or any(p.numel() % _ALIGN for p in u.params):
+                flat.zero_()                                              # padding between / behind the parameters, unused parameters
+            dst = [flat[o:o + p.numel()].view(p.shape) for p, o, g in zip(u.params, u.offsets, grads) if g is not None]
+            torch._foreach_copy_(dst, [g for g in grads if g is not None])                # bf16 -> fp32, one multi-tensor launch
+            if self._communicate:
+                side = self._comm is not None
+                if side:
+                    self._comm.wait_stream(torch.cuda.current_stream())   # the flat gradient is complete when the side stream starts
+                with (torch.cuda.stream(self._comm) if side else _null()):
+                    first = u.master.grad is None
+                    if u.grad_shard is None:
+                        u.grad_shard = torch.empty(u.shard, dtype=self.reduce_dtype, device=flat.device)      # once: kept across steps
+                    shard = u.grad_shard if first else torch.empty_like(u.grad_shard)                          # (micro-batches: a temporary)
                     dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM, group=self.group)
                     if self.divide != 1.0:
                         shard.div_(self.divide)
-                else:
-                    shard = flat if self.divide == 1.0 else flat.div_(self.divide)
-                if u.master.grad is None:
-                    u.master.grad = shard
-                else:
-                    u.master.grad.add_(shard)                             # gradient accumulation over micro-batches
-        u.held.append(grads)                                              # (alive until the side stream has read them: finish_backward)
+                    if persistent:
+                        ev = torch.cuda.Event()
+                        ev.record(self._comm)
+                        self._full_free[self._turn] = ev
+                    self._accumulate(u, shard)
+            else:
+                shard = flat if self.divide == 1.0 else flat.div_(self.divide)
+                self._accumulate(u, shard)
         for p in u.params:
             p.grad = None
         u.pending = len(u.params)
+
+    @staticmethod
+    def _accumulate(u: _Unit, shard: torch.Tensor):
+        if u.master.grad is None:
+            u.master.grad = shard
+        else:
+            u.master.grad.add_(shard)                                     # gradient accumulation over micro-batches
 
     def finish_backward(self):
         """Once per backward, before clipping / the optimizer: reduces units whose parameters did not all receive a gradient
@@ -175,15 +219,12 @@ class FlatFSDP:
         for u in self.units:
             if u.pending != len(u.params) or any(p.grad is not None for p in u.params):
                 self._reduce(u)
-        if self._cuda:
+        if self._comm is not None:
             torch.cuda.current_stream().wait_stream(self._comm)
-        for u in self.units:
-            u.held.clear()
 
     def zero_grad(self):
         for u in self.units:
-            u.master.grad = None
-            u.held.clear()
+            u.master.grad = None                              # (u.grad_shard, the storage, is kept for the next step)
             u.pending = len(u.params)
             for p in u.params:
                 p.grad = None
@@ -228,9 +269,9 @@ class FlatFSDP:
         self._hooks.clear()
         self._root_hook.remove()
         for u in self.units:
-            u.held.clear()
-            u.master.grad = None
+            u.master.grad = u.grad_shard = None
         self.units.clear()
+        self._full, self._full_free = [], []
 
 
 class _null:
