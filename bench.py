@@ -299,6 +299,8 @@ def size_warm_and_time(step, hk, remat_free_layers, warmup, steps, world):
                 hk.synchronize()
                 per_layer = max((hk.max_allocated() - peak0) / probe, 1.0)
                 n_free = int(max(0, min(hk.num_layers, (cap * hk.total_memory - peak0) // per_layer)))
+                log(f"sizing: peak with every layer re-materialised {peak0 / 2**30:.1f} GiB, + {per_layer / 2**30:.2f} GiB per free layer "
+                    f"({probe} probed), cap {cap * hk.total_memory / 2**30:.0f} GiB -> {n_free} layers")
             except hk.oom:
                 if world > 1:
                     raise                  # the other ranks sit in a collective: not recoverable
@@ -337,6 +339,7 @@ def size_warm_and_time(step, hk, remat_free_layers, warmup, steps, world):
             refinements += 1
             per_layer = max((hk.max_allocated() - peak0) / n_free, 1.0)
             better = int(max(0, min(hk.num_layers, (cap * hk.total_memory - peak0) // per_layer)))
+            log(f"sizing: peak at {n_free} free layers {hk.max_allocated() / 2**30:.1f} GiB ({per_layer / 2**30:.2f} GiB per layer) -> {better} layers")
             if fail_at is not None:
                 better = min(better, fail_at - 1)
             if world > 1:
@@ -466,7 +469,8 @@ def main():
                 a2.remat_free_layers = str(max(0, line["config"]["remat_free_layers"] - 1))
                 f = _run(a2, world, rank, local_rank, dev, no_fsdp=False, quiet=True, sharded=multi)
                 line["fsdp1"] = {"impl": multi, "value": f["value"], "ms_per_step": f["ms_per_step"], "steps": a2.steps,
-                                 "remat_free_layers": f["config"]["remat_free_layers"], "peak_mem_gib": f["peak_mem_gib"]}
+                                 "remat_free_layers": f["config"]["remat_free_layers"], "peak_mem_gib": f["peak_mem_gib"],
+                                 "ttt_mlp_bwd_ms": round(f["roofline"]["avg_launch_ms"], 3), "attn_bwd_ms": round(f["roofline"]["other"]["attn_bwd"]["avg_ms"], 3)}
             except Exception as ex:
                 line["fsdp1"] = {"error": repr(ex)[:300]}
             gc.collect()

@@ -37,6 +37,9 @@ def main():
     ap.add_argument("--ab", default=None, metavar="OPTION", help="interleaved A/B inside one process: the named debug option alternates 0 / 1 from iteration to iteration; the backward's average is reported per value (same box, same clocks)")
     ap.add_argument("--ab-restore", type=int, default=1, help="value the --ab option is left at for the --phases pass")
     ap.add_argument("--ab-fixed", default=None, metavar="OPTION=VALUE", help="set one more debug option for the whole run")
+    ap.add_argument("--ws-skew", type=int, default=0, help="DEBUG: the kernel workspace starts this many bytes (multiple of 256) into its allocation")
+    ap.add_argument("--io-skew", type=int, default=0, help="DEBUG: input tensor k (XQ, XK, XV, eta, dOut) starts k * this many bytes (multiple of 256) into its allocation")
+    ap.add_argument("--disturb", type=int, default=0, metavar="MB", help="DEBUG: between forward and backward, cast MB megabytes of bf16 to fp32 in 16 tensors (what a sharded path's per-unit gradient cast does in the middle of a backward)")
     ap.add_argument("--phases", action="store_true", help="also print per-phase cycle totals of workgroup 0")
     a = ap.parse_args()
     import test_time_training as ext
@@ -52,22 +55,36 @@ def main():
     ext.debug_option("overlap_tail", a.overlap)
     ext.debug_option("groups_per_chunk", a.gpc)
     dev = torch.device("cuda:0")
+    if a.ws_skew:
+        _orig_ws = ext._workspace
+        ext._workspace = lambda device, stream, nbytes: _orig_ws(device, stream, nbytes + a.ws_skew)[a.ws_skew:]
+    _k = [0]
+
+    def skewed(t):                      # the same values at an address k * io_skew bytes into a fresh allocation
+        k = _k[0]; _k[0] += 1
+        if not a.io_skew:
+            return t
+        off = k * a.io_skew // t.element_size()
+        buf = torch.empty(t.numel() + off, dtype=t.dtype, device=t.device)
+        v = buf[off:].view(t.shape)
+        v.copy_(t)
+        return v
     B, NH, NC, CS, F, G = a.b, a.nh, a.nc, a.cs, 64, a.g
     H = 4 * F if a.kind == "mlp" else F
     gen = torch.Generator(device=dev).manual_seed(0)
     rn = lambda *s: torch.randn(*s, device=dev, generator=gen)
-    XQ = torch.nn.functional.normalize(rn(B, NH, NC, CS, F), dim=-1).bfloat16().requires_grad_(True)
-    XK = torch.nn.functional.normalize(rn(B, NH, NC, CS, F), dim=-1).bfloat16().requires_grad_(True)
-    XV = rn(B, NH, NC, CS, F).bfloat16().requires_grad_(True)
+    XQ = skewed(torch.nn.functional.normalize(rn(B, NH, NC, CS, F), dim=-1).bfloat16()).requires_grad_(True)
+    XK = skewed(torch.nn.functional.normalize(rn(B, NH, NC, CS, F), dim=-1).bfloat16()).requires_grad_(True)
+    XV = skewed(rn(B, NH, NC, CS, F).bfloat16()).requires_grad_(True)
     base_lr = 0.1 if a.kind == "mlp" else 1.0
-    eta = (base_lr * torch.sigmoid(rn(B, NH, NC, 1, CS)) / (F * CS)).bfloat16().requires_grad_(True)
+    eta = skewed((base_lr * torch.sigmoid(rn(B, NH, NC, 1, CS)) / (F * CS)).bfloat16()).requires_grad_(True)
     ln_w = torch.ones(NH, F, device=dev, requires_grad=True)
     ln_b = torch.zeros(NH, F, device=dev, requires_grad=True)
     W1 = (0.02 * rn(NH, F, H)).requires_grad_(True)
     b1 = torch.zeros(NH, 1, H, device=dev, requires_grad=True)
     W2 = (0.02 * rn(NH, H, F)).requires_grad_(True)
     b2 = torch.zeros(NH, 1, F, device=dev, requires_grad=True)
-    dOut = rn(B, NH, NC, CS, F).bfloat16()
+    dOut = skewed(rn(B, NH, NC, CS, F).bfloat16())
     ex = lambda p: p.unsqueeze(0).expand(B, *p.shape)
 
     def fwd():
@@ -96,6 +113,11 @@ def main():
             ext.debug_option(a.ab, it & 1)
         n0, f0 = len(times["bwd"]), len(times["fwd"])
         out = fwd()
+        if a.disturb:
+            if it == 0:
+                _src = [torch.randn(a.disturb * (1 << 20) // 32, device=dev).bfloat16() for _ in range(16)]
+                _dst = [torch.empty_like(t, dtype=torch.float32) for t in _src]
+            torch._foreach_copy_(_dst, _src)
         if not a.fwd_only:
             out.backward(dOut)
         if a.ab and it >= 2:
@@ -107,6 +129,8 @@ def main():
     g = 2.0 * CS * F * H
     nfl = {"fwd": (7 if a.kind == "mlp" else 3) * g, "bwd": (14 if a.kind == "mlp" else 6) * g}
     res = {"kind": a.kind, "impl_requested": a.impl, "shape": [B, NH, NC, CS, F], "G": G}
+    res["ptr_mod_2MiB"] = {n: t.data_ptr() % (2 << 20) for n, t in (("XQ", XQ), ("XK", XK), ("XV", XV), ("eta", eta), ("dOut", dOut))}
+    res["ptr_mod_2MiB"].update({f"ws{i}": b.data_ptr() % (2 << 20) for i, b in enumerate(ext._ws_cache.values())})
     for k, ev in times.items():
         if not ev:
             continue

@@ -45,7 +45,7 @@ _ALIGN = 64          # elements: every parameter starts on a 128-byte boundary o
 
 class _Unit:
     __slots__ = ("module", "params", "names", "offsets", "numel", "padded", "shard", "gathered", "shard_view", "master", "pending",
-                 "ready", "grad_shard")
+                 "ready", "grad_shard", "held")
 
 
 class FlatFSDP:
@@ -112,7 +112,7 @@ class FlatFSDP:
         u.shard_view = u.gathered[lo:lo + u.shard]
         for p, o in zip(train, u.offsets):
             p.data = u.gathered[o:o + p.numel()].view(p.shape)
-        u.pending, u.ready, u.grad_shard = len(train), None, None
+        u.pending, u.ready, u.grad_shard, u.held = len(train), None, None, []
         for p in train:
             self._hooks.append(p.register_post_accumulate_grad_hook(lambda _p, _u=u: self._on_grad(_u)))
         if self._cuda:
@@ -202,6 +202,8 @@ class FlatFSDP:
             else:
                 shard = flat if self.divide == 1.0 else flat.div_(self.divide)
                 self._accumulate(u, shard)
+        if not self._defer:
+            u.held.append(grads)      # freed in finish_backward, not here: the backward's allocation pattern stays that of the replica path
         for p in u.params:
             p.grad = None
         u.pending = len(u.params)
@@ -221,10 +223,13 @@ class FlatFSDP:
                 self._reduce(u)
         if self._comm is not None:
             torch.cuda.current_stream().wait_stream(self._comm)
+        for u in self.units:
+            u.held.clear()
 
     def zero_grad(self):
         for u in self.units:
             u.master.grad = None                              # (u.grad_shard, the storage, is kept for the next step)
+            u.held.clear()
             u.pending = len(u.params)
             for p in u.params:
                 p.grad = None
