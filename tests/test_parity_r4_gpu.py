@@ -134,3 +134,25 @@ def test_forward_scan_half_chunk_swap_variant():
 
 
 SCAN_SWAP_DEFAULT = 1          # the library's (csrc/ttt_mfma2.hip g_scan_swap)
+
+
+def test_tail_gate_delay_same_bits():
+    """Debug option "tail_delay_us" of the backward's schedule (csrc/ttt_mfma_bwd2.hip): a one-wave gate kernel in front of each
+    tail kernel on its side stream, so that the next chunk's sweep is resident before the tail's workgroups arrive (the race the
+    rocprofv3 trace of round 4 shows, profiles/r4y_sweep_launches.txt).  Pure scheduling: the gradients must be bit-identical."""
+    from oracle import ttt_oracle as O
+    from test_kernels_gpu import round_acts, run_mlp
+    e = ext()
+    d = round_acts(O.make_inputs("mlp", 1, 8, 70, 64, 64, seed=8400), torch.bfloat16)
+    res = []
+    e.debug_groups_per_chunk(2)
+    try:
+        for v in (0, 25):
+            e.debug_option("tail_delay_us", v)
+            res.append(run_mlp(e, d, 16, torch.bfloat16, impl="mfma"))
+    finally:
+        e.debug_option("tail_delay_us", 0)
+        e.debug_groups_per_chunk(0)
+    assert e.sweep_error() == 0
+    for k in res[0][2]:
+        assert torch.equal(res[0][2][k], res[1][2][k]), k

@@ -43,6 +43,18 @@ static int g_own16 = 1;               // round 4: inner-LayerNorm owner rows of 
 void set_debug_own_bf16(int v) { g_own16 = v; }
 static int g_sweep_prefetch = 1;      // revision-4 sweep: L2 prefetch touches two steps ahead (0 = off, A/B)
 void set_debug_sweep_prefetch(int v) { g_sweep_prefetch = v; }
+// A/B option "tail_delay_us" (default 0 = off).  The tail kernel of a chunk and the next chunk's sweep become ready at the same
+// instant (both wait for the same recompute) and race for the compute units; a rocprofv3 trace of the one-GPU bench shows three
+// outcomes of that race (profiles/r4y_sweep_launches.txt: sweep / tail 919 / 419 us on the replica path; 932 / 364 or 1 124 / 459 us
+// on the sharded path, two launches in three the bad one).  With a delay > 0 a one-wave kernel in front of the tail holds its
+// stream for that many microseconds, so that the sweep's 192 workgroups are resident before the tail's 3 500 arrive.  Not measured
+// inside a training step yet (the GPU budget of round 4 ended): off.
+static int g_tail_delay_us = 0;
+void set_debug_tail_delay_us(int v) { g_tail_delay_us = v < 0 ? 0 : (v > 1000 ? 1000 : v); }
+__global__ __launch_bounds__(64) void tail_gate_kernel(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();                 // constant 100 MHz counter
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
 static int g_sweep_fault = 0;         // DEBUG fault injection (tests of the hand-over failure path)
 void set_debug_sweep_fault(int v) { g_sweep_fault = v; }
 
@@ -177,6 +189,7 @@ static int mlp_backward4(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws,
         s4::launch_recompute4(rp, nbh, max_wg, st);
     };
     auto tail = [&](int ch, hipStream_t st) {
+        if (g_tail_delay_us > 0 && st != s) hipLaunchKernelGGL(tail_gate_kernel, dim3(1), dim3(64), 0, st, 100ull * (unsigned long long)g_tail_delay_us);
         const int g0 = ch * gpc, ng = (K - g0 < gpc) ? K - g0 : gpc;
         const int lo = g0 * G, hi = ((g0 + ng) * G < NC) ? (g0 + ng) * G : NC;
         s4::launch_tail4((const __bf16*)a->grad_L_XQW, (const __bf16*)a->last_eta, (const __bf16*)a->grad_L_XV, slots + (size_t)(ch & 1) * slot_buf,
