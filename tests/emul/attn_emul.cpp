@@ -25,23 +25,6 @@ int emul_attn_forward(const attn::FwdParams* p, char* msg, int msg_len) {
     return races;
 }
 
-// forward_wide: NQ = 2 blocks of 32 query rows per wave (a workgroup covers 512 rows), nsub tiles of 64 keys per LDS stage
-int emul_attn_fwd_wide(const attn::FwdParams* p, int nsub, char* msg, int msg_len) {
-    const int nqb = (p->S + 2 * attnb::QB - 1) / (2 * attnb::QB), nbh = p->B * p->NH;
-    int races = 0;
-    for (int b = 0; b < nbh * nqb; ++b) {
-        int bh, qb;
-        attnb::head_of_block(b, nqb, nbh, bh, qb);
-        const emul::RaceReport r = emul::run_group(8, [&](emul::EmulWave& w) {
-            if (nsub == 2) attnb::forward_wide<2, 2>(w, *p, bh, qb);
-            else attnb::forward_wide<1, 2>(w, *p, bh, qb);
-        });
-        if (r.races && !races && msg) snprintf(msg, msg_len, "%s", r.first.c_str());
-        races += r.races;
-    }
-    return races;
-}
-
 // nsub = key tiles of 64 per LDS stage (1 = the shipped form, 2 = the opt-in form with half the barriers)
 int emul_attn_dq_n(const attn::BwdParams* p, int nsub, char* msg, int msg_len) {
     const int nqb = (p->S + attnb::QB - 1) / attnb::QB, nbh = p->B * p->NH;

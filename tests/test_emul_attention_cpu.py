@@ -68,7 +68,7 @@ def _strides(p, name, t):
         setattr(p, f"{name}_{s}", v)
 
 
-def _forward(lib, q, k, v, wide_nsub=0):
+def _forward(lib, q, k, v):
     B, NH, S, _ = q.shape
     out = torch.full((B, S, NH, 64), float("nan"), dtype=torch.bfloat16).transpose(1, 2)
     lse = torch.full((B, NH, S), float("nan"))
@@ -78,7 +78,7 @@ def _forward(lib, q, k, v, wide_nsub=0):
         _strides(p, n, t)
     p.B, p.NH, p.S, p.scale = B, NH, S, 1 / math.sqrt(64)
     msg = ctypes.create_string_buffer(256)
-    races = lib.emul_attn_fwd_wide(ctypes.byref(p), wide_nsub, msg, 256) if wide_nsub else lib.emul_attn_forward(ctypes.byref(p), msg, 256)
+    races = lib.emul_attn_forward(ctypes.byref(p), msg, 256)
     assert races == 0, msg.value.decode()
     return out, lse
 
@@ -102,23 +102,6 @@ def test_emulated_attention_forward_vs_oracle(emul, B, NH, S, layout):
     assert not torch.isnan(out.float()).any()
     assert rel_l2(out, ro) < 1e-2
     assert (lse.double() - rl).abs().max() < 2e-2
-
-
-@pytest.mark.parametrize("nsub", [1, 2])
-@pytest.mark.parametrize("B,NH,S,layout", [(1, 2, 40, "bshd"), (1, 2, 577, "bshd"), (1, 8, 130, "bhsd")])
-def test_emulated_forward_with_64_query_rows_per_wave_is_bit_identical(emul, B, NH, S, layout, nsub):
-    """forward_wide (attn_body.h: two blocks of 32 query rows per wave, every K / V fragment read from LDS feeds two MFMAs; 512
-    rows per workgroup; 1 or 2 key tiles per LDS stage) against forward(): the same arithmetic per row in the same order over the
-    keys - outputs and log-sum-exp identical bit for bit, no LDS race (ragged tails inside a tile, over several 512-row blocks and
-    both workgroup -> head mappings; the rescale path of the online softmax is exercised by the random scores' early tiles)."""
-    q, k, v, do = _make(B, NH, S, 11 + S, layout)
-    k = k.clone()
-    k[:, :, S - 7] = q[:, :, min(S - 1, 17)] * 6.0            # a late dominating key: the running-max rescale after many tiles
-    o1, l1 = _forward(emul, q, k, v)
-    o2, l2 = _forward(emul, q, k, v, wide_nsub=nsub)
-    assert not torch.isnan(o2.float()).any() and not torch.isnan(l2).any()
-    assert torch.equal(o1, o2)
-    assert torch.equal(l1, l2)
 
 
 def test_emulated_attention_forward_rescale_path(emul):

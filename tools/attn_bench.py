@@ -37,8 +37,6 @@ def main():
     ap.add_argument("--stages", default="", help="comma list of attention-backward variants to A/B in interleaved rounds in THIS process: "
                     "DQ:DKDV = tiles of 64 per LDS stage in the dQ (1 / 2) and the dK / dV kernel (1 .. 4), e.g. 1:1,2:2,2:3,2:4,1:2")
     ap.add_argument("--rounds", type=int, default=5)
-    ap.add_argument("--fwd-wide", action="store_true", help="A/B of the forward in interleaved rounds in THIS process: revision 1 (0) against the "
-                    "kernel with 64 query rows per wave, 1 and 2 key tiles per LDS stage (debug option attn_fwd_wide = 1 / 2); reports bit-identity too")
     a = ap.parse_args()
     import test_time_training as ext
     from ttt_amd.models.cogvideo.attention import SegmentAttention
@@ -80,23 +78,6 @@ def main():
         ext.debug_option("attn_stage_dq", 1)
         ext.debug_option("attn_stage_dkdv", 2)
         res["bwd_by_stage"] = {st: {"median_ms": sorted(v)[len(v) // 2], "min_ms": min(v)} for st, v in times.items()}
-    if a.fwd_wide:
-        times = {v: [] for v in (0, 1, 2)}
-        ref = None
-        for rnd in range(a.rounds):
-            for v_ in (0, 1, 2):
-                ext.debug_option("attn_fwd_wide", v_)
-                times[v_].append(timeit(lambda: ext.attn_forward(q, k, v, out, lse, 0.125), a.iters))
-                if rnd == 0:
-                    torch.cuda.synchronize()
-                    cur = (out.clone(), lse.clone())
-                    if ref is None:
-                        ref = cur
-                    else:
-                        res.setdefault("fwd_bit_identical_to_revision_1", {})[v_] = bool(torch.equal(cur[0], ref[0]) and torch.equal(cur[1], ref[1]))
-                        res.setdefault("fwd_max_abs_diff_vs_revision_1", {})[v_] = float((cur[0].float() - ref[0].float()).abs().max())
-        ext.debug_option("attn_fwd_wide", 0)         # library default
-        res["fwd_by_variant"] = {v_: {"median_ms": sorted(t_)[len(t_) // 2], "min_ms": min(t_)} for v_, t_ in times.items()}
     if not a.no_sdpa:
         qq, kk, vv = (x.detach().clone().requires_grad_(True) for x in (q, k, v))
         t = timeit(lambda: F.scaled_dot_product_attention(qq, kk, vv), a.iters)

@@ -33,8 +33,6 @@ void launch_forward(const FwdParams& p, hipStream_t s);
 void launch_backward(const BwdParams& p, hipStream_t s);
 
 // dQ and dK / dV through the workgroup bodies of attn_body.h (attn_v2.hip)
-bool launch_forward_wide(const FwdParams& p, hipStream_t s);   // true if the opt-in wide forward (debug option "attn_fwd_wide") took the launch
-void set_debug_attn_fwd_wide(int v);               // 0 (default) revision 1 of the forward; 1 / 2: 64 query rows per wave, 1 / 2 key tiles per LDS stage (A/B)
 void launch_dq_v2(const BwdParams& p, hipStream_t s);
 void launch_dkdv_v2(const BwdParams& p, hipStream_t s);
 void set_debug_attn_dq_wide(int v);                // 1: dQ with 64 query rows per wave (A/B), 0 default

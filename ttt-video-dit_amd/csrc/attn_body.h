@@ -289,157 +289,10 @@ TTT_BODY_FN void forward(BK& bk, const FwdParams& p, int bh, int qb) {
     }
 }
 
-// forward() with NQ blocks of 32 query rows per wave and NSUB key tiles per LDS stage (round 4, after dq_wide: every K row fragment
-// and every transposed V fragment read from LDS feeds NQ MFMAs - half the LDS bytes per MFMA at NQ = 2 -, 2 waves of <= 256
-// registers per SIMD, one 8-wave workgroup of 256 * NQ rows per CU).  The arithmetic of a query row and its order over the keys are
-// those of forward(): bit-identical (tests/test_emul_attention_cpu.py; the rescale test `any(mt > m)` is per block of 32 rows,
-// and alpha == 1 exactly where it would not have been applied).
-template <int NSUB, int NQ, class BK>
-TTT_BODY_FN void forward_wide(BK& bk, const FwdParams& p, int bh, int qb) {
-    const int tid = bk.thread(), wv = bk.wave(), l = bk.lane(), h = l >> 5, c = l & 31;
-    const int bb = bh / p.NH, hh = bh % p.NH;
-    const __bf16* Qp = p.Q + (long)bb * p.q_sb + (long)hh * p.q_sh;
-    const __bf16* Kp = p.K + (long)bb * p.k_sb + (long)hh * p.k_sh;
-    const __bf16* Vp = p.V + (long)bb * p.v_sb + (long)hh * p.v_sh;
-    __bf16* Op = p.O + (long)bb * p.o_sb + (long)hh * p.o_sh;
-
-    int qrow[NQ];
-    bool qvalid[NQ];
-    bf16x8 Qf[NQ][4];
-    f32x16 O[NQ][2];                           // O^T tiles: rows = d, lane = query
-    float m[NQ], lsum[NQ];
-#pragma unroll
-    for (int qi = 0; qi < NQ; ++qi) {
-        qrow[qi] = qb * (QB * NQ) + 32 * NQ * wv + 32 * qi + c;
-        qvalid[qi] = qrow[qi] < p.S;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-            Qf[qi][kk] = qvalid[qi] ? *reinterpret_cast<const bf16x8*>(Qp + (long)qrow[qi] * p.q_ss + 16 * kk + 8 * h) : zero_frag();
-        O[qi][0] = zero16();
-        O[qi][1] = zero16();
-        m[qi] = -1e30f;
-        lsum[qi] = 0.f;
-    }
-    const float sc = p.scale * LOG2E;
-    const int nt = (p.S + KB - 1) / KB;        // key tiles of 64
-    const int ns = (nt + NSUB - 1) / NSUB;     // LDS stages of NSUB tiles
-    constexpr int STAGE_ELEMS = NSUB * FWD_BUF_ELEMS;
-    KVStage st;
-
-    const typename BK::tile_t lds = bk.lds_base();
-#pragma unroll
-    for (int u = 0; u < NSUB; ++u) {
-        kv_issue(st, Kp, Vp, p.k_ss, p.v_ss, u * KB, p.S, tid);
-        kv_park(bk, st, lds + u * FWD_BUF_ELEMS, lds + u * FWD_BUF_ELEMS + KT_ELEMS, VS, tid);
-    }
-    bk.barrier();
-    for (int j = 0; j < ns; ++j) {
-        const typename BK::tile_t stage = lds + (j & 1) * STAGE_ELEMS;
-        const typename BK::tile_t nxt = lds + ((j + 1) & 1) * STAGE_ELEMS;
-        const bool more = j + 1 < ns;
-#pragma unroll
-        for (int u = 0; u < NSUB; ++u) {
-            const int jt = j * NSUB + u;       // key tile
-            if (more) kv_issue(st, Kp, Vp, p.k_ss, p.v_ss, ((j + 1) * NSUB + u) * KB, p.S, tid);
-            if (jt < nt) {                     // (workgroup-uniform: false only in the last stage of an odd tile count)
-            const typename BK::tile_t Kt = stage + u * FWD_BUF_ELEMS, Vt = Kt + KT_ELEMS;
-            // ---- S^T = K Q^T : two key blocks of 32, each K fragment for NQ query blocks ----
-            f32x16 Sc[NQ][2];
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-                for (int qi = 0; qi < NQ; ++qi) Sc[qi][kb] = zero16();
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const bf16x8 kf = row_frag(bk, Kt, AS, 32 * kb, 16 * kk, l);
-#pragma unroll
-                    for (int qi = 0; qi < NQ; ++qi) Sc[qi][kb] = bk.mma3216(kf, Qf[qi][kk], Sc[qi][kb]);
-                }
-            }
-            if (jt + 1 == nt && (p.S & (KB - 1))) {      // ragged last tile: keys >= S are masked (wave-uniform, a real branch)
-                const int kv0 = jt * KB;
-#pragma unroll
-                for (int qi = 0; qi < NQ; ++qi)
-#pragma unroll
-                    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            float v = Sc[qi][kb][r];
-                            if (kv0 + 32 * kb + row_of(r, h) >= p.S) v = -1e30f;
-                            TTT_PIN_IN_BRANCH(v);
-                            Sc[qi][kb][r] = v;
-                        }
-            }
-            // ---- online softmax per block of 32 query rows (one row per lane; the partner half-wave holds the other 32 keys) ----
-#pragma unroll
-            for (int qi = 0; qi < NQ; ++qi) {
-                float mt = Sc[qi][0][0];
-#pragma unroll
-                for (int r = 1; r < 16; ++r) mt = fmaxf(mt, Sc[qi][0][r]);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) mt = fmaxf(mt, Sc[qi][1][r]);
-                mt = fmaxf(mt, bk.xor_read(mt, 32));
-                if (bk.any(mt > m[qi])) {
-                    const float mn = fmaxf(m[qi], mt);
-                    const float alpha = bk.exp2((m[qi] - mn) * sc);
-                    m[qi] = mn;
-                    lsum[qi] *= alpha;
-#pragma unroll
-                    for (int db = 0; db < 2; ++db)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) O[qi][db][r] *= alpha;
-                }
-                const float msc = m[qi] * sc;
-                float ps = 0.f;
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float e = bk.exp2(__builtin_fmaf(Sc[qi][kb][r], sc, -msc));
-                        Sc[qi][kb][r] = e;
-                        ps += e;
-                    }
-                lsum[qi] += ps;
-            }
-            // ---- O^T += V^T P^T : each transposed V fragment for NQ query blocks ----
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const bf16x8 v0 = tr_frag_pi(bk, Vt, VS, 32 * kb, s, 0, l), v1 = tr_frag_pi(bk, Vt, VS, 32 * kb, s, 32, l);
-#pragma unroll
-                    for (int qi = 0; qi < NQ; ++qi) {
-                        const bf16x8 pf = pack(Sc[qi][kb], s);
-                        O[qi][0] = bk.mma3216(v0, pf, O[qi][0]);
-                        O[qi][1] = bk.mma3216(v1, pf, O[qi][1]);
-                    }
-                }
-            }
-            if (more) kv_park(bk, st, nxt + u * FWD_BUF_ELEMS, nxt + u * FWD_BUF_ELEMS + KT_ELEMS, VS, tid);
-        }
-        bk.barrier();
-    }
-
-    // ---- epilogue: normalise, store O[q][d] and the log-sum-exp ----
-#pragma unroll
-    for (int qi = 0; qi < NQ; ++qi) {
-        const float ltot = lsum[qi] + bk.xor_read(lsum[qi], 32);
-        const float inv = 1.0f / ltot;
-        if (qvalid[qi]) {
-            __bf16* orow = Op + (long)qrow[qi] * p.o_ss;
-#pragma unroll
-            for (int db = 0; db < 2; ++db)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    bf16x4 v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = (__bf16)(O[qi][db][4 * g + e] * inv);
-                    *reinterpret_cast<bf16x4*>(orow + 32 * db + 8 * g + 4 * h) = v;
-                }
-            if (h == 0 && p.LSE) p.LSE[(long)bh * p.S + qrow[qi]] = m[qi] * p.scale + bk.log(ltot);
-        }
-    }
-}
+// (Round 4 also measured forward() with 64 query rows per wave - `forward_wide`, the dq_wide idea applied to the forward: bit-identical
+// on the emulator and on the device, 18 % fewer issue cycles and half the LDS instructions per row, and 1.0 % SLOWER than revision 1
+// (4.30 against 4.26 ms at 48 heads x 18 048 tokens, profiles/r4zb_attn_fwd_wide_ab.txt): the forward needs its four waves per SIMD.
+// Removed; the commit "attention forward with 64 query rows per wave" has it.)
 
 // --------------------------------------------------------------------------------------------------------------------- dQ
 // dQ = scale * dS K,  dS = P * (dP - Delta),  P = exp(S*scale - LSE),  dP = dO V^T, for the 256 query rows of block qb

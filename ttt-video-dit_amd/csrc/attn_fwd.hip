@@ -196,7 +196,6 @@ __global__ __launch_bounds__(NTF) void attn_fwd_kernel(FwdParams p) {
 }
 
 void launch_forward(const FwdParams& p, hipStream_t s) {
-    if (launch_forward_wide(p, s)) return;      // opt-in A/B variant (attn_v2.hip), off by default
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FWD);

@@ -99,39 +99,6 @@ static void launch_dq_wide(const BwdParams& p, hipStream_t s) {
     hipLaunchKernelGGL((attn_dq_wide_kernel<NSUB>), dim3(p.B * p.NH * nb), dim3(512), NSUB * attnb::LDS_DQ, s, p);
 }
 
-// Forward with 64 query rows per wave (attn_body.h forward_wide: every K row fragment and every transposed V fragment read from LDS
-// feeds two MFMAs; one 8-wave workgroup of 512 rows per CU, NSUB key tiles per LDS stage).  Bit-identical to the body's forward()
-// on the emulator (tests/test_emul_attention_cpu.py) and held to revision 1 on the device by the opt-in test
-// tests/test_attention_gpu.py::test_forward_wide_variant.  NOT TIMED YET (written after round 4's GPU budget): debug option
-// "attn_fwd_wide" = 1 / 2, default 0; tools/attn_bench.py --fwd-wide is the A/B.
-template <int NSUB>
-__global__ __launch_bounds__(512, 2) void attn_fwd_wide_kernel(FwdParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    int bh, qb;
-    attnb::head_of_block(blockIdx.x, (p.S + 2 * attnb::QB - 1) / (2 * attnb::QB), p.B * p.NH, bh, qb);
-    AttnDeviceWave bk{reinterpret_cast<__bf16*>(smem)};
-    attnb::forward_wide<NSUB, 2>(bk, p, bh, qb);
-}
-static int g_fwd_wide = 0;
-void set_debug_attn_fwd_wide(int v) { g_fwd_wide = (v == 1 || v == 2) ? v : 0; }
-template <int NSUB>
-static void launch_fwd_wide(const FwdParams& p, hipStream_t s) {
-    static_assert(NSUB * attnb::LDS_FWD <= 160 * 1024, "LDS budget");
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)attn_fwd_wide_kernel<NSUB>, hipFuncAttributeMaxDynamicSharedMemorySize, NSUB * attnb::LDS_FWD);
-        attr = true;
-    }
-    const int nb = (p.S + 2 * attnb::QB - 1) / (2 * attnb::QB);
-    hipLaunchKernelGGL((attn_fwd_wide_kernel<NSUB>), dim3(p.B * p.NH * nb), dim3(512), NSUB * attnb::LDS_FWD, s, p);
-}
-bool launch_forward_wide(const FwdParams& p, hipStream_t s) {
-    if (g_fwd_wide == 1) launch_fwd_wide<1>(p, s);
-    else if (g_fwd_wide == 2) launch_fwd_wide<2>(p, s);
-    else return false;
-    return true;
-}
-
 // tiles of 64 per LDS stage: dQ 1 / 2 (two workgroups of 73 KiB share a CU), dK / dV 1 .. 4 (one workgroup of 768 threads per CU:
 // up to 148 KiB).  Debug option "attn_stage" sets both, "attn_stage_dq" / "attn_stage_dkdv" one of them (A/B).
 static int g_stage_dq = 1, g_stage_dkdv = 2;      // (dQ: the wide kernel holds one workgroup per CU; one tile per stage measured best there)

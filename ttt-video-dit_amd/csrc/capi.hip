@@ -60,7 +60,6 @@ int ttt_hip_debug_option(const char* name, int value) {
     else if (!strcmp(name, "rc_nt")) ttt::mfma::set_debug_rc_nt(value);
     else if (!strcmp(name, "sweep_prefetch")) ttt::mfma::set_debug_sweep_prefetch(value);      // revision-4 sweep: L2 prefetch touches (1 default / 0)
     else if (!strcmp(name, "attn_stage")) ttt::attn::set_debug_attn_stage(0, value);            // attention backward: tiles of 64 per LDS stage (default 2; 1 = round-3 kernels)
-    else if (!strcmp(name, "attn_fwd_wide")) ttt::attn::set_debug_attn_fwd_wide(value);         //   forward with 64 query rows per wave, 1 / 2 key tiles per stage (A/B; 0 default)
     else if (!strcmp(name, "attn_dq_wide")) ttt::attn::set_debug_attn_dq_wide(value);           //   dQ kernel with 64 query rows per wave (A/B)
     else if (!strcmp(name, "attn_stage_dq")) ttt::attn::set_debug_attn_stage(1, value);         //   dQ kernel only (1 / 2)
     else if (!strcmp(name, "attn_stage_dkdv")) ttt::attn::set_debug_attn_stage(2, value);       //   dK / dV kernel only (1 .. 4)
