@@ -136,10 +136,11 @@ def test_forward_scan_half_chunk_swap_variant():
 SCAN_SWAP_DEFAULT = 1          # the library's (csrc/ttt_mfma2.hip g_scan_swap)
 
 
-def test_tail_gate_delay_same_bits():
-    """Debug option "tail_delay_us" of the backward's schedule (csrc/ttt_mfma_bwd2.hip): a one-wave gate kernel in front of each
-    tail kernel on its side stream, so that the next chunk's sweep is resident before the tail's workgroups arrive (the race the
-    rocprofv3 trace of round 4 shows, profiles/r4y_sweep_launches.txt).  Pure scheduling: the gradients must be bit-identical."""
+def test_backward_schedule_options_same_bits():
+    """Scheduling options of the TTT-MLP backward (csrc/ttt_mfma_bwd2.hip), both aimed at the race between a chunk's tail kernel and
+    the next chunk's sweep that the rocprofv3 trace of round 4 shows (profiles/r4y_sweep_launches.txt): "tail_delay_us" (a one-wave
+    gate kernel in front of each tail kernel on its side stream) and "flags_memset_early" (the next sweep's hand-over flags cleared
+    behind the current sweep instead of in front of the next).  Pure scheduling: every gradient must be bit-identical."""
     from oracle import ttt_oracle as O
     from test_kernels_gpu import round_acts, run_mlp
     e = ext()
@@ -147,12 +148,15 @@ def test_tail_gate_delay_same_bits():
     res = []
     e.debug_groups_per_chunk(2)
     try:
-        for v in (0, 25):
-            e.debug_option("tail_delay_us", v)
+        for delay, early in ((0, 0), (25, 0), (0, 1), (25, 1)):
+            e.debug_option("tail_delay_us", delay)
+            e.debug_option("flags_memset_early", early)
             res.append(run_mlp(e, d, 16, torch.bfloat16, impl="mfma"))
+            assert e.sweep_error() == 0, (delay, early)
     finally:
         e.debug_option("tail_delay_us", 0)
+        e.debug_option("flags_memset_early", 0)
         e.debug_groups_per_chunk(0)
-    assert e.sweep_error() == 0
-    for k in res[0][2]:
-        assert torch.equal(res[0][2][k], res[1][2][k]), k
+    for other in res[1:]:
+        for k in res[0][2]:
+            assert torch.equal(res[0][2][k], other[2][k]), k

@@ -49,6 +49,13 @@ void set_debug_sweep_prefetch(int v) { g_sweep_prefetch = v; }
 // on the sharded path, two launches in three the bad one).  With a delay > 0 a one-wave kernel in front of the tail holds its
 // stream for that many microseconds, so that the sweep's 192 workgroups are resident before the tail's 3 500 arrive.  Not measured
 // inside a training step yet (the GPU budget of round 4 ended): off.
+// A/B option "flags_memset_early" (default 0): the hand-over flags of the NEXT sweep are cleared right behind the current sweep
+// (in front of the recompute) instead of in front of the next sweep.  Why: the trace (profiles/r4y_sweep_launches.txt) shows the
+// sweep starting 13 - 15 us after the recompute ends - the memset - and the tail, released by an event behind the same recompute,
+// after the same 13 - 15 us of cross-queue latency: a coin toss who is dispatched first, and "tail first" is the slow outcome
+// (1.00 - 1.12 against 0.92 ms).  With the memset out of the way the sweep follows the recompute kernel-to-kernel.
+static int g_memset_early = 0;
+void set_debug_flags_memset_early(int v) { g_memset_early = v ? 1 : 0; }
 static int g_tail_delay_us = 0;
 void set_debug_tail_delay_us(int v) { g_tail_delay_us = v < 0 ? 0 : (v > 1000 ? 1000 : v); }
 __global__ __launch_bounds__(64) void tail_gate_kernel(unsigned long long ticks) {
@@ -203,12 +210,13 @@ static int mlp_backward4(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws,
         bp.first = (ch == nchunks - 1);
         bp.last = (ch == 0);
         bp.dbg = get_debug_timing();
-        chk(hipMemsetAsync(flags, 0, flag_bytes, s));         // hand-over flags restart at 0 for every launch
+        if (!g_memset_early || ch == nchunks - 1) chk(hipMemsetAsync(flags, 0, flag_bytes, s));         // hand-over flags restart at 0 for every launch
         for (int bh0 = 0; bh0 < nbh; bh0 += per_launch) {
             bp.bh0 = bh0;
             bp.nbh = nbh - bh0 < per_launch ? nbh - bh0 : per_launch;
             s4::launch_sweep_cluster4(bp, bp.nbh, s);
         }
+        if (g_memset_early && ch > 0) chk(hipMemsetAsync(flags, 0, flag_bytes, s));   // for sweep(ch - 1): behind this sweep, in front of its recompute
     };
     if (ov) {           // the side stream starts after everything queued on `s` before this call (the inputs), not after A(n-1)
         chk(hipEventRecord(ov->entry, s));
