@@ -19,6 +19,7 @@
 #include "../../include/ttt_hip.h"
 #include "attn.h"
 #include "attn_dev.h"
+#include "once_per_device.h"
 
 namespace ttt {
 namespace attn {
@@ -196,11 +197,10 @@ __global__ __launch_bounds__(NTF) void attn_fwd_kernel(FwdParams p) {
 }
 
 void launch_forward(const FwdParams& p, hipStream_t s) {
-    static bool attr = false;
-    if (!attr) {
+    static ttt::OncePerDevice attr;
+    attr.run([&] {
         (void)hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FWD);
-        attr = true;
-    }
+    });
     const int nqb = (p.S + QB - 1) / QB;
     hipLaunchKernelGGL(attn_fwd_kernel, dim3(p.B * p.NH * nqb), dim3(NTF), LDS_FWD, s, p);
 }

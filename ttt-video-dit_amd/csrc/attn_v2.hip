@@ -7,6 +7,7 @@
 #include "../../include/ttt_hip.h"
 #include "attn.h"
 #include "attn_body.h"
+#include "once_per_device.h"
 
 namespace ttt {
 namespace attn {
@@ -90,11 +91,10 @@ static int g_dq_wide = 1;                // round 4, one box (profiles/r4c_attn_
 void set_debug_attn_dq_wide(int v) { g_dq_wide = v; }
 template <int NSUB>
 static void launch_dq_wide(const BwdParams& p, hipStream_t s) {
-    static bool attr = false;
-    if (!attr) {
+    static ttt::OncePerDevice attr;
+    attr.run([&] {
         (void)hipFuncSetAttribute((const void*)attn_dq_wide_kernel<NSUB>, hipFuncAttributeMaxDynamicSharedMemorySize, NSUB * attnb::LDS_DQ);
-        attr = true;
-    }
+    });
     const int nb = (p.S + 2 * attnb::QB - 1) / (2 * attnb::QB);
     hipLaunchKernelGGL((attn_dq_wide_kernel<NSUB>), dim3(p.B * p.NH * nb), dim3(512), NSUB * attnb::LDS_DQ, s, p);
 }
@@ -109,22 +109,20 @@ void set_debug_attn_stage(int which, int v) {
 
 template <int NSUB>
 static void launch_dq_staged(const BwdParams& p, hipStream_t s) {
-    static bool attr = false;
-    if (!attr) {
+    static ttt::OncePerDevice attr;
+    attr.run([&] {
         (void)hipFuncSetAttribute((const void*)attn_dq2s_kernel<4, NSUB>, hipFuncAttributeMaxDynamicSharedMemorySize, NSUB * attnb::LDS_DQ);
-        attr = true;
-    }
+    });
     const int nb = (p.S + attnb::QB - 1) / attnb::QB;
     hipLaunchKernelGGL((attn_dq2s_kernel<4, NSUB>), dim3(p.B * p.NH * nb), dim3(512), NSUB * attnb::LDS_DQ, s, p);
 }
 void launch_dq_v2(const BwdParams& p, hipStream_t s) {
     if (g_dq_wide) return g_stage_dq == 2 ? launch_dq_wide<2>(p, s) : launch_dq_wide<1>(p, s);
     if (g_stage_dq == 2) return launch_dq_staged<2>(p, s);
-    static bool attr = false;
-    if (!attr) {
+    static ttt::OncePerDevice attr;
+    attr.run([&] {
         (void)hipFuncSetAttribute((const void*)attn_dq2_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, attnb::LDS_DQ);
-        attr = true;
-    }
+    });
     const int nb = (p.S + attnb::QB - 1) / attnb::QB;
     hipLaunchKernelGGL(attn_dq2_kernel<4>, dim3(p.B * p.NH * nb), dim3(512), attnb::LDS_DQ, s, p);
 }
@@ -133,11 +131,10 @@ template <int NSUB>
 static void launch_dkdv_staged(const BwdParams& p, hipStream_t s) {
     constexpr int NW = 12;
     static_assert(NSUB * attnb::LDS_DKV <= 160 * 1024, "LDS budget");
-    static bool attr = false;
-    if (!attr) {
+    static ttt::OncePerDevice attr;
+    attr.run([&] {
         (void)hipFuncSetAttribute((const void*)attn_dkdv2s_kernel<NW, true, 3, NSUB>, hipFuncAttributeMaxDynamicSharedMemorySize, NSUB * attnb::LDS_DKV);
-        attr = true;
-    }
+    });
     const int nb = (p.S + 32 * NW - 1) / (32 * NW);
     hipLaunchKernelGGL((attn_dkdv2s_kernel<NW, true, 3, NSUB>), dim3(p.B * p.NH * nb), dim3(64 * NW), NSUB * attnb::LDS_DKV, s, p);
 }
@@ -146,11 +143,10 @@ void launch_dkdv_v2(const BwdParams& p, hipStream_t s) {       // accumulator-in
     if (g_stage_dkdv == 2) return launch_dkdv_staged<2>(p, s);
     if (g_stage_dkdv == 3) return launch_dkdv_staged<3>(p, s);
     if (g_stage_dkdv == 4) return launch_dkdv_staged<4>(p, s);
-    static bool attr = false;
-    if (!attr) {
+    static ttt::OncePerDevice attr;
+    attr.run([&] {
         (void)hipFuncSetAttribute((const void*)attn_dkdv2_kernel<NW, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, attnb::LDS_DKV);
-        attr = true;
-    }
+    });
     const int nb = (p.S + 32 * NW - 1) / (32 * NW);
     hipLaunchKernelGGL((attn_dkdv2_kernel<NW, true, 3>), dim3(p.B * p.NH * nb), dim3(64 * NW), attnb::LDS_DKV, s, p);
 }

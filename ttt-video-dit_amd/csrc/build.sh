@@ -8,7 +8,7 @@ OUT=../lib
 mkdir -p "$OUT" build
 pids=()
 for src in capi ttt_generic ttt_mfma ttt_mfma2 ttt_mfma16 ttt_mfma_bwd2 ttt_mfma_bwd4 ttt_mfma_rc4 ttt_prepost attn_fwd attn_bwd attn_pre attn_v2; do
-  if [ ! -f build/$src.o ] || [ $src.hip -nt build/$src.o ] || [ ttt_common.h -nt build/$src.o ] || [ ../../include/ttt_hip.h -nt build/$src.o ] || [ ttt_mfma_dev.h -nt build/$src.o ] || [ ttt_mfma_int.h -nt build/$src.o ] || [ ttt_mfma_bwd_dev.h -nt build/$src.o ] || [ ttt_bwd4_dev.h -nt build/$src.o ] || [ ttt_bwd4_aux_body.h -nt build/$src.o ] || [ ttt_prepost.h -nt build/$src.o ] || [ ttt_mfma.h -nt build/$src.o ] || [ attn.h -nt build/$src.o ] || [ attn_dev.h -nt build/$src.o ] || [ ttt_lin16_body.h -nt build/$src.o ] || [ ttt_mlp16_body.h -nt build/$src.o ] || [ ttt_wave_types.h -nt build/$src.o ] || [ attn_body.h -nt build/$src.o ] || [ attn_types.h -nt build/$src.o ]; then
+  if [ ! -f build/$src.o ] || [ $src.hip -nt build/$src.o ] || [ ttt_common.h -nt build/$src.o ] || [ ../../include/ttt_hip.h -nt build/$src.o ] || [ ttt_mfma_dev.h -nt build/$src.o ] || [ ttt_mfma_int.h -nt build/$src.o ] || [ ttt_mfma_bwd_dev.h -nt build/$src.o ] || [ ttt_bwd4_dev.h -nt build/$src.o ] || [ ttt_bwd4_aux_body.h -nt build/$src.o ] || [ ttt_prepost.h -nt build/$src.o ] || [ ttt_mfma.h -nt build/$src.o ] || [ attn.h -nt build/$src.o ] || [ attn_dev.h -nt build/$src.o ] || [ ttt_lin16_body.h -nt build/$src.o ] || [ ttt_mlp16_body.h -nt build/$src.o ] || [ ttt_wave_types.h -nt build/$src.o ] || [ attn_body.h -nt build/$src.o ] || [ attn_types.h -nt build/$src.o ] || [ once_per_device.h -nt build/$src.o ]; then
     $HIPCC $FLAGS -c $src.hip -o build/$src.o &
     pids+=($!)
   fi

@@ -38,6 +38,7 @@
 #define TTT_WV_FN __device__ __forceinline__
 #include "ttt_lin16_body.h"
 #include "ttt_mlp16_body.h"
+#include "once_per_device.h"
 
 namespace ttt {
 namespace mfma {
@@ -170,12 +171,11 @@ __global__ __launch_bounds__(64) void linear_bwd16_kernel(wv::Lin16Params p) {
 }  // namespace v16
 
 static void lin_attr_once() {
-    static bool done = false;
-    if (!done) {
+    static ttt::OncePerDevice done;
+    done.run([&] {
         (void)hipFuncSetAttribute((const void*)v16::linear_scan16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, v16::LDS_LIN);
         (void)hipFuncSetAttribute((const void*)v16::linear_bwd16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lin16::WAVE_LDS_BWD);
-        done = true;
-    }
+    });
 }
 void launch_linear_forward_cs16(const wv::Lin16Params& p, int n_bh, hipStream_t s) {
     lin_attr_once();
@@ -188,11 +188,10 @@ void launch_linear_backward_cs16(const wv::Lin16Params& p, int n_bh, hipStream_t
 }
 
 void launch_scan_forward_cs16(const ScanParams& p, int n_bh, unsigned long long*, hipStream_t s) {
-    static bool done = false;
-    if (!done) {
+    static ttt::OncePerDevice done;
+    done.run([&] {
         (void)hipFuncSetAttribute((const void*)v16::mlp_scan16_body_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, mlp16::GROUP_LDS);
-        done = true;
-    }
+    });
     wv::Mlp16Params q = {};
     q.XQ = p.XQ; q.XK = p.XK; q.XV = p.XV; q.eta = p.eta; q.ln_w = p.ln_w; q.ln_b = p.ln_b;
     q.W1 = p.W1; q.b1 = p.b1; q.W2 = p.W2; q.b2 = p.b2; q.W1c = p.W1c; q.b1c = p.b1c; q.W2c = p.W2c; q.b2c = p.b2c;

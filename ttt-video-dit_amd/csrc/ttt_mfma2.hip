@@ -35,6 +35,7 @@
 #include "ttt_mfma.h"
 #include "ttt_mfma_dev.h"
 #include "ttt_mfma_int.h"
+#include "once_per_device.h"
 
 namespace ttt {
 namespace mfma {
@@ -558,14 +559,13 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
 }
 
 static void set_attr_once() {
-    static bool done = false;
-    if (!done) {
+    static ttt::OncePerDevice done;
+    done.run([&] {
         (void)hipFuncSetAttribute((const void*)mlp_scan8_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_V2);
         (void)hipFuncSetAttribute((const void*)mlp_scan8_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_V2);
         (void)hipFuncSetAttribute((const void*)mlp_scan8_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_V2);
         (void)hipFuncSetAttribute((const void*)mlp_scan8_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_V2);
-        done = true;
-    }
+    });
 }
 
 }  // namespace v2

@@ -19,6 +19,7 @@
 #include "ttt_mfma_int.h"
 #include "ttt_mfma_bwd_dev.h"
 #include "ttt_bwd4_dev.h"
+#include "once_per_device.h"
 
 namespace ttt {
 namespace mfma {
@@ -421,12 +422,11 @@ __global__ __launch_bounds__(NT8) void mlp_recompute8_kernel(RecomputeParams p) 
 }
 
 void launch_recompute4(const RecomputeParams& p, int n_bh, int max_workgroups, hipStream_t s) {
-    static bool done = false;
-    if (!done) {
+    static ttt::OncePerDevice done;
+    done.run([&] {
         (void)hipFuncSetAttribute((const void*)mlp_recompute8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_RC4);
         (void)hipFuncSetAttribute((const void*)mlp_recompute8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_RC4);
-        done = true;
-    }
+    });
     RecomputeParams q = p;
     const int n_items = n_bh * p.chunk_groups;
     const int per = (max_workgroups > 0 && max_workgroups < n_items) ? max_workgroups : n_items;
