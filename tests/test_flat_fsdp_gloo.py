@@ -170,3 +170,71 @@ def test_flat_fsdp_without_a_process_group_is_the_replica_path():
         assert torch.allclose(g0[k], v, rtol=1e-5, atol=1e-8), k
     for k, v in ref_final.items():
         assert torch.allclose(final[k], v, rtol=1e-4, atol=1e-7), k
+
+
+def _resume_worker(rank, world, port, out_dir, phase):
+    for p in (ROOT, os.path.join(ROOT, "ttt-video-dit_amd")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    from oracle import cpu_ext
+    from ttt_amd.infra.flat_fsdp import FlatFSDP
+    cpu_ext.install()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def fresh(seed_shift=0):
+        m = _build("qkvo")
+        if seed_shift:                       # a model with OTHER values: everything must come from the checkpoint
+            with torch.no_grad():
+                for p in m.parameters():
+                    p.add_(0.01 * seed_shift)
+        m.remat_free_layers = 1
+        fs = FlatFSDP(m)
+        return m, fs, torch.optim.AdamW(fs.master_parameters(), lr=1e-3, weight_decay=1e-4)
+
+    if phase == "train":
+        # A: two steps without interruption
+        m, fs, opt = fresh()
+        _steps(m, fs, opt, rank, n_steps=2)
+        final_a = fs.full_parameters("param")
+        # B: one step, export, a NEW model / wrapper / optimizer loads it, one more step
+        m, fs, opt = fresh()
+        _steps(m, fs, opt, rank, n_steps=1)
+        ck = {"params": fs.full_parameters("param"), "opt": fs.optimizer_state_full(opt),
+              "frozen": {n: p.detach().float().clone() for n, p in m.named_parameters() if not p.requires_grad}}
+        m2, fs2, opt2 = fresh(seed_shift=1)
+        fs2.load_full_parameters({**ck["params"], **ck["frozen"]})
+        fs2.load_optimizer_state_full(opt2, ck["opt"])
+        _steps(m2, fs2, opt2, rank, n_steps=1)
+        final_b = fs2.full_parameters("param")
+        for k, v in final_a.items():
+            assert torch.equal(v, final_b[k]), (k, float((v - final_b[k]).abs().max()))
+        if rank == 0:
+            torch.save(ck, os.path.join(out_dir, "ck.pt"))
+    else:
+        # another world size reads the same checkpoint and hands back the same tensors
+        ck = torch.load(os.path.join(out_dir, "ck.pt"))
+        m, fs, opt = fresh(seed_shift=2)
+        fs.load_full_parameters({**ck["params"], **ck["frozen"]})
+        fs.load_optimizer_state_full(opt, ck["opt"])
+        back_p, back_o = fs.full_parameters("param"), fs.optimizer_state_full(opt)
+        assert set(back_p) == set(ck["params"]) and set(back_o) == set(ck["opt"])
+        for k, v in ck["params"].items():
+            assert torch.equal(back_p[k], v), k
+        for k, ent in ck["opt"].items():
+            for kk, v in ent.items():
+                assert torch.equal(torch.as_tensor(back_o[k][kk]), torch.as_tensor(v)), (k, kk)
+        for n, p in m.named_parameters():
+            if not p.requires_grad:
+                assert torch.equal(p.float(), ck["frozen"][n].to(torch.bfloat16).float()), n
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_flat_fsdp_export_and_resume(tmp_path):
+    """`full_parameters` / `optimizer_state_full` -> `load_full_parameters` / `load_optimizer_state_full`: a run that stops after
+    one step, exports, and continues in a NEW model + wrapper + optimizer ends with exactly the parameters of the uninterrupted
+    run (world 2); the same checkpoint read at world 3 (other shard sizes, padding) hands back identical tensors - parameters by
+    the reference's names, AdamW moments cut by parameter: the layout of an unsharded run, independent of the world size."""
+    mp.spawn(_resume_worker, args=(2, _free_port(), str(tmp_path), "train"), nprocs=2, join=True)
+    mp.spawn(_resume_worker, args=(3, _free_port(), str(tmp_path), "read"), nprocs=3, join=True)

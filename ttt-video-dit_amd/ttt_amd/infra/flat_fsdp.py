@@ -29,7 +29,11 @@ the N > 1 path are the same code.
     opt = torch.optim.AdamW(fs.master_parameters(), ...)
     loss.backward(); fs.finish_backward(); norm = fs.clip_grad_norm_(1.0); opt.step(); fs.publish()
 
-Covered on the CPU by ``tests/test_flat_fsdp_gloo.py`` (world 2 and 3, gloo) against a hand-written data-parallel reference.
+Export / resume: ``full_parameters()`` / ``optimizer_state_full(opt)`` and their ``load_*`` inverses work by the reference's
+parameter names and are independent of the world size (the layout of an unsharded run).
+
+Covered on the CPU by ``tests/test_flat_fsdp_gloo.py`` (world 2 and 3, gloo) against a hand-written data-parallel reference, and
+an interrupted-and-resumed run against an uninterrupted one (bit-identical).
 """
 from __future__ import annotations
 
@@ -265,6 +269,88 @@ class FlatFSDP:
             for n, p, o in zip(u.names, u.params, u.offsets):
                 out[n] = full[o:o + p.numel()].view(p.shape).clone()
         return out
+
+    # ------------------------------------------------------------------------------------------------- checkpoints (export / resume)
+    def _flat_from_named(self, u: _Unit, named: Dict[str, torch.Tensor], what: str, strict: bool) -> Optional[torch.Tensor]:
+        """this rank's fp32 shard of the unit's flat layout, filled from full per-parameter tensors (None if nothing is there)"""
+        full = torch.zeros(u.padded, dtype=torch.float32, device=u.master.device)
+        found = 0
+        for n, p, o in zip(u.names, u.params, u.offsets):
+            t = named.get(n)
+            if t is None:
+                if strict:
+                    raise KeyError(f"FlatFSDP: no {what} for parameter {n!r}")
+                continue
+            if tuple(t.shape) != tuple(p.shape):
+                raise ValueError(f"FlatFSDP: {what} of {n!r} has shape {tuple(t.shape)}, the parameter {tuple(p.shape)}")
+            full[o:o + p.numel()].copy_(t.detach().reshape(-1).to(full.device, torch.float32))
+            found += 1
+        if not found:
+            return None
+        lo = self.rank * u.shard
+        return full[lo:lo + u.shard].clone()
+
+    def load_full_parameters(self, named: Dict[str, torch.Tensor], strict: bool = True) -> None:
+        """{name: full tensor} by the reference's parameter names (a checkpoint of the reference, `full_parameters()` of another
+        run - any world size) -> this rank's fp32 master shards and, through `publish()`, the bf16 compute parameters of every
+        rank; frozen parameters go into their replicated copies.  Every rank passes the same dictionary."""
+        with torch.no_grad():
+            for u in self.units:
+                shard = self._flat_from_named(u, named, "value", strict)
+                if shard is not None:
+                    u.master.data.copy_(shard)
+            frozen = {n: p for n, p in self.dit.named_parameters() if not p.requires_grad}
+            for n, p in frozen.items():
+                if n in named:
+                    p.data.copy_(named[n].to(p.device, p.dtype))
+                elif strict and p.is_floating_point():
+                    raise KeyError(f"FlatFSDP: no value for frozen parameter {n!r}")
+        self.publish()
+
+    def optimizer_state_full(self, optimizer: torch.optim.Optimizer) -> Dict[str, Dict[str, torch.Tensor]]:
+        """The optimizer's per-element state (AdamW: exp_avg, exp_avg_sq) gathered from all ranks and cut by parameter -
+        {name: {"exp_avg": full fp32 tensor, "exp_avg_sq": ..., "step": scalar}}: the layout of an unsharded optimizer over the
+        reference's parameters, independent of the world size it was trained with.  Collective."""
+        out: Dict[str, Dict[str, torch.Tensor]] = {}
+        for u in self.units:
+            st = optimizer.state.get(u.master, {})
+            per = {}
+            for key, val in st.items():
+                if torch.is_tensor(val) and val.numel() == u.shard:
+                    full = torch.empty(u.padded, dtype=val.dtype, device=val.device)
+                    if self.world > 1:
+                        dist.all_gather_into_tensor(full, val.contiguous().reshape(-1), group=self.group)
+                    else:
+                        full.copy_(val.reshape(-1))
+                    per[key] = full
+            for n, p, o in zip(u.names, u.params, u.offsets):
+                ent = {k: f[o:o + p.numel()].view(p.shape).clone() for k, f in per.items()}
+                for key, val in st.items():
+                    if key not in per:
+                        ent[key] = val.clone() if torch.is_tensor(val) else val
+                if ent:
+                    out[n] = ent
+        return out
+
+    def load_optimizer_state_full(self, optimizer: torch.optim.Optimizer, state: Dict[str, Dict[str, torch.Tensor]], strict: bool = True) -> None:
+        """Inverse of `optimizer_state_full` (any world size on either side).  Scalar entries ("step") are taken from the unit's
+        first parameter that has them."""
+        with torch.no_grad():
+            for u in self.units:
+                # per-element entries = tensors of the parameter's own shape ("step" is 0-dimensional)
+                keys = {k for n, p in zip(u.names, u.params) for k, v in state.get(n, {}).items()
+                        if torch.is_tensor(v) and v.ndim > 0 and tuple(v.shape) == tuple(p.shape)}
+                new = {}
+                for k in sorted(keys):
+                    shard = self._flat_from_named(u, {n: state[n][k] for n in u.names if n in state and k in state[n]}, f"optimizer state {k!r}", strict)
+                    if shard is not None:
+                        new[k] = shard
+                for n in u.names:
+                    for k, v in state.get(n, {}).items():
+                        if k not in keys and k not in new:
+                            new[k] = v.clone() if torch.is_tensor(v) else v
+                if new:
+                    optimizer.state[u.master] = new
 
     def remove(self):
         """Detach from the module (hooks removed, buffers released): the parameters keep their last bf16 values as views of
