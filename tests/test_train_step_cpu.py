@@ -52,3 +52,45 @@ def test_non_finite_norm_without_an_error_word_also_skips():
     e = FakeExt(0)
     assert checked_optimizer_step(opt, m.parameters(), 1.0, extension=e) is None
     assert torch.equal(m.weight, w0) and e.cleared == 0
+
+
+def test_skipped_step_with_the_flat_sharded_path_leaves_it_usable():
+    """FlatFSDP (one process, no group) under checked_optimizer_step with its own clip function: a poisoned backward is dropped -
+    masters, compute parameters and AdamW state untouched -, and the same batch run again steps normally (the persistent gradient
+    storage of the wrapper is re-used, not left half-accumulated)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracle import cpu_ext
+    from test_flat_fsdp_gloo import _build, _loss
+    from ttt_amd.infra.flat_fsdp import FlatFSDP
+    cpu_ext.install()
+    try:
+        m = _build("qkvo")
+        m.remat_free_layers = 0
+        fs = FlatFSDP(m)
+        opt = torch.optim.AdamW(fs.master_parameters(), lr=1e-3)
+        before = [u.master.detach().clone() for u in fs.units]
+        bf16_before = [u.gathered.clone() for u in fs.units]
+
+        def backward():
+            fs.zero_grad()
+            _loss(m, 0).backward()
+            fs.finish_backward()
+
+        backward()
+        fs.units[0].master.grad[3] = float("nan")
+        e = FakeExt(5)
+        assert checked_optimizer_step(opt, fs.master_parameters(), 1.0, extension=e, clip_fn=fs.clip_grad_norm_) is None
+        assert e.cleared == 1 and len(opt.state) == 0
+        assert all(u.master.grad is None for u in fs.units)
+        assert all(torch.equal(a, u.master) for a, u in zip(before, fs.units))
+        assert all(torch.equal(a, u.gathered) for a, u in zip(bf16_before, fs.units))
+        backward()                                            # the batch again
+        n = checked_optimizer_step(opt, fs.master_parameters(), 1.0, extension=e, clip_fn=fs.clip_grad_norm_)
+        assert n is not None and bool(torch.isfinite(n)) and float(n) > 0
+        fs.publish()
+        assert any(not torch.equal(a, u.master) for a, u in zip(before, fs.units))
+        assert any(not torch.equal(a, u.gathered) for a, u in zip(bf16_before, fs.units))
+    finally:
+        cpu_ext.uninstall()
