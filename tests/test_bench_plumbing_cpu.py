@@ -136,3 +136,25 @@ def test_bare_multi_gpu_invocation_relaunches_itself(monkeypatch):
         with pytest.raises(AssertionError, match="needs a GPU"):
             bench.main()
     assert not calls
+
+
+def test_sweep_launch_summary_reproduces_from_the_committed_trace():
+    """tools/sweep_launches.py on profiles/r4y_ttt_bwd_launches.csv.gz (the sweep / tail / recompute / fill dispatches of round 4's
+    rocprofv3 trace of `python bench.py`): the numbers DESIGN.md section 5 quotes - the sweep is unimodal on the replica path and
+    bimodal on the sharded path, nothing foreign runs beside it, and 'tail dispatched first' is the slow outcome of the race."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("sweep_launches", os.path.join(ROOT, "tools", "sweep_launches.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    res = m.summarize(os.path.join(ROOT, "profiles", "r4y_ttt_bwd_launches.csv.gz"))
+    rep, sh = res["phases"]["replica"], res["phases"]["sharded (fsdp1)"]
+    assert (rep["launches"], sh["launches"]) == (7392, 3696)
+    assert abs(rep["p50"] - 915.3) < 0.5 and rep["p90"] - rep["p10"] < 50            # one mode
+    assert abs(sh["p50"] - 1067.1) < 0.5 and sh["p90"] - sh["p10"] > 200             # two
+    for p in (rep, sh):                                                              # only the flag memset's tail end overlaps a sweep
+        assert set(p["foreign"]) <= {"fill"} and sum(t for _, t in p["foreign"].values()) < 100.0
+    first = lambda p, order: sum(v["n"] for (speed, o), v in p["race"].items() if o == order)
+    assert first(rep, "tail first") / (first(rep, "tail first") + first(rep, "sweep first")) < 0.04
+    assert first(sh, "tail first") / (first(sh, "tail first") + first(sh, "sweep first")) > 0.55
+    assert sh["race"][("slow", "tail first")]["n"] > 1500 and sh["race"][("slow", "tail first")]["sweep_us"] > 1100
+    assert rep["race"][("fast", "sweep first")]["sweep_us"] < 925

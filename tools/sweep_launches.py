@@ -1,70 +1,122 @@
-"""Per-launch view of the TTT-MLP backward sweep in a rocprofv3 kernel trace of `python bench.py` (argv[1] = *_kernel_trace.csv).
+"""Per-launch view of the TTT-MLP backward sweep in a rocprofv3 kernel trace of `python bench.py`.
+
+    python tools/sweep_launches.py run_kernel_trace.csv                   # rocprofv3 --kernel-trace --output-format csv
+    python tools/sweep_launches.py profiles/r4y_ttt_bwd_launches.csv.gz   # the committed reduction of round 4's trace (sweep, tail,
+                                                                          # recompute and fill dispatches only, times from 0)
 
 The default one-GPU bench runs two phases in one process: the replica path (the driver line) and the `fsdp1` point (FlatFSDP with
 its RCCL collectives over one rank).  Averages hide what differs between them (profiles/r4q_*: the sweep is the only kernel that
-changes, 0.82 -> 0.95 ms), so this prints, per phase, the distribution of the sweep launches' durations and - launch by launch -
-which kernels of other queues were running beside them.  A phase boundary is the first RCCL kernel after the warm-up collective."""
+changes, 0.82 -> 0.95 ms), so this prints, per phase: the distribution of the sweep launches' durations; which kernels of other
+queues ran beside them; and the RACE between a sweep and the tail kernel of the previous chunk, which become ready together (both
+wait for the same recompute): who was dispatched first, and how long the sweep took then.  A phase boundary is the first RCCL kernel
+after the first sweep, or - one rank's collectives are copies, not kernels - a pause of more than 5 s between sweeps."""
+import bisect
 import collections
 import csv
+import gzip
 import sys
 
 
-def main():
-    rows = list(csv.DictReader(open(sys.argv[1])))
-    ks = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?")) for r in rows)
-    t0 = ks[0][0]
-    is_sweep = lambda n: "mlp_bwd_cluster4" in n
-    is_ttt = lambda n: "mlp_bwd_tail4" in n or "mlp_recompute8" in n
-    is_rccl = lambda n: "nccl" in n.lower() or "rccl" in n.lower()
+def load(path):
+    fh = gzip.open(path, "rt") if path.endswith(".gz") else open(path)
+    ks = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?")) for r in csv.DictReader(fh))
+    return ks
+
+
+def is_sweep(n):
+    return "mlp_bwd_cluster4" in n or n == "sweep"
+
+
+def is_tail(n):
+    return "mlp_bwd_tail4" in n or n == "tail"
+
+
+def is_recompute(n):
+    return "mlp_recompute8" in n or n == "recompute"
+
+
+def phases(ks):
     sweeps = [k for k in ks if is_sweep(k[2])]
-    rc = [k for k in ks if is_rccl(k[2])]
-    # the sharded phase: from the first RCCL kernel that comes AFTER the first sweep (the warm-up all-reduce comes before any)
-    first_sweep = sweeps[0][0]
-    later = [k for k in rc if k[0] > first_sweep]
-    boundary = later[0][0] if later else None
-    print(f"{len(ks)} dispatches over {(ks[-1][1] - t0) / 1e9:.1f} s, {len(sweeps)} sweep launches, {len(rc)} RCCL kernels; "
-          f"sharded phase from t = {((boundary - t0) / 1e9 if boundary else float('nan')):.1f} s")
+    rc = [k for k in ks if ("nccl" in k[2].lower() or "rccl" in k[2].lower()) and k[0] > sweeps[0][0]]
+    boundary = rc[0][0] if rc else None
+    if boundary is None:
+        gaps = [(sweeps[i + 1][0] - sweeps[i][1], sweeps[i][1]) for i in range(len(sweeps) - 1)]
+        g, at = max(gaps)
+        if g > 5e9:
+            boundary = at + 1
+    first = [k for k in sweeps if boundary is None or k[0] < boundary]
+    second = [k for k in sweeps if boundary is not None and k[0] >= boundary]
+    return [("replica", first)] + ([("sharded (fsdp1)", second)] if second else []), boundary
+
+
+def race(sel, tails, recomputes):
+    """{(outcome, order): [sweep us, tail offset us, tail us, gap behind the recompute us]} for full-size sweep / tail pairs"""
+    tstarts = [k[0] for k in tails]
+    rends = sorted(k[1] for k in recomputes)
+    d = sorted((e - s) / 1e3 for s, e, *_ in sel)
+    med = d[len(d) // 2]
+    out = collections.defaultdict(list)
+    for s, e, *_ in sel:
+        dur = (e - s) / 1e3
+        if dur <= 0.6 * med:
+            continue                                            # the short last chunk of a scan
+        i = bisect.bisect_left(tstarts, s - 50_000)
+        if not (i < len(tails) and tails[i][0] < s + 50_000 and tails[i][1] - tails[i][0] > 100_000):
+            continue                                            # no full-size tail beside it (the first full chunk of a scan)
+        off = (tails[i][0] - s) / 1e3
+        j = bisect.bisect_right(rends, s) - 1
+        gap = (s - rends[j]) / 1e3 if j >= 0 else float("nan")
+        out[("slow" if dur > 1.12 * med_fast(d) else "fast", "tail first" if off < 0 else "sweep first")].append((dur, off, (tails[i][1] - tails[i][0]) / 1e3, gap))
+    return out
+
+
+def med_fast(sorted_durations):
+    """the fast mode's typical duration: the 25th percentile of the full-size launches"""
+    full = [x for x in sorted_durations if x > 0.6 * sorted_durations[len(sorted_durations) // 2]]
+    return full[len(full) // 4]
+
+
+def summarize(path):
+    ks = load(path)
+    t0 = ks[0][0]
+    ph, boundary = phases(ks)
+    tails = [k for k in ks if is_tail(k[2])]
+    recomputes = [k for k in ks if is_recompute(k[2])]
     others = [k for k in ks if not is_sweep(k[2])]
     starts = [k[0] for k in others]
-    import bisect
-
-    def beside(s, e):
-        out = []
-        i = bisect.bisect_left(starts, s - 50_000_000)            # kernels are shorter than 50 ms
-        while i < len(others) and others[i][0] < e:
-            a, b, n, q = others[i]
-            if b > s:
-                out.append((min(e, b) - max(s, a), n, q))
-            i += 1
-        return out
-
-    for phase, sel in (("replica", [k for k in sweeps if boundary is None or k[0] < boundary]), ("sharded (fsdp1)", [k for k in sweeps if boundary is not None and k[0] >= boundary])):
-        if not sel:
-            continue
+    res = {"dispatches": len(ks), "boundary_s": None if boundary is None else (boundary - t0) / 1e9, "phases": {}}
+    for name, sel in ph:
         d = sorted((e - s) / 1e3 for s, e, *_ in sel)
-        full = [x for x in d if x > 0.6 * d[len(d) // 2]]          # (the short last chunk of a scan is a launch of its own)
+        full = [x for x in d if x > 0.6 * d[len(d) // 2]]
         q = lambda p: full[min(len(full) - 1, int(p * len(full)))]
-        print(f"\n== {phase}: {len(sel)} launches, full-size ones: mean {sum(full) / len(full):.1f} us, p10 {q(0.1):.1f}, p50 {q(0.5):.1f}, p90 {q(0.9):.1f}, max {full[-1]:.1f}")
-        med = d[len(d) // 2]
-        alone, foreign = [], []
-        agg = collections.defaultdict(lambda: [0, 0.0])
-        for s, e, n, qq in sel:
-            dur = (e - s) / 1e3
-            if dur <= 0.6 * med:
-                continue
-            ov = [(t, nn, q2) for t, nn, q2 in beside(s, e) if not is_ttt(nn)]
-            t_for = sum(t for t, *_ in ov) / 1e3
-            (foreign if t_for > 0.05 * dur else alone).append(dur)
-            for t, nn, q2 in ov:
-                a = agg[nn[:80]]
-                a[0] += 1; a[1] += t / 1e3
-        m = lambda v: (sum(v) / len(v)) if v else float("nan")
-        print(f"   with only its own tail / recompute beside it: {len(alone)} launches, mean {m(alone):.1f} us;  with a foreign kernel beside it (> 5 % of its time): {len(foreign)} launches, mean {m(foreign):.1f} us")
-        for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:8]:
-            print(f"   beside a sweep: {c:5d} x, {t / 1e3:8.2f} ms overlapped  {n}")
-        # slow launches in time order: do they cluster?
-        slow = [(s - t0) / 1e9 for s, e, *_ in sel if (e - s) / 1e3 > 1.1 * q(0.5)]
-        print(f"   launches slower than 1.1 x the median: {len(slow)}" + (f", first at {slow[0]:.2f} s, last at {slow[-1]:.2f} s" if slow else ""))
+        foreign = collections.defaultdict(lambda: [0, 0.0])
+        for s, e, *_ in sel:
+            i = bisect.bisect_left(starts, s - 50_000_000)     # kernels are shorter than 50 ms
+            while i < len(others) and others[i][0] < e:
+                a, b, n, _q = others[i]
+                if b > s and not (is_tail(n) or is_recompute(n)):
+                    f = foreign[n[:80]]
+                    f[0] += 1; f[1] += (min(e, b) - max(s, a)) / 1e3
+                i += 1
+        r = race(sel, tails, recomputes)
+        res["phases"][name] = {"launches": len(sel), "mean": sum(full) / len(full), "p10": q(0.1), "p50": q(0.5), "p90": q(0.9), "max": full[-1],
+                               "foreign": dict(foreign),
+                               "race": {k: {"n": len(v), "sweep_us": sum(x[0] for x in v) / len(v), "tail_offset_us": sum(x[1] for x in v) / len(v),
+                                            "tail_us": sum(x[2] for x in v) / len(v), "gap_behind_recompute_us": sum(x[3] for x in v) / len(v)} for k, v in r.items()}}
+    return res
+
+
+def main():
+    res = summarize(sys.argv[1])
+    print(f"{res['dispatches']} dispatches; sharded phase from t = {res['boundary_s']} s")
+    for name, p in res["phases"].items():
+        print(f"\n== {name}: {p['launches']} sweep launches; full-size ones: mean {p['mean']:.1f} us, p10 {p['p10']:.1f}, p50 {p['p50']:.1f}, p90 {p['p90']:.1f}, max {p['max']:.1f}")
+        for n, (c, t) in sorted(p["foreign"].items(), key=lambda kv: -kv[1][1])[:6]:
+            print(f"   beside a sweep (not its own tail / recompute): {c:5d} x, {t / 1e3:8.2f} ms overlapped  {n}")
+        tot = sum(v["n"] for v in p["race"].values())
+        for (speed, order), v in sorted(p["race"].items()):
+            print(f"   {order:11s} / {speed}: {v['n']:5d} ({100 * v['n'] / max(1, tot):4.1f} %)  sweep {v['sweep_us']:7.1f} us  tail starts {v['tail_offset_us']:+5.2f} us, runs {v['tail_us']:5.1f} us;"
+                  f" sweep starts {v['gap_behind_recompute_us']:4.1f} us behind its recompute")
 
 
 if __name__ == "__main__":
