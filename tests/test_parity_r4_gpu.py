@@ -155,7 +155,7 @@ def test_backward_schedule_options_same_bits():
             assert e.sweep_error() == 0, (delay, early)
     finally:
         e.debug_option("tail_delay_us", 0)
-        e.debug_option("flags_memset_early", 0)
+        e.debug_option("flags_memset_early", 1)              # the library's default (csrc/ttt_mfma_bwd2.hip g_memset_early)
         e.debug_groups_per_chunk(0)
     for other in res[1:]:
         for k in res[0][2]:

@@ -49,12 +49,17 @@ void set_debug_sweep_prefetch(int v) { g_sweep_prefetch = v; }
 // on the sharded path, two launches in three the bad one).  With a delay > 0 a one-wave kernel in front of the tail holds its
 // stream for that many microseconds, so that the sweep's 192 workgroups are resident before the tail's 3 500 arrive.  Not measured
 // inside a training step yet (the GPU budget of round 4 ended): off.
-// A/B option "flags_memset_early" (default 0): the hand-over flags of the NEXT sweep are cleared right behind the current sweep
-// (in front of the recompute) instead of in front of the next sweep.  Why: the trace (profiles/r4y_sweep_launches.txt) shows the
-// sweep starting 13 - 15 us after the recompute ends - the memset - and the tail, released by an event behind the same recompute,
-// after the same 13 - 15 us of cross-queue latency: a coin toss who is dispatched first, and "tail first" is the slow outcome
-// (1.00 - 1.12 against 0.92 ms).  With the memset out of the way the sweep follows the recompute kernel-to-kernel.
-static int g_memset_early = 0;
+// Option "flags_memset_early" (default 1; 0 = the round-3 order, A/B): the hand-over flags of the NEXT sweep are cleared right behind
+// the current sweep (in front of the recompute) instead of in front of the next sweep.  Why: a rocprofv3 trace of the training step
+// (profiles/r4y_ttt_bwd_launches.csv.gz, tools/sweep_launches.py) shows the sweep starting 13 - 15 us after its recompute ends -
+// the memset - and the previous chunk's tail, released by an event behind the same recompute, after the same 13 - 15 us of
+// cross-queue latency: a coin toss who is dispatched first, and "tail first" is the slow outcome (1.00 - 1.12 against 0.92 ms: the
+// sweep's 192 whole-CU workgroups are then placed one by one between the tail's 3 500 small ones, and a cluster's early members
+// spin at their first hand-over).  It happens to 3 % of the launches on the replica path and to 60 % on the sharded path.  With
+// the memset out of the way the sweep follows its recompute kernel-to-kernel and has the chip before the tail arrives.
+// Bit-identical (tests/test_parity_r4_gpu.py); op level 11.16 against 11.24 ms; NOT yet measured inside a step (round 4's GPU
+// budget ended) - tools/_run_next_round_first_call.sh does that first.
+static int g_memset_early = 1;
 void set_debug_flags_memset_early(int v) { g_memset_early = v ? 1 : 0; }
 static int g_tail_delay_us = 0;
 void set_debug_tail_delay_us(int v) { g_tail_delay_us = v < 0 ? 0 : (v > 1000 ? 1000 : v); }
