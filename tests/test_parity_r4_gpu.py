@@ -139,8 +139,9 @@ SCAN_SWAP_DEFAULT = 1          # the library's (csrc/ttt_mfma2.hip g_scan_swap)
 def test_backward_schedule_options_same_bits():
     """Scheduling options of the TTT-MLP backward (csrc/ttt_mfma_bwd2.hip), both aimed at the race between a chunk's tail kernel and
     the next chunk's sweep that the rocprofv3 trace of round 4 shows (profiles/r4y_sweep_launches.txt): "tail_delay_us" (a one-wave
-    gate kernel in front of each tail kernel on its side stream) and "flags_memset_early" (the next sweep's hand-over flags cleared
-    behind the current sweep instead of in front of the next).  Pure scheduling: every gradient must be bit-identical."""
+    gate kernel in front of each tail kernel on its side stream), "flags_memset_early" (the next sweep's hand-over flags cleared
+    behind the current sweep instead of in front of the next) and "tail_gate_resident" (the gate waits until the next sweep's
+    workgroups have counted themselves in).  Pure scheduling: every gradient must be bit-identical."""
     from oracle import ttt_oracle as O
     from test_kernels_gpu import round_acts, run_mlp
     e = ext()
@@ -148,13 +149,15 @@ def test_backward_schedule_options_same_bits():
     res = []
     e.debug_groups_per_chunk(2)
     try:
-        for delay, early in ((0, 0), (25, 0), (0, 1), (25, 1)):
+        for delay, early, resident in ((0, 0, 0), (25, 0, 0), (0, 1, 0), (25, 1, 0), (0, 1, 1)):
             e.debug_option("tail_delay_us", delay)
             e.debug_option("flags_memset_early", early)
+            e.debug_option("tail_gate_resident", resident)   # the tail's gate waits for the next sweep's workgroups (counted in a flag word)
             res.append(run_mlp(e, d, 16, torch.bfloat16, impl="mfma"))
-            assert e.sweep_error() == 0, (delay, early)
+            assert e.sweep_error() == 0, (delay, early, resident)
     finally:
         e.debug_option("tail_delay_us", 0)
+        e.debug_option("tail_gate_resident", 0)
         e.debug_option("flags_memset_early", 1)              # the library's default (csrc/ttt_mfma_bwd2.hip g_memset_early)
         e.debug_groups_per_chunk(0)
     for other in res[1:]:

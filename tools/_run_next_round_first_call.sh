@@ -9,6 +9,7 @@
 #      default at the end of round 4 WITHOUT an in-step measurement (op level only) - this call is that measurement:
 #        TTT_FLAGS_MEMSET_EARLY=1   the memset moved behind the previous sweep: the sweep follows its recompute kernel-to-kernel
 #        TTT_TAIL_DELAY_US=25       a gate kernel in front of the tail
+#        TTT_TAIL_GATE_RESIDENT=1   the gate waits until the next sweep's workgroups have all started (never run on a device yet)
 #      (bench.py hands both to ext.debug_option); fsdp1.ttt_mlp_bwd_ms: 12.3 -> 10.9 ?  Adopt the winner as the default if the fsdp1
 #      point comes within 1 % of `value` AND the replica line does not move (it should gain too: 3 % of its launches are slow).  If it does not help: rocprofv3 --kernel-trace of that run, then
 #      tools/sweep_launches.py - compare which CUs / XCDs the tail's workgroups get in fast and slow launches
@@ -18,7 +19,7 @@
 cd /root/repo; mkdir -p gpurun_out/r5a; O=$GRAFT_REPO_ROOT/gpurun_out/r5a
 export TMPDIR=/tmp
 timeout 600 python -m pytest tests -x -q -m gpu > $O/gpu_suite.log 2>&1; echo "suite rc=$?"; tail -2 $O/gpu_suite.log
-for cfg in "TTT_FLAGS_MEMSET_EARLY=0" "TTT_FLAGS_MEMSET_EARLY=1" "TTT_FLAGS_MEMSET_EARLY=0 TTT_TAIL_DELAY_US=25" "TTT_FLAGS_MEMSET_EARLY=1 TTT_TAIL_DELAY_US=25"; do
+for cfg in "TTT_FLAGS_MEMSET_EARLY=0" "TTT_FLAGS_MEMSET_EARLY=1" "TTT_FLAGS_MEMSET_EARLY=0 TTT_TAIL_DELAY_US=25" "TTT_FLAGS_MEMSET_EARLY=1 TTT_TAIL_DELAY_US=25" "TTT_TAIL_GATE_RESIDENT=1"; do
   tag=$(echo $cfg | tr ' =' '__')
   env $cfg timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_$tag.json 2> $O/bench_$tag.err; echo "$cfg rc=$?"
   grep -h "^{" $O/bench_$tag.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print(round(d['value'],1), round(d['ms_per_step'],1), 'ttt bwd', round(r['avg_launch_ms'],3), 'fsdp1', d.get('fsdp1'))"

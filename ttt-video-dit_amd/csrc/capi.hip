@@ -67,6 +67,7 @@ int ttt_hip_debug_option(const char* name, int value) {
     else if (!strcmp(name, "sweep_deriver_wave0")) ttt::mfma::set_debug_sweep_deriver_wave0(value);      // 4 (default) / 2: which waves take the deriver role (A/B of the SIMD placement)
     else if (!strcmp(name, "own_bf16")) ttt::mfma::set_debug_own_bf16(value);                          // step record: inner-LayerNorm owner rows as bf16 (A/B)
     else if (!strcmp(name, "flags_memset_early")) ttt::mfma::set_debug_flags_memset_early(value);      // backward: hand-over flags of the next sweep cleared behind the current one (1 default / 0)
+    else if (!strcmp(name, "tail_gate_resident")) ttt::mfma::set_debug_tail_gate_resident(value);      // backward: the tail waits for the next sweep's workgroups to be resident (A/B, 0 default)
     else if (!strcmp(name, "tail_delay_us")) ttt::mfma::set_debug_tail_delay_us(value);                // backward: gate kernel of `value` us in front of each tail kernel (0 off)
     else if (!strcmp(name, "scan_swap")) ttt::mfma::set_debug_scan_swap(value);                        // forward scan: half-chunk swap of the LDS tile rows (A/B)
     else if (!strcmp(name, "sweep_fault")) ttt::mfma::set_debug_sweep_fault(value);              // fault injection: workgroup 3 of every sweep cluster leaves early

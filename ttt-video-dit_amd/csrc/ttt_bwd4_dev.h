@@ -65,6 +65,7 @@ struct SweepParams4 : b2::SweepParams2 {
     int G, K;
     int prefetch;                          // 1: owners / derivers touch the records of step i - 2 (L2 prefetch); 0: off (A/B)
     int own16;                             // as RecomputeParams::own16 (both kernels of a backward call agree)
+    unsigned* resident;                    // optional: every workgroup adds 1 when it starts (the tail's gate kernel waits for all of them: option tail_gate_resident)
 };
 constexpr size_t PARK4_BYTES = 12 * FRAG_BYTES;
 void launch_sweep_cluster4(const SweepParams4& bp, int nbh, hipStream_t s);

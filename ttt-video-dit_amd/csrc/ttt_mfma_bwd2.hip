@@ -61,6 +61,16 @@ void set_debug_sweep_prefetch(int v) { g_sweep_prefetch = v; }
 // budget ended) - tools/_run_next_round_first_call.sh does that first.
 static int g_memset_early = 1;
 void set_debug_flags_memset_early(int v) { g_memset_early = v ? 1 : 0; }
+// A/B option "tail_gate_resident" (default 0; needs flags_memset_early): instead of a fixed delay the gate kernel in front of a tail
+// waits until every workgroup of the NEXT sweep has started (they count themselves in word 1 of the first flag line, which the
+// early memset clears before the recompute), at most 200 us: the tail can then never be placed between the sweep's clusters.
+// Prepared after round 4's GPU budget ended: compiles, never run on a device.
+static int g_tail_gate_resident = 0;
+void set_debug_tail_gate_resident(int v) { g_tail_gate_resident = v ? 1 : 0; }
+__global__ __launch_bounds__(64) void tail_gate_resident_kernel(const unsigned* counter, unsigned expected, unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();                 // constant 100 MHz counter
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected && wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
 static int g_tail_delay_us = 0;
 void set_debug_tail_delay_us(int v) { g_tail_delay_us = v < 0 ? 0 : (v > 1000 ? 1000 : v); }
 __global__ __launch_bounds__(64) void tail_gate_kernel(unsigned long long ticks) {
@@ -187,6 +197,7 @@ static int mlp_backward4(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws,
     bp.xch = xch; bp.flags = flags; bp.fast_records = g_fast_records;
     bp.err = err_word; bp.fault = g_sweep_fault;
     bp.W1c = a->W1_checkpoints; bp.W2c = a->W2_checkpoints; bp.wfinal = wfinal; bp.park = park; bp.G = G; bp.K = K; bp.prefetch = g_sweep_prefetch; bp.own16 = g_own16 && sweep_supports_own16();
+    bp.resident = (g_tail_gate_resident && g_memset_early) ? flags + 1 : nullptr;
 
     int rc = 0;                               // a failed event / stream call leaves the two streams unordered: the call fails (-12)
     auto chk = [&](hipError_t e) { if (e != hipSuccess) rc = -12; };
@@ -202,6 +213,8 @@ static int mlp_backward4(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws,
     };
     auto tail = [&](int ch, hipStream_t st) {
         if (g_tail_delay_us > 0 && st != s) hipLaunchKernelGGL(tail_gate_kernel, dim3(1), dim3(64), 0, st, 100ull * (unsigned long long)g_tail_delay_us);
+        if (g_tail_gate_resident && g_memset_early && st != s && ch > 0)       // (chunk 0's tail has no sweep beside it)
+            hipLaunchKernelGGL(tail_gate_resident_kernel, dim3(1), dim3(64), 0, st, (const unsigned*)(flags + 1), 4u * (unsigned)(nbh < per_launch ? nbh : per_launch), 20000ull);
         const int g0 = ch * gpc, ng = (K - g0 < gpc) ? K - g0 : gpc;
         const int lo = g0 * G, hi = ((g0 + ng) * G < NC) ? (g0 + ng) * G : NC;
         s4::launch_tail4((const __bf16*)a->grad_L_XQW, (const __bf16*)a->last_eta, (const __bf16*)a->grad_L_XV, slots + (size_t)(ch & 1) * slot_buf,

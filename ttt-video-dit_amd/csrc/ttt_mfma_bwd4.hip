@@ -198,6 +198,7 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
     float* db2L = db1L + 64;
     float* gamL = db2L + 64;
     unsigned* syncw = reinterpret_cast<unsigned*>(gamL + 64);      // [0] hand-over number the owners have seen complete, [1] fast-path verdict, [2] poisoned
+    if (p.resident != nullptr && threadIdx.x == 0) __hip_atomic_fetch_add(p.resident, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // Round 4: the OUTPUT path's share of db2 (column sums of dZ2b over the 64 tokens of a step) is summed by the owners from
     // their fp32 dZ2b values, not by a ones-MFMA over the bf16 tile the compute waves consume: db2 enters d(eta) of every token
     // of every earlier step, so the rounding of that tile showed up 1 : 1 in the learning-rate-gate gradients (0.32 on the

@@ -40,6 +40,7 @@ void set_debug_sweep_fault(int v);     // DEBUG fault injection: workgroup 3 of 
 void set_debug_rc_nt(int v);           // revision-4 recompute: non-temporal stores of the step records (A/B)
 void set_debug_sweep_prefetch(int v);  // revision-4 sweep: 1 (default) L2 prefetch touches two steps ahead, 0 off
 void set_debug_flags_memset_early(int v);  // backward schedule: clear the next sweep's hand-over flags behind the current sweep (1) (1, default) instead of in front of the next (0)
+void set_debug_tail_gate_resident(int v);  // backward schedule: the tail's gate waits until the next sweep's workgroups have all started (0 default; needs flags_memset_early)
 void set_debug_tail_delay_us(int v);   // backward schedule: a gate kernel of v microseconds in front of each tail kernel on its side stream (0 = off, default)
 void set_debug_scan_swap(int v);       // forward scan: 1 = the two 8-byte units of a 16-byte tile chunk swapped in rows with bit 3 ^ bit 4 set (bank conflicts of the row walkers), 0 off
 void set_debug_sweep_records_bf16(int v);   // revision-4 sweep: hand-over records carry the partial d(gZ2) tiles as bf16 (0 default until timed)
