@@ -1,6 +1,6 @@
 #!/bin/bash
 # Prepared at the end of round 4 (GPU budget spent): the measurements that decide round 4's open items, for the FIRST gpurun call
-# of the next round (~10 GPU-minutes, one box, back to back).
+# of the next round (~17 GPU-minutes: the suite 3.5, five bench runs of 2.7; one box, back to back).
 #   1. the full GPU suite on the final tree (incl. test_tail_gate_delay_same_bits, which has not run on a device yet)
 #   2. THE open question of the sharded path (profiles/r4y_sweep_launches.txt): on the fsdp1 point two sweep
 #      launches in three run 1.12 instead of 0.92 ms, paired with a slower tail kernel beside them, with no third kernel involved.
