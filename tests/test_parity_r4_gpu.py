@@ -1,4 +1,6 @@
 """Round-4 parity tests on the device (all through the C ABI of libttt_hip.so)."""
+import os
+
 import pytest
 import torch
 
@@ -149,7 +151,10 @@ def test_backward_schedule_options_same_bits():
     res = []
     e.debug_groups_per_chunk(2)
     try:
-        for delay, early, resident in ((0, 0, 0), (25, 0, 0), (0, 1, 0), (25, 1, 0), (0, 1, 1)):
+        # the last combination - the gate that waits for the sweep's workgroups - was written after round 4's GPU budget had ended
+        # and has never run on a device: opt-in (TTT_TEST_VARIANTS=1, set by tools/_run_next_round_first_call.sh) until it has
+        combos = [(0, 0, 0), (25, 0, 0), (0, 1, 0), (25, 1, 0)] + ([(0, 1, 1)] if os.environ.get("TTT_TEST_VARIANTS", "0") == "1" else [])
+        for delay, early, resident in combos:
             e.debug_option("tail_delay_us", delay)
             e.debug_option("flags_memset_early", early)
             e.debug_option("tail_gate_resident", resident)   # the tail's gate waits for the next sweep's workgroups (counted in a flag word)

@@ -18,7 +18,7 @@
 #      confirm that only the timing of the reduce decides the regime.
 cd /root/repo; mkdir -p gpurun_out/r5a; O=$GRAFT_REPO_ROOT/gpurun_out/r5a
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests -x -q -m gpu > $O/gpu_suite.log 2>&1; echo "suite rc=$?"; tail -2 $O/gpu_suite.log
+TTT_TEST_VARIANTS=1 timeout 600 python -m pytest tests -x -q -m gpu > $O/gpu_suite.log 2>&1; echo "suite rc=$?"; tail -2 $O/gpu_suite.log
 for cfg in "TTT_FLAGS_MEMSET_EARLY=0" "TTT_FLAGS_MEMSET_EARLY=1" "TTT_FLAGS_MEMSET_EARLY=0 TTT_TAIL_DELAY_US=25" "TTT_FLAGS_MEMSET_EARLY=1 TTT_TAIL_DELAY_US=25" "TTT_TAIL_GATE_RESIDENT=1"; do
   tag=$(echo $cfg | tr ' =' '__')
   env $cfg timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_$tag.json 2> $O/bench_$tag.err; echo "$cfg rc=$?"
