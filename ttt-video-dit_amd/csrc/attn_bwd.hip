@@ -108,6 +108,13 @@ void launch_backward(const BwdParams& p, hipStream_t s) {
     launch_dkdv_v2(p, s);
     launch_dq_v2(p, s);
 }
+// single pass (attn_body.h bwd_fused, round 5): delta, then ONE kernel for dK, dV and the fp32 dQ accumulator, then its conversion
+void launch_backward_fused(const BwdParams& p, float* dq_acc, hipStream_t s) {
+    const long rows = (long)p.B * p.NH * p.S;
+    const int dgrid = (int)((rows * 8 + 255) / 256 < 65536 ? (rows * 8 + 255) / 256 : 65536);
+    hipLaunchKernelGGL(attn_delta_kernel, dim3(dgrid), dim3(256), 0, s, p);
+    launch_bwd_fused(p, dq_acc, s);
+}
 
 }  // namespace attn
 }  // namespace ttt
