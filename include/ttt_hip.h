@@ -41,7 +41,7 @@ extern "C" {
  * ttt_hip_sweep_error_clear), -10 (fewer than 4 compute units visible), -11 (no host-mapped error word), -12 (a HIP event /
  * stream call of the backward's two-stream schedule failed); the round-1 exports ttt_hip_debug_variant / ttt_hip_debug_helpers
  * are gone.  1: rounds 1 - 3. */
-#define TTT_HIP_ABI_VERSION 3
+#define TTT_HIP_ABI_VERSION 2
 
 enum { TTT_DTYPE_BF16 = 0, TTT_DTYPE_F32 = 1 };
 /* implementation selector: AUTO picks the MFMA kernels when the geometry is supported - bf16, F=64 and
@@ -206,13 +206,6 @@ typedef struct ttt_attn_bwd_args {
 } ttt_attn_bwd_args;
 int ttt_hip_attn_forward(const ttt_attn_fwd_args* a, void* stream);
 int ttt_hip_attn_backward(const ttt_attn_bwd_args* a, void* stream);
-/* The same backward in ONE pass over the score tiles (S and dP computed once: 5 matrix products per tile instead of 7): dK and dV
- * as above; the dQ blocks of all key blocks are added into the caller's fp32 accumulator dq_acc [B*NH][S][64]
- * (ttt_hip_attn_backward_fused_workspace(B, NH, S) bytes, 16-byte aligned; zeroed by the call) with L2 atomics and then scaled
- * and rounded into dQ.  dK / dV are bit-identical run to run, dQ is not (the order of the atomic additions is not fixed; the
- * differences are at the level of the last bf16 bit). */
-size_t ttt_hip_attn_backward_fused_workspace(int B, int NH, int S);
-int ttt_hip_attn_backward_fused(const ttt_attn_bwd_args* a, float* dq_acc, size_t dq_acc_bytes, void* stream);
 
 /* Fused per-head LayerNorm(64, eps) + 3-D RoPE of the attention's q and k (reference cogvideo/dit.py:184-195,
  * cogvideo/utils.py:424-437): q_raw / k_raw / q / k / dq_raw / dk_raw are contiguous [B, S, NH*64] bf16; tokens

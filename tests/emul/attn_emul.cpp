@@ -89,21 +89,6 @@ int emul_attn_dkdv_n(const attn::BwdParams* p, int variant, int nsub, char* msg,
 
 int emul_attn_dkdv(const attn::BwdParams* p, int variant, char* msg, int msg_len) { return emul_attn_dkdv_n(p, variant, 1, msg, msg_len); }
 
-// single-pass backward (attn_body.h bwd_fused): dK, dV and the fp32 dQ accumulator [B*NH][S][64] (zeroed by the caller; the emulated
-// workgroups run one after the other, so the accumulation order is fixed here - on the device it is not)
-int emul_attn_bwd_fused(const attn::BwdParams* p, float* dq_acc, char* msg, int msg_len) {
-    const int nkb = (p->S + attnb::F1_KEYS - 1) / attnb::F1_KEYS, nbh = p->B * p->NH;
-    int races = 0;
-    for (int b = 0; b < nbh * nkb; ++b) {
-        int bh, kvb;
-        attnb::head_of_block(b, nkb, nbh, bh, kvb);
-        const emul::RaceReport r = emul::run_group(attnb::F1_NW, [&](emul::EmulWave& w) { attnb::bwd_fused(w, *p, dq_acc, bh, kvb); });
-        if (r.races && !races && msg) snprintf(msg, msg_len, "%s", r.first.c_str());
-        races += r.races;
-    }
-    return races;
-}
-
 // LDS bank model (wave_emul.h bank_cost) over the first workgroup of the dQ (kernel 0) or 12-wave dK / dV (kernel 1) body:
 // out[0..8] = {passes, conflict passes, instructions} of the plain reads (b128 row fragments, row scalars), the stores, and the
 // transposed reads.  Returns the number of LDS races (0).
@@ -112,10 +97,6 @@ int emul_attn_bank_model(const attn::BwdParams* p, int kernel, long* out) {
     if (kernel == 0) r = emul::run_group(8, [&](emul::EmulWave& w) { attnb::dq(w, *p, 0, 0); }, true);
     else if (kernel == 1) r = emul::run_group(12, [&](emul::EmulWave& w) { attnb::dkdv<12, true>(w, *p, 0, 0); }, true);
     else if (kernel == 2) r = emul::run_group(8, [&](emul::EmulWave& w) { attnb::dq_staged<2, true>(w, *p, 0, 0); }, true);      // swizzled tiles
-    else if (kernel == 4) {                                                                                                     // single-pass backward
-        std::vector<float> acc((size_t)p->B * p->NH * p->S * 64, 0.f);
-        r = emul::run_group(attnb::F1_NW, [&](emul::EmulWave& w) { attnb::bwd_fused(w, *p, acc.data(), 0, 0); }, true);
-    }
     else r = emul::run_group(12, [&](emul::EmulWave& w) { attnb::dkdv_staged<12, true, 2, true>(w, *p, 0, 0); }, true);
     const emul::BankCount* c[3] = {&r.rd, &r.wr, &r.tr};
     for (int k = 0; k < 3; ++k) { out[3 * k] = c[k]->passes; out[3 * k + 1] = c[k]->conflicts; out[3 * k + 2] = c[k]->instructions; }

@@ -9,7 +9,6 @@
 //   ds_read_b64_tr_b16       : within a 16-lane group, lane i receives element (i & 3) of the 8-byte chunks addressed by
 //                              lanes 4e + (i >> 2), e = 0..3   (probe: tools/probe_tr.hip)
 #pragma once
-#include <atomic>
 #include <barrier>
 #include <cmath>
 #include <cstring>
@@ -164,7 +163,6 @@ struct EmulWave {
     template <class T> T ld(tile_t p) { return lds_load<T>(2 * p.e); }
     template <class T> void st(tile_t p, T v) { lds_store<T>(2 * p.e, v); }
     bf16x4 tr(tile_t p) { return tr_read(2 * p.e); }
-    void atomic_add(float* p, float v) const { std::atomic_ref<float>(*p).fetch_add(v, std::memory_order_relaxed); }   // global_atomic_add_f32
     float log(float x) const { return std::log(x); }
     float rsq(float x) const { return 1.0f / std::sqrt(x); }
     float exp2(float x) const { return std::exp2(x); }

@@ -256,51 +256,3 @@ def test_dq_with_64_query_rows_per_wave_is_bit_identical(emul, B, NH, S, layout)
         assert emul.emul_attn_dq_wide(ctypes.byref(p), nsub, msg, 256) == 0, msg.value.decode()
         assert not torch.isnan(dq.float()).any()
         assert torch.equal(dq.float(), ref), nsub
-
-
-def _fused(emul, p, B, NH, S):
-    acc = torch.zeros(B * NH, S, 64)
-    msg = ctypes.create_string_buffer(256)
-    emul.emul_attn_bwd_fused.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
-    races = emul.emul_attn_bwd_fused(ctypes.byref(p), acc.data_ptr(), msg, 256)
-    assert races == 0, msg.value.decode()
-    return acc
-
-
-# one workgroup of 256 keys partly filled (40), two workgroups with a ragged key AND query tail (300), exact tiles (256, bhsd),
-# four key blocks / ten query tiles (577), a second head mapping (8 heads: whole heads per XCD)
-@pytest.mark.parametrize("B,NH,S,layout", [(1, 2, 40, "bshd"), (2, 3, 300, "bshd"), (1, 8, 128, "bhsd"), (1, 1, 256, "bhsd"), (1, 1, 577, "bshd")])
-def test_emulated_single_pass_backward_vs_oracle(emul, B, NH, S, layout):
-    """bwd_fused (csrc/attn_body.h, round 5): dK, dV and dQ from ONE pass over the score tiles - dS goes through an LDS image to
-    the waves that contract it over the keys, the dQ blocks are added to an fp32 accumulator (atomics on the device).  Against
-    the fp64 oracle at the tolerances of the two-kernel path, dK / dV bit-identical to dkdv<8, ACC_INIT> (the same arithmetic
-    in the same order), dQ within the bf16 rounding of dS of the two-kernel dQ; no LDS race between the image being filled and
-    the image being read."""
-    q, k, v, do = _make(B, NH, S, 31 + S, layout)
-    ro, rl, rq, rk, rv = _oracle(q, k, v, do)
-    p, (dq, dk, dv), keep = _bwd_params(q, k, v, do, ro, rl)
-    acc = _fused(emul, p, B, NH, S)
-    dq1 = (acc * p.scale).view(B, NH, S, 64)
-    assert not torch.isnan(dk.float()).any() and not torch.isnan(dv.float()).any() and not torch.isnan(dq1).any()
-    errs = (rel_l2(dq1.bfloat16(), rq), rel_l2(dk, rk), rel_l2(dv, rv))
-    print((B, NH, S), errs)
-    assert max(errs) < 2e-2, errs
-    k1, v1 = dk.float().clone(), dv.float().clone()
-    p2, (dq2, dk2, dv2), keep2 = _bwd_params(q, k, v, do, ro, rl)
-    msg = ctypes.create_string_buffer(256)
-    assert emul.emul_attn_dkdv(ctypes.byref(p2), 3, msg, 256) == 0, msg.value.decode()
-    assert torch.equal(dk2.float(), k1) and torch.equal(dv2.float(), v1)
-    assert emul.emul_attn_dq(ctypes.byref(p2), msg, 256) == 0
-    assert rel_l2(dq1.bfloat16(), dq2) < 1e-2
-
-
-def test_single_pass_backward_bank_model(emul):
-    """LDS bank model of bwd_fused: what its dS image costs (stores by key row, transposed reads by the dQ waves)."""
-    q, k, v, do = _make(1, 1, 768, 5, "bshd")
-    ro, rl, *_ = _oracle(q, k, v, do)
-    p, outs, keep = _bwd_params(q, k, v, do, ro, rl)
-    out = (ctypes.c_long * 9)()
-    assert emul.emul_attn_bank_model(ctypes.byref(p), 4, out) == 0
-    rd, wr, tr = out[0:3], out[3:6], out[6:9]
-    print("single pass: reads", rd, "stores", wr, "transposed", tr)
-    assert rd[1] == 0

@@ -37,8 +37,6 @@ def main():
     ap.add_argument("--stages", default="", help="comma list of attention-backward variants to A/B in interleaved rounds in THIS process: "
                     "DQ:DKDV = tiles of 64 per LDS stage in the dQ (1 / 2) and the dK / dV kernel (1 .. 4), e.g. 1:1,2:2,2:3,2:4,1:2")
     ap.add_argument("--rounds", type=int, default=5)
-    ap.add_argument("--fused", action="store_true", help="A/B of the single-pass backward (dQ through fp32 L2 atomics) against the dK / dV + dQ "
-                    "kernel pair: interleaved rounds in THIS process, medians, dQ difference, run-to-run spread of dQ")
     a = ap.parse_args()
     import test_time_training as ext
     from ttt_amd.models.cogvideo.attention import SegmentAttention
@@ -80,29 +78,6 @@ def main():
         ext.debug_option("attn_stage_dq", 1)
         ext.debug_option("attn_stage_dkdv", 2)
         res["bwd_by_stage"] = {st: {"median_ms": sorted(v)[len(v) // 2], "min_ms": min(v)} for st, v in times.items()}
-    if a.fused:
-        acc = torch.empty(B * NH, S, 64, device=dev, dtype=torch.float32)
-        def probe(n):
-            def fn():
-                ext.debug_option("attn_fused_probe", n)
-                ext.attn_backward(q, k, v, out, do, lse, delta, dq, dk, dv, 0.125, dq_acc=acc)
-                ext.debug_option("attn_fused_probe", 0)
-            return fn
-        run = {"two_kernel": lambda: ext.attn_backward(q, k, v, out, do, lse, delta, dq, dk, dv, 0.125),
-               "fused": lambda: ext.attn_backward(q, k, v, out, do, lse, delta, dq, dk, dv, 0.125, dq_acc=acc),
-               "probe_no_atomics": probe(1), "probe_no_dq_phase": probe(2)}
-        times, grads = {m: [] for m in run}, {}
-        for rnd in range(a.rounds):
-            for m, fn in run.items():
-                times[m].append(timeit(fn, a.iters))
-                torch.cuda.synchronize()
-                grads.setdefault(m, []).append([x.clone() for x in (dq, dk, dv)] if rnd < 2 else None)
-        rl2 = lambda x, y: float((x.double() - y.double()).norm() / y.double().norm())
-        res["bwd_fused_ab"] = {m: {"median_ms": sorted(v)[len(v) // 2], "min_ms": min(v), "tflops_median": 2.5 * flops / sorted(v)[len(v) // 2] / 1e9} for m, v in times.items()}
-        res["bwd_fused_ab"]["dq_fused_vs_two_kernel_rel_l2"] = rl2(grads["fused"][0][0], grads["two_kernel"][0][0])
-        res["bwd_fused_ab"]["dq_fused_run_to_run_rel_l2"] = rl2(grads["fused"][1][0], grads["fused"][0][0])
-        res["bwd_fused_ab"]["dk_dv_bit_identical"] = bool(torch.equal(grads["fused"][0][1], grads["two_kernel"][0][1]) and torch.equal(grads["fused"][0][2], grads["two_kernel"][0][2]))
-        res["bwd_fused_ab"]["two_kernel_deterministic"] = bool(all(torch.equal(x, y) for x, y in zip(grads["two_kernel"][0], grads["two_kernel"][1])))
     if not a.no_sdpa:
         qq, kk, vv = (x.detach().clone().requires_grad_(True) for x in (q, k, v))
         t = timeit(lambda: F.scaled_dot_product_attention(qq, kk, vv), a.iters)

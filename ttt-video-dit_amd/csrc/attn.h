@@ -35,11 +35,6 @@ void launch_backward(const BwdParams& p, hipStream_t s);
 // dQ and dK / dV through the workgroup bodies of attn_body.h (attn_v2.hip)
 void launch_dq_v2(const BwdParams& p, hipStream_t s);
 void launch_dkdv_v2(const BwdParams& p, hipStream_t s);
-// single-pass backward (attn_body.h bwd_fused): dK, dV and dQ from one pass; dq_acc = caller's fp32 workspace [B*NH][S][64]
-size_t bwd_fused_workspace_bytes(int B, int NH, int S);
-void launch_bwd_fused(const BwdParams& p, float* dq_acc, hipStream_t s);      // (the kernels; attn_v2.hip)
-void launch_backward_fused(const BwdParams& p, float* dq_acc, hipStream_t s);  // delta + the above (attn_bwd.hip)
-void set_debug_attn_fused_probe(int v);           // timing probes of the single-pass backward (1: no atomics, 2: no dQ phase), 0 default
 void set_debug_attn_dq_wide(int v);                // 1: dQ with 64 query rows per wave (A/B), 0 default
 void set_debug_attn_stage(int which, int v);      // tiles of 64 per LDS stage: which = 0 both kernels, 1 dQ (1 / 2), 2 dK / dV (1 .. 4); default 2
 

@@ -893,155 +893,5 @@ TTT_BODY_FN void dkdv_staged(BK& bk, const BwdParams& p, int bh, int kvb) {
         }
 }
 
-// ---------------------------------------------------------------------------------------------- single-pass backward (round 5)
-// dK, dV AND dQ from ONE pass over the score tiles: S and dP are computed once (5 matrix products per tile instead of the 7 of
-// the dkdv + dq kernel pair, one exp2 per score instead of two).  Decomposition of dkdv<8, ACC_INIT>: a workgroup owns 256 keys,
-// wave w the keys [32 w, 32 w + 32) as register-resident B operands with its dK / dV accumulators, query tiles of 64 stream
-// through LDS.  The score tiles come out as (rows = query, lane = key): in place they are the A operands of the products that
-// contract over the QUERY index (dV, dK), but dQ = dS K contracts over the KEY index, i.e. over the lanes - so the bf16 dS block a
-// wave packs for its dK product is ALSO written to an LDS image [256 keys][64 queries] (4 x ds_write_b64 per block), and one
-// iteration later (double-buffered image, no extra barrier) every wave forms one 32 x 32 block of the tile's dQ = dS K over half
-// of the workgroup's keys: A = transposed reads of the dS image (lane = query, k-slots = keys), B = this wave's K^T fragments,
-// fetched ONCE per workgroup (through the same image area) and kept in 32 registers.  The partial block is added to an fp32
-// accumulator [B*NH][S][64] with no-return L2 atomics (a head's workgroups share an XCD - head_of_block - and sweep the query
-// tiles together, so the lines they add into sit in that XCD's L2); attn_dqacc_convert_kernel scales and rounds it to bf16.
-// The summation order of dQ over key blocks is therefore not fixed: dQ is NOT run-to-run bit-reproducible (dK, dV are);
-// the two-kernel deterministic path stays selectable (debug option "attn_bwd_fused" = 0).
-// Per wave and tile: 32 + 8 MFMAs, 32 + 8 fragment reads and 8 x 8-byte stores of LDS traffic, 16 atomic instructions.
-constexpr int F1_NW = 8, F1_KEYS = 32 * F1_NW;
-constexpr int DS_ELEMS = F1_KEYS * AS;                          // one dS image [256 keys][64 queries], row stride 72
-constexpr int LDS_BWD1 = (2 * DKV_BUF_ELEMS + 2 * DS_ELEMS) * 2;
-
-TTT_BODY_FN bf16x4 lo4(const bf16x8& v) { return __builtin_shufflevector(v, v, 0, 1, 2, 3); }
-TTT_BODY_FN bf16x4 hi4(const bf16x8& v) { return __builtin_shufflevector(v, v, 4, 5, 6, 7); }
-
-// PROBE (timing probes of the device A/B, never shipped as a result): 1 = the dQ blocks are formed but not added (what the atomics
-// cost), 2 = no dQ phase at all (what the dS image + the 8 extra MFMAs cost)
-template <int PROBE = 0, class BK>
-TTT_BODY_FN void bwd_fused(BK& bk, const BwdParams& p, float* dq_acc, int bh, int kvb) {
-    const int tid = bk.thread(), wv = bk.wave(), l = bk.lane(), h = l >> 5, c = l & 31;
-    const int bb = bh / p.NH, hh = bh % p.NH;
-    const __bf16* Qp = p.Q + (long)bb * p.q_sb + (long)hh * p.q_sh;
-    const __bf16* Kp = p.K + (long)bb * p.k_sb + (long)hh * p.k_sh;
-    const __bf16* Vp = p.V + (long)bb * p.v_sb + (long)hh * p.v_sh;
-    const __bf16* dOp = p.dO + (long)bb * p.do_sb + (long)hh * p.do_sh;
-    const float* lse = p.LSE + (long)bh * p.S;
-    const float* del = p.Delta + (long)bh * p.S;
-    float* acc_base = dq_acc + (long)bh * p.S * 64;
-
-    const int wkey0 = kvb * F1_KEYS;                   // the workgroup's first key
-    const int key0 = wkey0 + 32 * wv;                  // this wave's first key
-    const int krow = key0 + c;
-    bf16x8 Kf[4], Vf[4];                               // B operands of S = Q K^T, dP = dO V^T: lane = key, 8 contiguous d per k-slice
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-        Kf[kk] = krow < p.S ? *reinterpret_cast<const bf16x8*>(Kp + (long)krow * p.k_ss + 16 * kk + 8 * h) : zero_frag();
-        Vf[kk] = krow < p.S ? *reinterpret_cast<const bf16x8*>(Vp + (long)krow * p.v_ss + 16 * kk + 8 * h) : zero_frag();
-    }
-    f32x16 dK[2] = {zero16(), zero16()}, dV[2] = {zero16(), zero16()};   // tiles (rows = key, lane = d in block db)
-    const float sc = p.scale * LOG2E, inv_scale = 1.0f / p.scale;
-
-    // role in the dQ product of a tile: block (query block qx, feature block dx) over the keys [128 kh, 128 kh + 128)
-    const int qx = (wv >> 1) & 1, dx = wv & 1, kh = wv >> 2;
-
-    const int nt = (p.S + 63) / 64;
-    const typename BK::tile_t lds = bk.lds_base();
-    const typename BK::tile_t ds0 = lds + 2 * DKV_BUF_ELEMS;
-    QStage st;
-    qstage_issue<true>(st, p, Qp, dOp, lse, del, inv_scale, 0, tid);
-    qstage_park(bk, st, lds, tid);
-    {   // the workgroup's K rows -> image 1 (rows = keys; keys >= S are zero rows: their dS columns contribute nothing to dQ)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int id = tid + 512 * i, row = id >> 3, col = (id & 7) * 8;
-            const int key = wkey0 + row;
-            const u32x4 v = key < p.S ? *reinterpret_cast<const u32x4*>(Kp + (long)key * p.k_ss + col) : zero_u4();
-            bk.st(ds0 + (DS_ELEMS + row * AS + col), v);
-        }
-    }
-    bk.barrier();
-    bf16x8 KTf[4][2];                                  // B operands of dQ = dS K: lane = d (32 dx + c), k-slots = keys (pi order)
-#pragma unroll
-    for (int jb = 0; jb < 4; ++jb)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) KTf[jb][s] = tr_frag_pi(bk, ds0 + DS_ELEMS, AS, 128 * kh + 32 * jb, s, 32 * dx, l);
-    // (image 1 is first overwritten in iteration 1, behind the barrier that ends iteration 0)
-
-    for (int j = 0; j <= nt; ++j) {
-        const typename BK::tile_t buf = lds + (j & 1) * DKV_BUF_ELEMS;
-        const typename BK::tile_t Qt = buf, Dt = buf + KT_ELEMS;
-        const typename BK::tile_t dsw = ds0 + (j & 1) * DS_ELEMS, dsr = ds0 + ((j + 1) & 1) * DS_ELEMS;
-        const bool more = j + 1 < nt;
-        if (more) qstage_issue<true>(st, p, Qp, dOp, lse, del, inv_scale, (j + 1) * 64, tid);
-        if (j < nt) {
-#pragma unroll
-            for (int qb = 0; qb < 2; ++qb) {
-                f32x16 Sc = rows_from_lds(bk, buf, 0, 32 * qb, h);      // -LSE / scale
-                f32x16 dP = rows_from_lds(bk, buf, 1, 32 * qb, h);      // -Delta
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    Sc = bk.mma3216(row_frag(bk, Qt, AS, 32 * qb, 16 * kk, l), Kf[kk], Sc);
-                    dP = bk.mma3216(row_frag(bk, Dt, AS, 32 * qb, 16 * kk, l), Vf[kk], dP);
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float pr = bk.exp2(Sc[r] * sc);
-                    TTT_PIN_IN_BRANCH(pr);
-                    Sc[r] = pr;
-                    float ds = pr * dP[r];
-                    TTT_PIN_IN_BRANCH(ds);
-                    dP[r] = ds;
-                }
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const bf16x8 pf = pack(Sc, s), df = pack(dP, s);
-                    // dS block -> image [key][query]: lane (c, h) holds key 32 wv + c, queries 32 qb + 16 s + 8 (e >> 2) + 4 h + (e & 3)
-                    const typename BK::tile_t cell = dsw + ((32 * wv + c) * AS + 32 * qb + 16 * s + 4 * h);
-                    bk.st(cell, lo4(df));
-                    bk.st(cell + 8, hi4(df));
-#pragma unroll
-                    for (int db = 0; db < 2; ++db) {
-                        dV[db] = bk.mma3216(pf, tr_frag_pi(bk, Dt, AS, 32 * qb, s, 32 * db, l), dV[db]);
-                        dK[db] = bk.mma3216(df, tr_frag_pi(bk, Qt, AS, 32 * qb, s, 32 * db, l), dK[db]);
-                    }
-                }
-            }
-        }
-        if (j > 0 && PROBE != 2) {                      // dQ of tile j - 1 from the image the previous iteration filled
-            f32x16 acc = zero16();                      // block (rows = query, lane = d)
-#pragma unroll
-            for (int jb = 0; jb < 4; ++jb)
-#pragma unroll
-                for (int s = 0; s < 2; ++s)
-                    acc = bk.mma3216(tr_frag_pi(bk, dsr, AS, 128 * kh + 32 * jb, s, 32 * qx, l), KTf[jb][s], acc);
-            const int q0 = (j - 1) * 64 + 32 * qx;
-            float* out = acc_base + (long)q0 * 64 + 32 * dx + c;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int qr = row_of(r, h);
-                if (PROBE == 1) {
-                    if (acc[r] == 1.2345e33f) bk.atomic_add(out + qr * 64, acc[r]);      // (keeps the MFMAs alive, never true)
-                } else if (q0 + qr < p.S) bk.atomic_add(out + qr * 64, acc[r]);
-            }
-        }
-        if (more) qstage_park(bk, st, lds + ((j + 1) & 1) * DKV_BUF_ELEMS, tid);
-        bk.barrier();
-    }
-
-    // epilogue: lane (c,h) register r of tile db holds element [key = key0 + row_of(r,h)][d = 32 db + c]
-    __bf16* dKp = p.dK + (long)bb * p.dk_sb + (long)hh * p.dk_sh;
-    __bf16* dVp = p.dV + (long)bb * p.dv_sb + (long)hh * p.dv_sh;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = key0 + row_of(r, h);
-            if (key < p.S) {
-                dKp[(long)key * p.dk_ss + 32 * db + c] = (__bf16)(dK[db][r] * p.scale);
-                dVp[(long)key * p.dv_ss + 32 * db + c] = (__bf16)dV[db][r];
-            }
-        }
-}
-
 }  // namespace attnb
 }  // namespace ttt

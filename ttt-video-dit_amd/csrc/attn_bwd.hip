@@ -16,8 +16,11 @@
 // dk_dv stays at one 8-wave workgroup per CU (189 VGPRs): bounding it to 128 registers or splitting it into 4-wave
 // workgroups (3 per CU) spills inside the loop and was 2.5x slower (measured).
 // No atomics: dQ, dK, dV are each written by exactly one workgroup (deterministic); the price is that S and dP are
-// computed in both kernels (7 GEMM units instead of 5), the usual trade at S ~ 18 k where a dQ atomic stream would be
-// 15+ GB per call.  Math = autograd of the reference's F.scaled_dot_product_attention (cogvideo/dit.py:196-198).
+// computed in both kernels (7 GEMM units instead of 5).  Round 5 built the single-pass form (commit 1fb5d95: dS through an LDS
+// image to the waves that contract it over the keys, the dQ blocks of the 73 key blocks added to an fp32 accumulator by
+// global_atomic_add_f32) and measured it at 48 heads x S = 18 048 (profiles/r5a_attn_single_pass_ab.json): parity-green and
+// 25.6 ms against 13.0 ms for this pair - the 32.5 GB of atomic traffic alone cost 14.4 ms (2.3 TB/s: gfx950 executes them at
+// the memory side, the lines are dropped from L2), the kernel without them 11.1 ms, without its dQ phase 8.6 ms.  Removed.  Math = autograd of the reference's F.scaled_dot_product_attention (cogvideo/dit.py:196-198).
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include "../../include/ttt_hip.h"
@@ -107,13 +110,6 @@ void launch_backward(const BwdParams& p, hipStream_t s) {
     hipLaunchKernelGGL(attn_delta_kernel, dim3(dgrid), dim3(256), 0, s, p);
     launch_dkdv_v2(p, s);
     launch_dq_v2(p, s);
-}
-// single pass (attn_body.h bwd_fused, round 5): delta, then ONE kernel for dK, dV and the fp32 dQ accumulator, then its conversion
-void launch_backward_fused(const BwdParams& p, float* dq_acc, hipStream_t s) {
-    const long rows = (long)p.B * p.NH * p.S;
-    const int dgrid = (int)((rows * 8 + 255) / 256 < 65536 ? (rows * 8 + 255) / 256 : 65536);
-    hipLaunchKernelGGL(attn_delta_kernel, dim3(dgrid), dim3(256), 0, s, p);
-    launch_bwd_fused(p, dq_acc, s);
 }
 
 }  // namespace attn

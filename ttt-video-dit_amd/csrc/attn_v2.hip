@@ -30,7 +30,6 @@ struct AttnDeviceWave {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     }
     __device__ __forceinline__ float xor_read(float v, int mask) const { return __shfl_xor(v, mask, 64); }
-    __device__ __forceinline__ void atomic_add(float* p, float v) const { unsafeAtomicAdd(p, v); }    // global_atomic_add_f32, no return
     __device__ __forceinline__ bool any(bool b) const { return __builtin_amdgcn_ballot_w64(b) != 0; }
 };
 
@@ -88,53 +87,6 @@ __global__ __launch_bounds__(512, 2) void attn_dq_wide_kernel(BwdParams p) {
     AttnDeviceWave bk{reinterpret_cast<__bf16*>(smem)};
     attnb::dq_wide<NSUB, 2>(bk, p, bh, qb);
 }
-// ---- single-pass backward (attn_body.h bwd_fused): dK, dV and the fp32 dQ accumulator from ONE pass over the score tiles ----------
-template <int PROBE>
-__global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(BwdParams p, float* dq_acc) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    int bh, kvb;
-    attnb::head_of_block(blockIdx.x, (p.S + attnb::F1_KEYS - 1) / attnb::F1_KEYS, p.B * p.NH, bh, kvb);
-    AttnDeviceWave bk{reinterpret_cast<__bf16*>(smem)};
-    attnb::bwd_fused<PROBE>(bk, p, dq_acc, bh, kvb);
-}
-// dQ = bf16(scale * accumulator): [B*NH][S][64] fp32 -> the caller's (batch, head, token)-strided bf16 tensor; 8 features per thread
-__global__ __launch_bounds__(256) void attn_dqacc_convert_kernel(BwdParams p, const float* dq_acc) {
-    const long rows = (long)p.B * p.NH * p.S;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < rows * 8; idx += (long)gridDim.x * blockDim.x) {
-        const long row = idx >> 3;
-        const int o = idx & 7;
-        const int s = row % p.S;
-        const int bh = row / p.S;
-        const int b = bh / p.NH, h = bh % p.NH;
-        const float4 a0 = *reinterpret_cast<const float4*>(dq_acc + row * 64 + 8 * o);
-        const float4 a1 = *reinterpret_cast<const float4*>(dq_acc + row * 64 + 8 * o + 4);
-        wv::bf16x8 v;
-        v[0] = (__bf16)(a0.x * p.scale); v[1] = (__bf16)(a0.y * p.scale); v[2] = (__bf16)(a0.z * p.scale); v[3] = (__bf16)(a0.w * p.scale);
-        v[4] = (__bf16)(a1.x * p.scale); v[5] = (__bf16)(a1.y * p.scale); v[6] = (__bf16)(a1.z * p.scale); v[7] = (__bf16)(a1.w * p.scale);
-        *reinterpret_cast<wv::bf16x8*>(p.dQ + (long)b * p.dq_sb + (long)h * p.dq_sh + (long)s * p.dq_ss + 8 * o) = v;
-    }
-}
-size_t bwd_fused_workspace_bytes(int B, int NH, int S) { return (size_t)B * NH * S * 64 * sizeof(float); }
-static int g_fused_probe = 0;            // debug option "attn_fused_probe": timing probes 1 / 2 of attn_body.h bwd_fused (wrong dQ by construction)
-void set_debug_attn_fused_probe(int v) { g_fused_probe = (v == 1 || v == 2) ? v : 0; }
-void launch_bwd_fused(const BwdParams& p, float* dq_acc, hipStream_t s) {
-    static ttt::OncePerDevice attr;
-    attr.run([&] {
-        (void)hipFuncSetAttribute((const void*)attn_bwd1_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, attnb::LDS_BWD1);
-        (void)hipFuncSetAttribute((const void*)attn_bwd1_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, attnb::LDS_BWD1);
-        (void)hipFuncSetAttribute((const void*)attn_bwd1_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, attnb::LDS_BWD1);
-    });
-    (void)hipMemsetAsync(dq_acc, 0, bwd_fused_workspace_bytes(p.B, p.NH, p.S), s);
-    const int nb = (p.S + attnb::F1_KEYS - 1) / attnb::F1_KEYS;
-    const dim3 grid(p.B * p.NH * nb), block(512);
-    if (g_fused_probe == 1) hipLaunchKernelGGL(attn_bwd1_kernel<1>, grid, block, attnb::LDS_BWD1, s, p, dq_acc);
-    else if (g_fused_probe == 2) hipLaunchKernelGGL(attn_bwd1_kernel<2>, grid, block, attnb::LDS_BWD1, s, p, dq_acc);
-    else hipLaunchKernelGGL(attn_bwd1_kernel<0>, grid, block, attnb::LDS_BWD1, s, p, dq_acc);
-    const long rows = (long)p.B * p.NH * p.S;
-    const int cgrid = (int)((rows * 8 + 255) / 256 < 65536 ? (rows * 8 + 255) / 256 : 65536);
-    hipLaunchKernelGGL(attn_dqacc_convert_kernel, dim3(cgrid), dim3(256), 0, s, p, (const float*)dq_acc);
-}
-
 static int g_dq_wide = 1;                // round 4, one box (profiles/r4c_attn_dq_wide_ab.log): 13.26 - 13.44 ms per backward against 13.79
 void set_debug_attn_dq_wide(int v) { g_dq_wide = v; }
 template <int NSUB>

@@ -61,7 +61,6 @@ int ttt_hip_debug_option(const char* name, int value) {
     else if (!strcmp(name, "sweep_prefetch")) ttt::mfma::set_debug_sweep_prefetch(value);      // revision-4 sweep: L2 prefetch touches (1 default / 0)
     else if (!strcmp(name, "attn_stage")) ttt::attn::set_debug_attn_stage(0, value);            // attention backward: tiles of 64 per LDS stage (default 2; 1 = round-3 kernels)
     else if (!strcmp(name, "attn_dq_wide")) ttt::attn::set_debug_attn_dq_wide(value);           //   dQ kernel with 64 query rows per wave (A/B)
-    else if (!strcmp(name, "attn_fused_probe")) ttt::attn::set_debug_attn_fused_probe(value);   //   single-pass backward: timing probes (1 no atomics, 2 no dQ phase; wrong dQ)
     else if (!strcmp(name, "attn_stage_dq")) ttt::attn::set_debug_attn_stage(1, value);         //   dQ kernel only (1 / 2)
     else if (!strcmp(name, "attn_stage_dkdv")) ttt::attn::set_debug_attn_stage(2, value);       //   dK / dV kernel only (1 .. 4)
     else if (!strcmp(name, "sweep_records_bf16")) ttt::mfma::set_debug_sweep_records_bf16(value);        // partial d(gZ2) tiles of the hand-over records as bf16 (A/B)
@@ -283,7 +282,7 @@ int ttt_hip_attn_forward(const ttt_attn_fwd_args* a, void* stream) {
     return post_launch("attn_forward");
 }
 
-static int attn_backward_impl(const ttt_attn_bwd_args* a, float* dq_acc, size_t dq_acc_bytes, void* stream) {
+int ttt_hip_attn_backward(const ttt_attn_bwd_args* a, void* stream) {
     if (!a) return fail("ttt_hip: null args");
     if (a->D != 64) return fail("ttt_hip: attention: head_dim must be 64");
     if (a->B <= 0 || a->NH <= 0 || a->S <= 0) return fail("ttt_hip: attention: non-positive dimension");
@@ -303,23 +302,8 @@ static int attn_backward_impl(const ttt_attn_bwd_args* a, float* dq_acc, size_t 
     p.dk_sb = a->dK.stride_b; p.dk_sh = a->dK.stride_h; p.dk_ss = a->dK.stride_s;
     p.dv_sb = a->dV.stride_b; p.dv_sh = a->dV.stride_h; p.dv_ss = a->dV.stride_s;
     p.B = a->B; p.NH = a->NH; p.S = a->S; p.scale = a->scale;
-    if (dq_acc) {
-        if (((uintptr_t)dq_acc & 15) || dq_acc_bytes < ttt::attn::bwd_fused_workspace_bytes(a->B, a->NH, a->S))
-            return fail("ttt_hip: attention backward (single pass): the dQ accumulator must be 16-byte aligned and hold B*NH*S*64 floats");
-        ttt::attn::launch_backward_fused(p, dq_acc, (hipStream_t)stream);
-        return post_launch("attn_backward_fused");
-    }
     ttt::attn::launch_backward(p, (hipStream_t)stream);
     return post_launch("attn_backward");
-}
-
-int ttt_hip_attn_backward(const ttt_attn_bwd_args* a, void* stream) { return attn_backward_impl(a, nullptr, 0, stream); }
-size_t ttt_hip_attn_backward_fused_workspace(int B, int NH, int S) {
-    return (B <= 0 || NH <= 0 || S <= 0) ? 0 : ttt::attn::bwd_fused_workspace_bytes(B, NH, S);
-}
-int ttt_hip_attn_backward_fused(const ttt_attn_bwd_args* a, float* dq_acc, size_t dq_acc_bytes, void* stream) {
-    if (!dq_acc) return fail("ttt_hip: attention backward (single pass): null dQ accumulator");
-    return attn_backward_impl(a, dq_acc, dq_acc_bytes, stream);
 }
 
 

@@ -63,8 +63,8 @@ _LinFwd = _ptr_struct("_LinFwd", LIN_FWD_FIELDS)
 _LinBwd = _ptr_struct("_LinBwd", LIN_BWD_FIELDS)
 
 # TTT_HIP_ABI_VERSION of include/ttt_hip.h this binding was written against (2: return codes -3 / -10 / -11 / -12 of the TTT-MLP
-# entry points, the round-1 debug exports ttt_hip_debug_variant / _helpers gone; 3: ttt_hip_attn_backward_fused + _workspace)
-ABI_VERSION = 3
+# entry points, the round-1 debug exports ttt_hip_debug_variant / _helpers gone)
+ABI_VERSION = 2
 
 # every extern "C" symbol declared in include/ttt_hip.h
 EXPORTED_SYMBOLS = (
@@ -75,7 +75,6 @@ EXPORTED_SYMBOLS = (
     "ttt_hip_pre_forward", "ttt_hip_pre_backward_partials", "ttt_hip_pre_backward", "ttt_hip_post_partials",
     "ttt_hip_post_forward", "ttt_hip_post_backward", "ttt_hip_gate_forward", "ttt_hip_gate_backward_partials",
     "ttt_hip_gate_backward", "ttt_hip_attn_forward", "ttt_hip_attn_backward",
-    "ttt_hip_attn_backward_fused_workspace", "ttt_hip_attn_backward_fused",
     "ttt_hip_attn_pre_forward", "ttt_hip_attn_pre_partials", "ttt_hip_attn_pre_backward",
     "ttt_hip_adaln_forward", "ttt_hip_adaln_backward_partials", "ttt_hip_adaln_backward",
     "ttt_hip_resgate_forward", "ttt_hip_resgate_backward_partials", "ttt_hip_resgate_backward",
@@ -545,47 +544,14 @@ def attn_forward(q, k, v, out, lse, scale):
     _call("ttt_hip_attn_forward", ctypes.byref(a), device=q.device)
 
 
-# How the attention backward runs: "fused" = ONE pass over the score tiles (ttt_hip_attn_backward_fused: dQ accumulated in fp32 by
-# L2 atomics - not bit-reproducible run to run), "two_kernel" = the dK / dV and dQ kernels (deterministic).  The callers
-# (ttt_amd/models/cogvideo/attention.py) ask attn_backward_mode() and allocate the accumulator for "fused".
-_attn_bwd_mode = os.environ.get("TTT_ATTN_BWD", "two_kernel")
-
-
-def attn_backward_mode() -> str:
-    return _attn_bwd_mode
-
-
-def set_attn_backward_mode(mode: str) -> str:
-    """"fused" | "two_kernel"; returns the previous mode."""
-    global _attn_bwd_mode
-    if mode not in ("fused", "two_kernel"):
-        raise ValueError(f"attention backward mode {mode!r}: expected 'fused' or 'two_kernel'")
-    prev, _attn_bwd_mode = _attn_bwd_mode, mode
-    return prev
-
-
-def attn_backward_fused_workspace(B, NH, S) -> int:
-    """bytes of the fp32 dQ accumulator of the single-pass backward"""
-    lib = load_library()
-    lib.ttt_hip_attn_backward_fused_workspace.restype = ctypes.c_size_t
-    return int(lib.ttt_hip_attn_backward_fused_workspace(int(B), int(NH), int(S)))
-
-
-def attn_backward(q, k, v, out, dout, lse, delta, dq, dk, dv, scale, dq_acc=None):
-    """``dq_acc`` (fp32, >= B*NH*S*64 elements): the single-pass backward (dQ through an fp32 accumulator and L2 atomics);
-    None: the deterministic two-kernel backward."""
+def attn_backward(q, k, v, out, dout, lse, delta, dq, dk, dv, scale):
     B, NH, S, D = q.shape
     sh = (B, NH, S, D)
     _req(lse, "lse", torch.float32); _req(delta, "delta", torch.float32)
     a = _AttnBwd(_attn_tensor(q, "q", sh), _attn_tensor(k, "k", sh), _attn_tensor(v, "v", sh), _attn_tensor(out, "out", sh),
                  _attn_tensor(dout, "dout", sh), _attn_tensor(dq, "dq", sh), _attn_tensor(dk, "dk", sh), _attn_tensor(dv, "dv", sh),
                  lse.data_ptr(), delta.data_ptr(), B, NH, S, D, float(scale))
-    if dq_acc is None:
-        _call("ttt_hip_attn_backward", ctypes.byref(a), device=q.device)
-    else:
-        _req(dq_acc, "dq_acc", torch.float32)
-        load_library().ttt_hip_attn_backward_fused.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
-        _call("ttt_hip_attn_backward_fused", ctypes.byref(a), _p(dq_acc), ctypes.c_size_t(dq_acc.numel() * 4), device=q.device)
+    _call("ttt_hip_attn_backward", ctypes.byref(a), device=q.device)
 
 
 def attn_pre_forward(q_raw, k_raw, wq, bq, wk, bk, cos, sin, q, k, NH, n_text, eps):

@@ -23,13 +23,6 @@ def _ext():
     return test_time_training
 
 
-def _dq_accumulator(ext, B, NH, S, device):
-    """fp32 workspace of the single-pass backward (``ttt_hip_attn_backward_fused``) when that mode is selected, else None"""
-    if ext.attn_backward_mode() != "fused":
-        return None
-    return torch.empty(B * NH, S, 64, device=device, dtype=torch.float32)
-
-
 class SegmentAttention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v):
@@ -53,7 +46,7 @@ class SegmentAttention(torch.autograd.Function):
         mk = lambda: torch.empty(B, S, NH, D, device=q.device, dtype=q.dtype).transpose(1, 2)
         dq, dk, dv = mk(), mk(), mk()
         delta = torch.empty(B, NH, S, device=q.device, dtype=torch.float32)
-        ext.attn_backward(q, k, v, out, dout, lse, delta, dq, dk, dv, ctx.scale, dq_acc=_dq_accumulator(ext, B, NH, S, q.device))
+        ext.attn_backward(q, k, v, out, dout, lse, delta, dq, dk, dv, ctx.scale)
         return dq, dk, dv
 
 
@@ -156,7 +149,7 @@ class FusedSegmentAttention(torch.autograd.Function):
         mk = lambda: torch.empty(B, S, NH, Dh, device=qr.device, dtype=qr.dtype).transpose(1, 2)
         dq, dk, dv = mk(), mk(), mk()
         delta = torch.empty(B, NH, S, device=qr.device, dtype=torch.float32)
-        ext.attn_backward(view(q), view(k), v, out, dout, lse, delta, dq, dk, dv, scale, dq_acc=_dq_accumulator(ext, B, NH, S, qr.device))
+        ext.attn_backward(view(q), view(k), v, out, dout, lse, delta, dq, dk, dv, scale)
         del q, k
         dq_raw, dk_raw = torch.empty_like(qr), torch.empty_like(kr)
         P = ext.attn_pre_partials(B, S, NH)
