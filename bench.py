@@ -107,6 +107,16 @@ def parse():
                          "one rank, profiles/r4i_*).  on = the reference's own FSDP2 wrapping (apply_fsdp).  off (one GPU only): "
                          "ReplicaMixedPrecision, the same arithmetic without any sharding machinery.  auto = off on one GPU, flat on several")
     ap.add_argument("--no-fsdp", action="store_true", help="same as --fsdp off")
+    ap.add_argument("--role", default=None, choices=["orchestrate", "worker"],
+                    help="worker = a measuring process (one per GPU; what a launcher starts).  orchestrate (the default WITHOUT a launcher "
+                         "environment) = a thin parent that holds no GPU context: it starts the measurement as child process(es) - under "
+                         "torch.distributed.run for --gpus N > 1 -, retries ONCE with conservative memory settings if that fails, then (N = 1, "
+                         "default workload) runs the metric's other contexts as legs `ctx3s` / `ctx63s` and the CPU baseline, and prints the ONE JSON line")
+    ap.add_argument("--no-legs", action="store_true", help="N=1: skip the `ctx3s` / `ctx63s` legs (BASELINE configs[1] and the metric's 63 s context)")
+    ap.add_argument("--leg-steps", type=int, default=2, help="timed steps of each leg (after one warm-up step)")
+    ap.add_argument("--time-budget", type=float, default=1500.0,
+                    help="seconds the whole default run may take: a leg whose estimated duration does not fit is skipped with a stated reason")
+    ap.add_argument("--retry-reason", default=None, help=argparse.SUPPRESS)          # set by the orchestrator on its second attempt
     ap.add_argument("--layers", type=int, default=None, help="DEBUG: fewer layers (result flagged invalid)")
     ap.add_argument("--torch-profile", default=None, metavar="FILE",
                     help="DEBUG: after the timed region run ONE more step under torch.profiler and write per-operator tables "
@@ -114,6 +124,11 @@ def parse():
     return ap.parse_args()
 
 
+# [optimizer] / [training] of the reference's configs/train/ttt-mlp/{3s,9s,18s,30s,63s}.toml
+_OPT = {"lr": 1e-5, "lr_ssm": 1e-5, "lr_end": 1e-5, "gradient_clipping_norm": 0.1}
+OPTIMIZER = {"3sec": dict(_OPT, lr_ssm=1e-4, warmup_steps=100, steps=5000), "9sec": dict(_OPT, warmup_steps=100, steps=5000),
+             "18sec": dict(_OPT, warmup_steps=50, steps=1000), "30sec": dict(_OPT, warmup_steps=50, steps=1000),
+             "63sec": dict(_OPT, warmup_steps=25, steps=250)}
 TEXT_LEN = {"3sec": 498, "9sec": 502, "18sec": 471, "30sec": 497, "63sec": 458}   # configs/eval/ttt-mlp/*.toml:16 (L % 64 == 0)
 
 
@@ -393,9 +408,9 @@ def size_warm_and_time(step, hk, remat_free_layers, warmup, steps, world):
 
 
 def launcher_argv(gpus, argv, port=None):
-    """The command line a bare ``python bench.py --gpus N ...`` (N > 1, no launcher environment) replaces itself with: one rank per
-    GPU of this node under torch.distributed.run, rendezvous on 127.0.0.1 (the container's hostname may not resolve) on a free
-    port - what the reference's scripts/*.sh do with torchrun.  The ranks inherit stdout: rank 0 still prints the one JSON line."""
+    """The command line of an N-GPU measurement: one rank per GPU of this node under torch.distributed.run, rendezvous on 127.0.0.1
+    (the container's hostname may not resolve) on a free port - what the reference's scripts/train_singlenode.sh:25-38 does with
+    torchrun.  The ranks inherit stdout: rank 0 prints the one JSON line."""
     if port is None:
         import socket
         with socket.socket() as so:
@@ -405,18 +420,181 @@ def launcher_argv(gpus, argv, port=None):
             "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
 
+def worker_command(gpus, argv, port=None):
+    """command line of the measuring process(es) for `argv` (bench.py's own arguments)"""
+    argv = [a for a in argv] + ["--role", "worker"]
+    return launcher_argv(gpus, argv, port) if gpus > 1 else [sys.executable, os.path.abspath(__file__)] + argv
+
+
+# what the orchestrator's second attempt adds: every layer re-materialised, kernel outputs kept - the smallest activation footprint
+# that still avoids recomputing the sequence kernels (an out-of-memory error of ONE rank of an N-GPU run cannot be recovered inside the run)
+SAFE_MEMORY_ARGS = ["--remat-free-layers", "0", "--remat-keep", "attn,scan,fc2"]
+
+
+def run_child(cmd, timeout, env=None):
+    """Runs one child to its end.  stdout is captured (the JSON line), stderr is passed through line by line and its tail kept.
+    Returns (return code, the LAST JSON object line of stdout or None, tail of stderr).  (tests replace this function)"""
+    import subprocess
+    import threading
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+    tail, out = [], []
+
+    def pump_err():
+        for ln in proc.stderr:
+            sys.stderr.write(ln)
+            sys.stderr.flush()
+            tail.append(ln.rstrip())
+            del tail[:-30]
+
+    def pump_out():
+        for ln in proc.stdout:
+            out.append(ln)
+
+    th = [threading.Thread(target=pump_err, daemon=True), threading.Thread(target=pump_out, daemon=True)]
+    for t in th:
+        t.start()
+    try:
+        rc = proc.wait(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        proc.kill()
+        rc = -9
+        tail.append(f"bench.py: child exceeded {timeout:.0f} s and was killed")
+    for t in th:
+        t.join(timeout=10)
+    line = None
+    for ln in reversed(out):
+        ln = ln.strip()
+        if ln.startswith("{"):
+            try:
+                line = json.loads(ln)
+                break
+            except ValueError:
+                continue
+    return rc, line, tail
+
+
+def rccl_summary(log_dir):
+    """What RCCL decided for this job, from its own INIT / GRAPH log lines (NCCL_DEBUG_FILE of the ranks): channel count, ring / tree
+    lines of rank 0 - a first look at the topology an 8-GPU run actually got.  {} when nothing was logged."""
+    import glob
+    import re
+    res = {}
+    files = sorted(glob.glob(os.path.join(log_dir, "rccl.*.log")))
+    if not files:
+        return res
+    rings, trees, chans, nranks = [], [], set(), None
+    for ln in open(files[0], errors="replace"):
+        m = re.search(r"Channel (\d+)/(\d+)\s*:\s*(.*)", ln)
+        if m and "Ring" not in ln and "Tree" not in ln:
+            chans.add(int(m.group(1)))
+            if len(rings) < 4:
+                rings.append(f"channel {m.group(1)}: {m.group(3).strip()[:80]}")
+        if "Trees" in ln and len(trees) < 2:
+            trees.append(ln.split("Trees", 1)[1].strip()[:120])
+        m = re.search(r"nranks (\d+)", ln)
+        if m:
+            nranks = int(m.group(1))
+    res = {"rank_logs": len(files), "nranks": nranks, "channels": len(chans), "rings_head": rings, "trees_head": trees}
+    return res
+
+
+LEG_ESTIMATE_S = {"ctx3s": 150.0, "ctx63s": 480.0}          # generous: model build + sizing + 1 warm-up + 2 timed steps (53 s each at 63 s)
+
+
+def leg_command(name, args):
+    """`ctx3s` = BASELINE configs[1] (configs/train/ttt-mlp/3s.toml: one segment, adapter sft), `ctx63s` = the metric's second context
+    (63s.toml: 21 scenes, L = 351 168; every layer re-materialised and nothing kept - what fits ONE 288-GB GPU, DESIGN.md section 6;
+    the reference shards this stage over 4 x 4 GPUs).  A leg is its own process: memory state and failures stay its own."""
+    length = {"ctx3s": "3sec", "ctx63s": "63sec"}[name]
+    argv = ["--gpus", "1", "--video-length", length, "--steps", str(max(1, args.leg_steps)), "--warmup", "1", "--no-fsdp1-compare",
+            "--ssm-layer", args.ssm_layer, "--impl", args.impl]
+    if name == "ctx63s":
+        argv += ["--remat-free-layers", "0", "--remat-keep", "none"]
+    if args.no_tuned_gemms:
+        argv.append("--no-tuned-gemms")
+    return worker_command(1, argv)
+
+
+def leg_summary(line):
+    r = line.get("roofline") or {}
+    other = r.get("other") or {}
+    dom_bwd = "bwd" in (r.get("kernel") or "")
+    pick = lambda k: round(other[k]["avg_ms"], 3) if k in other else None
+    return {"value": line["value"], "unit": line["unit"], "ms_per_step": line["ms_per_step"], "steps": line["steps"], "warmup": line["warmup"],
+            "workload": line["config"]["workload"], "remat_free_layers": line["config"]["remat_free_layers"],
+            "remat_keep": line["config"].get("remat_keep"), "peak_mem_gib": line.get("peak_mem_gib"), "peak_reserved_gib": line.get("peak_reserved_gib"),
+            "ttt_mlp_bwd_ms": round(r["avg_launch_ms"], 3) if dom_bwd else pick("bwd"), "scan_fwd_ms": pick("fwd") if dom_bwd else round(r.get("avg_launch_ms", 0.0), 3),
+            "attn_fwd_ms": pick("attn_fwd"), "attn_bwd_ms": pick("attn_bwd"), "roofline_frac": r.get("frac"), "valid": line["config"].get("valid")}
+
+
+def orchestrate(args, argv):
+    """The default entry (no launcher environment): see --role.  Prints ONE JSON line; exits non-zero when no measurement succeeded."""
+    import tempfile
+    t_start = time.time()
+    argv = [a for a in argv]
+    env = dict(os.environ)
+    rccl_dir = None
+    if args.gpus > 1:
+        # RCCL: warnings on stderr as usual; unless the caller chose otherwise, its INIT / GRAPH decisions go to per-rank files that
+        # the summary below reads (the first multi-GPU run of this code may be the only one: leave evidence)
+        if "NCCL_DEBUG" not in env:
+            rccl_dir = tempfile.mkdtemp(prefix="bench_rccl_")
+            env.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,GRAPH,ENV", NCCL_DEBUG_FILE=os.path.join(rccl_dir, "rccl.%h.%p.log"))
+    line, failures = None, []
+    for attempt, extra in enumerate(([], SAFE_MEMORY_ARGS)):
+        if attempt:
+            extra = extra + ["--retry-reason", failures[-1][:300]]
+            log(f"measurement failed ({failures[-1][:200]}): retrying ONCE with {' '.join(SAFE_MEMORY_ARGS)}")
+        rc, line, tail = run_child(worker_command(args.gpus, argv + extra), timeout=max(600.0, args.time_budget), env=env)
+        if rc == 0 and line is not None:
+            break
+        why = next((t for t in reversed(tail) if "OutOfMemory" in t or "out of memory" in t), None) or \
+            next((t for t in reversed(tail) if "Error" in t or "error" in t), tail[-1] if tail else "no output")
+        failures.append(f"rc {rc}: {why.strip()}")
+        line = None
+    if line is None:
+        print(f"bench.py: no measurement ({'; '.join(failures)})", file=sys.stderr, flush=True)
+        sys.exit(1)
+    if rccl_dir:
+        line["rccl"] = rccl_summary(rccl_dir)
+        log(f"RCCL: {line['rccl']}")
+    default_workload = args.video_length == "9sec" and args.layers is None and not args.tp and args.local_batch == 1
+    if args.gpus == 1 and not args.no_legs and default_workload:
+        for name in ("ctx3s", "ctx63s"):
+            left = args.time_budget - (time.time() - t_start)
+            if left < LEG_ESTIMATE_S[name]:
+                line[name] = {"skipped": f"{left:.0f} s of the {args.time_budget:.0f} s budget left, the leg needs ~{LEG_ESTIMATE_S[name]:.0f} s"}
+                log(f"{name}: skipped ({line[name]['skipped']})")
+                continue
+            log(f"{name} leg (child process)")
+            t0 = time.time()
+            rc, leg, tail = run_child(leg_command(name, args), timeout=max(300.0, left))
+            if rc == 0 and leg is not None:
+                line[name] = leg_summary(leg)
+                line[name]["leg_wall_s"] = round(time.time() - t0, 1)
+            else:
+                line[name] = {"error": f"rc {rc}: {(tail[-1] if tail else 'no output')[:300]}"}
+    if args.gpus == 1 and not args.no_cpu_baseline:
+        # the CPU leg runs in a child process with a wall-clock limit: whatever happens to it (host out-of-memory kill, a slow
+        # box) the GPU measurement above is still printed
+        log("cpu_baseline leg (child process)")
+        rc, cb, tail = run_child([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--ssm-layer", args.ssm_layer,
+                                  "--cpu-baseline-budget", str(args.cpu_baseline_budget)], timeout=max(240.0, 12 * args.cpu_baseline_budget))
+        line["cpu_baseline"] = cb["cpu_baseline"] if (rc == 0 and cb and "cpu_baseline" in cb) else {"error": f"rc {rc}: {(tail[-1] if tail else 'no output')[:300]}"}
+    line["bench_wall_s"] = round(time.time() - t_start, 1)
+    print(json.dumps(line), flush=True)
+
+
 def main():
     args = parse()
     if args.cpu_baseline_only:
         print(json.dumps({"cpu_baseline": cpu_baseline(args.ssm_layer, args.cpu_baseline_budget)}))
         return
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
-        # started without a launcher: become one (the driver may call `python bench.py --gpus 8` exactly like `--gpus 1`)
-        cmd = launcher_argv(args.gpus, sys.argv[1:])
-        log("no launcher environment: re-executing as " + " ".join(cmd[1:9]) + " bench.py ...")
-        sys.stdout.flush()
-        os.execv(cmd[0], cmd)
-        raise AssertionError("unreachable")           # (tests replace os.execv)
+    under_launcher = "WORLD_SIZE" in os.environ or "RANK" in os.environ
+    if args.role == "orchestrate" or (args.role is None and not under_launcher):
+        # started without a launcher (the driver calls `python bench.py --gpus N` for every N): a thin parent starts the measuring
+        # process(es) as children - under torch.distributed.run for N > 1 - and survives their failure (one retry)
+        return orchestrate(args, sys.argv[1:])
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -478,18 +656,8 @@ def main():
     else:
         line = _run(args, world, rank, local_rank, dev, no_fsdp=False, sharded=multi)
     if rank == 0 and line is not None:
-        if world == 1 and not args.no_cpu_baseline:
-            # the CPU leg runs in a child process with a wall-clock limit: whatever happens to it (host out-of-memory kill,
-            # a slow box) the GPU measurement above is still printed
-            log("cpu_baseline leg (child process)")
-            import subprocess
-            try:
-                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--ssm-layer", args.ssm_layer,
-                                    "--cpu-baseline-budget", str(args.cpu_baseline_budget)], capture_output=True, text=True,
-                                   timeout=max(240.0, 12 * args.cpu_baseline_budget))
-                line["cpu_baseline"] = json.loads(r.stdout.strip().splitlines()[-1])["cpu_baseline"]
-            except Exception as ex:
-                line["cpu_baseline"] = {"error": repr(ex)[:300]}
+        if args.retry_reason:
+            line["config"]["retry_reason"] = args.retry_reason
         print(json.dumps(line), flush=True)
     dist.barrier(device_ids=[local_rank])
     dist.destroy_process_group()
@@ -559,8 +727,18 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False, tp=False, sha
     if not no_fsdp and not tp and sharded == "flat":      # the same partitioning on flat buffers (ttt_amd/infra/flat_fsdp.py)
         from ttt_amd.infra.flat_fsdp import FlatFSDP
         flat = FlatFSDP(model.dit, always_communicate=communicate)
-    train_params = replica.master_parameters() if replica else flat.master_parameters() if flat else [p for p in model.parameters() if p.requires_grad]
-    opt = torch.optim.AdamW(train_params, lr=1e-5, weight_decay=1e-4, fused=True)
+    # the reference's optimizer (ttt/infra/optimizers.py:200-264 with the values of configs/train/ttt-mlp/*.toml): four AdamW groups by
+    # parameter NAME - TTT / SSM parameters at lr_ssm, the others at lr; bias / norm / b1 / b2 without weight decay -, betas
+    # (0.9, 0.95), one LambdaLR schedule per group, gradient clipping at 0.1.  Works on the masters of either holder.
+    from ttt_amd.infra.optimizers import ScheduleType, create_grouped_lr_scheduler, create_specialized_optimizer
+    oc = OPTIMIZER[args.video_length]
+    opt, sched_cfgs = create_specialized_optimizer(model, oc["lr"], oc["lr_ssm"], oc["lr_end"], oc["warmup_steps"], oc["steps"],
+                                                   ScheduleType.LINEAR, ScheduleType.COSINE, args.adapter)
+    lr_sched = create_grouped_lr_scheduler(opt, sched_cfgs)
+    train_params = [p for g_ in opt.param_groups for p in g_["params"]]
+    clip = oc["gradient_clipping_norm"]
+    if flat:
+        flat.attach_optimizer(opt)              # step pre-hook: finish_backward + the sweep-error gate; post-hook: publish (all-gathers)
 
     g = torch.Generator(device=dev).manual_seed(100 + dp_rank)
     LB = args.local_batch
@@ -571,23 +749,29 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False, tp=False, sha
     timer.install()
 
     def step():
+        # the reference's loop (train.py:131-166): zero_grad, loss, backward, clip, optimizer.step, lr_scheduler.step
         opt.zero_grad(set_to_none=True)
         loss = model(vid, text).mean()
         loss.backward()
-        if tp and no_fsdp:
-            tp_sync_gradients(model)                # partial parameter gradients (a rank's tokens / heads) summed over the group
-        if replica:
-            replica.collect_grads()                 # bf16 gradients -> fp32 gradients of the masters (what FSDP's reduce does)
         if flat:
-            flat.finish_backward()                  # (the units' reduce-scatters were queued by their last gradients' hooks)
-        # clip -> ONE device synchronisation (the hand-over error word of the TTT-MLP backward; a production loop needs it before
-        # optimizer.step(), so the benchmark pays for it too) -> fused AdamW
-        if checked_optimizer_step(opt, train_params, 1.0, clip_fn=flat.clip_grad_norm_ if flat else None) is None:
-            raise RuntimeError("a TTT-MLP backward hand-over timed out (or the gradient norm is not finite): step skipped")
-        if replica:
-            replica.publish()                       # fp32 masters -> bf16 compute copies (what FSDP's all-gather does)
-        if flat:
-            flat.publish()                          # masters -> bf16 shards, one in-place all-gather per unit on the side stream
+            # (the units' reduce-scatters were queued by their last gradients' hooks; optimizer.step()'s hooks finish the backward,
+            # look at the hand-over error word of the TTT-MLP backward - ONE device synchronisation, which a production loop needs
+            # before AdamW, so the benchmark pays for it too - and publish the new parameters)
+            flat.finish_backward()
+            flat.clip_grad_norm_(clip)
+            opt.step()
+            if flat.last_step_skipped:
+                raise RuntimeError("a TTT-MLP backward hand-over timed out (or the gradient norm is not finite): step skipped")
+        else:
+            if tp and no_fsdp:
+                tp_sync_gradients(model)            # partial parameter gradients (a rank's tokens / heads) summed over the group
+            if replica:
+                replica.collect_grads()             # bf16 gradients -> fp32 gradients of the masters (what FSDP's reduce does)
+            if checked_optimizer_step(opt, train_params, clip, on_skip=replica.zero_grad if replica else None) is None:
+                raise RuntimeError("a TTT-MLP backward hand-over timed out (or the gradient norm is not finite): step skipped")
+            if replica:
+                replica.publish()                   # fp32 masters -> bf16 compute copies (what FSDP's all-gather does)
+        lr_sched.step()
         return loss
 
     # ---- activation re-materialisation sized for this GPU (untimed), warm-up, timed region: size_warm_and_time() ------------
@@ -668,6 +852,8 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False, tp=False, sha
     dt = float(tmax)
     loss_val = float(loss.detach())
     peak_mem = torch.cuda.max_memory_allocated() / 2 ** 30
+    peaks = [torch.zeros(2, device=dev, dtype=torch.float64) for _ in range(world)]      # (allocated, reserved) GiB of every rank
+    dist.all_gather(peaks, torch.tensor([peak_mem, torch.cuda.max_memory_reserved() / 2 ** 30], device=dev, dtype=torch.float64))
     fast_wgs = ext.sweep_fast_count() - fast0
     # a cluster hand-over of the TTT-MLP backward that gave up inside the timed region poisons that step's gradients (NaN) and
     # makes the next extension call raise; a line measured with one is not a measurement (synchronises: region is over)
@@ -747,7 +933,10 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False, tp=False, sha
                            "global_batch": dp * LB, "seq_len": L, "parallelism": (f"tp{tp}" if no_fsdp else f"fsdp{world}(dp{dp}xtp{tp})") if tp else ("replica1" if no_fsdp else (f"flat_fsdp{world}" if (communicate or world > 1) else "flat1") if flat else f"fsdp2_{world}"), "ttt_impl": args.impl,
                            "remat_free_layers": n_free, "remat_keep": list(dit.remat_keep), "fsdp_reshard_after_forward": bool(args.reshard_after_forward), "tuned_gemm_selections": bool(tuned),
                            "sweep_error": sweep_err, "valid": args.layers is None and sweep_err == 0},
-                "roofline": roof, "loss": loss_val, "peak_mem_gib": peak_mem, "peak_reserved_gib": torch.cuda.max_memory_reserved() / 2 ** 30, "alloc_retries_total": Hooks.alloc_retries(), "total_tokens_per_s": dp * L / (dt / args.steps)}
+                "roofline": roof, "loss": loss_val, "peak_mem_gib": peak_mem, "peak_reserved_gib": torch.cuda.max_memory_reserved() / 2 ** 30, "alloc_retries_total": Hooks.alloc_retries(), "total_tokens_per_s": dp * L / (dt / args.steps),
+                "peak_mem_gib_per_rank": [[round(float(x), 1) for x in pk] for pk in peaks],
+                "optimizer": {"groups": [c.group_name for c in sched_cfgs], "lr": oc["lr"], "lr_ssm": oc["lr_ssm"], "clip": clip,
+                              "weight_decay": [g_["weight_decay"] for g_ in opt.param_groups]}}
         if flat:
             flat.remove()
         return line

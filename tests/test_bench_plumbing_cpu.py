@@ -96,46 +96,120 @@ def test_forward_scan_lds_model_is_near_the_device_counter():
     assert all(by3[k] == by[k] for k in by if k.startswith("tr "))
 
 
-def test_bare_multi_gpu_invocation_relaunches_itself(monkeypatch):
-    """`python bench.py --gpus N` without a launcher environment (how the driver starts the N = 1 run) must not die on an
-    assertion for N > 1: it replaces itself with torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1, and hands
-    its own arguments through (round-3 verdict, weak #6).  Under a launcher (WORLD_SIZE set) nothing is re-executed."""
+_LINE = {"metric": "DiT+TTT fwd/bwd video-tokens/sec", "value": 7000.0, "unit": "video-tokens/s", "n_gpus": 1, "steps": 7, "warmup": 2,
+         "ms_per_step": 7000.0, "config": {"workload": "w", "remat_free_layers": 13, "remat_keep": ["attn"], "valid": True},
+         "roofline": {"kernel": "ttt_mlp_bwd_scan[mfma]", "avg_launch_ms": 10.9, "frac": 0.04,
+                      "other": {"fwd": {"avg_ms": 6.0}, "attn_fwd": {"avg_ms": 4.4}, "attn_bwd": {"avg_ms": 13.0}}},
+         "peak_mem_gib": 236.0, "peak_reserved_gib": 245.0}
+
+
+def _orchestrate(monkeypatch, capsys, argv, replies):
+    """bench.main() as the driver starts it (no launcher environment) with run_child replaced by a script of replies;
+    returns (the commands it ran, the JSON objects it printed)"""
+    import copy
     import bench
     calls = []
 
-    class Stop(Exception):
-        pass
+    def fake_run_child(cmd, timeout, env=None):
+        calls.append((list(cmd), dict(env) if env else None))
+        r = replies[min(len(calls) - 1, len(replies) - 1)]
+        return r[0], copy.deepcopy(r[1]), list(r[2])
 
-    def fake_execv(path, argv):
-        calls.append((path, list(argv)))
-        raise Stop
-
-    monkeypatch.setattr(os, "execv", fake_execv)
-    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+    monkeypatch.setattr(bench, "run_child", fake_run_child)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "NCCL_DEBUG"):
         monkeypatch.delenv(k, raising=False)
-    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7", "--warmup", "2"])
-    with pytest.raises(Stop):
+    monkeypatch.setattr(sys, "argv", ["bench.py"] + argv)
+    try:
         bench.main()
-    (path, argv), = calls
-    assert path == sys.executable and argv[:3] == [sys.executable, "-m", "torch.distributed.run"]
+        rc = 0
+    except SystemExit as ex:
+        rc = ex.code
+    out = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
+    return calls, out, rc
+
+
+def test_bare_multi_gpu_invocation_starts_the_ranks_as_children(monkeypatch, capsys):
+    """`python bench.py --gpus N` without a launcher environment (how the driver starts every run): a thin parent starts one rank
+    per GPU under torch.distributed.run as a CHILD (rendezvous on 127.0.0.1, its own arguments handed through, RCCL's INIT / GRAPH
+    decisions logged to per-rank files), and prints the child's one JSON line.  Reference: scripts/train_singlenode.sh:25-38."""
+    import bench
+    calls, out, rc = _orchestrate(monkeypatch, capsys, ["--gpus", "4", "--steps", "7", "--warmup", "2"], [(0, dict(_LINE, n_gpus=4), [])])
+    assert rc == 0 and len(calls) == 1 and len(out) == 1 and out[0]["value"] == 7000.0 and out[0]["n_gpus"] == 4
+    argv, env = calls[0]
+    assert argv[:3] == [sys.executable, "-m", "torch.distributed.run"]
     assert "--nnodes=1" in argv and "--nproc-per-node=4" in argv
     assert argv[argv.index("--master-addr") + 1] == "127.0.0.1" and int(argv[argv.index("--master-port") + 1]) > 0
     i = argv.index(os.path.abspath(bench.__file__))
-    assert argv[i + 1:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]
-    # under a launcher: no re-execution (the GPU assertion is what stops a CPU-only box here)
-    calls.clear()
+    assert argv[i + 1:] == ["--gpus", "4", "--steps", "7", "--warmup", "2", "--role", "worker"]
+    assert env["NCCL_DEBUG"] == "INFO" and "rccl." in env["NCCL_DEBUG_FILE"]
+    assert "ctx3s" not in out[0] and "cpu_baseline" not in out[0]           # legs and the CPU baseline are N = 1 only
+
+
+def test_failed_multi_gpu_attempt_is_retried_once_with_safe_memory_settings(monkeypatch, capsys):
+    """The first 8-GPU run may be the only one: a rank that runs out of memory kills the job (the others sit in a collective), so
+    the parent retries ONCE with every layer re-materialised and says why in the line; a second failure exits non-zero."""
+    import bench
+    oom = (1, None, ["[rank3]: torch.OutOfMemoryError: HIP out of memory. Tried to allocate 2.00 GiB", "ChildFailedError"])
+    calls, out, rc = _orchestrate(monkeypatch, capsys, ["--gpus", "8"], [oom, (0, dict(_LINE, n_gpus=8), [])])
+    assert rc == 0 and len(calls) == 2 and len(out) == 1
+    second = calls[1][0]
+    j = second.index("--remat-free-layers")
+    assert second[j:j + 4] == bench.SAFE_MEMORY_ARGS
+    assert "OutOfMemoryError" in second[second.index("--retry-reason") + 1]
+    # the worker copies --retry-reason into config.retry_reason (bench.main, role worker); both attempts failing: no line, rc 1
+    calls, out, rc = _orchestrate(monkeypatch, capsys, ["--gpus", "8"], [oom, oom])
+    assert rc == 1 and len(calls) == 2 and not out
+
+
+def test_one_gpu_default_run_carries_the_other_contexts_as_legs(monkeypatch, capsys):
+    """N = 1, default workload: after the 9 s measurement the parent runs BASELINE configs[1] (3 s) and the metric's second context
+    (63 s) as legs - own processes, one warm-up + two timed steps - and the CPU baseline, and merges them into the ONE line; a leg
+    that does not fit the time budget is skipped with a stated reason; a failing leg costs nothing but itself."""
+    import bench
+    leg3 = dict(_LINE, value=7500.0, ms_per_step=2340.0, steps=2, warmup=1, config=dict(_LINE["config"], workload="3sec"))
+    leg63 = dict(_LINE, value=6400.0, ms_per_step=53000.0, steps=2, warmup=1, config=dict(_LINE["config"], workload="63sec", remat_free_layers=0, remat_keep=[]))
+    calls, out, rc = _orchestrate(monkeypatch, capsys, ["--gpus", "1", "--steps", "7", "--warmup", "2"],
+                                  [(0, _LINE, []), (0, leg3, []), (0, leg63, []), (0, {"cpu_baseline": {"value": 1.2}}, [])])
+    assert rc == 0 and len(out) == 1 and len(calls) == 4
+    line = out[0]
+    assert line["value"] == 7000.0 and line["ctx3s"]["value"] == 7500.0 and line["ctx63s"]["ms_per_step"] == 53000.0
+    assert line["ctx63s"]["ttt_mlp_bwd_ms"] == 10.9 and line["ctx63s"]["attn_bwd_ms"] == 13.0 and line["ctx3s"]["steps"] == 2
+    assert line["cpu_baseline"] == {"value": 1.2}
+    assert calls[0][0][:2] == [sys.executable, os.path.abspath(bench.__file__)] and calls[0][0][-2:] == ["--role", "worker"]
+    c3, c63 = calls[1][0], calls[2][0]
+    assert c3[c3.index("--video-length") + 1] == "3sec" and c63[c63.index("--video-length") + 1] == "63sec"
+    assert c63[c63.index("--remat-keep") + 1] == "none" and "--no-fsdp1-compare" in c3 and c3[-2:] == ["--role", "worker"]
+    # no time left: both legs skipped with a reason, the main line and the CPU baseline still there
+    calls, out, rc = _orchestrate(monkeypatch, capsys, ["--gpus", "1", "--time-budget", "100"], [(0, _LINE, []), (0, {"cpu_baseline": {"value": 1.2}}, [])])
+    assert rc == 0 and len(calls) == 2 and "budget" in out[0]["ctx3s"]["skipped"] and "budget" in out[0]["ctx63s"]["skipped"]
+    # a leg that dies: its entry says so
+    calls, out, rc = _orchestrate(monkeypatch, capsys, ["--gpus", "1", "--no-cpu-baseline"], [(0, _LINE, []), (1, None, ["HIP error"]), (0, leg63, [])])
+    assert rc == 0 and "error" in out[0]["ctx3s"] and out[0]["ctx63s"]["value"] == 6400.0
+    # another workload than the metric's: no legs
+    calls, out, rc = _orchestrate(monkeypatch, capsys, ["--gpus", "1", "--video-length", "3sec", "--no-cpu-baseline"], [(0, _LINE, [])])
+    assert len(calls) == 1 and "ctx3s" not in out[0]
+
+
+def test_under_a_launcher_the_process_is_a_worker(monkeypatch):
+    import bench
+    monkeypatch.setattr(bench, "run_child", lambda *a, **k: (_ for _ in ()).throw(AssertionError("a worker must not start children")))
     monkeypatch.setenv("WORLD_SIZE", "4"); monkeypatch.setenv("RANK", "0")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4"])
     if not __import__("torch").cuda.is_available():
         with pytest.raises(AssertionError, match="needs a GPU"):
             bench.main()
-    assert not calls
-    # one GPU: never
-    monkeypatch.delenv("WORLD_SIZE"); monkeypatch.delenv("RANK")
-    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "1"])
-    if not __import__("torch").cuda.is_available():
-        with pytest.raises(AssertionError, match="needs a GPU"):
-            bench.main()
-    assert not calls
+
+
+def test_rccl_summary_reads_the_ranks_log_files(tmp_path):
+    import bench
+    (tmp_path / "rccl.host.1.log").write_text(
+        "host:1:1 [0] NCCL INFO comm 0x1 rank 0 nranks 8 cudaDev 0 busId 1000 - Init START\n"
+        "host:1:1 [0] NCCL INFO Channel 00/16 :    0   1   2   3   4   5   6   7\n"
+        "host:1:1 [0] NCCL INFO Channel 01/16 :    0   2   4   6   1   3   5   7\n"
+        "host:1:1 [0] NCCL INFO Trees [0] 1/-1/-1->0->-1 [1] 2/-1/-1->0->-1\n")
+    r = bench.rccl_summary(str(tmp_path))
+    assert r["nranks"] == 8 and r["channels"] == 2 and r["rank_logs"] == 1 and len(r["rings_head"]) == 2 and r["trees_head"]
+    assert bench.rccl_summary(str(tmp_path / "nothing")) == {}
 
 
 def test_sweep_launch_summary_reproduces_from_the_committed_trace():

@@ -79,11 +79,11 @@ def test_skipped_step_with_the_flat_sharded_path_leaves_it_usable():
             fs.finish_backward()
 
         backward()
-        fs.units[0].master.grad[3] = float("nan")
+        fs.units[0].grad_shard[3] = float("nan")
         e = FakeExt(5)
-        assert checked_optimizer_step(opt, fs.master_parameters(), 1.0, extension=e, clip_fn=fs.clip_grad_norm_) is None
+        assert checked_optimizer_step(opt, fs.master_parameters(), 1.0, extension=e, clip_fn=fs.clip_grad_norm_, on_skip=fs.zero_grad) is None
         assert e.cleared == 1 and len(opt.state) == 0
-        assert all(u.master.grad is None for u in fs.units)
+        assert all(m.grad is None for m in fs.master_parameters()) and not any(u.has_grad for u in fs.units)
         assert all(torch.equal(a, u.master) for a, u in zip(before, fs.units))
         assert all(torch.equal(a, u.gathered) for a, u in zip(bf16_before, fs.units))
         backward()                                            # the batch again
@@ -92,5 +92,47 @@ def test_skipped_step_with_the_flat_sharded_path_leaves_it_usable():
         fs.publish()
         assert any(not torch.equal(a, u.master) for a, u in zip(before, fs.units))
         assert any(not torch.equal(a, u.gathered) for a, u in zip(bf16_before, fs.units))
+    finally:
+        cpu_ext.uninstall()
+
+
+def test_the_optimizer_hooks_of_the_flat_sharded_path_gate_and_publish():
+    """``FlatFSDP.attach_optimizer``: under the reference's unchanged loop (optimizer.zero_grad, backward, clip, optimizer.step) the
+    step PRE-hook finishes the backward and looks at the hand-over error word - a poisoned backward is dropped, AdamW changes
+    nothing, ``last_step_skipped`` says so, the word is acknowledged - and the POST-hook publishes the new masters into the bf16
+    compute parameters; ``optimizer.zero_grad()`` also resets the holder."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracle import cpu_ext
+    from test_flat_fsdp_gloo import _build, _loss
+    from ttt_amd.infra.flat_fsdp import FlatFSDP
+    from ttt_amd.infra.optimizers import ScheduleType, create_specialized_optimizer
+    cpu_ext.install()
+    try:
+        m = _build("qkvo")
+        m.remat_free_layers = 0
+        fs = FlatFSDP(m)
+        opt, _ = create_specialized_optimizer(m, 1e-3, 1e-3, 1e-4, 1, 4, ScheduleType.LINEAR, ScheduleType.COSINE, "qkvo")
+        e = FakeExt(0)
+        fs.attach_optimizer(opt, extension=e)
+        before = [u.master.detach().clone() for u in fs.units]
+        bf16_before = [u.gathered.clone() for u in fs.units]
+        opt.zero_grad()
+        _loss(m, 0).backward()
+        fs.clip_grad_norm_(0.1)
+        fs.units[0].grad_shard[5] = float("inf")             # a poisoned backward
+        opt.step()
+        assert fs.last_step_skipped and len(opt.state) == 0
+        assert all(torch.equal(a, u.master) for a, u in zip(before, fs.units))
+        assert all(torch.equal(a, u.gathered) for a, u in zip(bf16_before, fs.units))
+        opt.zero_grad()                                       # the batch again
+        assert not any(u.has_grad for u in fs.units)
+        _loss(m, 0).backward()
+        n = fs.clip_grad_norm_(0.1)
+        opt.step()
+        assert not fs.last_step_skipped and bool(torch.isfinite(n))
+        assert any(not torch.equal(a, u.master) for a, u in zip(before, fs.units))
+        assert any(not torch.equal(a, u.gathered) for a, u in zip(bf16_before, fs.units))     # published by the post-hook
     finally:
         cpu_ext.uninstall()

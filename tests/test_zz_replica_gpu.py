@@ -182,6 +182,7 @@ os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29677", RANK="0", WORLD_
 import torch
 import test_time_training as ext
 from ttt_amd.infra.flat_fsdp import FlatFSDP
+from ttt_amd.infra.optimizers import ScheduleType, create_grouped_lr_scheduler, create_specialized_optimizer
 from ttt_amd.infra.parallelisms import ReplicaMixedPrecision, end_distributed, init_distributed
 from ttt_amd.models.cogvideo.dit import DiffusionTransformer
 from ttt_amd.models.configs import ModelConfig
@@ -214,11 +215,14 @@ for adapter in ("sft", "qkvo"):
         m = build(adapter)
         if mode == "flat":
             fs, rep = FlatFSDP(m, always_communicate=True), None          # RCCL all-gather / reduce-scatter over the one rank
-            params = fs.master_parameters()
         else:
             fs, rep = None, ReplicaMixedPrecision(m)
-            params = rep.master_parameters()
-        opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=1e-4, fused=True)
+        # the reference's four AdamW groups by parameter name on either holder's masters (ttt_amd/infra/optimizers.py)
+        opt, cfgs = create_specialized_optimizer(m, 1e-3, 3e-3, 1e-4, 1, 5, ScheduleType.LINEAR, ScheduleType.COSINE, adapter)
+        sched = create_grouped_lr_scheduler(opt, cfgs)
+        params = [p for g_ in opt.param_groups for p in g_["params"]]
+        if fs:
+            fs.attach_optimizer(opt)              # the step hooks: finish_backward + the error-word gate (real extension), publish
         trace = []
         for _ in range(3):
             opt.zero_grad(set_to_none=True)
@@ -227,11 +231,13 @@ for adapter in ("sft", "qkvo"):
             if rep:
                 rep.collect_grads()
                 norm = torch.nn.utils.clip_grad_norm_(params, 1.0)
-            else:
-                fs.finish_backward()
+                opt.step()
+                rep.publish()
+            else:                                  # the reference's loop, train.py:131-166
                 norm = fs.clip_grad_norm_(1.0)
-            opt.step()
-            (rep or fs).publish()
+                opt.step()
+                assert not fs.last_step_skipped
+            sched.step()
             trace.append((float(loss.detach()), float(norm)))
         if rep:
             names = [k for k, _ in m.named_parameters()]
@@ -252,8 +258,10 @@ end_distributed()
 def test_flat_fsdp_with_its_collectives_equals_replica_on_one_gpu(tmp_path):
     """FlatFSDP (ttt_amd/infra/flat_fsdp.py) over a one-rank RCCL group WITH its collectives - the in-place all-gather of the flat
     bf16 buffers and the reduce-scatter of the flat fp32 gradients on the side stream, the units' hooks, the events a unit's
-    forward waits for - against ReplicaMixedPrecision on the same small DiT with the HIP kernels underneath: three AdamW steps,
-    losses / clipped norms to 1e-5 / 1e-4, parameters to 1e-5; everything trainable and the "qkvo" adapter (frozen parameters)."""
+    forward waits for - against ReplicaMixedPrecision on the same small DiT with the HIP kernels underneath: three AdamW steps with
+    the reference's four optimizer groups by parameter name (FlatFSDP under the reference's unchanged loop: its optimizer step
+    hooks finish the backward, read the real extension's error word and publish), losses / clipped norms to 1e-5 / 1e-4,
+    parameters to 1e-5; everything trainable and the "qkvo" adapter (frozen parameters)."""
     script = tmp_path / "flat_vs_replica.py"
     script.write_text(FLAT_SCRIPT)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", TORCHDYNAMO_DISABLE="1")

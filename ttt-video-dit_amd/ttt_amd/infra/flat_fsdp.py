@@ -26,8 +26,17 @@ them.  With one rank this class does what ``ReplicaMixedPrecision`` does (the co
 the N > 1 path are the same code.
 
     fs = FlatFSDP(model.dit)                                  # after init; parameters become bf16 views
-    opt = torch.optim.AdamW(fs.master_parameters(), ...)
-    loss.backward(); fs.finish_backward(); norm = fs.clip_grad_norm_(1.0); opt.step(); fs.publish()
+    opt, schedules = create_specialized_optimizer(model, ...)  # ttt_amd/infra/optimizers.py: the reference's four AdamW groups by NAME
+    fs.attach_optimizer(opt)                                   # step pre-hook: finish_backward + the sweep-error gate; post-hook: publish
+    loss.backward(); norm = fs.clip_grad_norm_(1.0); opt.step(); lr_scheduler.step()          # the reference's loop, train.py:131-166
+
+Optimizer groups.  The reference builds four AdamW groups by parameter name (``ttt/infra/optimizers.py``:31-89: "ttt" / "ssm" names at
+``ssm_lr``, the others at ``base_lr``; "bias" / "norm" / "b1" / "b2" names without weight decay).  A unit mixes all four classes, so
+its flat buffer is laid out GROUP-MAJOR (the parameters of one class are contiguous) and the rank's fp32 master shard is handed to
+the optimizer as one ``Parameter`` per (unit, class) - a VIEW of the shard, with a gradient that is a view of the reduce-scattered
+gradient shard: ``named_master_parameters()`` yields them under names that carry the class (``"layers.3.<ttt_no_wd>"`` contains
+"ttt" and "bias"), so the reference's name rules classify them unchanged.  A rank owns the elements of a class that fall into
+its shard - possibly none.
 
 Export / resume: ``full_parameters()`` / ``optimizer_state_full(opt)`` and their ``load_*`` inverses work by the reference's
 parameter names and are independent of the world size (the layout of an unsharded run).
@@ -49,13 +58,21 @@ _ALIGN = 64          # elements: every parameter starts on a 128-byte boundary o
 
 class _Unit:
     __slots__ = ("module", "params", "names", "offsets", "numel", "padded", "shard", "gathered", "shard_view", "master", "pending",
-                 "ready", "grad_shard", "held")
+                 "ready", "grad_shard", "held", "prefix", "regions", "masters", "has_grad")
 
 
 class FlatFSDP:
     def __init__(self, dit: torch.nn.Module, process_group: Optional[dist.ProcessGroup] = None, param_dtype=torch.bfloat16,
-                 reduce_dtype=torch.float32, gradient_divide_factor: Optional[float] = None, always_communicate: bool = False):
+                 reduce_dtype=torch.float32, gradient_divide_factor: Optional[float] = None, always_communicate: bool = False,
+                 group_of=None):
+        """``group_of(name) -> class key``: which optimizer class a parameter belongs to (default: the reference's four, by name -
+        ``ttt_amd.infra.optimizers.ParameterGroupManager.group_of``); ``group_of=lambda n: ""`` gives one master per unit."""
         self.dit, self.param_dtype, self.reduce_dtype = dit, param_dtype, reduce_dtype
+        if group_of is None:
+            from ttt_amd.infra.optimizers import ParameterGroupManager
+            group_of = ParameterGroupManager.group_of
+        self._group_of = group_of
+        self._optimizers = []
         self.group = process_group
         on = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(process_group) if on else 1
@@ -92,16 +109,25 @@ class FlatFSDP:
             if train:
                 self.units.append(self._build_unit(mod, train, names))
         self._root_hook = dit.register_forward_pre_hook(self._cast_inputs, with_kwargs=True)
+        dit._master_holder = self                             # (ttt_amd.infra.optimizers.named_trainable finds the masters here)
+        self.last_step_skipped = False
         self._published = True                                # the gathered buffers were filled from the full initial values
 
     # ------------------------------------------------------------------------------------------------------------ construction
     def _build_unit(self, mod, train, names) -> _Unit:
         u = _Unit()
+        # group-major layout: the parameters of one optimizer class are contiguous (stable within a class)
+        keys = [self._group_of(names[id(p)]) for p in train]
+        order = sorted(range(len(train)), key=lambda i: (self._class_rank(keys[i]), i))
+        train, keys = [train[i] for i in order], [keys[i] for i in order]
         u.module, u.params, u.names = mod, train, [names[id(p)] for p in train]
-        u.offsets, off = [], 0
-        for p in train:
+        u.prefix = next((f"layers.{i}" for i, m in enumerate(getattr(self.dit, "layers", [])) if m is mod), "root")
+        u.offsets, off, regions = [], 0, {}
+        for p, k in zip(train, keys):
             u.offsets.append(off)
+            lo_hi = regions.setdefault(k, [off, off])
             off += -(-p.numel() // _ALIGN) * _ALIGN
+            lo_hi[1] = off
         u.numel = off
         q = self.world * _ALIGN
         u.padded = -(-off // q) * q
@@ -111,25 +137,90 @@ class FlatFSDP:
         for p, o in zip(train, u.offsets):
             full32[o:o + p.numel()].copy_(p.detach().reshape(-1))
         lo = self.rank * u.shard
-        u.master = torch.nn.Parameter(full32[lo:lo + u.shard].clone(), requires_grad=True)
+        u.master = full32[lo:lo + u.shard].clone()           # the rank's fp32 shard (a plain tensor; the optimizer steps views of it)
+        u.regions, u.masters = {}, {}
+        for k, (a, b) in regions.items():                     # this rank's part of every class: [a, b) in shard coordinates
+            a, b = max(a, lo) - lo, min(b, lo + u.shard) - lo
+            if b > a:
+                u.regions[k] = (a, b)
+                m = torch.nn.Parameter(u.master[a:b], requires_grad=True)
+                assert m.data_ptr() == u.master[a:b].data_ptr()
+                u.masters[k] = m
         u.gathered = full32.to(self.param_dtype)
         u.shard_view = u.gathered[lo:lo + u.shard]
         for p, o in zip(train, u.offsets):
             p.data = u.gathered[o:o + p.numel()].view(p.shape)
-        u.pending, u.ready, u.grad_shard, u.held = len(train), None, None, []
+        u.pending, u.ready, u.grad_shard, u.held, u.has_grad = len(train), None, None, [], False
         for p in train:
             self._hooks.append(p.register_post_accumulate_grad_hook(lambda _p, _u=u: self._on_grad(_u)))
         if self._cuda:
             self._hooks.append(mod.register_forward_pre_hook(lambda _m, _a, _u=u: self._wait_ready(_u)))
         return u
 
+    @staticmethod
+    def _class_rank(key) -> tuple:
+        from ttt_amd.infra.optimizers import GROUP_NAMES
+        return (GROUP_NAMES.index(key), "") if key in GROUP_NAMES else (len(GROUP_NAMES), str(key))
+
     def _cast_inputs(self, module, args, kwargs):
         cast = lambda t: t.to(self.param_dtype) if isinstance(t, torch.Tensor) and t.is_floating_point() else t
         return tuple(cast(a) for a in args), {k: cast(v) for k, v in kwargs.items()}
 
     def master_parameters(self) -> List[torch.nn.Parameter]:
-        """The rank's fp32 shards (one flat parameter per unit): what the optimizer steps."""
-        return [u.master for u in self.units]
+        """What the optimizer steps: this rank's fp32 master slices, one per (unit, optimizer class)."""
+        return [m for _, m in self.named_master_parameters()]
+
+    def named_master_parameters(self):
+        """(name, master slice) pairs; the name is ``"<unit>.<class>"`` - e.g. ``"layers.3.<ttt_no_wd_bias>"`` - spelled so that the
+        reference's NAME rules (optimizers.py:31-46: "ttt" / "ssm", "bias" / "norm" / "b1" / "b2") put it into the class it holds."""
+        tag = {"ttt_no_wd": "<ttt_no_wd_bias>", "ttt_wd": "<ttt_wd>", "other_no_wd": "<other_no_wd_bias>", "other_wd": "<other_wd>"}
+        return [(f"{u.prefix}.{tag.get(k, k)}", m) for u in self.units for k, m in u.masters.items()]
+
+    def attach_optimizer(self, optimizer: torch.optim.Optimizer, gate: bool = True, extension=None):
+        """Makes the reference's unchanged loop work on this holder (train.py:131-166: zero_grad, backward, clip, ``optimizer.step()``,
+        ``lr_scheduler.step()``).  Step PRE-hook: ``finish_backward()`` (idempotent) and, with ``gate``, the look at the TTT-MLP
+        backward's hand-over error word that must come before AdamW (one device synchronisation; all ranks agree by a MAX
+        all-reduce): after a timed-out hand-over or with non-finite gradients the gradients are dropped, so that the step changes
+        nothing (AdamW skips parameters without a gradient; ``last_step_skipped`` says so).  Step POST-hook: ``publish()``."""
+        def pre(opt, args, kwargs):
+            self.finish_backward()
+            self.last_step_skipped = False
+            if gate:
+                self.last_step_skipped = self._gate(extension)
+            return None
+
+        def post(opt, args, kwargs):
+            self.publish()
+
+        # optimizer.zero_grad() also ends this holder's step (held bf16 gradients, pending counters, the "has a gradient" marks)
+        stock = optimizer.zero_grad
+
+        def zero_grad(set_to_none: bool = True):
+            stock(set_to_none=set_to_none)
+            self.zero_grad()
+
+        optimizer.zero_grad = zero_grad
+        self._optimizers.append((optimizer, optimizer.register_step_pre_hook(pre), optimizer.register_step_post_hook(post)))
+        return optimizer
+
+    def _gate(self, extension) -> bool:
+        err = 0
+        if self._cuda or extension is not None:
+            if extension is None:
+                import test_time_training as extension
+            err = int(extension.sweep_error())               # synchronises: everything the backward enqueued has run
+        grads = [m.grad for u in self.units for m in u.masters.values() if m.grad is not None]
+        dev = self.units[0].master.device
+        finite = bool(torch.isfinite(torch.stack(torch._foreach_norm(grads)).sum())) if grads else True
+        bad = torch.tensor([1 if (err != 0 or not finite) else 0], device=dev, dtype=torch.int32)
+        if self.world > 1:
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=self.group)
+        if int(bad):
+            self.zero_grad()
+            if err:
+                extension.sweep_error_clear()
+            return True
+        return False
 
     # ---------------------------------------------------------------------------------------------------------------- forward
     def _wait_ready(self, u: _Unit):
@@ -144,7 +235,7 @@ class FlatFSDP:
             if side:
                 self._comm.wait_stream(torch.cuda.current_stream())       # the step's reads of the old parameters are queued in front
             with (torch.cuda.stream(self._comm) if side else _null()):
-                torch._foreach_copy_([u.shard_view for u in self.units], [u.master.data for u in self.units])
+                torch._foreach_copy_([u.shard_view for u in self.units], [u.master for u in self.units])
                 for u in self.units:
                     if self._communicate:
                         dist.all_gather_into_tensor(u.gathered, u.shard_view, group=self.group)
@@ -191,7 +282,7 @@ class FlatFSDP:
                 if side:
                     self._comm.wait_stream(torch.cuda.current_stream())   # the flat gradient is complete when the side stream starts
                 with (torch.cuda.stream(self._comm) if side else _null()):
-                    first = u.master.grad is None
+                    first = not self._holds_grad(u)
                     if u.grad_shard is None:
                         u.grad_shard = torch.empty(u.shard, dtype=self.reduce_dtype, device=flat.device)      # once: kept across steps
                     shard = u.grad_shard if first else torch.empty_like(u.grad_shard)                          # (micro-batches: a temporary)
@@ -213,11 +304,21 @@ class FlatFSDP:
         u.pending = len(u.params)
 
     @staticmethod
-    def _accumulate(u: _Unit, shard: torch.Tensor):
-        if u.master.grad is None:
-            u.master.grad = shard
+    def _holds_grad(u: _Unit) -> bool:
+        """a reduced gradient of this step is already there (micro-batches accumulate into it); ``optimizer.zero_grad()`` and
+        ``zero_grad()`` both end that"""
+        return u.has_grad and all(m.grad is not None for m in u.masters.values())
+
+    @classmethod
+    def _accumulate(cls, u: _Unit, shard: torch.Tensor):
+        """the unit's reduced gradient shard -> the gradients of its master slices (views of ONE shard-sized tensor)"""
+        if not cls._holds_grad(u):
+            u.grad_shard = shard
+            for k, (a, b) in u.regions.items():
+                u.masters[k].grad = shard[a:b]
+            u.has_grad = True
         else:
-            u.master.grad.add_(shard)                                     # gradient accumulation over micro-batches
+            u.grad_shard.add_(shard)                                      # gradient accumulation over micro-batches
 
     def finish_backward(self):
         """Once per backward, before clipping / the optimizer: reduces units whose parameters did not all receive a gradient
@@ -232,7 +333,9 @@ class FlatFSDP:
 
     def zero_grad(self):
         for u in self.units:
-            u.master.grad = None                              # (u.grad_shard, the storage, is kept for the next step)
+            for m in u.masters.values():
+                m.grad = None                                 # (u.grad_shard, the storage, is kept for the next step)
+            u.has_grad = False
             u.held.clear()
             u.pending = len(u.params)
             for p in u.params:
@@ -240,16 +343,22 @@ class FlatFSDP:
 
     def clip_grad_norm_(self, max_norm: float) -> torch.Tensor:
         """Global 2-norm over all ranks' shards (one scalar all-reduce), gradients scaled in place like
-        ``torch.nn.utils.clip_grad_norm_``; returns the norm."""
-        grads = [u.master.grad for u in self.units if u.master.grad is not None]
-        if not grads:
+        ``torch.nn.utils.clip_grad_norm_``; returns the norm.  Finishes the backward first (idempotent), so that the reference's
+        order - backward, clip, ``optimizer.step()`` - needs no extra call.  (``torch.nn.utils.clip_grad_norm_(model.parameters())``
+        itself cannot serve: the module's parameters are bf16 views whose gradients have been reduced into fp32 SHARDS; FSDP2
+        answers the same call through DTensor.  This method is the one-line change of an unchanged ``train.py``, INTEGRATION.md.)"""
+        self.finish_backward()
+        grads = [m.grad for u in self.units for m in u.masters.values() if m.grad is not None]
+        if not grads and self.world == 1:
             return torch.zeros((), device=self.units[0].master.device)
+        if not grads:                                         # this rank owns no element of any class: it still joins the all-reduce
+            grads = [torch.zeros(1, device=self.units[0].master.device)]
         sq = torch.stack([n * n for n in torch._foreach_norm(grads)]).sum()
         if self.world > 1:
             dist.all_reduce(sq, op=dist.ReduceOp.SUM, group=self.group)
         total = sq.sqrt()
         coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
-        torch._foreach_mul_(grads, coef)
+        torch._foreach_mul_([u.grad_shard for u in self.units if self._holds_grad(u) and u.masters], coef)      # (one tensor per unit)
         return total
 
     # ------------------------------------------------------------------------------------------------------------ inspection
@@ -258,7 +367,7 @@ class FlatFSDP:
         for tests and checkpoints; collective."""
         out = {}
         for u in self.units:
-            src = u.master.data if what == "param" else u.master.grad
+            src = u.master if what == "param" else (u.grad_shard if u.has_grad else None)
             if src is None:
                 continue
             full = torch.empty(u.padded, dtype=src.dtype, device=src.device)
@@ -298,7 +407,7 @@ class FlatFSDP:
             for u in self.units:
                 shard = self._flat_from_named(u, named, "value", strict)
                 if shard is not None:
-                    u.master.data.copy_(shard)
+                    u.master.copy_(shard)
             frozen = {n: p for n, p in self.dit.named_parameters() if not p.requires_grad}
             for n, p in frozen.items():
                 if n in named:
@@ -313,21 +422,47 @@ class FlatFSDP:
         reference's parameters, independent of the world size it was trained with.  Collective."""
         out: Dict[str, Dict[str, torch.Tensor]] = {}
         for u in self.units:
-            st = optimizer.state.get(u.master, {})
-            per = {}
-            for key, val in st.items():
-                if torch.is_tensor(val) and val.numel() == u.shard:
-                    full = torch.empty(u.padded, dtype=val.dtype, device=val.device)
-                    if self.world > 1:
-                        dist.all_gather_into_tensor(full, val.contiguous().reshape(-1), group=self.group)
+            # the rank's shard of every per-element entry, assembled from the state of its master slices (a class this rank
+            # owns nothing of, or an optimizer that has not stepped yet, contributes zeros / nothing)
+            keys, scalars = [], {}
+            for k, m in u.masters.items():
+                for key, val in optimizer.state.get(m, {}).items():
+                    if torch.is_tensor(val) and val.ndim > 0 and val.numel() == m.numel():
+                        if key not in keys:
+                            keys.append(key)
                     else:
-                        full.copy_(val.reshape(-1))
-                    per[key] = full
+                        scalars.setdefault(k, {})[key] = val
+            if self.world > 1:                                # every rank must walk the same collectives: agree on the entries
+                names = [None] * self.world
+                dist.all_gather_object(names, keys, group=self.group)
+                keys = sorted({k for ks in names for k in ks})
+            per = {}
+            for key in keys:
+                mine = torch.zeros(u.shard, dtype=torch.float32, device=u.master.device)
+                for k, m in u.masters.items():
+                    val = optimizer.state.get(m, {}).get(key)
+                    if val is not None:
+                        a, b = u.regions[k]
+                        mine[a:b].copy_(val.reshape(-1))
+                full = torch.empty(u.padded, dtype=mine.dtype, device=mine.device)
+                if self.world > 1:
+                    dist.all_gather_into_tensor(full, mine, group=self.group)
+                else:
+                    full.copy_(mine)
+                per[key] = full
+            if self.world > 1:                                # scalar entries ("step") of a class live where the class has elements
+                allsc = [None] * self.world
+                dist.all_gather_object(allsc, {k: {kk: (float(v) if torch.is_tensor(v) else v) for kk, v in d.items()} for k, d in scalars.items()},
+                                       group=self.group)
+                merged = {}
+                for d in allsc:
+                    for k, dd in d.items():
+                        merged.setdefault(k, dd)
+                scalars = {k: {kk: torch.tensor(v, dtype=torch.float32) if isinstance(v, float) else v for kk, v in dd.items()} for k, dd in merged.items()}
             for n, p, o in zip(u.names, u.params, u.offsets):
                 ent = {k: f[o:o + p.numel()].view(p.shape).clone() for k, f in per.items()}
-                for key, val in st.items():
-                    if key not in per:
-                        ent[key] = val.clone() if torch.is_tensor(val) else val
+                for key, val in scalars.get(self._group_of(n), {}).items():
+                    ent[key] = val.clone() if torch.is_tensor(val) else val
                 if ent:
                     out[n] = ent
         return out
@@ -340,17 +475,22 @@ class FlatFSDP:
                 # per-element entries = tensors of the parameter's own shape ("step" is 0-dimensional)
                 keys = {k for n, p in zip(u.names, u.params) for k, v in state.get(n, {}).items()
                         if torch.is_tensor(v) and v.ndim > 0 and tuple(v.shape) == tuple(p.shape)}
-                new = {}
+                shards = {}
                 for k in sorted(keys):
                     shard = self._flat_from_named(u, {n: state[n][k] for n in u.names if n in state and k in state[n]}, f"optimizer state {k!r}", strict)
                     if shard is not None:
-                        new[k] = shard
-                for n in u.names:
-                    for k, v in state.get(n, {}).items():
-                        if k not in keys and k not in new:
-                            new[k] = v.clone() if torch.is_tensor(v) else v
-                if new:
-                    optimizer.state[u.master] = new
+                        shards[k] = shard
+                for cls, m in u.masters.items():
+                    a, b = u.regions[cls]
+                    new = {k: sh[a:b].clone() for k, sh in shards.items()}
+                    for n in u.names:                         # scalar entries from the first parameter of this class that has them
+                        if self._group_of(n) != cls:
+                            continue
+                        for k, v in state.get(n, {}).items():
+                            if k not in keys and k not in new:
+                                new[k] = v.clone().to(m.device) if torch.is_tensor(v) else v
+                    if new:
+                        optimizer.state[m] = new
 
     def remove(self):
         """Detach from the module (hooks removed, buffers released): the parameters keep their last bf16 values as views of
@@ -359,8 +499,16 @@ class FlatFSDP:
             h.remove()
         self._hooks.clear()
         self._root_hook.remove()
+        for opt, h0, h1 in self._optimizers:
+            h0.remove()
+            h1.remove()
+        self._optimizers.clear()
+        if getattr(self.dit, "_master_holder", None) is self:
+            del self.dit._master_holder
         for u in self.units:
-            u.master.grad = u.grad_shard = None
+            for m in u.masters.values():
+                m.grad = None
+            u.grad_shard = None
         self.units.clear()
         self._full, self._full_free = [], []
 

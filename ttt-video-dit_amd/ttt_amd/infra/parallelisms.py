@@ -225,11 +225,12 @@ class ReplicaMixedPrecision:
 
     def __init__(self, module: torch.nn.Module, param_dtype=torch.bfloat16, reduce_dtype=torch.float32):
         self.module, self.param_dtype, self.reduce_dtype = module, param_dtype, reduce_dtype
-        self._compute, self._master = [], []
+        self._compute, self._master, self._names = [], [], []
         seen = {}
-        for p in module.parameters():
+        for name, p in module.named_parameters():
             if id(p) in seen or not p.is_floating_point():
                 continue
+            self._names.append(name)
             seen[id(p)] = True
             if p.requires_grad:
                 master = torch.nn.Parameter(p.detach().to(torch.float32, copy=True), requires_grad=True)
@@ -242,6 +243,7 @@ class ReplicaMixedPrecision:
             self._compute.append(p)
             self._master.append(master)
         self._hook = module.register_forward_pre_hook(self._cast_inputs, with_kwargs=True)
+        module._master_holder = self                          # (ttt_amd.infra.optimizers.named_trainable finds the masters here)
 
     def _cast_inputs(self, module, args, kwargs):
         cast = lambda t: t.to(self.param_dtype) if isinstance(t, torch.Tensor) and t.is_floating_point() else t
@@ -249,6 +251,10 @@ class ReplicaMixedPrecision:
 
     def master_parameters(self):
         return [m for m in self._master if m.requires_grad]
+
+    def named_master_parameters(self):
+        """(the module's parameter name, its fp32 master) of every trainable parameter: what the optimizer's name rules see"""
+        return [(n, m) for n, m in zip(self._names, self._master) if m.requires_grad]
 
     def collect_grads(self):
         """Gradients of the compute copies -> ``reduce_dtype`` gradients of the masters (accumulating if one is already

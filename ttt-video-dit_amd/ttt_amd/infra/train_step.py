@@ -17,7 +17,7 @@ import torch.distributed as dist
 
 
 def checked_optimizer_step(optimizer: torch.optim.Optimizer, parameters: Iterable[torch.nn.Parameter], max_norm: float,
-                           process_group: Optional[dist.ProcessGroup] = None, extension=None, clip_fn=None) -> Optional[torch.Tensor]:
+                           process_group: Optional[dist.ProcessGroup] = None, extension=None, clip_fn=None, on_skip=None) -> Optional[torch.Tensor]:
     """Clip, verify, step.  Returns the total gradient norm, or ``None`` when the step was SKIPPED because a backward
     hand-over timed out on some rank (or the norm is not finite): the gradients are dropped (``zero_grad``), the error word is
     acknowledged on every rank, parameters and optimizer state are untouched, and the caller may run the batch again.
@@ -29,14 +29,23 @@ def checked_optimizer_step(optimizer: torch.optim.Optimizer, parameters: Iterabl
     if clip_fn is not None:                                  # e.g. FlatFSDP.clip_grad_norm_: the norm over all ranks' shards
         total = clip_fn(max_norm)
     else:
-        total = torch.nn.utils.clip_grad_norm_(params, max_norm) if params else torch.zeros(())
+        total = torch.nn.utils.clip_grad_norm_(params, max_norm) if params else None
     err = int(extension.sweep_error())                      # synchronises the device: everything the backward enqueued has run
+    # the flag lives where the process group can reduce it: the current accelerator under RCCL, the host under gloo (a rank
+    # without gradients has no norm tensor to borrow a device from)
+    on = dist.is_available() and dist.is_initialized()
+    rccl = on and "nccl" in str(dist.get_backend(process_group)) and torch.cuda.is_available()
+    flag_dev = torch.device("cuda", torch.cuda.current_device()) if rccl else torch.device("cpu")
+    if total is None:
+        total = torch.zeros((), device=flag_dev)
     norm = total.full_tensor() if hasattr(total, "full_tensor") else total      # (FSDP2: the norm of sharded gradients is a DTensor)
-    bad = torch.tensor([1 if (err != 0 or not bool(torch.isfinite(norm))) else 0], device=norm.device, dtype=torch.int32)
-    if dist.is_available() and dist.is_initialized():
+    bad = torch.tensor([1 if (err != 0 or not bool(torch.isfinite(norm))) else 0], device=flag_dev, dtype=torch.int32)
+    if on:
         dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=process_group)
     if int(bad):
         optimizer.zero_grad(set_to_none=True)
+        if on_skip is not None:
+            on_skip()
         if err:
             extension.sweep_error_clear()
         return None
