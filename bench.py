@@ -117,6 +117,9 @@ def parse():
     ap.add_argument("--time-budget", type=float, default=1500.0,
                     help="seconds the whole default run may take: a leg whose estimated duration does not fit is skipped with a stated reason")
     ap.add_argument("--retry-reason", default=None, help=argparse.SUPPRESS)          # set by the orchestrator on its second attempt
+    ap.add_argument("--pipeline-parts", type=int, default=None,
+                    help="TTT-MLP layer forward as a pipeline over this many parts of the sequence (the scan of one part on a side stream beside "
+                         "the projections of the next, ttt_amd/models/ssm/pipeline.py); 0 = one piece; default: the library's (TTT_PIPELINE_PARTS)")
     ap.add_argument("--layers", type=int, default=None, help="DEBUG: fewer layers (result flagged invalid)")
     ap.add_argument("--torch-profile", default=None, metavar="FILE",
                     help="DEBUG: after the timed region run ONE more step under torch.profiler and write per-operator tables "
@@ -137,7 +140,8 @@ class KernelTimer:
     (torch's current stream - the extension launches there)."""
 
     def __init__(self, ext):
-        self.ext, self.active, self.events = ext, False, {"fwd": [], "bwd": [], "attn_fwd": [], "attn_bwd": []}
+        self.ext, self.active, self.events = ext, False, {"fwd": [], "bwd": [], "attn_fwd": [], "attn_bwd": [], "fwd_part": []}
+        self.part_calls = 0          # pipelined forwards (ttt_forward_chunk launches that start at step 0)
         self._orig = {}
 
     def install(self):
@@ -145,7 +149,7 @@ class KernelTimer:
             self.ext._bench_timer.uninstall()
         self.ext._bench_timer = self
         for name, key in (("ttt_forward", "fwd"), ("ttt_backward", "bwd"), ("ttt_linear_forward", "fwd"), ("ttt_linear_backward", "bwd"),
-                          ("attn_forward", "attn_fwd"), ("attn_backward", "attn_bwd")):
+                          ("attn_forward", "attn_fwd"), ("attn_backward", "attn_bwd"), ("ttt_forward_chunk", "fwd_part")):
             orig = getattr(self.ext, name)
             self._orig[name] = orig
 
@@ -157,11 +161,14 @@ class KernelTimer:
                 _o(*a)
                 e.record()
                 self.events[_k].append((s, e, tuple(a[0].shape)))
+                if _k == "fwd_part" and int(a[16]) == 0:
+                    self.part_calls += 1
             setattr(self.ext, name, wrapped)
 
     def reset(self):
         for ev in self.events.values():
             ev.clear()
+        self.part_calls = 0
 
     def uninstall(self):
         for name, orig in self._orig.items():
@@ -175,6 +182,17 @@ class KernelTimer:
             if ev:
                 ms = [s.elapsed_time(e) for s, e, _ in ev]
                 out[k] = {"launches": len(ms), "avg_ms": sum(ms) / len(ms), "total_ms": sum(ms), "shape": ev[0][2]}
+        if "fwd_part" in out and self.part_calls:
+            # a pipelined forward scan = several launches (parts of the sequence) on the side stream: reported per whole scan
+            p = out.pop("fwd_part")
+            merged = {"launches": self.part_calls, "avg_ms": p["total_ms"] / self.part_calls, "total_ms": p["total_ms"], "shape": p["shape"],
+                      "parts_per_scan": p["launches"] / self.part_calls}
+            if "fwd" in out:         # (re-materialised layers that keep no scan result run the one-call scan too)
+                f = out["fwd"]
+                merged["total_ms"] += f["total_ms"]
+                merged["launches"] += f["launches"]
+                merged["avg_ms"] = merged["total_ms"] / merged["launches"]
+            out["fwd"] = merged
         return out
 
 
@@ -512,6 +530,8 @@ def leg_command(name, args):
         argv += ["--remat-free-layers", "0", "--remat-keep", "none"]
     if args.no_tuned_gemms:
         argv.append("--no-tuned-gemms")
+    if args.pipeline_parts is not None:
+        argv += ["--pipeline-parts", str(args.pipeline_parts)]
     return worker_command(1, argv)
 
 
@@ -722,6 +742,12 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False, tp=False, sha
         init_model_parameters(model)
         model.init_ssm_weights()
     model.setup_generator(seed=dp_rank, device=dev)        # (a TP group works on ONE sample: same draws on its ranks)
+    parts_used = None
+    for mod in model.modules():
+        if hasattr(mod, "pipeline_parts"):
+            if args.pipeline_parts is not None:
+                mod.pipeline_parts = args.pipeline_parts
+            parts_used = mod.pipeline_parts
     replica = ReplicaMixedPrecision(model.dit) if no_fsdp else None
     flat = None
     if not no_fsdp and not tp and sharded == "flat":      # the same partitioning on flat buffers (ttt_amd/infra/flat_fsdp.py)
@@ -931,7 +957,7 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False, tp=False, sha
                 "config": {"workload": f"CogVideoX-5B+{args.ssm_layer} {args.video_length} training step (fwd+bwd+AdamW), "
                                        f"{cfg.num_layers} layers, L={L} tokens/sample, adapter={args.adapter}",
                            "global_batch": dp * LB, "seq_len": L, "parallelism": (f"tp{tp}" if no_fsdp else f"fsdp{world}(dp{dp}xtp{tp})") if tp else ("replica1" if no_fsdp else (f"flat_fsdp{world}" if (communicate or world > 1) else "flat1") if flat else f"fsdp2_{world}"), "ttt_impl": args.impl,
-                           "remat_free_layers": n_free, "remat_keep": list(dit.remat_keep), "fsdp_reshard_after_forward": bool(args.reshard_after_forward), "tuned_gemm_selections": bool(tuned),
+                           "remat_free_layers": n_free, "remat_keep": list(dit.remat_keep), "ttt_pipeline_parts": parts_used, "fsdp_reshard_after_forward": bool(args.reshard_after_forward), "tuned_gemm_selections": bool(tuned),
                            "sweep_error": sweep_err, "valid": args.layers is None and sweep_err == 0},
                 "roofline": roof, "loss": loss_val, "peak_mem_gib": peak_mem, "peak_reserved_gib": torch.cuda.max_memory_reserved() / 2 ** 30, "alloc_retries_total": Hooks.alloc_retries(), "total_tokens_per_s": dp * L / (dt / args.steps),
                 "peak_mem_gib_per_rank": [[round(float(x), 1) for x in pk] for pk in peaks],

@@ -41,7 +41,7 @@ extern "C" {
  * ttt_hip_sweep_error_clear), -10 (fewer than 4 compute units visible), -11 (no host-mapped error word), -12 (a HIP event /
  * stream call of the backward's two-stream schedule failed); the round-1 exports ttt_hip_debug_variant / ttt_hip_debug_helpers
  * are gone.  1: rounds 1 - 3. */
-#define TTT_HIP_ABI_VERSION 2
+#define TTT_HIP_ABI_VERSION 3
 
 enum { TTT_DTYPE_BF16 = 0, TTT_DTYPE_F32 = 1 };
 /* implementation selector: AUTO picks the MFMA kernels when the geometry is supported - bf16, F=64 and
@@ -146,6 +146,15 @@ size_t ttt_hip_linear_backward_workspace(const ttt_dims* d);
 
 int ttt_hip_mlp_forward(const ttt_dims* d, const ttt_mlp_fwd_args* a, void* workspace, size_t workspace_bytes, void* stream);
 int ttt_hip_mlp_backward(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* workspace, size_t workspace_bytes, void* stream);
+/* An extension BESIDE the 15-tensor forward (round 5), not instead of it: the TTT-MLP forward over steps [step0, step0 + nsteps)
+ * of the sequence that `d` and `a` describe (d->NC = the whole sequence; the tensors of `a` are the whole sequence's), started
+ * from the state in a->W1_init .. b2_init and leaving the state after its last step in W1_final .. b2_final ([B,NH,...] fp32 like
+ * the initial state; may alias it; all four NULL: not stored).  Parts start and end at checkpoint-group boundaries (step0 % G
+ * == 0); their outputs and checkpoints land where the one-call forward puts them, with the same bits (the state is handed on
+ * in fp32, exactly as the kernel holds it).  Lets a caller run the projections of the next part of the sequence on the CUs the
+ * sequential scan leaves idle (ttt_amd/models/ssm/pipeline.py).  MFMA scan at mini-batches of 64 only. */
+int ttt_hip_mlp_forward_chunk(const ttt_dims* d, const ttt_mlp_fwd_args* a, int step0, int nsteps, float* W1_final, float* b1_final,
+                              float* W2_final, float* b2_final, void* workspace, size_t workspace_bytes, void* stream);
 int ttt_hip_linear_forward(const ttt_dims* d, const ttt_linear_fwd_args* a, void* workspace, size_t workspace_bytes, void* stream);
 int ttt_hip_linear_backward(const ttt_dims* d, const ttt_linear_bwd_args* a, void* workspace, size_t workspace_bytes, void* stream);
 
@@ -163,14 +172,26 @@ int ttt_hip_linear_backward(const ttt_dims* d, const ttt_linear_bwd_args* a, voi
 int ttt_hip_pre_forward(int B, int L, int NH, int F, const void* XQ_raw, const void* XK_raw, const void* XV_raw,
                         const float* rope /* [n_pos, F/2, 2] (cos, sin) */, const int32_t* src, const int32_t* pos,
                         const float* ln_w, const float* ln_b /* [NH, F] */, void* XQ, void* XK, void* XV, void* stream);
+/* The same for the scan positions [t0, t0 + tn) only - a part of the sequence (round 5: the projections / pre-processing of the next
+ * part run beside the scan of the current one, ttt_hip_mlp_forward_chunk).  The tensors are the whole sequence's. */
+int ttt_hip_pre_forward_range(int B, int L, int NH, int F, const void* XQ_raw, const void* XK_raw, const void* XV_raw,
+                              const float* rope, const int32_t* src, const int32_t* pos, const float* ln_w, const float* ln_b,
+                              void* XQ, void* XK, void* XV, int t0, int tn, void* stream);
 int ttt_hip_pre_backward_partials(int NH);
 int ttt_hip_pre_backward(int B, int L, int NH, int F, const void* XQ_raw, const void* XK_raw, const void* XV_raw,
                          const float* rope, const int32_t* src, const int32_t* pos, const float* ln_w,
                          const void* dXQ, const void* dXK, const void* dXV, void* dXQ_raw, void* dXK_raw, void* dXV_raw,
                          float* dlnw_part, float* dlnb_part /* [P, NH*F] */, void* stream);
+/* The same with the raw gradients' token rows `ld_out` elements apart (see ttt_hip_attn_pre_backward_ld). */
+int ttt_hip_pre_backward_ld(int B, int L, int NH, int F, const void* XQ_raw, const void* XK_raw, const void* XV_raw,
+                            const float* rope, const int32_t* src, const int32_t* pos, const float* ln_w,
+                            const void* dXQ, const void* dXK, const void* dXV, void* dXQ_raw, void* dXK_raw, void* dXV_raw, int64_t ld_out,
+                            float* dlnw_part, float* dlnb_part, void* stream);
 int ttt_hip_post_partials(int B, int L);
 int ttt_hip_post_forward(int B, int L, int NH, int F, float eps, const void* Y, const int32_t* src, const float* w, const float* b,
                          void* out, void* stream);
+int ttt_hip_post_forward_range(int B, int L, int NH, int F, float eps, const void* Y, const int32_t* src, const float* w, const float* b,
+                               void* out, int t0, int tn, void* stream);      /* scan positions [t0, t0 + tn) only */
 int ttt_hip_post_backward(int B, int L, int NH, int F, float eps, const void* Y, const void* dOut, const int32_t* src, const float* w,
                           void* dY, float* dw_part, float* db_part /* [P, NH*F] */, void* stream);
 int ttt_hip_gate_forward(int B, int L, int D, int n_text, const void* res, const void* y, const float* tanh_text,
@@ -220,6 +241,13 @@ int ttt_hip_attn_pre_backward(int B, int S, int NH, int n_text, float eps, const
                               const ttt_attn_tensor* dq, const ttt_attn_tensor* dk, const float* wq, const float* wk,
                               const float* cos_table, const float* sin_table, void* dq_raw, void* dk_raw, float* part,
                               void* stream);
+/* The same with the raw gradients' token rows `ld_out` elements apart (>= NH*64, a multiple of 8): dq_raw / dk_raw (and the
+ * attention backward's dV, a strided ttt_attn_tensor anyway) can then be the column blocks of ONE [B, S, 3*NH*64] buffer, which
+ * makes the weight gradients of the q / k / v projections one GEMM over the concatenated output gradient (round 5). */
+int ttt_hip_attn_pre_backward_ld(int B, int S, int NH, int n_text, float eps, const void* q_raw, const void* k_raw,
+                                 const ttt_attn_tensor* dq, const ttt_attn_tensor* dk, const float* wq, const float* wk,
+                                 const float* cos_table, const float* sin_table, void* dq_raw, void* dk_raw, int64_t ld_out, float* part,
+                                 void* stream);
 
 /* ---- TransformerLayer glue (bf16 activations, fp32 parameter vectors) --------------------------------------------------
  * adaln: out[B, Lt+Lv, D] = [ shift_t + LN(text) * scale1p_t | shift_v + LN(vid) * scale1p_v ]  - LayerNorm(D, eps) with

@@ -27,3 +27,37 @@ def test_linear3_equals_three_linears():
     assert got[2] is None and want[2] is None
     for g, w in ((got[1], want[1]), (got[3], want[3])):
         assert torch.allclose(g, w, rtol=1e-5, atol=1e-6)
+
+
+def test_linear3_backward_over_column_blocks_of_one_buffer():
+    """Round 5: when the three output gradients are the column blocks of ONE [.., n0 + n1 + n2] buffer (what the consumers' backward
+    kernels write, ttt_amd/models/ssm/fused.py: qkv_grad_blocks), Linear3.backward forms the weight gradients as one GEMM over the
+    concatenation and the input gradient as one GEMM - the same numbers as the three-GEMM path up to the summation order; any other
+    layout (separate tensors, blocks out of order, a missing gradient) takes the three-GEMM path."""
+    from ttt_amd.infra import fused_linear as FL
+    torch.manual_seed(0)
+    B, L, D = 2, 37, 16
+    x = torch.randn(B, L, D, requires_grad=True)
+    ws = [torch.randn(n, D, requires_grad=(i != 1)) for i, n in enumerate((16, 24, 8))]          # (one frozen weight)
+    bs = [torch.randn(n, requires_grad=True) for n in (16, 24, 8)]
+    buf = torch.randn(B, L, 48)
+    blocks = [buf[..., :16], buf[..., 16:40], buf[..., 40:]]
+    assert FL._column_blocks(blocks) is not None and FL._column_blocks(blocks).shape == (B * L, 48)
+    assert FL._column_blocks([b.contiguous() for b in blocks]) is None
+    assert FL._column_blocks([blocks[0], None, blocks[2]]) is None
+    assert FL._column_blocks([buf[..., 16:32], buf[..., :16], buf[..., 32:]]) is None
+    assert FL._column_blocks([buf[:, 1:, :16], buf[:, 1:, 16:40], buf[:, 1:, 40:]]) is None       # (rows of a larger buffer: not one matrix)
+    ys = FL.Linear3.apply(x, ws[0], bs[0], ws[1], bs[1], ws[2], bs[2])
+    ins = [x, ws[0], ws[2]] + bs
+    three = torch.autograd.grad(ys, ins, [b.contiguous() for b in blocks], retain_graph=True)
+    for mode in ("dgrad", "both"):
+        FL.FUSE_QKV_BACKWARD = mode
+        try:
+            fused = torch.autograd.grad(ys, ins, blocks, retain_graph=True)
+        finally:
+            FL.FUSE_QKV_BACKWARD = "dgrad"
+        for a, b in zip(fused, three):
+            assert a.shape == b.shape and torch.allclose(a, b, rtol=1e-5, atol=1e-5), mode
+    ref = torch.autograd.grad([torch.nn.functional.linear(x, w, b) for w, b in zip(ws, bs)], ins, blocks)
+    for a, b in zip(fused, ref):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-5)

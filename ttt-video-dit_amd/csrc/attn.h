@@ -20,7 +20,8 @@ struct PreBwdParams {
     const __bf16 *q_raw, *k_raw, *dq, *dk;
     long dq_sb, dq_sh, dq_ss, dk_sb, dk_sh, dk_ss;   // dq / dk are [B, NH, S, 64] views
     const float *wq, *wk, *cos, *sin;
-    __bf16 *dq_raw, *dk_raw;
+    __bf16 *dq_raw, *dk_raw;            // [B, S, NH*64], token rows `ld_out` elements apart (NH*64 = contiguous)
+    long ld_out;
     float* part;                        // [P, 4, 64]: dwq, dbq, dwk, dbk partial sums, P = pre_blocks(B*S*NH)
     int B, S, NH, n_text;
     float eps;

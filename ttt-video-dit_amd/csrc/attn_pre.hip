@@ -151,11 +151,12 @@ __global__ __launch_bounds__(256) void attn_pre_bwd_kernel(PreBwdParams a) {
         ld8(a.q_raw + idx * 8, x);
         ld8(a.dq + (long)b * a.dq_sb + (long)hd * a.dq_sh + (long)s * a.dq_ss + 8 * o, g);
         ln_rope_bwd(x, wq, a.eps, cosr, sinr, g, dx, dwq, dbq);
-        st8(a.dq_raw + idx * 8, dx);
+        const long raw_off = tok * a.ld_out + hd * 64 + 8 * o;
+        st8(a.dq_raw + raw_off, dx);
         ld8(a.k_raw + idx * 8, x);
         ld8(a.dk + (long)b * a.dk_sb + (long)hd * a.dk_sh + (long)s * a.dk_ss + 8 * o, g);
         ln_rope_bwd(x, wk, a.eps, cosr, sinr, g, dx, dwk, dbk);
-        st8(a.dk_raw + idx * 8, dx);
+        st8(a.dk_raw + raw_off, dx);
     }
     // block reduction over the 32 threads that share a feature octet -> partial [blockIdx][4][64]
 #pragma unroll

@@ -136,6 +136,25 @@ int ttt_hip_mlp_forward(const ttt_dims* d, const ttt_mlp_fwd_args* a, void* ws, 
     return post_launch("mlp_forward");
 }
 
+int ttt_hip_mlp_forward_chunk(const ttt_dims* d, const ttt_mlp_fwd_args* a, int step0, int nsteps, float* W1_final, float* b1_final,
+                              float* W2_final, float* b2_final, void* ws, size_t wsb, void* stream) {
+    (void)ws; (void)wsb;
+    if (check_dims(d)) return -1;
+    if (!a) return fail("ttt_hip: null args");
+    NEED(XQ); NEED(XK); NEED(XV); NEED(last_eta); NEED(ttt_norm_weight); NEED(ttt_norm_bias);
+    NEED(W1_init); NEED(b1_init); NEED(W2_init); NEED(b2_init);
+    NEED(W1_checkpoints); NEED(b1_checkpoints); NEED(W2_checkpoints); NEED(b2_checkpoints); NEED(XQW);
+    if (resolve(d, true, false) != TTT_IMPL_MFMA || d->CS != 64)
+        return fail("ttt_hip: mlp_forward_chunk: only the MFMA scan at mini-batches of 64 continues from a state");
+    if (step0 < 0 || nsteps <= 0 || step0 + nsteps > d->NC || step0 % d->G != 0 || ((step0 + nsteps) % d->G != 0 && step0 + nsteps != d->NC))
+        return fail("ttt_hip: mlp_forward_chunk: a part of the sequence starts and ends at checkpoint-group boundaries (or at the end)");
+    if ((W1_final || b1_final || W2_final || b2_final) && !(W1_final && b1_final && W2_final && b2_final))
+        return fail("ttt_hip: mlp_forward_chunk: give all four final-state buffers or none");
+    if (check_sweep_error("mlp_forward_chunk")) return -3;
+    ttt::mfma::mlp_forward_chunk(d, a, step0, nsteps, W1_final, b1_final, W2_final, b2_final, (hipStream_t)stream);
+    return post_launch("mlp_forward_chunk");
+}
+
 int ttt_hip_mlp_backward(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, size_t wsb, void* stream) {
     if (check_dims(d)) return -1;
     if (!a) return fail("ttt_hip: null args");
@@ -200,11 +219,17 @@ static int check_pp(int B, int L, int NH, int F) {
 int ttt_hip_pre_forward(int B, int L, int NH, int F, const void* XQ_raw, const void* XK_raw, const void* XV_raw,
                         const float* rope, const int32_t* src, const int32_t* pos, const float* ln_w, const float* ln_b,
                         void* XQ, void* XK, void* XV, void* stream) {
+    return ttt_hip_pre_forward_range(B, L, NH, F, XQ_raw, XK_raw, XV_raw, rope, src, pos, ln_w, ln_b, XQ, XK, XV, 0, L, stream);
+}
+int ttt_hip_pre_forward_range(int B, int L, int NH, int F, const void* XQ_raw, const void* XK_raw, const void* XV_raw,
+                              const float* rope, const int32_t* src, const int32_t* pos, const float* ln_w, const float* ln_b,
+                              void* XQ, void* XK, void* XV, int t0, int tn, void* stream) {
     if (check_pp(B, L, NH, F)) return -1;
     if (!XQ_raw || !XK_raw || !XV_raw || !ln_w || !ln_b || !XQ || !XK || !XV) return fail("ttt_hip: pre_forward: null pointer");
     if (pos && !rope) return fail("ttt_hip: pre_forward: positions without a rotation table");
+    if (t0 < 0 || tn <= 0 || t0 + tn > L) return fail("ttt_hip: pre_forward: the range of scan positions must lie inside the sequence");
     ttt::prepost::PreArgs a = {(const __bf16*)XQ_raw, (const __bf16*)XK_raw, (const __bf16*)XV_raw, rope, src, pos, ln_w, ln_b,
-                               (__bf16*)XQ, (__bf16*)XK, (__bf16*)XV, B, L, NH};
+                               (__bf16*)XQ, (__bf16*)XK, (__bf16*)XV, B, L, NH, t0, tn};
     ttt::prepost::pre_forward(a, (hipStream_t)stream);
     return post_launch("pre_forward");
 }
@@ -213,21 +238,35 @@ int ttt_hip_pre_backward(int B, int L, int NH, int F, const void* XQ_raw, const 
                          const float* rope, const int32_t* src, const int32_t* pos, const float* ln_w,
                          const void* dXQ, const void* dXK, const void* dXV, void* dXQ_raw, void* dXK_raw, void* dXV_raw,
                          float* dlnw_part, float* dlnb_part, void* stream) {
+    return ttt_hip_pre_backward_ld(B, L, NH, F, XQ_raw, XK_raw, XV_raw, rope, src, pos, ln_w, dXQ, dXK, dXV, dXQ_raw, dXK_raw, dXV_raw,
+                                   (int64_t)NH * F, dlnw_part, dlnb_part, stream);
+}
+int ttt_hip_pre_backward_ld(int B, int L, int NH, int F, const void* XQ_raw, const void* XK_raw, const void* XV_raw,
+                            const float* rope, const int32_t* src, const int32_t* pos, const float* ln_w,
+                            const void* dXQ, const void* dXK, const void* dXV, void* dXQ_raw, void* dXK_raw, void* dXV_raw, int64_t ld_out,
+                            float* dlnw_part, float* dlnb_part, void* stream) {
     if (check_pp(B, L, NH, F)) return -1;
+    if (ld_out < (int64_t)NH * F || (ld_out & 7) || ((uintptr_t)dXQ_raw & 15) || ((uintptr_t)dXK_raw & 15) || ((uintptr_t)dXV_raw & 15))
+        return fail("ttt_hip: pre_backward: the raw gradients' row stride must be >= NH*F and a multiple of 8 elements, their bases 16-byte aligned");
     if (!XQ_raw || !XK_raw || !XV_raw || !ln_w || !dXQ || !dXK || !dXV || !dXQ_raw || !dXK_raw || !dXV_raw || !dlnw_part || !dlnb_part)
         return fail("ttt_hip: pre_backward: null pointer");
     ttt::prepost::PreBwdArgs a = {(const __bf16*)XQ_raw, (const __bf16*)XK_raw, (const __bf16*)XV_raw, rope, src, pos, ln_w,
                                   (const __bf16*)dXQ, (const __bf16*)dXK, (const __bf16*)dXV,
-                                  (__bf16*)dXQ_raw, (__bf16*)dXK_raw, (__bf16*)dXV_raw, dlnw_part, dlnb_part, B, L, NH};
+                                  (__bf16*)dXQ_raw, (__bf16*)dXK_raw, (__bf16*)dXV_raw, dlnw_part, dlnb_part, B, L, NH, (long)ld_out};
     ttt::prepost::pre_backward(a, (hipStream_t)stream);
     return post_launch("pre_backward");
 }
 int ttt_hip_post_partials(int B, int L) { return ttt::prepost::post_blocks(B, L); }
 int ttt_hip_post_forward(int B, int L, int NH, int F, float eps, const void* Y, const int32_t* src, const float* w, const float* b,
                          void* out, void* stream) {
+    return ttt_hip_post_forward_range(B, L, NH, F, eps, Y, src, w, b, out, 0, L, stream);
+}
+int ttt_hip_post_forward_range(int B, int L, int NH, int F, float eps, const void* Y, const int32_t* src, const float* w, const float* b,
+                               void* out, int t0, int tn, void* stream) {
     if (check_pp(B, L, NH, F)) return -1;
     if (!Y || !w || !b || !out) return fail("ttt_hip: post_forward: null pointer");
-    ttt::prepost::PostArgs a = {(const __bf16*)Y, src, w, b, (__bf16*)out, B, L, NH, eps};
+    if (t0 < 0 || tn <= 0 || t0 + tn > L) return fail("ttt_hip: post_forward: the range of scan positions must lie inside the sequence");
+    ttt::prepost::PostArgs a = {(const __bf16*)Y, src, w, b, (__bf16*)out, B, L, NH, eps, t0, tn};
     ttt::prepost::post_forward(a, (hipStream_t)stream);
     return post_launch("post_forward");
 }
@@ -325,6 +364,15 @@ int ttt_hip_attn_pre_backward(int B, int S, int NH, int n_text, float eps, const
                               const ttt_attn_tensor* dq, const ttt_attn_tensor* dk, const float* wq, const float* wk,
                               const float* cos_table, const float* sin_table, void* dq_raw, void* dk_raw, float* part,
                               void* stream) {
+    return ttt_hip_attn_pre_backward_ld(B, S, NH, n_text, eps, q_raw, k_raw, dq, dk, wq, wk, cos_table, sin_table, dq_raw, dk_raw,
+                                        (int64_t)NH * 64, part, stream);
+}
+int ttt_hip_attn_pre_backward_ld(int B, int S, int NH, int n_text, float eps, const void* q_raw, const void* k_raw,
+                                 const ttt_attn_tensor* dq, const ttt_attn_tensor* dk, const float* wq, const float* wk,
+                                 const float* cos_table, const float* sin_table, void* dq_raw, void* dk_raw, int64_t ld_out, float* part,
+                                 void* stream) {
+    if (ld_out < (int64_t)NH * 64 || (ld_out & 7) || ((uintptr_t)dq_raw & 15) || ((uintptr_t)dk_raw & 15))
+        return fail("ttt_hip: attn_pre_backward: the raw gradients' row stride must be >= NH*64 and a multiple of 8 elements, their bases 16-byte aligned");
     if (B <= 0 || S <= 0 || NH <= 0 || n_text < 0) return fail("ttt_hip: attn_pre: bad dimension");
     if (!q_raw || !k_raw || !dq || !dk || !wq || !wk || !dq_raw || !dk_raw || !part) return fail("ttt_hip: attn_pre_backward: null pointer");
     if (n_text < S && (!cos_table || !sin_table)) return fail("ttt_hip: attn_pre_backward: null rope table");
@@ -334,7 +382,7 @@ int ttt_hip_attn_pre_backward(int B, int S, int NH, int n_text, float eps, const
     p.dq_sb = dq->stride_b; p.dq_sh = dq->stride_h; p.dq_ss = dq->stride_s;
     p.dk_sb = dk->stride_b; p.dk_sh = dk->stride_h; p.dk_ss = dk->stride_s;
     p.wq = wq; p.wk = wk; p.cos = cos_table; p.sin = sin_table;
-    p.dq_raw = (__bf16*)dq_raw; p.dk_raw = (__bf16*)dk_raw; p.part = part;
+    p.dq_raw = (__bf16*)dq_raw; p.dk_raw = (__bf16*)dk_raw; p.part = part; p.ld_out = (long)ld_out;
     p.B = B; p.S = S; p.NH = NH; p.n_text = n_text; p.eps = eps;
     ttt::attn::launch_pre_backward(p, (hipStream_t)stream);
     return post_launch("attn_pre_backward");

@@ -217,7 +217,7 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
     const int ot = tid >> 3, of0 = 8 * (tid & 7);
 
     // ---- first tiles ------------------------------------------------------------------------------
-    const size_t tile0 = (size_t)bh * NC;
+    const size_t tile0 = (size_t)bh * (p.NCs ? p.NCs : NC);
     const int prow = tid >> 3, pcol = (tid & 7) * 8;          // one 16-byte chunk per thread per tile
     uint4 pfK, pfQ, pfV;
     unsigned short pfE = 0;      // eta row of the next step as raw bf16 bits, every wave its own copy: converted when it is parked -
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
         const int xo = SW ? sw_x(ot) : 0;                     // the 16-byte accessors' swap (row ot == prow)
 
         if (i % G == 0) {   // checkpoint: state entering step i (mlp_tk.py:95-98)
-            const size_t ck = (size_t)bh * p.K + i / G;
+            const size_t ck = (size_t)bh * p.K + p.ck0 + i / G;
             float* W1g = p.W1c + ck * 64 * 256;
             float* W2g = p.W2c + ck * 256 * 64;
 #pragma unroll
@@ -555,6 +555,23 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
             *reinterpret_cast<bf16x8*>(p.out + tile * 4096 + (size_t)ot * 64 + of0) = o;
         }
         TTT_STAMP2(6)
+    }
+    if (p.W1f) {        // the state after the last step of this launch: what the next part of the sequence starts from (fp32, exact)
+        float* W1g = p.W1f + (size_t)bh * 64 * 256;
+        float* W2g = p.W2f + (size_t)bh * 256 * 64;
+        int l_op = threadIdx.x & 63;          // an opaque lane index of its own: addresses formed from the function-scope one would be
+        asm volatile("" : "+v"(l_op));        // hoisted in front of the step loop and spilled across it (see the loop's own copies)
+        const int l = l_op, h = l >> 5, c = l & 31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ro = row_of(r, h);
+            W1g[(size_t)ro * 256 + nO + c] = W1t[0][r];
+            W1g[(size_t)(32 + ro) * 256 + nO + c] = W1t[1][r];
+            W2g[(size_t)(nO + ro) * 64 + fO + c] = W2t[0][r];
+            W2g[(size_t)(nX + ro) * 64 + fO + c] = W2t[1][r];
+        }
+        if (h == 0) p.b1f[(size_t)bh * 256 + nO + c] = b1v;
+        if (w == 0 && h == 0) p.b2f[(size_t)bh * 64 + fO + c] = b2v;
     }
 }
 

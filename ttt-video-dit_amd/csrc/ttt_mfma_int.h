@@ -16,6 +16,11 @@ struct ScanParams {
     __bf16* out;                           // XQW (forward only)
     int NH, NC, G, K;
     float eps;
+    // a launch over a PART of the sequence (round 5, ttt_hip_mlp_forward_chunk): NC steps starting at a checkpoint-group boundary.
+    // The tile pointers are pre-offset to the first step; consecutive heads are NCs tiles apart (0: NC), checkpoint index ck0 + i / G,
+    // the state after the last step goes to W1f .. b2f ([B,NH,...] like the initial state, may alias it; null: not stored).
+    int NCs, ck0;
+    float *W1f, *b1f, *W2f, *b2f;
     unsigned long long* dbg;               // optional per-phase cycle totals of workgroup 0
     float* dump;                           // DEBUG: intermediates of workgroup 0, step 0 (revision-2 forward)
 };

@@ -13,6 +13,7 @@ struct PreArgs {
     const float *ln_w, *ln_b;                 // [NH, 64]
     __bf16 *XQ, *XK, *XV;                     // [B, NH, L, 64]
     int B, L, NH;
+    int t0, tn;                               // scan positions [t0, t0 + tn) only (tn = 0: all L) - a part of the sequence
 };
 struct PreBwdArgs {
     const __bf16 *XQ_raw, *XK_raw, *XV_raw;
@@ -20,9 +21,10 @@ struct PreBwdArgs {
     const int32_t *src, *pos;
     const float* ln_w;
     const __bf16 *dXQ, *dXK, *dXV;            // [B, NH, L, 64]
-    __bf16 *dXQ_raw, *dXK_raw, *dXV_raw;      // [B, L, NH*64]
-    float *dlnw_part, *dlnb_part;             // [P, NH*64]
+    __bf16 *dXQ_raw, *dXK_raw, *dXV_raw;      // [B, L, NH*64], token rows `ld_out` elements apart (NH*64: contiguous; 3*NH*64: the
+    float *dlnw_part, *dlnb_part;             // [P, NH*64]                      three column blocks of ONE [B, L, 3*NH*64] buffer)
     int B, L, NH;
+    long ld_out;
 };
 struct PostArgs {
     const __bf16* Y;                          // [B, NH, L, 64]
@@ -31,6 +33,7 @@ struct PostArgs {
     __bf16* out;                              // [B, L, NH*64]
     int B, L, NH;
     float eps;
+    int t0, tn;                               // scan positions [t0, t0 + tn) only (tn = 0: all L)
 };
 struct PostBwdArgs {
     const __bf16 *Y, *dOut;

@@ -86,14 +86,15 @@ __device__ __forceinline__ void norm_rope(const float (&x)[8], const float* cs, 
 
 // ------------------------------------------------------------------------------------------------ pre forward
 __global__ __launch_bounds__(256) void pre_fwd_kernel(PreArgs a) {
-    const long total = (long)a.B * a.L * a.NH * 8;
+    const int tn = a.tn ? a.tn : a.L;          // (a part of the sequence: positions [t0, t0 + tn))
+    const long total = (long)a.B * tn * a.NH * 8;
     const int D = a.NH * 64;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int o = idx & 7;
         const int h = (idx >> 3) % a.NH;
         const long bt = (idx >> 3) / a.NH;
-        const int tp = bt % a.L;               // position in scan order
-        const int b = bt / a.L;
+        const int tp = a.t0 + bt % tn;         // position in scan order
+        const int b = bt / tn;
         const int src = a.src ? a.src[tp] : tp;
         const int pos = a.pos ? a.pos[tp] : -1;
         const size_t in_off = ((size_t)b * a.L + src) * D + h * 64 + 8 * o;
@@ -207,11 +208,12 @@ __global__ __launch_bounds__(256) void pre_bwd_kernel(PreBwdArgs a) {
             dx[j] = dd;                     // dV_raw
             gk[j] += gv[j] - dd;            // kb receives the residual path of vout minus the (v - kb) path
         }
-        st8(a.dXV_raw + in_off, dx);
+        const size_t raw_off = ((size_t)b * a.L + src) * a.ld_out + h * 64 + 8 * o;      // (ld_out = D: the inputs' own layout)
+        st8(a.dXV_raw + raw_off, dx);
         norm_rope_bwd(k, cs, gk, dx);
-        st8(a.dXK_raw + in_off, dx);
+        st8(a.dXK_raw + raw_off, dx);
         norm_rope_bwd(q, cs, gq, dx);
-        st8(a.dXQ_raw + in_off, dx);
+        st8(a.dXQ_raw + raw_off, dx);
     }
     // partials [P][NH*64], P = nthreads / (NH*8)
     const long prow = tid0 / ((long)a.NH * 8);
@@ -325,8 +327,9 @@ __global__ void post_fwd_kernel(PostArgs a) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) { w8[j] = 0.f; b8[j] = 0.f; }
     if (act) { ldf8(a.w + h * 64 + 8 * o, w8); ldf8(a.b + h * 64 + 8 * o, b8); }
-    for (long bt = blockIdx.x; bt < (long)a.B * a.L; bt += gridDim.x) {
-        const int tp = bt % a.L, b = bt / a.L;
+    const int tn = a.tn ? a.tn : a.L;          // (a part of the sequence: positions [t0, t0 + tn))
+    for (long bt = blockIdx.x; bt < (long)a.B * tn; bt += gridDim.x) {
+        const int tp = a.t0 + bt % tn, b = bt / tn;
         const int src = a.src ? a.src[tp] : tp;
         float y[8];
 #pragma unroll
@@ -731,7 +734,7 @@ static int grid_for(long total_threads, int block, int cap_blocks) {
 }
 
 void pre_forward(const PreArgs& a, hipStream_t s) {
-    const long total = (long)a.B * a.L * a.NH * 8;
+    const long total = (long)a.B * (a.tn ? a.tn : a.L) * a.NH * 8;
     hipLaunchKernelGGL(pre_fwd_kernel, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, a);
 }
 int pre_backward_partials(int NH) {          // P for a launch of pre_backward
@@ -751,7 +754,7 @@ int post_blocks(int B, int L) {
     return (int)(n < 1024 ? n : 1024);
 }
 void post_forward(const PostArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(post_fwd_kernel, dim3(post_blocks(a.B, a.L)), dim3((a.NH * 8 + 63) / 64 * 64), 0, s, a);
+    hipLaunchKernelGGL(post_fwd_kernel, dim3(post_blocks(a.B, a.tn ? a.tn : a.L)), dim3((a.NH * 8 + 63) / 64 * 64), 0, s, a);
 }
 void post_backward(const PostBwdArgs& a0, hipStream_t s) {
     PostBwdArgs a = a0;

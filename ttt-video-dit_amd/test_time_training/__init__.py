@@ -63,19 +63,20 @@ _LinFwd = _ptr_struct("_LinFwd", LIN_FWD_FIELDS)
 _LinBwd = _ptr_struct("_LinBwd", LIN_BWD_FIELDS)
 
 # TTT_HIP_ABI_VERSION of include/ttt_hip.h this binding was written against (2: return codes -3 / -10 / -11 / -12 of the TTT-MLP
-# entry points, the round-1 debug exports ttt_hip_debug_variant / _helpers gone)
-ABI_VERSION = 2
+# entry points, the round-1 debug exports ttt_hip_debug_variant / _helpers gone; 3: ttt_hip_pre_backward_ld / ttt_hip_attn_pre_backward_ld,
+# ttt_hip_mlp_forward_chunk, ttt_hip_pre_forward_range / ttt_hip_post_forward_range)
+ABI_VERSION = 3
 
 # every extern "C" symbol declared in include/ttt_hip.h
 EXPORTED_SYMBOLS = (
     "ttt_hip_mlp_forward_workspace", "ttt_hip_mlp_backward_workspace", "ttt_hip_linear_forward_workspace",
-    "ttt_hip_linear_backward_workspace", "ttt_hip_mlp_forward", "ttt_hip_mlp_backward", "ttt_hip_linear_forward",
+    "ttt_hip_linear_backward_workspace", "ttt_hip_mlp_forward", "ttt_hip_mlp_forward_chunk", "ttt_hip_mlp_backward", "ttt_hip_linear_forward",
     "ttt_hip_linear_backward", "ttt_hip_resolve_impl", "ttt_hip_abi_version", "ttt_hip_last_error",
     "ttt_hip_debug_timing", "ttt_hip_debug_groups_per_chunk", "ttt_hip_debug_dump", "ttt_hip_debug_option", "ttt_hip_debug_sweep_error", "ttt_hip_sweep_error_clear", "ttt_hip_debug_occupy_cus",
-    "ttt_hip_pre_forward", "ttt_hip_pre_backward_partials", "ttt_hip_pre_backward", "ttt_hip_post_partials",
+    "ttt_hip_pre_forward", "ttt_hip_pre_forward_range", "ttt_hip_post_forward_range", "ttt_hip_pre_backward_partials", "ttt_hip_pre_backward", "ttt_hip_pre_backward_ld", "ttt_hip_post_partials",
     "ttt_hip_post_forward", "ttt_hip_post_backward", "ttt_hip_gate_forward", "ttt_hip_gate_backward_partials",
     "ttt_hip_gate_backward", "ttt_hip_attn_forward", "ttt_hip_attn_backward",
-    "ttt_hip_attn_pre_forward", "ttt_hip_attn_pre_partials", "ttt_hip_attn_pre_backward",
+    "ttt_hip_attn_pre_forward", "ttt_hip_attn_pre_partials", "ttt_hip_attn_pre_backward", "ttt_hip_attn_pre_backward_ld",
     "ttt_hip_adaln_forward", "ttt_hip_adaln_backward_partials", "ttt_hip_adaln_backward",
     "ttt_hip_resgate_forward", "ttt_hip_resgate_backward_partials", "ttt_hip_resgate_backward",
 )
@@ -286,6 +287,39 @@ def ttt_forward(XQ, XK, XV, last_eta, ttt_norm_weight, ttt_norm_bias, W1_init, b
     _launch("ttt_hip_mlp_forward", _dims(B, NH, NC, CS, F, G, act), args, XQ.device)
 
 
+def ttt_forward_chunk(XQ, XK, XV, last_eta, ttt_norm_weight, ttt_norm_bias, W1_state, b1_state, W2_state, b2_state,
+                      W1_checkpoints, b1_checkpoints, W2_checkpoints, b2_checkpoints, XQW_batch, checkpoint_group_size, step0, nsteps):
+    """The TTT-MLP forward over steps [step0, step0 + nsteps) of the sequence the (whole-sequence) tensors describe - an extension
+    beside ``ttt_forward``'s 15-tensor call (``ttt_hip_mlp_forward_chunk``): started from the fp32 state in ``*_state``
+    ([B,NH,F,H], [B,NH,1,H], [B,NH,H,F], [B,NH,1,F]), which it REPLACES by the state after its last step, so that consecutive
+    calls walk the sequence with the bits of the one-call forward.  Parts start at checkpoint-group boundaries."""
+    _check5(XQ)
+    B, NH, NC, CS, F = XQ.shape
+    G = int(checkpoint_group_size)
+    K = -(-NC // G)
+    H = 4 * F
+    act, f32 = XQ.dtype, torch.float32
+    t = dict(XQ=XQ, XK=XK, XV=XV, last_eta=last_eta, ttt_norm_weight=ttt_norm_weight, ttt_norm_bias=ttt_norm_bias,
+             W1_init=W1_state, b1_init=b1_state, W2_init=W2_state, b2_init=b2_state, W1_checkpoints=W1_checkpoints,
+             b1_checkpoints=b1_checkpoints, W2_checkpoints=W2_checkpoints, b2_checkpoints=b2_checkpoints, XQW=XQW_batch)
+    spec = dict(XQ=((B, NH, NC, CS, F), act), XK=((B, NH, NC, CS, F), act), XV=((B, NH, NC, CS, F), act),
+                last_eta=((B, NH, NC, CS, 1), act), ttt_norm_weight=((1, NH, 1, F), f32), ttt_norm_bias=((1, NH, 1, F), f32),
+                W1_init=((B, NH, F, H), f32), b1_init=((B, NH, 1, H), f32), W2_init=((B, NH, H, F), f32),
+                b2_init=((B, NH, 1, F), f32), W1_checkpoints=((B, NH, K, F, H), f32), b1_checkpoints=((B, NH, K, 1, H), f32),
+                W2_checkpoints=((B, NH, K, H, F), f32), b2_checkpoints=((B, NH, K, 1, F), f32), XQW=((B, NH, NC, CS, F), act))
+    for k, (shape, dt) in spec.items():
+        _check(t[k], k, shape, dt)
+    args = _MlpFwd(*[t[k].data_ptr() for k in MLP_FWD_FIELDS])
+    dims = _dims(B, NH, NC, CS, F, G, act)
+    lib = load_library()
+    stream = torch.cuda.current_stream(XQ.device).cuda_stream
+    with torch.cuda.device(XQ.device):
+        rc = lib.ttt_hip_mlp_forward_chunk(ctypes.byref(dims), ctypes.byref(args), ctypes.c_int(int(step0)), ctypes.c_int(int(nsteps)),
+                                           _p(W1_state), _p(b1_state), _p(W2_state), _p(b2_state), None, ctypes.c_size_t(0), ctypes.c_void_p(stream))
+    if rc != 0:
+        raise RuntimeError(lib.ttt_hip_last_error().decode())
+
+
 def ttt_backward(XQ, XK, XV, last_eta, ttt_norm_weight, ttt_norm_bias, W1_checkpoints, b1_checkpoints, W2_checkpoints,
                  b2_checkpoints, XQW_batch, W1_init_group, b1_init_group, W2_init_group, b2_init_group, x_hat_ln_group,
                  std_ln_group, X2_group, Z1_group, Z1_bar_group, X2_bar_group, grad_l_wrt_Z2_group, grad_l_wrt_Z1_group,
@@ -445,40 +479,57 @@ def _req_maps(rope, src, pos, L, F, n_pos):
                            f"config.compressed_num_frames?)")
 
 
-def pre_forward(XQ_raw, XK_raw, XV_raw, rope, src, pos, ln_w, ln_b, XQ, XK, XV, NH, n_pos=None):
+def pre_forward(XQ_raw, XK_raw, XV_raw, rope, src, pos, ln_w, ln_b, XQ, XK, XV, NH, n_pos=None, t0=0, tn=None):
+    """``t0``, ``tn``: the scan positions [t0, t0 + tn) only (a part of the sequence; default: all of it)"""
     B, L, D = XQ_raw.shape
     _req_maps(rope, src, pos, L, D // NH, n_pos)
     for t, n in ((XQ_raw, "XQ_raw"), (XK_raw, "XK_raw"), (XV_raw, "XV_raw"), (XQ, "XQ"), (XK, "XK"), (XV, "XV")):
         _req(t, n, torch.bfloat16)
     for t, n in ((ln_w, "ln_w"), (ln_b, "ln_b")):
         _req(t, n, torch.float32)
-    _call("ttt_hip_pre_forward", B, L, NH, D // NH, _p(XQ_raw), _p(XK_raw), _p(XV_raw), _p(rope), _p(src), _p(pos), _p(ln_w), _p(ln_b),
-          _p(XQ), _p(XK), _p(XV), device=XQ_raw.device)
+    _call("ttt_hip_pre_forward_range", B, L, NH, D // NH, _p(XQ_raw), _p(XK_raw), _p(XV_raw), _p(rope), _p(src), _p(pos), _p(ln_w), _p(ln_b),
+          _p(XQ), _p(XK), _p(XV), int(t0), int(L - t0 if tn is None else tn), device=XQ_raw.device)
 
 
 def pre_backward_partials(NH):
     return load_library().ttt_hip_pre_backward_partials(int(NH))
 
 
-def pre_backward(XQ_raw, XK_raw, XV_raw, rope, src, pos, ln_w, dXQ, dXK, dXV, dXQ_raw, dXK_raw, dXV_raw, dlnw_part, dlnb_part, NH):
+def _req_rows(t, name, shape, ld):
+    """a bf16 [B, L, D] tensor on a HIP device whose token rows are `ld` elements apart (a column block of a wider buffer)"""
+    if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.bfloat16 or tuple(t.shape) != tuple(shape) \
+            or t.stride(2) != 1 or t.stride(1) != ld or (shape[0] > 1 and t.stride(0) != shape[1] * ld) or t.data_ptr() % 16:
+        raise RuntimeError(f"{name}: expected a bf16 {tuple(shape)} tensor on a HIP device with token rows {ld} elements apart")
+
+
+def pre_backward(XQ_raw, XK_raw, XV_raw, rope, src, pos, ln_w, dXQ, dXK, dXV, dXQ_raw, dXK_raw, dXV_raw, dlnw_part, dlnb_part, NH, ld_out=None):
+    """``ld_out``: row stride (elements) of the three raw-gradient outputs - None: contiguous [B, L, D] tensors; 3 * D: the column
+    blocks of one [B, L, 3 D] buffer (the q / k / v projections' weight gradients are then one GEMM, ttt_amd/infra/fused_linear.py)."""
     B, L, D = XQ_raw.shape
-    for t, n in ((XQ_raw, "XQ_raw"), (XK_raw, "XK_raw"), (XV_raw, "XV_raw"), (dXQ, "dXQ"), (dXK, "dXK"), (dXV, "dXV"),
-                 (dXQ_raw, "dXQ_raw"), (dXK_raw, "dXK_raw"), (dXV_raw, "dXV_raw")):
+    for t, n in ((XQ_raw, "XQ_raw"), (XK_raw, "XK_raw"), (XV_raw, "XV_raw"), (dXQ, "dXQ"), (dXK, "dXK"), (dXV, "dXV")):
         _req(t, n, torch.bfloat16)
+    for t, n in ((dXQ_raw, "dXQ_raw"), (dXK_raw, "dXK_raw"), (dXV_raw, "dXV_raw")):
+        if ld_out is None:
+            _req(t, n, torch.bfloat16)
+        else:
+            _req_rows(t, n, (B, L, D), int(ld_out))
     for t, n in ((ln_w, "ln_w"), (dlnw_part, "dlnw_part"), (dlnb_part, "dlnb_part")):
         _req(t, n, torch.float32)
-    _call("ttt_hip_pre_backward", B, L, NH, D // NH, _p(XQ_raw), _p(XK_raw), _p(XV_raw), _p(rope), _p(src), _p(pos), _p(ln_w),
-          _p(dXQ), _p(dXK), _p(dXV), _p(dXQ_raw), _p(dXK_raw), _p(dXV_raw), _p(dlnw_part), _p(dlnb_part), device=XQ_raw.device)
+    _call("ttt_hip_pre_backward_ld", B, L, NH, D // NH, _p(XQ_raw), _p(XK_raw), _p(XV_raw), _p(rope), _p(src), _p(pos), _p(ln_w),
+          _p(dXQ), _p(dXK), _p(dXV), _p(dXQ_raw), _p(dXK_raw), _p(dXV_raw), ctypes.c_int64(D if ld_out is None else int(ld_out)),
+          _p(dlnw_part), _p(dlnb_part), device=XQ_raw.device)
 
 
 def post_partials(B, L):
     return load_library().ttt_hip_post_partials(int(B), int(L))
 
 
-def post_forward(Y, src, w, b, out, eps):
+def post_forward(Y, src, w, b, out, eps, t0=0, tn=None):
+    """``t0``, ``tn``: the scan positions [t0, t0 + tn) only (default: all)"""
     B, NH, L, F = Y.shape
     _req(Y, "Y", torch.bfloat16); _req(out, "out", torch.bfloat16); _req(w, "w", torch.float32); _req(b, "b", torch.float32)
-    _call("ttt_hip_post_forward", B, L, NH, F, ctypes.c_float(eps), _p(Y), _p(src), _p(w), _p(b), _p(out), device=Y.device)
+    _call("ttt_hip_post_forward_range", B, L, NH, F, ctypes.c_float(eps), _p(Y), _p(src), _p(w), _p(b), _p(out),
+          int(t0), int(L - t0 if tn is None else tn), device=Y.device)
 
 
 def post_backward(Y, dOut, src, w, dY, dw_part, db_part, eps):
@@ -571,15 +622,22 @@ def attn_pre_partials(B, S, NH):
     return load_library().ttt_hip_attn_pre_partials(int(B), int(S), int(NH))
 
 
-def attn_pre_backward(q_raw, k_raw, dq, dk, wq, wk, cos, sin, dq_raw, dk_raw, part, NH, n_text, eps):
+def attn_pre_backward(q_raw, k_raw, dq, dk, wq, wk, cos, sin, dq_raw, dk_raw, part, NH, n_text, eps, ld_out=None):
+    """``ld_out``: as in ``pre_backward`` (dq_raw / dk_raw as column blocks of one [B, S, 3 D] buffer whose third block is dV)."""
     B, S, D = q_raw.shape
-    for t, n in ((q_raw, "q_raw"), (k_raw, "k_raw"), (dq_raw, "dq_raw"), (dk_raw, "dk_raw")):
+    for t, n in ((q_raw, "q_raw"), (k_raw, "k_raw")):
         _req(t, n, torch.bfloat16)
+    for t, n in ((dq_raw, "dq_raw"), (dk_raw, "dk_raw")):
+        if ld_out is None:
+            _req(t, n, torch.bfloat16)
+        else:
+            _req_rows(t, n, (B, S, D), int(ld_out))
     for t, n in ((wq, "wq"), (wk, "wk"), (cos, "cos"), (sin, "sin"), (part, "part")):
         _req(t, n, torch.float32)
     tq, tk = _attn_tensor(dq, "dq", (B, NH, S, 64)), _attn_tensor(dk, "dk", (B, NH, S, 64))
-    _call("ttt_hip_attn_pre_backward", B, S, NH, int(n_text), ctypes.c_float(eps), _p(q_raw), _p(k_raw), ctypes.byref(tq), ctypes.byref(tk),
-          _p(wq), _p(wk), _p(cos), _p(sin), _p(dq_raw), _p(dk_raw), _p(part), device=q_raw.device)
+    _call("ttt_hip_attn_pre_backward_ld", B, S, NH, int(n_text), ctypes.c_float(eps), _p(q_raw), _p(k_raw), ctypes.byref(tq), ctypes.byref(tk),
+          _p(wq), _p(wk), _p(cos), _p(sin), _p(dq_raw), _p(dk_raw), ctypes.c_int64(D if ld_out is None else int(ld_out)), _p(part),
+          device=q_raw.device)
 
 
 # ------------------------------------------------------------------------------------------------

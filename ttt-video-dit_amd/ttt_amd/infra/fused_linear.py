@@ -9,6 +9,8 @@ profiles/r2h_bench_3s_overlap_wgrad.json: the cluster sweep leaves 64 CUs idle, 
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -23,19 +25,44 @@ class Linear3(torch.autograd.Function):
     accumulation chain - ``dX = dY0 W0`` then two GEMMs with ``beta = 1`` into the same buffer - instead of three GEMM outputs
     and the two full-size additions autograd inserts for a tensor with three consumers (2 x 333 MB of traffic per group at
     the 3 s geometry, 6 such additions per layer; accumulated in the GEMM's fp32 epilogue, so also rounded once instead of
-    three times)."""
+    three times).  Round 5: when the three output gradients arrive as the column blocks of one buffer (the consumers' backward kernels
+    write them that way), the input gradient is ONE GEMM with the contraction over all three (see ``backward``)."""
 
     @staticmethod
     def forward(ctx, x, w0, b0, w1, b1, w2, b2):
         ctx.save_for_backward(x)
         ctx.set_materialize_grads(False)             # an unused output arrives as None, not as a tensor of zeros
         ctx.ws, ctx.bs = (w0, w1, w2), (b0, b1, b2)
+        from ttt_amd.models.ssm.pipeline import injected
+        pre = injected("linear3")            # a pipelined TTT forward has formed the three projections part by part already
+        if pre is not None:
+            return pre
         return F.linear(x, w0, b0), F.linear(x, w1, b1), F.linear(x, w2, b2)
 
     @staticmethod
     def backward(ctx, *dys):
         (x,) = ctx.saved_tensors
         x2 = x.reshape(-1, x.shape[-1])
+        cat = _column_blocks(dys) if FUSE_QKV_BACKWARD else None
+        if cat is not None:
+            # the three output gradients are the column blocks of ONE [rows, n0 + n1 + n2] buffer (the backward kernels of the
+            # consumers write them that way, ttt_amd/models/ssm/fused.py: qkv_grad_blocks): the input gradient is ONE GEMM with the
+            # contraction over all three (measured at the 5B / 9 s shapes, profiles/r5b_*: 1.83 ms against 0.79 + 2 x 0.85 for the
+            # accumulation chain at 51 456 rows, 0.62 against 0.82 at 18 052).  The weight gradients stay one GEMM per projection
+            # over the strided blocks: the concatenated 9216 x 3072 x L product is no faster than three of 3072 x 3072 x L
+            # (2.85 against 3 x 0.90 ms - that shape is bound by its K-major operands, not by tile quantisation); "both" keeps
+            # the one-GEMM form selectable.
+            ns = [w.shape[0] for w in ctx.ws]
+            dx = cat.mm(torch.cat(ctx.ws, dim=0)).view(x.shape) if ctx.needs_input_grad[0] else None
+            blocks = cat.split(ns, dim=1)
+            if FUSE_QKV_BACKWARD == "both":
+                gwc = cat.t().mm(x2) if any(w.requires_grad for w in ctx.ws) else None
+                gw = [None if gwc is None or not w.requires_grad else g for w, g in zip(ctx.ws, gwc.split(ns, dim=0) if gwc is not None else [None] * 3)]
+            else:
+                gw = [blk.t().mm(x2) if w.requires_grad else None for w, blk in zip(ctx.ws, blocks)]
+            gbc = cat.sum(0) if any(b is not None and b.requires_grad for b in ctx.bs) else None
+            gb = [None if gbc is None or b is None or not b.requires_grad else g for b, g in zip(ctx.bs, gbc.split(ns) if gbc is not None else [None] * 3)]
+            return dx, gw[0], gb[0], gw[1], gb[1], gw[2], gb[2]
         dx2 = None
         gw, gb = [None] * 3, [None] * 3
         for i, (dy, w, b) in enumerate(zip(dys, ctx.ws, ctx.bs)):
@@ -53,6 +80,39 @@ class Linear3(torch.autograd.Function):
                 gb[i] = dy2.sum(0)
         dx = None if dx2 is None else dx2.view(x.shape)
         return dx, gw[0], gb[0], gw[1], gb[1], gw[2], gb[2]
+
+
+# "dgrad" (default): one input-gradient GEMM over the concatenation, one weight-gradient GEMM per projection; "both": the weight
+# gradients as one GEMM too; "" / "0": three GEMMs each (A/B switch: tools/qkv_backward_bench.py, bench.py)
+FUSE_QKV_BACKWARD = {"0": "", "1": "dgrad"}.get(os.environ.get("TTT_FUSE_QKV_BACKWARD", "dgrad"), os.environ.get("TTT_FUSE_QKV_BACKWARD", "dgrad"))
+
+
+def _column_blocks(dys):
+    """The 2-D ``[rows, n0 + n1 + n2]`` view that the three gradients are consecutive column blocks of, or None."""
+    if any(d is None for d in dys):
+        return None
+    d0 = dys[0]
+    if d0.dim() < 2 or any(d.dim() != d0.dim() or d.shape[:-1] != d0.shape[:-1] or d.dtype != d0.dtype or d.stride(-1) != 1 for d in dys):
+        return None
+    ld = sum(d.shape[-1] for d in dys)
+    base = d0.untyped_storage().data_ptr()
+    off = d0.storage_offset()
+    rows = 1
+    for n in d0.shape[:-1]:
+        rows *= n
+    want = tuple(ld * (rows // _prod(d0.shape[:k + 1])) for k in range(d0.dim() - 1)) + (1,)       # a contiguous [..., ld] buffer's strides
+    for d in dys:
+        if d.untyped_storage().data_ptr() != base or d.storage_offset() != off or tuple(d.stride()) != want:
+            return None
+        off += d.shape[-1]
+    return torch.as_strided(d0, (rows, ld), (ld, 1), d0.storage_offset())
+
+
+def _prod(xs):
+    r = 1
+    for v in xs:
+        r *= v
+    return r
 
 
 def linear3(m0: torch.nn.Linear, m1: torch.nn.Linear, m2: torch.nn.Linear, x: torch.Tensor):

@@ -59,6 +59,12 @@ def suspended():
     return _Scope(None, None)
 
 
+def replaying(kind: str) -> bool:
+    """True inside the RECOMPUTATION of a region that kept ``kind``: ``kernel_result(kind, ...)`` will hand the kept tensors back."""
+    cur = getattr(_state, "cur", None)
+    return cur is not None and cur[1] == "recompute" and kind in cur[0].kinds
+
+
 def kernel_result(kind: str, compute):
     """``compute() -> tuple of tensors`` (the kernel's outputs).  Outside a keeping region: just ``compute()``.  In the forward
     pass of a region that keeps ``kind``: compute and remember.  In its recomputation: hand the remembered tuple back (the

@@ -147,13 +147,17 @@ class FusedSegmentAttention(torch.autograd.Function):
         if dout.stride(3) != 1:
             dout = dout.contiguous()
         mk = lambda: torch.empty(B, S, NH, Dh, device=qr.device, dtype=qr.dtype).transpose(1, 2)
-        dq, dk, dv = mk(), mk(), mk()
+        dq, dk = mk(), mk()
+        # d q_raw, d k_raw and dV as the column blocks of ONE [B, S, 3 D] buffer: the q / k / v projections' weight gradients become one
+        # GEMM over the concatenated output gradient (Linear3.backward); dV is written there directly through its strides
+        from ttt_amd.models.ssm.fused import qkv_grad_blocks
+        dq_raw, dk_raw, dv_blk = qkv_grad_blocks(qr)
+        dv = dv_blk.view(B, S, NH, Dh).transpose(1, 2)                      # [B, NH, S, 64] view, token stride 3 D
         delta = torch.empty(B, NH, S, device=qr.device, dtype=torch.float32)
         ext.attn_backward(view(q), view(k), v, out, dout, lse, delta, dq, dk, dv, scale)
         del q, k
-        dq_raw, dk_raw = torch.empty_like(qr), torch.empty_like(kr)
         P = ext.attn_pre_partials(B, S, NH)
         part = torch.empty(P, 4, 64, device=qr.device, dtype=torch.float32)
-        ext.attn_pre_backward(qr, kr, dq, dk, wq32, wk32, cos, sin, dq_raw, dk_raw, part, NH, n_text, eps)
+        ext.attn_pre_backward(qr, kr, dq, dk, wq32, wk32, cos, sin, dq_raw, dk_raw, part, NH, n_text, eps, ld_out=dq_raw.stride(1))
         g = part.sum(0).to(pdt)
         return dq_raw, dk_raw, dv, g[0], g[1], g[2], g[3], None, None, None, None, None

@@ -23,6 +23,17 @@ def fused_available(x: torch.Tensor, head_dim: int) -> bool:
     return x.is_cuda and x.dtype == _BF16 and head_dim == 64
 
 
+def qkv_grad_blocks(like: torch.Tensor):
+    """Three ``[B, L, D]`` gradient tensors (d q_raw, d k_raw, d v_raw of projections that read the SAME input) as the column blocks
+    of ONE ``[B, L, 3 D]`` buffer: ``Linear3.backward`` (``ttt_amd/infra/fused_linear.py``) recognises the layout and forms the
+    three weight gradients as one ``[3 D, L] x [L, D]`` GEMM and the input gradient as one ``[L, 3 D] x [3 D, D]`` GEMM instead of
+    three each (the 3072 x 3072 x L weight-gradient shape fills 144 of 256 CUs' worth of tiles and runs at 43 % of the MFMA roof,
+    profiles/r4y_bench_default_kernel_stats.csv).  The kernels that write them take the row stride (``ld_out``)."""
+    B, L, D = like.shape
+    buf = torch.empty(B, L, 3 * D, device=like.device, dtype=like.dtype)
+    return buf[..., :D], buf[..., D:2 * D], buf[..., 2 * D:]
+
+
 class FusedPre(torch.autograd.Function):
     """(XQ_raw, XK_raw, XV_raw [B,L,NH*64], ln_w, ln_b [NH,64], rope [n,32,2] | None, src, pos [L] int32 | None)
     -> XQ, XK, XV [B,NH,L,64] in scan order (token permutation, L2-norm, RoPE, LayerNorm target fused)."""
@@ -45,10 +56,11 @@ class FusedPre(torch.autograd.Function):
         q, k, v, w32, rope, src, pos = ctx.saved_tensors
         NH = ctx.NH
         P = ext.pre_backward_partials(NH)
-        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        dq, dk, dv = qkv_grad_blocks(q)
         pw = torch.empty(P, q.shape[-1], device=q.device, dtype=_F32)
         pb = torch.empty_like(pw)
-        ext.pre_backward(q, k, v, rope, src, pos, w32, dXQ.contiguous(), dXK.contiguous(), dXV.contiguous(), dq, dk, dv, pw, pb, NH)
+        ext.pre_backward(q, k, v, rope, src, pos, w32, dXQ.contiguous(), dXK.contiguous(), dXV.contiguous(), dq, dk, dv, pw, pb, NH,
+                         ld_out=dq.stride(1))
         dw = pw.sum(0).view(NH, -1).to(ctx.param_dtype)
         db = pb.sum(0).view(NH, -1).to(ctx.param_dtype)
         return dq, dk, dv, dw, db, None, None, None, None
@@ -63,8 +75,11 @@ class FusedPost(torch.autograd.Function):
         B, NH, L, F = Y.shape
         y = Y.contiguous()
         w32, b32 = weight.detach().to(_F32).contiguous(), bias.detach().to(_F32).contiguous()
-        out = torch.empty(B, L, NH * F, device=y.device, dtype=_BF16)
-        ext.post_forward(y, src, w32, b32, out, float(eps))
+        from ttt_amd.models.ssm.pipeline import injected
+        out = injected("post")
+        if out is None:
+            out = torch.empty(B, L, NH * F, device=y.device, dtype=_BF16)
+            ext.post_forward(y, src, w32, b32, out, float(eps))
         ctx.save_for_backward(y, w32, src)
         ctx.eps, ctx.param_dtype = float(eps), weight.dtype
         return out
@@ -135,6 +150,10 @@ class FusedPreScanMLP(torch.autograd.Function):
         last_eta = eta.to(_BF16)[:, :, :, -1, :, None].contiguous()
 
         def run():
+            from ttt_amd.models.ssm.pipeline import injected
+            pre = injected("scan")           # (a pipelined forward: the scan has walked the sequence part by part already)
+            if pre is not None:
+                return pre
             XQ, XK, XV = (torch.empty(B, NH, L, Fh, device=q.device, dtype=_BF16) for _ in range(3))
             ext.pre_forward(q, k, v, rope, src, pos, w32, b32, XQ, XK, XV, NH, n_pos=getattr(pos, "_ttt_max_pos", None))
             mb = lambda t: t.view(B, NH, NC, CS, Fh)
@@ -188,11 +207,11 @@ class FusedPreScanMLP(torch.autograd.Function):
         del XQ, XK, XV
         # pre backward (re-uses the raw projections)
         P = ext.pre_backward_partials(NH)
-        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        dq, dk, dv = qkv_grad_blocks(q)
         pw = torch.empty(P, D, device=dev, dtype=_F32)
         pb = torch.empty_like(pw)
         flat = lambda t: t.view(B, NH, L, Fh)
-        ext.pre_backward(q, k, v, rope, src, pos, w32, flat(dQ), flat(dK), flat(dV), dq, dk, dv, pw, pb, NH)
+        ext.pre_backward(q, k, v, rope, src, pos, w32, flat(dQ), flat(dK), flat(dV), dq, dk, dv, pw, pb, NH, ld_out=dq.stride(1))
         g_w = (pw.sum(0).view(NH, Fh) + d_lnw.sum(dim=0).squeeze(1)).to(ln_dt)
         g_b = (pb.sum(0).view(NH, Fh) + d_lnb.sum(dim=0).squeeze(1)).to(ln_dt)
         row = d_eta.transpose(-2, -1)

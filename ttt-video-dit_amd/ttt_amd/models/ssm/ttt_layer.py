@@ -16,6 +16,7 @@ MI355X-first differences in how the same math is organised:
 """
 from __future__ import annotations
 
+import os
 from typing import Dict
 
 import torch
@@ -130,6 +131,9 @@ class TTTBase(nn.Module):
         self._tp = None
         self.use_kernel = True
         self.use_fused = True          # fused HIP pre/post-processing when the activations are bf16 on a HIP device
+        # TTT-MLP forward as a pipeline over this many parts of the sequence: the scan of one part on a side stream beside the
+        # projections of the next and the post-norm / output projection of the previous (ttt_amd/models/ssm/pipeline.py); 0 / 1 = off
+        self.pipeline_parts = int(os.environ.get("TTT_PIPELINE_PARTS", "0"))
 
         D, NH, Fh = self.width, self.num_heads, self.head_dim
         self.wq = nn.Linear(D, NH * Fh, bias=True)
@@ -354,22 +358,76 @@ class TTTBase(nn.Module):
 
     def _forward_fused(self, x, freqs_cis, meta: SequenceMetadata, reverse: bool, heads_only: bool = False):
         B, L, _ = x.shape
-        NH, Fh, CS = self.num_heads, self.head_dim, self.mini_batch_size
-        NC = L // CS
         src, pos, rev = self._token_maps(meta, L, x.device, reverse)
-        XQr, XKr, XVr = self.get_qkv_projections(x)
         rope = freqs_cis if freqs_cis.dtype == torch.float32 and freqs_cis.is_contiguous() else freqs_cis.float().contiguous()
-        mb = lambda t: t.view(B, NH, NC, CS, Fh)
-        # eta (tiny: [B, L, NH]): per-token learning rate in the order of the (reversed) sequence, then the
-        # reference's tile bookkeeping - the kernels read the row of the mini-batch the LAST token of a tile came from
+        eta = self._eta_rows(x, rev, meta, L)
+        parts = self._pipeline_plan(x, meta, L, reverse, heads_only)
+        if parts is None:
+            return self._fused_nodes(x, rope, src, pos, eta, heads_only, piped=False)
+        # Pipelined forward (ttt_amd/models/ssm/pipeline.py): every kernel and GEMM of the forward runs in the pre-pass, part by part,
+        # the scan on a side stream beside the neighbouring parts' projections; the autograd Functions then TAKE its results.
+        import test_time_training as ext
+        from ttt_amd.models.ssm import pipeline
+        with torch.no_grad():
+            st = [self._per_batch(p, B) for p in (self.W1, self.b1, self.W2, self.b2)]
+            last_eta = eta.detach().to(torch.bfloat16)[:, :, :, -1, :, None].contiguous()
+            w32 = self.ttt_norm_weight.detach().to(torch.float32).contiguous()
+            b32 = self.ttt_norm_bias.detach().to(torch.float32).contiguous()
+            res = pipeline.prepass(ext, x.detach(), self.wq, self.wk, self.wv, self.wo, self.post_norm, w32, b32, rope, src, pos,
+                                   getattr(pos, "_ttt_max_pos", None), self.num_heads, st, last_eta,
+                                   self._group_size(L // self.mini_batch_size), parts)
+        with pipeline.injecting(res):
+            return self._fused_nodes(x, rope, src, pos, eta, heads_only, piped=True)
+
+    def _pipeline_plan(self, x, meta, L, reverse, heads_only):
+        """the parts of a pipelined forward, or None when this call runs as one piece: not TTT-MLP on the MFMA scan at mini-batches of
+        64, fewer than two checkpoint groups per part, a head shard, a re-materialisation that gets its scan result handed back"""
+        from ttt_amd.infra import remat_cache
+        n = self.pipeline_parts
+        CS = self.mini_batch_size
+        if n < 2 or heads_only or not isinstance(self, TTTMLP) or CS != 64 or remat_cache.replaying("scan"):
+            return None
+        NC = L // CS
+        G = self._group_size(NC)
+        if -(-NC // G) < 2 * n:
+            return None
+        import test_time_training as ext
+        if ext.resolved_impl(x.shape[0], self.num_heads, NC, CS, self.head_dim, G, torch.bfloat16, mlp=True, backward=False) != "mfma":
+            return None
+        key = ("parts", n, meta.num_chunks, meta.text_length, meta.seq_text_length, meta.init_offset, meta.base_offset, L, reverse)
+        hit = self._perm_cache.get(key)
+        if hit is None:
+            from ttt_amd.models.ssm.pipeline import plan_parts
+            seq = scene_permutation(meta, L) if meta.is_multiscene else None      # scan position -> index in the (reversed) sequence
+            if reverse:
+                r = reversal_map(meta, L)
+                seq = r if seq is None else r[seq]                                 # -> token of the input sequence (= the maps' src)
+            hit = self._perm_cache[key] = plan_parts(seq, L, CS, G, n)
+        return hit
+
+    def _eta_rows(self, x, rev, meta, L):
+        """eta (tiny: [B, L, NH]): per-token learning rate in the order of the (reversed) sequence, then the reference's tile
+        bookkeeping - the kernels read the row of the mini-batch the LAST token of a tile came from: [B,NH,NC,1,CS]"""
+        B = x.shape[0]
+        Fh, CS = self.head_dim, self.mini_batch_size
+        NC = L // CS
         w = self.learnable_ttt_lr_weight.squeeze(1)
         lr = torch.sigmoid(F.linear(x, w.to(x.dtype), self.learnable_ttt_lr_bias.reshape(-1).to(x.dtype)))      # [B, L, NH]
         if rev is not None:
             lr = lr.index_select(1, rev)
-        eta = (self.ttt_base_lr * lr.view(B, NC, CS, NH).permute(0, 3, 1, 2).unsqueeze(3) / Fh) / CS               # [B,NH,NC,1,CS]
+        eta = (self.ttt_base_lr * lr.view(B, NC, CS, self.num_heads).permute(0, 3, 1, 2).unsqueeze(3) / Fh) / CS    # [B,NH,NC,1,CS]
         if meta.is_multiscene:
             p, _ = self._perm(meta, L, x.device)
             eta = eta.index_select(2, torch.div(p, CS, rounding_mode="floor")[CS - 1::CS])
+        return eta
+
+    def _fused_nodes(self, x, rope, src, pos, eta, heads_only, piped):
+        """the autograd nodes of the fused path: projections -> pre + scan -> post-norm -> output projection"""
+        B, L, _ = x.shape
+        NH, Fh, CS = self.num_heads, self.head_dim, self.mini_batch_size
+        NC = L // CS
+        mb = lambda t: t.view(B, NH, NC, CS, Fh)
+        XQr, XKr, XVr = self.get_qkv_projections(x)
         if isinstance(self, TTTMLP):       # pre + scan as one autograd node: only the raw projections stay alive for backward
             st = [self._per_batch(p, B) for p in (self.W1, self.b1, self.W2, self.b2)]
             Y = FusedPreScanMLP.apply(XQr, XKr, XVr, self.ttt_norm_weight, self.ttt_norm_bias, rope, src, pos, NH, *st, eta,
@@ -382,6 +440,9 @@ class TTTBase(nn.Module):
             out.index_copy_(1, src.long(), Y.reshape(B, NH, L, Fh).transpose(1, 2))
             return out.view(B, L, NH * Fh)
         y = FusedPost.apply(Y.reshape(B, NH, L, Fh), self.post_norm.weight, self.post_norm.bias, src, self.post_norm.eps)
+        if piped:          # (the output projection takes the pre-pass's result too)
+            from ttt_amd.models.ssm.pipeline import InjectedLinear
+            return InjectedLinear.apply(y, self.wo.weight, self.wo.bias)
         return self.wo(y)
 
     # helpers shared by the two variants
