@@ -693,12 +693,6 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False, tp=False, sha
 
     ext.load_library()
     ext.set_impl(args.impl)
-    if os.environ.get("TTT_TAIL_DELAY_US"):          # A/Bs of the backward's schedule (tools/_run_next_round_first_call.sh); default: off
-        ext.debug_option("tail_delay_us", int(os.environ["TTT_TAIL_DELAY_US"]))
-    if os.environ.get("TTT_FLAGS_MEMSET_EARLY"):
-        ext.debug_option("flags_memset_early", int(os.environ["TTT_FLAGS_MEMSET_EARLY"]))
-    if os.environ.get("TTT_TAIL_GATE_RESIDENT"):
-        ext.debug_option("tail_gate_resident", int(os.environ["TTT_TAIL_GATE_RESIDENT"]))
     init_distributed("nccl")
     # RCCL builds its communicator (and allocates ~0.5 GiB of device buffers) at the FIRST collective: do that now, while the
     # device is empty - at 30 s the first collective used to come when the model had filled HBM and RCCL's allocation failed

@@ -278,22 +278,14 @@ void        ttt_hip_debug_timing(void* device_buffer);
 /* DEBUG: force the number of checkpoint groups the MFMA backward re-materialises per chunk (0 = automatic,
  * sized to cover the 256 CUs); lets tests exercise the chunk-to-chunk gradient hand-over at small sizes. */
 void        ttt_hip_debug_groups_per_chunk(int groups);
-/* DEBUG / A-B knobs by name: "groups_per_chunk" (checkpoint groups per backward chunk, 0 = automatic), "overlap_tail" (TTT-MLP
- * backward: 1 (default) = the tail kernel of a chunk runs on an internal side stream beside the next chunk's sweep and the
- * caller's stream joins it before the call returns; 2 = the recompute of the chunk after next runs there too; 0 = everything on
- * the caller's stream; identical results), "sweep_prefetch" (1 default / 0: L2 prefetch touches of the backward sweep), "rc_nt"
- * (1 default / 0: non-temporal stores of the backward's step records), "fast_records" (TTT-MLP
- * backward sweep hand-over: 1 (default) = plain, L2-resident records once the four workgroups of a cluster have proven that they
- * share an XCD; 0 = write-through records always), "sweep_fast_count" (query: returns -2 - the number of cluster workgroup
- * launches that took the plain form), "sweep_fault" (fault injection for the tests of the hand-over failure path: workgroup 3 of
- * every backward cluster leaves before its first hand-over), "sweep_records_bf16" (1 default / 0: the sweep's hand-over records
- * carry the partial d(gZ2) tiles as bf16 and the owner waves do their partner-independent arithmetic under the record loads; 0 =
- * the round-3 sweep), "sweep_deriver_wave0" (2 default / 4: which waves take the deriver role), "own_bf16" (the inner
- * LayerNorm's owner rows of the backward's step record as bf16), "attn_stage" (attention backward: tiles of 64 per LDS stage in
- * the dQ and dK / dV kernels, default 2 - half the workgroup barriers of 1, the round-3 kernels; bit-identical results),
- * "attn_stage_dq" (1 / 2) and "attn_stage_dkdv" (1 .. 4) for one kernel only.
- * Returns 0, or -1 for an unknown name.  (The round-1 knobs - kernel revisions, prefetch
- * helpers, attention / scan variants - were A/B-ed on hardware in round 2 and removed together with the losing code.) */
+/* DEBUG knobs by name (five; every A/B option of rounds 2 - 4 was decided on hardware and removed with the losing code in round 5):
+ * "groups_per_chunk" (checkpoint groups per backward chunk, 0 = automatic: tests exercise the chunk hand-over at small sizes),
+ * "overlap_tail" (TTT-MLP backward: 1 (default) = the tail kernel of a chunk runs on an internal side stream beside the next chunk's
+ * sweep and the caller's stream joins it before the call returns; 0 = everything on the caller's stream; identical results),
+ * "fast_records" (sweep hand-over: 1 (default) = plain, L2-resident records once the four workgroups of a cluster have proven that they
+ * share an XCD; 0 = write-through records always; identical results), "sweep_fast_count" (query: returns -2 - the number of cluster
+ * workgroup launches that took the plain form), "sweep_fault" (fault injection for the tests of the hand-over failure path: workgroup
+ * 3 of every backward cluster leaves before its first hand-over).  Returns 0, or -1 for an unknown name. */
 int         ttt_hip_debug_option(const char* name, int value);
 /* DEBUG: device buffer (>= 120000 floats) receiving the step-0 intermediates of workgroup 0 (NULL = off). */
 /* TTT-MLP backward, cluster form (four workgroups per (b,h) exchanging partial tiles inside the launch; at most n_cu / 4

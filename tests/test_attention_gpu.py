@@ -1,4 +1,4 @@
-"""GPU parity tests (-m gpu) of the local-attention kernels (csrc/attn_fwd.hip, attn_bwd.hip, attn_pre.hip), called
+"""GPU parity tests (-m gpu) of the local-attention kernels (csrc/attn_fwd.hip, attn_bwd.hip, attn_v2.hip, attn_pre.hip), called
 through the C ABI (ttt_hip_attn_*), against the fp64 CPU oracle (oracle/attn_oracle.py) on the same bf16-rounded
 inputs.  Tolerances: bf16 operands with fp32 accumulation and bf16-rounded probabilities -> outputs rel-L2 <= 1e-2,
 gradients <= 2e-2 (the reference's own bf16 SDPA is at 3-6e-3 / 1e-2 on these inputs).  Shapes cover the ragged tail
@@ -174,63 +174,3 @@ def test_fused_attention_node_equals_two_nodes():
         res.append([out.detach()] + [t.grad for t in (qr, kr, vr)] + [t.grad for t in par])
     for a, b in zip(*res):
         assert torch.equal(a, b)
-
-
-def _attn_defaults(e):
-    """the library's defaults of the attention-backward debug options (csrc/attn_v2.hip)"""
-    e.debug_option("attn_dq_wide", 1)
-    e.debug_option("attn_stage_dq", 1)
-    e.debug_option("attn_stage_dkdv", 2)
-
-
-@pytest.mark.parametrize("B,NH,S,layout", [(2, 3, 300, "bshd"), (1, 8, 1024, "bhsd"), (1, 2, 40, "bshd"), (1, 16, 833, "bshd")])
-def test_attention_tiles_per_stage_equal_the_one_tile_kernels(B, NH, S, layout):
-    """The backward kernels with SEVERAL tiles of 64 per LDS stage (csrc/attn_body.h dq_staged / dkdv_staged; the default since
-    round 4 is two: 13.5 against 14.2 ms per backward at the training geometry) against the one-tile kernels of round 3 (debug
-    option "attn_stage" = 1): the same arithmetic in the same order, so dQ / dK / dV must have the same bits - one tile in all,
-    odd tile counts (300: 5, 833: 14 with a ragged tail), a multiple of every stage depth (1024).  The emulator runs the
-    same comparison with its LDS race detector (tests/test_emul_attention_cpu.py)."""
-    e = ext()
-    from ttt_amd.models.cogvideo.attention import SegmentAttention
-    q, k, v, do = make(B, NH, S, 31 + S, layout)
-    res = {}
-    try:
-        e.debug_option("attn_dq_wide", 0)
-        for dq_st, dkdv_st in ((1, 1), (2, 2), (2, 3), (1, 4)):
-            e.debug_option("attn_stage_dq", dq_st)
-            e.debug_option("attn_stage_dkdv", dkdv_st)
-            qq, kk, vv = (t.detach().clone().requires_grad_(True) for t in (q, k, v))
-            SegmentAttention.apply(qq, kk, vv).backward(do)
-            torch.cuda.synchronize()
-            res[(dq_st, dkdv_st)] = (qq.grad.clone(), kk.grad.clone(), vv.grad.clone())
-    finally:
-        _attn_defaults(e)
-    for key in ((2, 2), (2, 3), (1, 4)):
-        for a, b, name in zip(res[(1, 1)], res[key], ("dq", "dk", "dv")):
-            assert not torch.isnan(b.float()).any(), (key, name)
-            assert torch.equal(a, b), (key, name)
-
-
-@pytest.mark.parametrize("B,NH,S,layout", [(2, 3, 300, "bshd"), (1, 8, 1024, "bhsd"), (1, 2, 40, "bshd"), (1, 16, 833, "bshd")])
-def test_attention_dq_wide_equals_default(B, NH, S, layout):
-    """dQ with 64 query rows per wave (csrc/attn_body.h dq_wide, debug option "attn_dq_wide"): every K / V fragment read from LDS
-    feeds two MFMAs; a query row's arithmetic and its order over the keys are unchanged, so dQ must have the same bits as the
-    default kernel's - with one and with two key tiles per LDS stage."""
-    e = ext()
-    from ttt_amd.models.cogvideo.attention import SegmentAttention
-    q, k, v, do = make(B, NH, S, 57 + S, layout)
-    res = {}
-    try:
-        for wide, st in ((0, 2), (1, 2), (1, 1)):
-            e.debug_option("attn_dq_wide", wide)
-            e.debug_option("attn_stage_dq", st)
-            qq, kk, vv = (t.detach().clone().requires_grad_(True) for t in (q, k, v))
-            SegmentAttention.apply(qq, kk, vv).backward(do)
-            torch.cuda.synchronize()
-            res[(wide, st)] = qq.grad.clone()
-    finally:
-        _attn_defaults(e)
-    for key in ((1, 2), (1, 1)):
-        assert not torch.isnan(res[key].float()).any(), key
-        assert torch.equal(res[(0, 2)], res[key]), key
-

@@ -89,7 +89,7 @@ def test_forward_scan_lds_model_is_near_the_device_counter():
     P2, C2, by2 = share(m.Layout(72, True))
     assert P2 < 0.75 * P
     assert all(v == 0 for k, v in by2.items() if k.startswith(("pi_read", "tr ", "st_image", "tile park")))
-    # the variant the kernel carries (debug option "scan_swap"): the row walkers' conflicts go, the transposed reads' stay
+    # the variant the kernel carries (always on since round 5): the row walkers' conflicts go, the transposed reads' stay
     P3, C3, by3 = share(m.Layout(72, False, True))
     assert (P3, C3) == (P - 1280, C - 1280)
     assert all(v == 0 for k, v in by3.items() if k.startswith(("pi_read", "st_image", "tile park")))

@@ -35,10 +35,10 @@ def test_sweep_rounding_budget_lr_gate(emul):
     r4, worst4 = emul.run(set(emul.POINTS) - {"dZ2b_colsum"}, g)
     assert all(v < bound[k] for k, v in r4.items()), (r4, bound)
     assert worst4 < 8e-2
-    # the bf16 hand-over records (debug option "sweep_records_bf16") stay inside the same budget
+    # the bf16 hand-over records (shipped since round 4) stay inside the same budget
     r16, worst16 = emul.run(set(emul.POINTS) - {"dZ2b_colsum"} | {"P_rec"}, g)
     assert all(v < bound[k] for k, v in r16.items()) and worst16 < 8e-2, (r16, worst16)
-    # ... and so do bf16 inner-LayerNorm owner rows of the step record (option "own_bf16"); the OUTPUT LayerNorm's x_hat does not
+    # ... and so do bf16 inner-LayerNorm owner rows of the step record (shipped since round 4); the OUTPUT LayerNorm's x_hat does not
     r_own, worst_own = emul.run(set(emul.POINTS) - {"dZ2b_colsum"} | {"P_rec", "own_xh", "own_go"}, g)
     assert all(v < bound[k] for k, v in r_own.items()) and worst_own < 8e-2, (r_own, worst_own)
     r_xl, _ = emul.run(set(emul.POINTS) - {"dZ2b_colsum"} | {"own_xl"}, g)

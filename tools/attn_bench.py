@@ -34,9 +34,6 @@ def main():
     ap.add_argument("--b", type=int, default=1)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--no-sdpa", action="store_true")
-    ap.add_argument("--stages", default="", help="comma list of attention-backward variants to A/B in interleaved rounds in THIS process: "
-                    "DQ:DKDV = tiles of 64 per LDS stage in the dQ (1 / 2) and the dK / dV kernel (1 .. 4), e.g. 1:1,2:2,2:3,2:4,1:2")
-    ap.add_argument("--rounds", type=int, default=5)
     a = ap.parse_args()
     import test_time_training as ext
     from ttt_amd.models.cogvideo.attention import SegmentAttention
@@ -56,28 +53,6 @@ def main():
     delta = torch.empty(B, NH, S, device=dev)
     t = timeit(lambda: ext.attn_backward(q, k, v, out, do, lse, delta, dq, dk, dv, 0.125), a.iters)
     res["hip_bwd"] = {"ms": t, "tflops": 2.5 * flops / t / 1e9}
-    if a.stages:
-        # interleaved rounds, one process (the guide's rule for perf deltas): median and minimum per variant, and bit-identity
-        stages = [x if ":" in x else f"{x}:{x}" for x in a.stages.split(",")]
-        times = {st: [] for st in stages}
-        ref = None
-        for rnd in range(a.rounds):
-            for st in stages:
-                ext.debug_option("attn_dq_wide", 1 if st.split(":")[0].endswith("w") else 0)      # "2w:2" = dQ with 64 query rows per wave
-                ext.debug_option("attn_stage_dq", int(st.split(":")[0].rstrip("w")))
-                ext.debug_option("attn_stage_dkdv", int(st.split(":")[1]))
-                times[st].append(timeit(lambda: ext.attn_backward(q, k, v, out, do, lse, delta, dq, dk, dv, 0.125), a.iters))
-                if rnd == 0:
-                    torch.cuda.synchronize()
-                    cur = [x.clone() for x in (dq, dk, dv)]
-                    if ref is None:
-                        ref = cur
-                    else:
-                        res.setdefault("bit_identical_to_first", {})[st] = all(torch.equal(x, y) for x, y in zip(cur, ref))
-        ext.debug_option("attn_dq_wide", 1)          # library defaults (csrc/attn_v2.hip)
-        ext.debug_option("attn_stage_dq", 1)
-        ext.debug_option("attn_stage_dkdv", 2)
-        res["bwd_by_stage"] = {st: {"median_ms": sorted(v)[len(v) // 2], "min_ms": min(v)} for st, v in times.items()}
     if not a.no_sdpa:
         qq, kk, vv = (x.detach().clone().requires_grad_(True) for x in (q, k, v))
         t = timeit(lambda: F.scaled_dot_product_attention(qq, kk, vv), a.iters)

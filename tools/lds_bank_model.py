@@ -12,7 +12,7 @@ reads ...), so the numbers are as good as that enumeration; the check is the dev
     python tools/lds_bank_model.py --ts 80         # another row stride (elements) of the bf16 tiles
     python tools/lds_bank_model.py --swizzle       # unpadded 64-element rows, 8-byte units XOR-ed by a function of the row
     python tools/lds_bank_model.py --half-swap     # padded rows, the two 8-byte units of a 16-byte chunk swapped by row bits 3 ^ 4
-                                                   # (csrc/ttt_mfma2.hip, debug option "scan_swap": address selection only)
+                                                   # (csrc/ttt_mfma2.hip, always on since round 5: address selection only)
 """
 import argparse
 from collections import defaultdict

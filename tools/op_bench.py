@@ -32,8 +32,6 @@ def main():
     ap.add_argument("--overlap", type=int, default=1, help="A/B: TTT-MLP backward schedule, 0 = one stream, 1 = tail kernel of a chunk beside the next sweep (default), 2 = the next recompute too")
     ap.add_argument("--gpc", type=int, default=0, help="DEBUG A/B: checkpoint groups per backward chunk (0 = automatic)")
     ap.add_argument("--write-through-records", action="store_true", help="DEBUG A/B: the backward sweep's hand-over records always write-through (sc1), never plain")
-    ap.add_argument("--rc-nt", type=int, default=1, help="A/B: revision-4 recompute, non-temporal stores of the step records")
-    ap.add_argument("--prefetch", type=int, default=1, help="A/B: revision-4 sweep, L2 prefetch touches two steps ahead (1 default, 0 off)")
     ap.add_argument("--ab", default=None, metavar="OPTION", help="interleaved A/B inside one process: the named debug option alternates 0 / 1 from iteration to iteration; the backward's average is reported per value (same box, same clocks)")
     ap.add_argument("--ab-restore", type=int, default=1, help="value the --ab option is left at for the --phases pass")
     ap.add_argument("--ab-fixed", default=None, metavar="OPTION=VALUE", help="set one more debug option for the whole run")
@@ -48,10 +46,8 @@ def main():
     ext.load_library()
     ext.set_impl(a.impl)
     ext.debug_option("fast_records", 0 if a.write_through_records else 1)
-    ext.debug_option("sweep_prefetch", a.prefetch)
     if a.ab_fixed:
         ext.debug_option(a.ab_fixed.split("=")[0], int(a.ab_fixed.split("=")[1]))
-    ext.debug_option("rc_nt", a.rc_nt)
     ext.debug_option("overlap_tail", a.overlap)
     ext.debug_option("groups_per_chunk", a.gpc)
     dev = torch.device("cuda:0")

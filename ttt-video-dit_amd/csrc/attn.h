@@ -36,8 +36,6 @@ void launch_backward(const BwdParams& p, hipStream_t s);
 // dQ and dK / dV through the workgroup bodies of attn_body.h (attn_v2.hip)
 void launch_dq_v2(const BwdParams& p, hipStream_t s);
 void launch_dkdv_v2(const BwdParams& p, hipStream_t s);
-void set_debug_attn_dq_wide(int v);                // 1: dQ with 64 query rows per wave (A/B), 0 default
-void set_debug_attn_stage(int which, int v);      // tiles of 64 per LDS stage: which = 0 both kernels, 1 dQ (1 / 2), 2 dK / dV (1 .. 4); default 2
 
 }  // namespace attn
 }  // namespace ttt

@@ -57,19 +57,6 @@ int ttt_hip_debug_option(const char* name, int value) {
     else if (!strcmp(name, "sweep_fast_count")) return -2 - (int)ttt::mfma::read_sweep_fast_count();      // query: returns -2 - count
     else if (!strcmp(name, "overlap_tail")) ttt::mfma::set_debug_overlap_tail(value);            // backward: 1 (default) / 0 = tail kernel on the caller's stream
     else if (!strcmp(name, "groups_per_chunk")) ttt::mfma::set_debug_groups_per_chunk(value);
-    else if (!strcmp(name, "rc_nt")) ttt::mfma::set_debug_rc_nt(value);
-    else if (!strcmp(name, "sweep_prefetch")) ttt::mfma::set_debug_sweep_prefetch(value);      // revision-4 sweep: L2 prefetch touches (1 default / 0)
-    else if (!strcmp(name, "attn_stage")) ttt::attn::set_debug_attn_stage(0, value);            // attention backward: tiles of 64 per LDS stage (default 2; 1 = round-3 kernels)
-    else if (!strcmp(name, "attn_dq_wide")) ttt::attn::set_debug_attn_dq_wide(value);           //   dQ kernel with 64 query rows per wave (A/B)
-    else if (!strcmp(name, "attn_stage_dq")) ttt::attn::set_debug_attn_stage(1, value);         //   dQ kernel only (1 / 2)
-    else if (!strcmp(name, "attn_stage_dkdv")) ttt::attn::set_debug_attn_stage(2, value);       //   dK / dV kernel only (1 .. 4)
-    else if (!strcmp(name, "sweep_records_bf16")) ttt::mfma::set_debug_sweep_records_bf16(value);        // partial d(gZ2) tiles of the hand-over records as bf16 (A/B)
-    else if (!strcmp(name, "sweep_deriver_wave0")) ttt::mfma::set_debug_sweep_deriver_wave0(value);      // 4 (default) / 2: which waves take the deriver role (A/B of the SIMD placement)
-    else if (!strcmp(name, "own_bf16")) ttt::mfma::set_debug_own_bf16(value);                          // step record: inner-LayerNorm owner rows as bf16 (A/B)
-    else if (!strcmp(name, "flags_memset_early")) ttt::mfma::set_debug_flags_memset_early(value);      // backward: hand-over flags of the next sweep cleared behind the current one (1 default / 0)
-    else if (!strcmp(name, "tail_gate_resident")) ttt::mfma::set_debug_tail_gate_resident(value);      // backward: the tail waits for the next sweep's workgroups to be resident (A/B, 0 default)
-    else if (!strcmp(name, "tail_delay_us")) ttt::mfma::set_debug_tail_delay_us(value);                // backward: gate kernel of `value` us in front of each tail kernel (0 off)
-    else if (!strcmp(name, "scan_swap")) ttt::mfma::set_debug_scan_swap(value);                        // forward scan: half-chunk swap of the LDS tile rows (A/B)
     else if (!strcmp(name, "sweep_fault")) ttt::mfma::set_debug_sweep_fault(value);              // fault injection: workgroup 3 of every sweep cluster leaves early
     else return -1;
     return 0;

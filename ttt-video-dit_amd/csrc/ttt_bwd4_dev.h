@@ -63,9 +63,8 @@ struct SweepParams4 : b2::SweepParams2 {
     const float* wfinal;                   // [B NH][FINAL_FLOATS]: the state after the last step of the sequence (phase A)
     char* park;                            // [B NH][4 workgroups][2 deriver waves][PARK4_BYTES]: R4 fragments between derivation and staging
     int G, K;
-    int prefetch;                          // 1: owners / derivers touch the records of step i - 2 (L2 prefetch); 0: off (A/B)
+    int prefetch;                          // 1 (always, since round 5): owners / derivers touch the records of step i - 2 (L2 prefetch)
     int own16;                             // as RecomputeParams::own16 (both kernels of a backward call agree)
-    unsigned* resident;                    // optional: every workgroup adds 1 when it starts (the tail's gate kernel waits for all of them: option tail_gate_resident)
 };
 constexpr size_t PARK4_BYTES = 12 * FRAG_BYTES;
 void launch_sweep_cluster4(const SweepParams4& bp, int nbh, hipStream_t s);

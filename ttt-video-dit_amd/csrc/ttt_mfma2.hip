@@ -578,8 +578,6 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
 static void set_attr_once() {
     static ttt::OncePerDevice done;
     done.run([&] {
-        (void)hipFuncSetAttribute((const void*)mlp_scan8_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_V2);
-        (void)hipFuncSetAttribute((const void*)mlp_scan8_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_V2);
         (void)hipFuncSetAttribute((const void*)mlp_scan8_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_V2);
         (void)hipFuncSetAttribute((const void*)mlp_scan8_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_V2);
     });
@@ -589,21 +587,16 @@ static void set_attr_once() {
 
 static float* g_dump = nullptr;
 void set_debug_dump(float* buf) { g_dump = buf; }
-static int g_scan_swap = 1;           // forward scan: half-chunk swap of the LDS tiles (sw_x above): 6.06 against 6.22 ms at NC = 804, 2.14 against 2.19 at NC = 282, identical bits (profiles/r4m_*); 0 = off (A/B option "scan_swap")
-void set_debug_scan_swap(int v) { g_scan_swap = v; }
+// (the half-chunk swap of the LDS tile rows - template parameter SW, sw_x above - is always on since round 5: 6.06 against 6.22 ms at
+// NC = 804, 2.14 against 2.19 at NC = 282, identical bits, profiles/r4m_*)
 void launch_scan_forward_v2(const ScanParams& p0, int n_bh, unsigned long long* dbg, hipStream_t s) {
     ScanParams p = p0;
     p.dbg = dbg;
     p.dump = g_dump;
     v2::set_attr_once();
     const bool dbg_build = p.dbg || p.dump;
-    if (g_scan_swap) {
-        if (dbg_build) hipLaunchKernelGGL((v2::mlp_scan8_kernel<true, true>), dim3(n_bh), dim3(v2::NT2), v2::LDS_V2, s, p);
-        else hipLaunchKernelGGL((v2::mlp_scan8_kernel<false, true>), dim3(n_bh), dim3(v2::NT2), v2::LDS_V2, s, p);
-    } else {
-        if (dbg_build) hipLaunchKernelGGL((v2::mlp_scan8_kernel<true, false>), dim3(n_bh), dim3(v2::NT2), v2::LDS_V2, s, p);
-        else hipLaunchKernelGGL((v2::mlp_scan8_kernel<false, false>), dim3(n_bh), dim3(v2::NT2), v2::LDS_V2, s, p);
-    }
+    if (dbg_build) hipLaunchKernelGGL((v2::mlp_scan8_kernel<true, true>), dim3(n_bh), dim3(v2::NT2), v2::LDS_V2, s, p);
+    else hipLaunchKernelGGL((v2::mlp_scan8_kernel<false, true>), dim3(n_bh), dim3(v2::NT2), v2::LDS_V2, s, p);
 }
 
 }  // namespace mfma

@@ -9,9 +9,9 @@
 //      sweep stores those and this fully parallel kernel (one workgroup per step) finishes
 //      dK = -eta (gZ1 dW1'^T) + dZ1 W1^T - dt   and   dQ = dOut + dZ1b W1'^T.
 // Schedules (debug option "overlap_tail"; measured on one MI355X at NC = 804, profiles/r3g_*): 0 = one stream, 15.8 ms;
-// 1 (default) = the tail of chunk c on a side stream beside the sweep of chunk c-1 (two record buffers), 14.3 ms; 2 = the
-// recompute of chunk c-2 beside that sweep too, in launches of at most as many workgroups as CUs are free: 14.6 ms - it hides
-// 0.17 ms per chunk and slows the sweep, which is bound by what its CUs' memory pipelines move, by as much.
+// 1 (default) = the tail of chunk c on a side stream beside the sweep of chunk c-1 (two record buffers), 14.3 ms.  (The recompute
+// of chunk c-2 beside that sweep too measured 14.6 ms - it hides 0.17 ms per chunk and slows the sweep, which is bound by what its
+// CUs' memory pipelines move, by as much - and is gone.)
 // History: revisions 1 - 3 (4-wave sweep; 8-wave single-workgroup sweep; cluster sweep over 570-KiB register-image records)
 // were removed in rounds 2 and 3, each after losing its A/B on hardware; revision 2's sweep was also found to be inaccurate on
 // model-like inputs.
@@ -33,50 +33,18 @@ bool bwd_available() { return true; }
 
 static int g_forced_gpc = 0;
 void set_debug_groups_per_chunk(int g) { g_forced_gpc = g; }
-static int g_overlap = 1;             // 1: tail of chunk c on a side stream beside the sweep of chunk c-1; 2 (revision 4): the recompute of chunk c-2 too; 0 = one stream
+static int g_overlap = 1;             // 1: tail of chunk c on a side stream beside the sweep of chunk c-1; 0 = one stream
 void set_debug_overlap_tail(int v) { g_overlap = v; }
 static int g_fast_records = 1;        // cluster hand-over: plain (L2-resident) records once same-XCD placement is proven; 0 = always write-through
 void set_debug_fast_records(int v) { g_fast_records = v; }
-static int g_rc_nt = 1;               // revision-4 recompute: 1 (default) = non-temporal stores of the step records (they are read a launch later, from HBM: keep them out of the sweep's L2 working set), 0 = plain (A/B)
-void set_debug_rc_nt(int v) { g_rc_nt = v; }
-static int g_own16 = 1;               // round 4: inner-LayerNorm owner rows of the step record as bf16: 11.35 against 11.63 ms per backward at NC = 804, 4.09 against 4.21 at NC = 282 (profiles/r4g_*)
-void set_debug_own_bf16(int v) { g_own16 = v; }
-static int g_sweep_prefetch = 1;      // revision-4 sweep: L2 prefetch touches two steps ahead (0 = off, A/B)
-void set_debug_sweep_prefetch(int v) { g_sweep_prefetch = v; }
-// A/B option "tail_delay_us" (default 0 = off).  The tail kernel of a chunk and the next chunk's sweep become ready at the same
-// instant (both wait for the same recompute) and race for the compute units; a rocprofv3 trace of the one-GPU bench shows three
-// outcomes of that race (profiles/r4y_sweep_launches.txt: sweep / tail 919 / 419 us on the replica path; 932 / 364 or 1 124 / 459 us
-// on the sharded path, two launches in three the bad one).  With a delay > 0 a one-wave kernel in front of the tail holds its
-// stream for that many microseconds, so that the sweep's 192 workgroups are resident before the tail's 3 500 arrive.  Not measured
-// inside a training step yet (the GPU budget of round 4 ended): off.
-// Option "flags_memset_early" (default 1; 0 = the round-3 order, A/B): the hand-over flags of the NEXT sweep are cleared right behind
-// the current sweep (in front of the recompute) instead of in front of the next sweep.  Why: a rocprofv3 trace of the training step
-// (profiles/r4y_ttt_bwd_launches.csv.gz, tools/sweep_launches.py) shows the sweep starting 13 - 15 us after its recompute ends -
-// the memset - and the previous chunk's tail, released by an event behind the same recompute, after the same 13 - 15 us of
-// cross-queue latency: a coin toss who is dispatched first, and "tail first" is the slow outcome (1.00 - 1.12 against 0.92 ms: the
-// sweep's 192 whole-CU workgroups are then placed one by one between the tail's 3 500 small ones, and a cluster's early members
-// spin at their first hand-over).  It happens to 3 % of the launches on the replica path and to 60 % on the sharded path.  With
-// the memset out of the way the sweep follows its recompute kernel-to-kernel and has the chip before the tail arrives.
-// Bit-identical (tests/test_parity_r4_gpu.py); op level 11.16 against 11.24 ms; NOT yet measured inside a step (round 4's GPU
-// budget ended) - tools/_run_next_round_first_call.sh does that first.
-static int g_memset_early = 1;
-void set_debug_flags_memset_early(int v) { g_memset_early = v ? 1 : 0; }
-// A/B option "tail_gate_resident" (default 0; needs flags_memset_early): instead of a fixed delay the gate kernel in front of a tail
-// waits until every workgroup of the NEXT sweep has started (they count themselves in word 1 of the first flag line, which the
-// early memset clears before the recompute), at most 200 us: the tail can then never be placed between the sweep's clusters.
-// Prepared after round 4's GPU budget ended: compiles, never run on a device.
-static int g_tail_gate_resident = 0;
-void set_debug_tail_gate_resident(int v) { g_tail_gate_resident = v ? 1 : 0; }
-__global__ __launch_bounds__(64) void tail_gate_resident_kernel(const unsigned* counter, unsigned expected, unsigned long long ticks) {
-    const unsigned long long t0 = wall_clock64();                 // constant 100 MHz counter
-    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected && wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
-}
-static int g_tail_delay_us = 0;
-void set_debug_tail_delay_us(int v) { g_tail_delay_us = v < 0 ? 0 : (v > 1000 ? 1000 : v); }
-__global__ __launch_bounds__(64) void tail_gate_kernel(unsigned long long ticks) {
-    const unsigned long long t0 = wall_clock64();                 // constant 100 MHz counter
-    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
-}
+// Decided by A/Bs on hardware and no longer options (rounds 3 - 5): non-temporal stores of the step records (14.28 against 14.68 ms per
+// backward), bf16 inner-LayerNorm owner rows (11.35 against 11.63), L2 prefetch touches two steps ahead (14.68 against 16.03), and
+// the hand-over flags of the NEXT sweep cleared right behind the current one instead of in front of the next: a rocprofv3 trace of
+// the training step (profiles/r4y_ttt_bwd_launches.csv.gz, tools/sweep_launches.py) showed the sweep starting 13 - 15 us after its
+// recompute - the memset - and the previous chunk's tail, released by an event behind the same recompute, after the same latency:
+// a coin toss who is dispatched first, and "tail first" is the slow outcome (1.00 - 1.12 against 0.92 ms).  With the memset out of
+// the way the sweep follows its recompute kernel-to-kernel; round 4's driver line confirmed it inside the step (the sharded
+// `fsdp1` point within 0.1 % of the replica line, where it had been 2.4 % behind).  The gate kernels tried beside it are gone.
 static int g_sweep_fault = 0;         // DEBUG fault injection (tests of the hand-over failure path)
 void set_debug_sweep_fault(int v) { g_sweep_fault = v; }
 
@@ -84,9 +52,9 @@ void set_debug_sweep_fault(int v) { g_sweep_fault = v; }
 // CU (157 KiB of LDS each), so a launch carries at most n_cu / 4 clusters.
 static std::mutex g_dev_mutex;         // guards the per-device caches below (two autograd threads may enter with one device each - or the same)
 static int device_cus() {
-    static int cus[16] = {0};
+    static int cus[64] = {0};
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
     std::lock_guard<std::mutex> lock(g_dev_mutex);
     if (!cus[dev]) {
         int n = 0;
@@ -131,9 +99,9 @@ struct OverlapRes {
     int state = 0;                      // 0 = not tried, 1 = usable, -1 = creation failed (one stream from then on)
 };
 static OverlapRes* overlap_resources() {
-    static OverlapRes res[16];
+    static OverlapRes res[64];
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
     std::lock_guard<std::mutex> lock(g_dev_mutex);
     OverlapRes& r = res[dev];
     if (r.state == 0) {
@@ -183,7 +151,7 @@ static int mlp_backward4(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws,
     rp.ln_w = a->ttt_norm_weight; rp.ln_b = a->ttt_norm_bias;
     rp.W1c = a->W1_checkpoints; rp.b1c = a->b1_checkpoints; rp.W2c = a->W2_checkpoints; rp.b2c = a->b2_checkpoints;
     rp.slot_stride_bh = slot_stride; rp.wfinal = wfinal;
-    rp.NH = d->NH; rp.NC = NC; rp.G = G; rp.K = K; rp.eps = d->eps; rp.nt = g_rc_nt; rp.own16 = g_own16 && sweep_supports_own16();
+    rp.NH = d->NH; rp.NC = NC; rp.G = G; rp.K = K; rp.eps = d->eps; rp.nt = 1; rp.own16 = 1;
 
     s4::SweepParams4 bp = {};
     bp.XQ = (const __bf16*)a->XQ; bp.XK = (const __bf16*)a->XK; bp.dOut = (const __bf16*)a->grad_L_XQW; bp.eta = (const __bf16*)a->last_eta;
@@ -196,8 +164,7 @@ static int mlp_backward4(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws,
     bp.NH = d->NH; bp.NC = NC;
     bp.xch = xch; bp.flags = flags; bp.fast_records = g_fast_records;
     bp.err = err_word; bp.fault = g_sweep_fault;
-    bp.W1c = a->W1_checkpoints; bp.W2c = a->W2_checkpoints; bp.wfinal = wfinal; bp.park = park; bp.G = G; bp.K = K; bp.prefetch = g_sweep_prefetch; bp.own16 = g_own16 && sweep_supports_own16();
-    bp.resident = (g_tail_gate_resident && g_memset_early) ? flags + 1 : nullptr;
+    bp.W1c = a->W1_checkpoints; bp.W2c = a->W2_checkpoints; bp.wfinal = wfinal; bp.park = park; bp.G = G; bp.K = K; bp.prefetch = 1; bp.own16 = 1;
 
     int rc = 0;                               // a failed event / stream call leaves the two streams unordered: the call fails (-12)
     auto chk = [&](hipError_t e) { if (e != hipSuccess) rc = -12; };
@@ -212,9 +179,6 @@ static int mlp_backward4(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws,
         s4::launch_recompute4(rp, nbh, max_wg, st);
     };
     auto tail = [&](int ch, hipStream_t st) {
-        if (g_tail_delay_us > 0 && st != s) hipLaunchKernelGGL(tail_gate_kernel, dim3(1), dim3(64), 0, st, 100ull * (unsigned long long)g_tail_delay_us);
-        if (g_tail_gate_resident && g_memset_early && st != s && ch > 0)       // (chunk 0's tail has no sweep beside it)
-            hipLaunchKernelGGL(tail_gate_resident_kernel, dim3(1), dim3(64), 0, st, (const unsigned*)(flags + 1), 4u * (unsigned)(nbh < per_launch ? nbh : per_launch), 20000ull);
         const int g0 = ch * gpc, ng = (K - g0 < gpc) ? K - g0 : gpc;
         const int lo = g0 * G, hi = ((g0 + ng) * G < NC) ? (g0 + ng) * G : NC;
         s4::launch_tail4((const __bf16*)a->grad_L_XQW, (const __bf16*)a->last_eta, (const __bf16*)a->grad_L_XV, slots + (size_t)(ch & 1) * slot_buf,
@@ -228,13 +192,13 @@ static int mlp_backward4(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws,
         bp.first = (ch == nchunks - 1);
         bp.last = (ch == 0);
         bp.dbg = get_debug_timing();
-        if (!g_memset_early || ch == nchunks - 1) chk(hipMemsetAsync(flags, 0, flag_bytes, s));         // hand-over flags restart at 0 for every launch
+        if (ch == nchunks - 1) chk(hipMemsetAsync(flags, 0, flag_bytes, s));         // hand-over flags restart at 0 for every launch
         for (int bh0 = 0; bh0 < nbh; bh0 += per_launch) {
             bp.bh0 = bh0;
             bp.nbh = nbh - bh0 < per_launch ? nbh - bh0 : per_launch;
             s4::launch_sweep_cluster4(bp, bp.nbh, s);
         }
-        if (g_memset_early && ch > 0) chk(hipMemsetAsync(flags, 0, flag_bytes, s));   // for sweep(ch - 1): behind this sweep, in front of its recompute
+        if (ch > 0) chk(hipMemsetAsync(flags, 0, flag_bytes, s));   // for sweep(ch - 1): behind this sweep, in front of its recompute
     };
     if (ov) {           // the side stream starts after everything queued on `s` before this call (the inputs), not after A(n-1)
         chk(hipEventRecord(ov->entry, s));
@@ -249,7 +213,7 @@ static int mlp_backward4(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws,
         }
         return rc;
     }
-    if (g_overlap == 1) {
+    {
         // Tail beside the next sweep only (round 2's schedule): stream s: A(n-1) B(n-1) A(n-2) B(n-2) ... ; side: C(c) beside B(c-1).
         // C(c) is released when A(c-1) is complete - the moment B(c-1) starts -, and A(c-2), which overwrites C(c)'s buffer, waits.
         for (int ch = nchunks - 1; ch >= 0; --ch) {
@@ -267,36 +231,6 @@ static int mlp_backward4(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws,
         chk(hipStreamWaitEvent(s, ov->tail_done[0], 0));
         return rc;
     }
-    // Two streams.  The sweep B(c) occupies 4 nbh CUs with latency-bound work; everything else of the backward runs BESIDE it on
-    // the CUs it leaves free: the tail C(c+1) of the chunk before, then the recompute A(c-1) of the chunk after - in launches
-    // of at most `free_cus` workgroups (a recompute workgroup needs a CU to itself, and more workgroups than free CUs would
-    // queue in front of the NEXT sweep's clusters).  Phase A is 0.17 ms per chunk in a full launch, 4 rounds of
-    // that on 64 CUs: it fits under a 1.1-ms sweep together with the 0.4-ms tail, so a backward is the chain of its sweeps.
-    // (the side stream first waits for everything queued on `s` before this call: the inputs of the recompute)
-    //   stream s:     A(n-1) B(n-1)        B(n-2)             B(n-3)           ...  B(0)
-    //   side stream:         A(n-2)        C(n-1) A(n-3)      C(n-2) A(n-4)    ...  C(1)      C(0)
-    // Buffer of chunk c = c & 1: A(c-1) overwrites the buffer of chunk c+1, read by B(c+1) (done: stream order of B(c)) and by
-    // C(c+1) (done: side-stream order).  Events: ready[k] = "B of the chunk in buffer k is complete", tail_done[k] doubles as
-    // "A of the chunk in buffer k is complete".
-    for (int ch = nchunks - 1; ch >= 0; --ch) {
-        const int buf = ch & 1;
-        if (ch != nchunks - 1) chk(hipStreamWaitEvent(s, ov->tail_done[buf], 0));          // A(ch) ran on the side stream
-        sweep(ch);
-        chk(hipEventRecord(ov->ready[buf], s));
-        if (ch + 1 <= nchunks - 1) {
-            chk(hipStreamWaitEvent(ov->side, ov->ready[buf ^ 1], 0));                         // B(ch+1) complete
-            tail(ch + 1, ov->side);
-        }
-        if (ch - 1 >= 0) {
-            recompute(ch - 1, free_cus, ov->side);
-            chk(hipEventRecord(ov->tail_done[buf ^ 1], ov->side));
-        }
-    }
-    chk(hipStreamWaitEvent(ov->side, ov->ready[0], 0));
-    tail(0, ov->side);
-    chk(hipEventRecord(ov->tail_done[0], ov->side));
-    chk(hipStreamWaitEvent(s, ov->tail_done[0], 0));              // the caller's stream joins the side stream
-    return rc;
 }
 
 int mlp_backward(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws, hipStream_t s) {

@@ -198,7 +198,6 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
     float* db2L = db1L + 64;
     float* gamL = db2L + 64;
     unsigned* syncw = reinterpret_cast<unsigned*>(gamL + 64);      // [0] hand-over number the owners have seen complete, [1] fast-path verdict, [2] poisoned
-    if (p.resident != nullptr && threadIdx.x == 0) __hip_atomic_fetch_add(p.resident, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // Round 4: the OUTPUT path's share of db2 (column sums of dZ2b over the 64 tokens of a step) is summed by the owners from
     // their fp32 dZ2b values, not by a ones-MFMA over the bf16 tile the compute waves consume: db2 enters d(eta) of every token
     // of every earlier step, so the rounding of that tile showed up 1 : 1 in the learning-rate-gate gradients (0.32 on the
@@ -1185,44 +1184,30 @@ unsigned read_sweep_fast_count() {      // DEBUG statistic: cluster workgroup la
 
 // (the owners' partner-independent arithmetic under the record loads - template parameter OVL; one box, NC = 804: with fp32 records
 // 14.15 ms per backward against 13.44 without, with bf16 records 11.76 against 12.71 - goes with the bf16 records)
-bool sweep_supports_own16() ;
-static int g_deriver_wave0 = 2;           // 4: derivers = waves 4, 5 (SIMDs 0 / 1, beside the compute waves); 2: waves 2, 3 (beside two owner waves) - the
-                                          // default since round 4: 11.48 - 11.62 ms per backward against 11.79 - 11.94 in three interleaved A/Bs (profiles/r4d - r4f)
-void set_debug_sweep_deriver_wave0(int v) { g_deriver_wave0 = (v == 4 || v == 0) ? 4 : 2; }      // (0 = 4, 1 = 2: the 0 / 1 toggle of op_bench --ab)
-static int g_records_bf16 = 1;            // round 4, one box: 11.82 against 14.16 ms per backward at NC = 804, 4.24 against 5.11 at NC = 282
-void set_debug_sweep_records_bf16(int v) { g_records_bf16 = v; }
-
-bool sweep_supports_own16() { return g_records_bf16 != 0 && g_deriver_wave0 == 2; }
+// Shipped instantiation (every parameter decided by an interleaved A/B on one MI355X, profiles/r4b - r4h; the losing
+// instantiations and their options were removed in round 5): bf16 hand-over records with the owners' partner-independent arithmetic
+// under the record loads (11.82 against 14.16 ms per backward at NC = 804), derivers on waves 2, 3 = SIMDs 2 / 3 beside two owner
+// waves (11.48 - 11.62 against 11.79 - 11.94), bf16 inner-LayerNorm owner rows (11.35 against 11.63).
 
 namespace s4 {
 
 void launch_sweep_cluster4(const SweepParams4& bp, int nbh, hipStream_t s) {
-    static bool attr[16] = {false};           // per device: a function attribute is a property of the function ON a device
+    static bool attr[64] = {false};           // per device: a function attribute is a property of the function ON a device
     int dev = 0;
     (void)hipGetDevice(&dev);
     const dim3 grid(nbh * 4), blk(b4::NTC);
     {
         std::lock_guard<std::mutex> lock(g_err_mutex);
-        if (dev >= 0 && dev < 16 && !attr[dev]) {
-            // every instantiation a later call may select gets its attribute on this device now
+        if (dev >= 0 && dev < 64 && !attr[dev]) {
             auto set = [&](auto kern) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, b4::LDS_CL); };
-            set(b4::mlp_bwd_cluster4_kernel<false, false, false, 4, false>); set(b4::mlp_bwd_cluster4_kernel<true, false, false, 4, false>);
-            set(b4::mlp_bwd_cluster4_kernel<false, true, true, 4, false>);   set(b4::mlp_bwd_cluster4_kernel<true, true, true, 4, false>);
-            set(b4::mlp_bwd_cluster4_kernel<false, true, true, 2, false>);   set(b4::mlp_bwd_cluster4_kernel<true, true, true, 2, false>);
             set(b4::mlp_bwd_cluster4_kernel<false, true, true, 2, true>);    set(b4::mlp_bwd_cluster4_kernel<true, true, true, 2, true>);
             (void)hipFuncSetAttribute((const void*)b4::mlp_bwd_tail4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, b4::LDS_TAIL4);
             attr[dev] = true;
         }
     }
     auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, blk, b4::LDS_CL, s, bp); };
-    const bool dbg = bp.dbg != nullptr, r16 = g_records_bf16 != 0, dw2 = g_deriver_wave0 == 2;
-    // variants kept for the A/Bs of round 4: the round-3 sweep (fp32 records, round-3 owner order); bf16 records + owner overlap
-    // with the derivers on waves 4, 5 or 2, 3; the latter with bf16 inner-LayerNorm owner rows (bp.own16, set by the caller for
-    // both kernels of the backward)
-    if (!r16) { if (dbg) go(b4::mlp_bwd_cluster4_kernel<true, false, false, 4, false>); else go(b4::mlp_bwd_cluster4_kernel<false, false, false, 4, false>); }
-    else if (!dw2) { if (dbg) go(b4::mlp_bwd_cluster4_kernel<true, true, true, 4, false>); else go(b4::mlp_bwd_cluster4_kernel<false, true, true, 4, false>); }
-    else if (!bp.own16) { if (dbg) go(b4::mlp_bwd_cluster4_kernel<true, true, true, 2, false>); else go(b4::mlp_bwd_cluster4_kernel<false, true, true, 2, false>); }
-    else { if (dbg) go(b4::mlp_bwd_cluster4_kernel<true, true, true, 2, true>); else go(b4::mlp_bwd_cluster4_kernel<false, true, true, 2, true>); }
+    if (bp.dbg != nullptr) go(b4::mlp_bwd_cluster4_kernel<true, true, true, 2, true>);        // (stage stamps: tools/op_bench.py --phases)
+    else go(b4::mlp_bwd_cluster4_kernel<false, true, true, 2, true>);
 }
 
 void launch_tail4(const __bf16* dOut, const __bf16* eta, const __bf16* dXV, char* slots, size_t slot_stride_bh, __bf16* dXQ, __bf16* dXK,

@@ -35,23 +35,13 @@ void launch_linear_forward_cs16(const wv::Lin16Params& p, int n_bh, hipStream_t 
 void launch_linear_backward_cs16(const wv::Lin16Params& p, int n_bh, hipStream_t s);
 void set_debug_dump(float* buf);
 unsigned long long* get_debug_timing();
-void set_debug_overlap_tail(int v);   // backward schedule: 0 one stream, 1 (default) tail of chunk c beside the sweep of chunk c-1, 2 the next recompute too
+void set_debug_overlap_tail(int v);   // backward schedule: 0 one stream, 1 (default) tail of chunk c beside the sweep of chunk c-1
 void set_debug_fast_records(int v);   // cluster sweep: 1 (default) plain records on a proven common XCD, 0 write-through always
 unsigned read_sweep_error();           // 0, or 1 + (b,h) of a cluster workgroup whose partner never arrived (synchronises)
 unsigned peek_sweep_error();           // the same word without synchronising (entry check of the TTT-MLP calls)
 void clear_sweep_error();              // acknowledge (synchronises)
 unsigned* sweep_error_word();          // device pointer of the host-mapped word (allocated on first use; nullptr on failure)
 void set_debug_sweep_fault(int v);     // DEBUG fault injection: workgroup 3 of every sweep cluster leaves before its first hand-over
-void set_debug_rc_nt(int v);           // revision-4 recompute: non-temporal stores of the step records (A/B)
-void set_debug_sweep_prefetch(int v);  // revision-4 sweep: 1 (default) L2 prefetch touches two steps ahead, 0 off
-void set_debug_flags_memset_early(int v);  // backward schedule: clear the next sweep's hand-over flags behind the current sweep (1) (1, default) instead of in front of the next (0)
-void set_debug_tail_gate_resident(int v);  // backward schedule: the tail's gate waits until the next sweep's workgroups have all started (0 default; needs flags_memset_early)
-void set_debug_tail_delay_us(int v);   // backward schedule: a gate kernel of v microseconds in front of each tail kernel on its side stream (0 = off, default)
-void set_debug_scan_swap(int v);       // forward scan: 1 = the two 8-byte units of a 16-byte tile chunk swapped in rows with bit 3 ^ bit 4 set (bank conflicts of the row walkers), 0 off
-void set_debug_sweep_records_bf16(int v);   // revision-4 sweep: hand-over records carry the partial d(gZ2) tiles as bf16 (0 default until timed)
-void set_debug_sweep_deriver_wave0(int v);  // revision-4 sweep: deriver role on waves 4, 5 (default) or 2, 3 (A/B of the SIMD placement)
-bool sweep_supports_own16();                // (the instantiation the current options select reads bf16 owner rows)
-void set_debug_own_bf16(int v);             // revision-4 backward: inner-LayerNorm owner rows of the step record as bf16
 unsigned read_sweep_fast_count();   // DEBUG statistic (synchronises)
 
 }  // namespace mfma

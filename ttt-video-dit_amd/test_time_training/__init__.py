@@ -223,18 +223,24 @@ def _dims(B, NH, NC, CS, F, G, act_dtype) -> _Dims:
 # Workspaces (the TTT-MLP backward's step records: 2.2 GB at 48 heads) are kept per (device, stream) and grown on demand instead of
 # being drawn from torch's caching allocator at every call (84 times per training step at 9 s, in the phase where HBM is fullest:
 # round-3 verdict, weak #8).  Calls on one stream are ordered, so they can share the buffer; calls on different streams (two
-# autograd threads) get their own.  ``release_workspaces()`` returns the memory (e.g. before sampling).
+# autograd threads) get their own.  The key is the raw stream handle; a stream that was destroyed and whose handle the runtime
+# hands out again would inherit a buffer that torch's allocator associates with the old stream - harmless for ordering (the
+# buffer is only ever used on the stream of the key) but the entry of a dead stream would stay: at most `_WS_MAX` entries are kept,
+# the least recently used one goes first.  ``release_workspaces()`` returns the memory (sampling does, see
+# ttt_amd/models/cogvideo/sampling.py).
 _ws_cache = {}
+_WS_MAX = 4
 
 
 def _workspace(device, stream: int, nbytes: int):
     key = (torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device(), int(stream))
-    buf = _ws_cache.get(key)
+    buf = _ws_cache.pop(key, None)                  # (re-inserted below: dict order = recency)
     if buf is None or buf.numel() < nbytes:
-        _ws_cache.pop(key, None)
         del buf                                     # let the old block go before the larger one is requested
+        while len(_ws_cache) >= _WS_MAX:
+            _ws_cache.pop(next(iter(_ws_cache)))
         buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        _ws_cache[key] = buf
+    _ws_cache[key] = buf
     return buf
 
 

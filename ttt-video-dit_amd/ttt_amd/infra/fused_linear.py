@@ -115,12 +115,19 @@ def _prod(xs):
     return r
 
 
-def linear3(m0: torch.nn.Linear, m1: torch.nn.Linear, m2: torch.nn.Linear, x: torch.Tensor):
-    """``(m0(x), m1(x), m2(x))`` through ``Linear3`` when that is an exact substitute (plain-tensor parameters of x's dtype, no
-    autocast, gradients enabled); the three module calls otherwise."""
-    ok = torch.is_grad_enabled() and not torch.is_autocast_enabled(x.device.type) and x.dim() >= 2
+def linear3_applies(m0, m1, m2, x: torch.Tensor) -> bool:
+    """``Linear3`` is an exact substitute for the three module calls: plain-tensor parameters of x's dtype, no autocast"""
+    ok = not torch.is_autocast_enabled(x.device.type) and x.dim() >= 2
     for m in (m0, m1, m2):
         ok = ok and _plain(m.weight) and _plain(m.bias) and m.weight.dtype == x.dtype and (m.bias is None or m.bias.dtype == x.dtype)
-    if ok and (x.requires_grad or any(m.weight.requires_grad for m in (m0, m1, m2))):
+    return ok
+
+
+def linear3(m0: torch.nn.Linear, m1: torch.nn.Linear, m2: torch.nn.Linear, x: torch.Tensor, always: bool = False):
+    """``(m0(x), m1(x), m2(x))`` through ``Linear3`` when that is an exact substitute (``linear3_applies``) and gradients are enabled;
+    the three module calls otherwise.  ``always``: through the node whenever it applies (a pipelined TTT forward hands it the
+    projections it has formed already - also under ``no_grad``)."""
+    ok = linear3_applies(m0, m1, m2, x)
+    if ok and (always or (torch.is_grad_enabled() and (x.requires_grad or any(m.weight.requires_grad for m in (m0, m1, m2))))):
         return Linear3.apply(x, m0.weight, m0.bias, m1.weight, m1.bias, m2.weight, m2.bias)
     return m0(x), m1(x), m2(x)

@@ -263,5 +263,10 @@ class DenoiserSampler:
 
     @torch.no_grad()
     def sample(self, text_emb: torch.Tensor, neg_emb: torch.Tensor, shape: tuple, batch_size: int):
+        if torch.cuda.is_available() and str(self.device).startswith("cuda"):
+            # a training run in the same process leaves the TTT-MLP backward's step records cached (2.2 GB per stream at 48 heads,
+            # test_time_training._workspace): sampling never runs a backward, give the memory back
+            import test_time_training
+            test_time_training.release_workspaces()
         noise = torch.randn(batch_size, *shape, device=self.device, generator=self.noise_generator, dtype=torch.float32)
         return self.sampler(noise, {"crossattn": text_emb}, {"crossattn": neg_emb}).to(self.dtype)

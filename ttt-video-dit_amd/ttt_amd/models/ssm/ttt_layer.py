@@ -23,7 +23,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ttt_amd.infra.fused_linear import linear3
+from ttt_amd.infra.fused_linear import linear3, linear3_applies
 from ttt_amd.models.cogvideo.utils import SequenceMetadata
 from ttt_amd.models.configs import ModelConfig
 from ttt_amd.models.ssm.fused import FusedPost, FusedPre, FusedPreScanMLP, fused_available
@@ -387,6 +387,8 @@ class TTTBase(nn.Module):
         CS = self.mini_batch_size
         if n < 2 or heads_only or not isinstance(self, TTTMLP) or CS != 64 or remat_cache.replaying("scan"):
             return None
+        if not linear3_applies(self.wq, self.wk, self.wv, x) or not linear3_applies(self.wo, self.wo, self.wo, x):
+            return None                    # (DTensor parameters, autocast: the pre-pass's raw GEMMs would not be the modules' arithmetic)
         NC = L // CS
         G = self._group_size(NC)
         if -(-NC // G) < 2 * n:
@@ -427,7 +429,7 @@ class TTTBase(nn.Module):
         NH, Fh, CS = self.num_heads, self.head_dim, self.mini_batch_size
         NC = L // CS
         mb = lambda t: t.view(B, NH, NC, CS, Fh)
-        XQr, XKr, XVr = self.get_qkv_projections(x)
+        XQr, XKr, XVr = linear3(self.wq, self.wk, self.wv, x, always=piped)
         if isinstance(self, TTTMLP):       # pre + scan as one autograd node: only the raw projections stay alive for backward
             st = [self._per_batch(p, B) for p in (self.W1, self.b1, self.W2, self.b2)]
             Y = FusedPreScanMLP.apply(XQr, XKr, XVr, self.ttt_norm_weight, self.ttt_norm_bias, rope, src, pos, NH, *st, eta,
@@ -440,7 +442,10 @@ class TTTBase(nn.Module):
             out.index_copy_(1, src.long(), Y.reshape(B, NH, L, Fh).transpose(1, 2))
             return out.view(B, L, NH * Fh)
         y = FusedPost.apply(Y.reshape(B, NH, L, Fh), self.post_norm.weight, self.post_norm.bias, src, self.post_norm.eps)
-        if piped:          # (the output projection takes the pre-pass's result too)
+        if self.pipeline_parts >= 2 and isinstance(self, TTTMLP) and linear3_applies(self.wo, self.wo, self.wo, y):
+            # the output projection as a node of our own whenever this layer MAY run pipelined - also in the calls that do not (a
+            # re-materialisation that gets its scan result handed back): torch's checkpoint wants the recomputation to save what
+            # the forward pass saved, node for node; the node takes the pre-pass's result when there is one
             from ttt_amd.models.ssm.pipeline import InjectedLinear
             return InjectedLinear.apply(y, self.wo.weight, self.wo.bias)
         return self.wo(y)
