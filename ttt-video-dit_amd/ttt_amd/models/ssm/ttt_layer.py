@@ -132,8 +132,10 @@ class TTTBase(nn.Module):
         self.use_kernel = True
         self.use_fused = True          # fused HIP pre/post-processing when the activations are bf16 on a HIP device
         # TTT-MLP forward as a pipeline over this many parts of the sequence: the scan of one part on a side stream beside the
-        # projections of the next and the post-norm / output projection of the previous (ttt_amd/models/ssm/pipeline.py); 0 / 1 = off
-        self.pipeline_parts = int(os.environ.get("TTT_PIPELINE_PARTS", "0"))
+        # projections of the next and the post-norm / output projection of the previous (ttt_amd/models/ssm/pipeline.py); 0 / 1 = off.
+        # Default 4 (round 5, one MI355X, 5B / 9 s: layer forward 10.3 -> 7.8 ms, the training step +3.3 %; 6 parts measured the same,
+        # 8 slower; profiles/r5d_*, r5e_*).  Applies where a part has at least two checkpoint groups, on the MFMA scan at CS = 64.
+        self.pipeline_parts = int(os.environ.get("TTT_PIPELINE_PARTS", "4"))
 
         D, NH, Fh = self.width, self.num_heads, self.head_dim
         self.wq = nn.Linear(D, NH * Fh, bias=True)
