@@ -88,6 +88,9 @@ def parse():
     ap.add_argument("--remat-keep", default="attn,scan,fc2",
                     help="outputs a re-materialised layer keeps instead of recomputing them (comma list of attn, scan, fc2; 'none' = "
                          "the reference's behaviour: the whole layer is recomputed) - ttt_amd/infra/remat_cache.py")
+    ap.add_argument("--remat-keep-layers", type=int, default=None,
+                    help="only the first N re-materialised layers keep their kernel outputs (default: all of them) - the 63 s step on one GPU has "
+                         "room for the attention outputs of about ten layers")
     ap.add_argument("--remat-free-layers", default="auto",
                     help="transformer layers that keep their activations instead of being re-materialised in backward: "
                          "'auto' (sized to the free HBM of this GPU), or an integer; 0 = the reference's 80-GB-GPU setting")
@@ -365,8 +368,9 @@ def size_warm_and_time(step, hk, remat_free_layers, warmup, steps, world):
             ok = 0
         if world > 1:
             ok = hk.all_reduce_min(ok)
-        if ok and auto and refinements < 2 and 0 < n_free < hk.num_layers:
-            # up to two refinements with the footprint measured at the chosen setting (the probe over-estimates a layer's
+        if ok and auto and refinements < 3 and 0 < n_free < hk.num_layers:
+            # up to three refinements with the footprint measured at the chosen setting (round 5: the walk at 9 s is 3 -> 8 -> 13 and
+            # the footprint measured at 13 still leaves room for one more under the cap; the probe over-estimates a layer's
             # footprint - by a third when re-materialised layers keep their kernel outputs, which a layer that keeps everything
             # no longer needs)
             refinements += 1
@@ -516,18 +520,21 @@ def rccl_summary(log_dir):
     return res
 
 
+# the 63 s step on ONE GPU: every layer re-materialised; of the kernel outputs a re-materialised layer could keep only the attention
+# outputs (2.3 GB per layer at 63 s, 37 ms saved per GB) of the first ten layers fit beside 223 GiB (round 5, profiles/r5g_*)
+CTX63S_KEEP = ["--remat-keep", "attn", "--remat-keep-layers", "10"]
 LEG_ESTIMATE_S = {"ctx3s": 150.0, "ctx63s": 480.0}          # generous: model build + sizing + 1 warm-up + 2 timed steps (53 s each at 63 s)
 
 
 def leg_command(name, args):
     """`ctx3s` = BASELINE configs[1] (configs/train/ttt-mlp/3s.toml: one segment, adapter sft), `ctx63s` = the metric's second context
-    (63s.toml: 21 scenes, L = 351 168; every layer re-materialised and nothing kept - what fits ONE 288-GB GPU, DESIGN.md section 6;
-    the reference shards this stage over 4 x 4 GPUs).  A leg is its own process: memory state and failures stay its own."""
+    (63s.toml: 21 scenes, L = 351 168; every layer re-materialised, the first ten keep their attention outputs - what fits ONE 288-GB GPU,
+    DESIGN.md section 6; the reference shards this stage over 4 x 4 GPUs).  A leg is its own process: memory state and failures stay its own."""
     length = {"ctx3s": "3sec", "ctx63s": "63sec"}[name]
     argv = ["--gpus", "1", "--video-length", length, "--steps", str(max(1, args.leg_steps)), "--warmup", "1", "--no-fsdp1-compare",
             "--ssm-layer", args.ssm_layer, "--impl", args.impl]
     if name == "ctx63s":
-        argv += ["--remat-free-layers", "0", "--remat-keep", "none"]
+        argv += ["--remat-free-layers", "0"] + CTX63S_KEEP
     if args.no_tuned_gemms:
         argv.append("--no-tuned-gemms")
     if args.pipeline_parts is not None:
@@ -542,7 +549,7 @@ def leg_summary(line):
     pick = lambda k: round(other[k]["avg_ms"], 3) if k in other else None
     return {"value": line["value"], "unit": line["unit"], "ms_per_step": line["ms_per_step"], "steps": line["steps"], "warmup": line["warmup"],
             "workload": line["config"]["workload"], "remat_free_layers": line["config"]["remat_free_layers"],
-            "remat_keep": line["config"].get("remat_keep"), "peak_mem_gib": line.get("peak_mem_gib"), "peak_reserved_gib": line.get("peak_reserved_gib"),
+            "remat_keep": line["config"].get("remat_keep"), "remat_keep_layers": line["config"].get("remat_keep_layers"), "peak_mem_gib": line.get("peak_mem_gib"), "peak_reserved_gib": line.get("peak_reserved_gib"),
             "ttt_mlp_bwd_ms": round(r["avg_launch_ms"], 3) if dom_bwd else pick("bwd"), "scan_fwd_ms": pick("fwd") if dom_bwd else round(r.get("avg_launch_ms", 0.0), 3),
             "attn_fwd_ms": pick("attn_fwd"), "attn_bwd_ms": pick("attn_bwd"), "roofline_frac": r.get("frac"), "valid": line["config"].get("valid")}
 
@@ -711,6 +718,7 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False, tp=False, sha
     if args.ssm_layer == "ttt_linear":      # the reference trains TTT-Linear with these (configs/train/ttt-linear/3s.toml:9,32)
         over.update(mini_batch_size=16, scan_checkpoint_group_size=4)
     over["remat_keep"] = tuple(k for k in args.remat_keep.split(",") if k and k != "none")
+    over["remat_keep_layers"] = args.remat_keep_layers
     cfg = ModelConfig.get_preset("5B", args.video_length, ssm_layer=args.ssm_layer, adapter_method=args.adapter, **over)
     frames, text_len = cfg.compressed_num_frames, TEXT_LEN[args.video_length]
     scenes = max((frames - 1) // 12, 1)
@@ -951,7 +959,7 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False, tp=False, sha
                 "config": {"workload": f"CogVideoX-5B+{args.ssm_layer} {args.video_length} training step (fwd+bwd+AdamW), "
                                        f"{cfg.num_layers} layers, L={L} tokens/sample, adapter={args.adapter}",
                            "global_batch": dp * LB, "seq_len": L, "parallelism": (f"tp{tp}" if no_fsdp else f"fsdp{world}(dp{dp}xtp{tp})") if tp else ("replica1" if no_fsdp else (f"flat_fsdp{world}" if (communicate or world > 1) else "flat1") if flat else f"fsdp2_{world}"), "ttt_impl": args.impl,
-                           "remat_free_layers": n_free, "remat_keep": list(dit.remat_keep), "ttt_pipeline_parts": parts_used, "fsdp_reshard_after_forward": bool(args.reshard_after_forward), "tuned_gemm_selections": bool(tuned),
+                           "remat_free_layers": n_free, "remat_keep": list(dit.remat_keep), "remat_keep_layers": args.remat_keep_layers, "ttt_pipeline_parts": parts_used, "fsdp_reshard_after_forward": bool(args.reshard_after_forward), "tuned_gemm_selections": bool(tuned),
                            "sweep_error": sweep_err, "valid": args.layers is None and sweep_err == 0},
                 "roofline": roof, "loss": loss_val, "peak_mem_gib": peak_mem, "peak_reserved_gib": torch.cuda.max_memory_reserved() / 2 ** 30, "alloc_retries_total": Hooks.alloc_retries(), "total_tokens_per_s": dp * L / (dt / args.steps),
                 "peak_mem_gib_per_rank": [[round(float(x), 1) for x in pk] for pk in peaks],

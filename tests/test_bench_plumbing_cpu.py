@@ -178,7 +178,8 @@ def test_one_gpu_default_run_carries_the_other_contexts_as_legs(monkeypatch, cap
     assert calls[0][0][:2] == [sys.executable, os.path.abspath(bench.__file__)] and calls[0][0][-2:] == ["--role", "worker"]
     c3, c63 = calls[1][0], calls[2][0]
     assert c3[c3.index("--video-length") + 1] == "3sec" and c63[c63.index("--video-length") + 1] == "63sec"
-    assert c63[c63.index("--remat-keep") + 1] == "none" and "--no-fsdp1-compare" in c3 and c3[-2:] == ["--role", "worker"]
+    assert c63[c63.index("--remat-keep") + 1] == "attn" and c63[c63.index("--remat-keep-layers") + 1] == "10" and c63[c63.index("--remat-free-layers") + 1] == "0"
+    assert "--no-fsdp1-compare" in c3 and c3[-2:] == ["--role", "worker"]
     # no time left: both legs skipped with a reason, the main line and the CPU baseline still there
     calls, out, rc = _orchestrate(monkeypatch, capsys, ["--gpus", "1", "--time-budget", "100"], [(0, _LINE, []), (0, {"cpu_baseline": {"value": 1.2}}, [])])
     assert rc == 0 and len(calls) == 2 and "budget" in out[0]["ctx3s"]["skipped"] and "budget" in out[0]["ctx63s"]["skipped"]

@@ -169,3 +169,30 @@ def test_in_place_write_into_a_kept_output_is_caught():
     y = checkpoint(bad_block, x, w, use_reentrant=False, context_fn=remat_cache.context_fn(("attn",)))
     with pytest.raises(RuntimeError, match="modified in place"):
         y.sum().backward()
+
+
+def test_only_the_first_layers_keep_their_kernel_outputs():
+    """``DiffusionTransformer.remat_keep_layers = N``: of the re-materialised layers only the first N keep their kernel outputs (the
+    63 s step on one GPU has room for about ten layers' attention outputs); same loss and gradients as keeping everywhere or nowhere."""
+    import torch
+    from oracle import cpu_ext
+    from ttt_amd.models.cogvideo.dit import DiffusionTransformer
+    from ttt_amd.models.configs import ModelConfig
+    cpu_ext.install()
+    try:
+        torch.manual_seed(0)
+        cfg = ModelConfig(model_dim=64, num_heads=2, num_layers=3, mini_batch_size=16, latent_height=4, latent_width=8, compressed_num_frames=2,
+                          ssm_layer="ttt_linear", text_dim=16, time_embed_dim=32, attn_length=2, prefix_temporal_length=1, scan_checkpoint_group_size=2)
+        m = DiffusionTransformer(cfg)
+        vid, text, ts = torch.randn(1, 2, 16, 8, 16), torch.randn(1, 1, 16, 16), torch.tensor([100])
+        res = []
+        for keep, n in (((), None), (("attn", "scan", "fc2"), None), (("attn", "scan", "fc2"), 1), (("attn",), 0)):
+            m.remat_free_layers, m.remat_keep, m.remat_keep_layers = 1, keep, n
+            m.zero_grad(set_to_none=True)
+            out = m(vid, text, ts)
+            out.square().mean().backward()
+            res.append((out.detach().clone(), [p.grad.clone() for p in m.parameters() if p.grad is not None]))
+        for out, grads in res[1:]:
+            assert torch.equal(out, res[0][0]) and all(torch.equal(a, b) for a, b in zip(grads, res[0][1]))
+    finally:
+        cpu_ext.uninstall()

@@ -454,6 +454,9 @@ class DiffusionTransformer(nn.Module):
         # kernel outputs a re-materialised layer group keeps instead of recomputing them: any of "attn" (local-attention outputs),
         # "scan" (TTT scan outputs + state checkpoints); () = the reference's behaviour (ttt_amd/infra/remat_cache.py)
         self.remat_keep = tuple(getattr(config, "remat_keep", ()))
+        # ... and how many of the re-materialised layers do so (the FIRST ones; None = all of them): at 63 s on one GPU there is room
+        # for the kept attention outputs of about ten layers, not of 42
+        self.remat_keep_layers = getattr(config, "remat_keep_layers", None)
         assert config.num_layers % self.remat_transformer_layer_group_size == 0, "Remat group size must be divisible into num layers"
         self.model_dim = config.model_dim
         self.shard_transformer_inputs = config.shard_transformer_inputs
@@ -488,7 +491,8 @@ class DiffusionTransformer(nn.Module):
             vid_emb, text_emb = sp.shard_tokens(vid_emb), sp.shard_tokens(text_emb)
         for i in range(0, len(self.layers), self.remat_transformer_layer_group_size):
             if torch.is_grad_enabled() and i >= self.remat_free_layers:
-                if self.remat_keep:
+                keeps = self.remat_keep_layers is None or (i - self.remat_free_layers) < self.remat_keep_layers
+                if self.remat_keep and keeps:
                     vid_emb, text_emb = checkpoint(self._run_group, i, vid_emb, text_emb, meta, sp, use_reentrant=False,
                                                    context_fn=remat_cache.context_fn(self.remat_keep))
                 else:

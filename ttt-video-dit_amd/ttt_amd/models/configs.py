@@ -59,6 +59,7 @@ class ModelConfig:
     remat_free_layers: int = 0
     # MI355X: kernel outputs a re-materialised layer keeps instead of recomputing them ("attn", "scan"; () = reference behaviour)
     remat_keep: tuple = ()
+    remat_keep_layers: object = None      # int: only the first N re-materialised layers keep their kernel outputs (None: all)
     remat_forward_ssm: bool = False
     remat_reverse_ssm: bool = False
     remat_attention: bool = False
