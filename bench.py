@@ -368,9 +368,10 @@ def size_warm_and_time(step, hk, remat_free_layers, warmup, steps, world):
             ok = 0
         if world > 1:
             ok = hk.all_reduce_min(ok)
-        if ok and auto and refinements < 3 and 0 < n_free < hk.num_layers:
-            # up to three refinements with the footprint measured at the chosen setting (round 5: the walk at 9 s is 3 -> 8 -> 13 and
-            # the footprint measured at 13 still leaves room for one more under the cap; the probe over-estimates a layer's
+        if ok and auto and refinements < 2 and 0 < n_free < hk.num_layers:
+            # up to two refinements with the footprint measured at the chosen setting (the walk at 9 s is 3 -> 8 -> 13; a third
+            # refinement finds room for a 14th layer and buys nothing measurable: 8 139 / 8 114 against 8 155 / 8 104 video-tok/s on
+            # one box at 243 instead of 237 GiB, profiles/r5h_*; the probe over-estimates a layer's
             # footprint - by a third when re-materialised layers keep their kernel outputs, which a layer that keeps everything
             # no longer needs)
             refinements += 1
@@ -521,7 +522,8 @@ def rccl_summary(log_dir):
 
 
 # the 63 s step on ONE GPU: every layer re-materialised; of the kernel outputs a re-materialised layer could keep only the attention
-# outputs (2.3 GB per layer at 63 s, 37 ms saved per GB) of the first ten layers fit beside 223 GiB (round 5, profiles/r5g_*)
+# outputs (2.3 GB per layer at 63 s, 37 ms saved per GB) of the first ten layers fit beside 223 GiB (round 5, one box,
+# profiles/r5h_*: 6 929 against 6 804 video-tok/s, 49.3 against 50.2 s per step, 245.5 GiB allocated / 256.2 reserved)
 CTX63S_KEEP = ["--remat-keep", "attn", "--remat-keep-layers", "10"]
 LEG_ESTIMATE_S = {"ctx3s": 150.0, "ctx63s": 480.0}          # generous: model build + sizing + 1 warm-up + 2 timed steps (53 s each at 63 s)
 
