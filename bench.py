@@ -750,8 +750,8 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False, tp=False, sha
     for mod in model.modules():
         if hasattr(mod, "pipeline_parts"):
             if args.pipeline_parts is not None:
-                mod.pipeline_parts = args.pipeline_parts
-            parts_used = mod.pipeline_parts
+                mod.pipeline_parts, mod.pipeline_parts_auto = args.pipeline_parts, False
+            parts_used = f"{mod.pipeline_parts}{'+' if getattr(mod, 'pipeline_parts_auto', False) else ''}"      # "4+": up to 8 for long scans
     replica = ReplicaMixedPrecision(model.dit) if no_fsdp else None
     flat = None
     if not no_fsdp and not tp and sharded == "flat":      # the same partitioning on flat buffers (ttt_amd/infra/flat_fsdp.py)

@@ -136,6 +136,10 @@ class TTTBase(nn.Module):
         # Default 4 (round 5, one MI355X, 5B / 9 s: layer forward 10.3 -> 7.8 ms, the training step +3.3 %; 6 parts measured the same,
         # 8 slower; profiles/r5d_*, r5e_*).  Applies where a part has at least two checkpoint groups, on the MFMA scan at CS = 64.
         self.pipeline_parts = int(os.environ.get("TTT_PIPELINE_PARTS", "4"))
+        # ... and more of them for long scans (up to 8, one per ~40 checkpoint groups): what stays exposed is the first part's projections
+        # and the last part's output projection, which grow with the sequence - at 63 s (343 groups) 8 parts measured 7 122 against 7 001
+        # video-tok/s for 4 on one box (profiles/r5i_*); False: exactly `pipeline_parts`
+        self.pipeline_parts_auto = True
 
         D, NH, Fh = self.width, self.num_heads, self.head_dim
         self.wq = nn.Linear(D, NH * Fh, bias=True)
@@ -393,6 +397,8 @@ class TTTBase(nn.Module):
             return None                    # (DTensor parameters, autocast: the pre-pass's raw GEMMs would not be the modules' arithmetic)
         NC = L // CS
         G = self._group_size(NC)
+        if self.pipeline_parts_auto:
+            n = max(n, min(8, -(-NC // G) // 40))
         if -(-NC // G) < 2 * n:
             return None
         import test_time_training as ext
