@@ -3,7 +3,7 @@
 // tests/emul/attn_emul.cpp with the lane-level emulator, so `pytest -m "not gpu"` executes this very code against the fp64
 // attention oracle.
 //
-// Same algorithm, tiling and layout algebra as revision 1 (attn_fwd.hip, attn_bwd.hip: 8 waves x 32 query rows, keys / values
+// Same algorithm, tiling and layout algebra as revision 1 (attn_fwd.hip: 8 waves x 32 query rows, keys / values
 // streamed through LDS in tiles of 64, scores computed transposed so that a lane owns one query row, probabilities re-used
 // in place as the B operand of the second product).  What changed, and why (static instruction mix of the revision-1 loops,
 // tools/isa_mix.py - they are VALU-issue-bound, 16 / 24 MFMAs against ~270 / ~290 vector instructions per wave and tile):
@@ -381,9 +381,9 @@ TTT_BODY_FN void dq(BK& bk, const BwdParams& p, int bh, int qb) {
 
 // dq() with NSUB key tiles of 64 per LDS stage, i.e. one workgroup barrier per NSUB tiles: 2 halves the number of barriers and
 // doubles the loads in flight per stage.  Same arithmetic in the same order as dq() - bit-identical (tests/test_emul_attention_cpu.py) -;
-// a separate function so that the shipped kernel's code stays byte for byte what was measured.  NOT instantiated on the device yet:
-// the device kernels + the debug option that selects them are on the branch `attn-staged-device` (their first run on an MI355X ended
-// in an abort inside the first attention call of the process, with no GPU time left in that round to find out why).
+// measured on the device in round 4 (two tiles per stage: -5 %).  Since round 5 the device runs dq_wide() (below) for dQ and
+// dkdv_staged<12, true, 2>() for dK / dV; dq(), dq_staged() and dkdv() are the reference forms that the emulator tests hold those two
+// to, bit for bit (tests/test_emul_attention_cpu.py).
 template <int NSUB, bool SWZ = false, class BK>
 TTT_BODY_FN void dq_staged(BK& bk, const BwdParams& p, int bh, int qb) {
     const int tid = bk.thread(), wv = bk.wave(), l = bk.lane(), h = l >> 5, c = l & 31;

@@ -168,20 +168,20 @@ struct DeriverBackend {
                    "+v"(pa[2][0]), "+v"(pa[2][1]), "+v"(pa[2][2]), "+v"(pa[2][3]), "+v"(pa[3][0]), "+v"(pa[3][1]), "+v"(pa[3][2]), "+v"(pa[3][3]) \
                  : "v"(dep))
 
-// OVL (round 4, debug option "sweep_owner_overlap", default on): the owners' partner-independent arithmetic runs while the partner
-// records are in flight; off = the round-3 order (wait for the records, then all the arithmetic), kept for the A/B.
+// OVL (round 4; the shipped instantiation has it on, the template parameter remains): the owners' partner-independent arithmetic runs
+// while the partner records are in flight; off = the round-3 order (wait for the records, then all the arithmetic).
 #define TTT_PIN_RECORDS16(dep)                                                                                                            \
     asm volatile("; records consumed from here"                                                                                           \
                  : "+v"(pb[0][0]), "+v"(pb[0][1]), "+v"(pb[1][0]), "+v"(pb[1][1]), "+v"(pb[2][0]), "+v"(pb[2][1]), "+v"(pb[3][0]), "+v"(pb[3][1]) \
                  : "v"(dep))
-// R16 (round 4, debug option "sweep_records_bf16"): the partial d(gZ2) tiles of the hand-over records travel as bf16 - half the
+// R16 (round 4; on in the shipped instantiation): the partial d(gZ2) tiles of the hand-over records travel as bf16 - half the
 // bytes a workgroup publishes (and drains in front of barrier Bb) and half the loads of the owners' chain; every workgroup
 // still sums the same four rounded partials in the same order, so dZ2 stays bit-identical on the four CUs.  Precision budget:
 // tools/diag/lr_gate_full_emul_cpu.py point "P_rec" - no gradient of the DiT fixtures moves beyond its run-to-run spread of
 // the other roundings (worst 3.0e-2 -> 3.6e-2 / 2.6e-2 -> 2.5e-2).  [t][PS16] bf16 inside the fp32 tile's area of the record.
 constexpr int PS16 = 72;
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-// OWN16 (round 4, debug option "own_bf16"): the inner LayerNorm's owner rows of the step record (x_hat, y - target) are bf16
+// OWN16 (round 4; on in the shipped instantiation): the inner LayerNorm's owner rows of the step record (x_hat, y - target) are bf16
 template <bool DBG, bool OVL, bool R16, int DW0, bool OWN16>
 __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
     constexpr int OW0 = DW0 == 2 ? 4 : 2;                        // first owner wave (it polls the partner flags)
