@@ -629,6 +629,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus"
+    os.environ.setdefault("NCCL_DEBUG", "WARN")             # RCCL's warnings on stderr (the orchestrator sets INFO + per-rank files for N > 1)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
     os.environ.setdefault("RANK", "0")

@@ -355,3 +355,49 @@ def test_reference_training_loop_and_optimizer_groups_on_the_sharded_holder(tmp_
         d = (got[k] - v).abs()
         # three steps at up to 3e-3: isolated elements whose gradient is rounding noise may differ by whole steps, the mean must not
         assert float(d.max()) < 1e-2 and float(d.mean()) < 6e-5, (k, float(d.max()), float(d.mean()))
+
+
+def _accum_worker(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "ttt-video-dit_amd")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    from oracle import cpu_ext
+    from ttt_amd.infra.flat_fsdp import FlatFSDP
+    from ttt_amd.infra.optimizers import ScheduleType, create_specialized_optimizer
+    cpu_ext.install()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = {}
+    for micro in (1, 2):
+        m = _build("qkvo")
+        m.remat_free_layers = 1
+        fs = FlatFSDP(m)
+        opt, _ = create_specialized_optimizer(m, 1e-3, 3e-3, 1e-4, 1, 4, ScheduleType.COSINE, ScheduleType.LINEAR, "qkvo")
+        fs.attach_optimizer(opt)
+        opt.zero_grad()
+        if micro == 1:          # one backward over the sum of the two micro-batch losses ...
+            (0.5 * (_loss(m, 2 * rank) + _loss(m, 2 * rank + 1))).backward()
+        else:                   # ... against two backwards that accumulate (train.py:141-156, grad_accum_steps = 2)
+            for k in range(2):
+                (0.5 * _loss(m, 2 * rank + k)).backward()
+        norm = fs.clip_grad_norm_(1.0)
+        g = fs.full_parameters("grad")
+        opt.step()
+        res[micro] = (float(norm), g, fs.full_parameters("param"))
+    (n1, g1, p1), (n2, g2, p2) = res[1], res[2]
+    assert abs(n1 - n2) <= 2e-2 * n1, (n1, n2)
+    for k in g1:
+        den = float(g1[k].norm().clamp_min(1e-20))
+        assert float((g1[k] - g2[k]).norm()) / den < 5e-2, k         # (two bf16 gradient roundings instead of one)
+    worst = max(float((p1[k] - p2[k]).abs().mean()) for k in p1 if not k.endswith("k_norm.bias"))
+    assert worst < 2e-5, worst
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_flat_fsdp_accumulates_micro_batches_into_the_gradient_shards(tmp_path):
+    """Gradient accumulation on the sharded holder (the reference's ``grad_accum_steps``, train.py:141-156): a second backward before the
+    optimizer step reduces into a temporary and ADDS it to the rank's gradient shard, whose slices the (unit, class) masters hold as
+    their ``.grad`` views - the norm, the gathered gradients and the parameters after the step agree with one backward over the summed
+    loss (world 2, the reference's four optimizer groups, the optimizer's step hooks)."""
+    mp.spawn(_accum_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
