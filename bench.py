@@ -115,8 +115,9 @@ def parse():
                          "environment) = a thin parent that holds no GPU context: it starts the measurement as child process(es) - under "
                          "torch.distributed.run for --gpus N > 1 -, retries ONCE with conservative memory settings if that fails, then (N = 1, "
                          "default workload) runs the metric's other contexts as legs `ctx3s` / `ctx63s` and the CPU baseline, and prints the ONE JSON line")
-    ap.add_argument("--no-legs", action="store_true", help="N=1: skip the `ctx3s` / `ctx63s` legs (BASELINE configs[1] and the metric's 63 s context)")
+    ap.add_argument("--no-legs", action="store_true", help="N=1: skip the legs (`ctx3s` = BASELINE configs[1], `ctx63s` = the metric's 63 s context, `ctx30s` = configs[3], `sample63s` = configs[4])")
     ap.add_argument("--leg-steps", type=int, default=2, help="timed steps of each leg (after one warm-up step)")
+    ap.add_argument("--legs", default="all", help="N=1: which legs run after the main measurement: 'all' or a comma list of ctx3s, ctx63s, ctx30s, sample63s")
     ap.add_argument("--time-budget", type=float, default=1500.0,
                     help="seconds the whole default run may take: a leg whose estimated duration does not fit is skipped with a stated reason")
     ap.add_argument("--retry-reason", default=None, help=argparse.SUPPRESS)          # set by the orchestrator on its second attempt
@@ -197,6 +198,76 @@ class KernelTimer:
                 merged["avg_ms"] = merged["total_ms"] / merged["launches"]
             out["fwd"] = merged
         return out
+
+
+class ClockSampler:
+    """Shader clock (MHz) and socket power (W) of one GPU sampled by a background thread (amdsmi) during the timed region, so that
+    the 2.4 GHz behind the MFMA peak (MI355X_MICROARCH.md) can be checked against what the step actually ran at.  Best effort:
+    `summary()` is {"error": ...} when amdsmi is missing or refuses (the measurement itself never depends on it)."""
+
+    def __init__(self, index=0, period_s=0.25):
+        self.index, self.period_s, self.samples, self.error = index, period_s, [], None
+        self._stop, self._thread, self._h, self._smi = None, None, None, None
+        try:
+            import amdsmi
+            amdsmi.amdsmi_init()
+            hs = amdsmi.amdsmi_get_processor_handles()
+            # HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES renumber torch's devices; amdsmi sees all of them
+            vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES")
+            if vis:
+                try:
+                    index = int(vis.split(",")[index])
+                except (ValueError, IndexError):
+                    pass
+            self._h, self._smi = hs[index if index < len(hs) else 0], amdsmi
+        except Exception as ex:            # noqa: BLE001 - any failure of the SMI library only loses the clock fields
+            self.error = repr(ex)[:200]
+
+    def read(self):
+        """(MHz, W) now; a field is None when the library does not report it"""
+        smi, mhz, w = self._smi, None, None
+        try:
+            c = smi.amdsmi_get_clock_info(self._h, smi.AmdSmiClkType.GFX)
+            mhz = c.get("clk") if isinstance(c.get("clk"), (int, float)) else None
+        except Exception as ex:            # noqa: BLE001
+            self.error = repr(ex)[:200]
+        try:
+            p = smi.amdsmi_get_power_info(self._h)
+            for k in ("current_socket_power", "socket_power", "average_socket_power"):
+                if isinstance(p.get(k), (int, float)) and 0 < p[k] < 0xFFFF:
+                    w = p[k]
+                    break
+        except Exception as ex:            # noqa: BLE001
+            self.error = repr(ex)[:200]
+        return mhz, w
+
+    def start(self):
+        import threading
+        if self._h is None or self._thread is not None:
+            return
+        self.samples, self._stop = [], threading.Event()
+
+        def loop():
+            while not self._stop.is_set():
+                self.samples.append(self.read())
+                self._stop.wait(self.period_s)
+        self._thread = threading.Thread(target=loop, daemon=True)
+        self._thread.start()
+
+    def stop(self):
+        if self._thread is not None:
+            self._stop.set()
+            self._thread.join(timeout=5)
+            self._thread = None
+
+    def summary(self):
+        mhz = [m for m, _ in self.samples if m]
+        w = [p for _, p in self.samples if p]
+        if not mhz and not w:
+            return {"error": self.error or "no samples"}
+        avg = lambda v: round(sum(v) / len(v), 1) if v else None
+        return {"clock_mhz_avg": avg(mhz), "clock_mhz_min": min(mhz) if mhz else None, "clock_mhz_max": max(mhz) if mhz else None,
+                "power_w_avg": avg(w), "power_w_max": max(w) if w else None, "samples": len(self.samples), "period_s": self.period_s}
 
 
 def pmc_traffic(kernel, B, NH, NC):
@@ -454,12 +525,41 @@ def worker_command(gpus, argv, port=None):
 SAFE_MEMORY_ARGS = ["--remat-free-layers", "0", "--remat-keep", "attn,scan,fc2"]
 
 
+def kill_process_group(proc, grace_s=10.0):
+    """SIGTERM, then SIGKILL, to the process GROUP of `proc` (started with start_new_session=True), and wait until the group's
+    leader is gone.  Falls back to the child alone where the group cannot be signalled."""
+    import signal
+    import subprocess
+    for sig in (signal.SIGTERM, signal.SIGKILL):
+        try:
+            os.killpg(proc.pid, sig)
+        except (ProcessLookupError, PermissionError, OSError):
+            try:
+                proc.send_signal(sig)
+            except (ProcessLookupError, OSError):
+                pass
+        try:
+            proc.wait(timeout=grace_s)
+            break
+        except subprocess.TimeoutExpired:
+            continue
+    t_end = time.time() + grace_s                       # the ranks of a launcher die a moment after it: let the group drain
+    while time.time() < t_end:
+        try:
+            os.killpg(proc.pid, 0)
+        except (ProcessLookupError, PermissionError, OSError):
+            break
+        time.sleep(0.2)
+
+
 def run_child(cmd, timeout, env=None):
     """Runs one child to its end.  stdout is captured (the JSON line), stderr is passed through line by line and its tail kept.
     Returns (return code, the LAST JSON object line of stdout or None, tail of stderr).  (tests replace this function)"""
     import subprocess
     import threading
-    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+    # own session = own process group: for --gpus N > 1 the child is the torch.distributed.run launcher, and its rank processes must
+    # not outlive a time-out (they would hold the GPUs under the retry and the legs)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, start_new_session=True)
     tail, out = [], []
 
     def pump_err():
@@ -479,9 +579,9 @@ def run_child(cmd, timeout, env=None):
     try:
         rc = proc.wait(timeout=timeout)
     except subprocess.TimeoutExpired:
-        proc.kill()
+        kill_process_group(proc)
         rc = -9
-        tail.append(f"bench.py: child exceeded {timeout:.0f} s and was killed")
+        tail.append(f"bench.py: child exceeded {timeout:.0f} s and was killed (with its process group)")
     for t in th:
         t.join(timeout=10)
     line = None
@@ -525,14 +625,22 @@ def rccl_summary(log_dir):
 # outputs (2.3 GB per layer at 63 s, 37 ms saved per GB) of the first ten layers fit beside 223 GiB (round 5, one box,
 # profiles/r5h_*: 6 929 against 6 804 video-tok/s, 49.3 against 50.2 s per step, 245.5 GiB allocated / 256.2 reserved)
 CTX63S_KEEP = ["--remat-keep", "attn", "--remat-keep-layers", "10"]
-LEG_ESTIMATE_S = {"ctx3s": 150.0, "ctx63s": 480.0}          # generous: model build + sizing + 1 warm-up + 2 timed steps (53 s each at 63 s)
+# generous estimates (model build + sizing probes + 1 warm-up + 2 timed steps; 24 s per step at 30 s, 49 s at 63 s; sampling: two
+# network evaluations of 22 s on the guidance pair + the build)
+LEG_ESTIMATE_S = {"ctx3s": 150.0, "ctx63s": 480.0, "ctx30s": 380.0, "sample63s": 240.0}
+LEG_ORDER = ("ctx3s", "ctx63s", "ctx30s", "sample63s")     # the metric's two contexts first, then BASELINE configs[3] and configs[4]
 
 
 def leg_command(name, args):
     """`ctx3s` = BASELINE configs[1] (configs/train/ttt-mlp/3s.toml: one segment, adapter sft), `ctx63s` = the metric's second context
     (63s.toml: 21 scenes, L = 351 168; every layer re-materialised, the first ten keep their attention outputs - what fits ONE 288-GB GPU,
-    DESIGN.md section 6; the reference shards this stage over 4 x 4 GPUs).  A leg is its own process: memory state and failures stay its own."""
-    length = {"ctx3s": "3sec", "ctx63s": "63sec"}[name]
+    DESIGN.md section 6; the reference shards this stage over 4 x 4 GPUs), `ctx30s` = BASELINE configs[3] (30s.toml: 10 scenes,
+    L = 168 320, the long-sequence chunked scan) as a training step on one GPU, `sample63s` = BASELINE configs[4] (configs/eval/ttt-mlp/63s.toml:
+    mini-batches of 16, no scan checkpoints): ONE denoising step of the mirrored DPM-Solver++ sampler on the batched guidance pair
+    (tools/sample_bench.py).  A leg is its own process: memory state and failures stay its own."""
+    if name == "sample63s":
+        return [sys.executable, os.path.join(ROOT, "tools", "sample_bench.py"), "--video-length", "63sec", "--steps", "1", "--impl", args.impl]
+    length = {"ctx3s": "3sec", "ctx63s": "63sec", "ctx30s": "30sec"}[name]
     argv = ["--gpus", "1", "--video-length", length, "--steps", str(max(1, args.leg_steps)), "--warmup", "1", "--no-fsdp1-compare",
             "--ssm-layer", args.ssm_layer, "--impl", args.impl]
     if name == "ctx63s":
@@ -545,6 +653,12 @@ def leg_command(name, args):
 
 
 def leg_summary(line):
+    if line.get("metric") == "sampling_denoising_step_seconds":          # tools/sample_bench.py
+        c = line.get("config", {})
+        return {"value": line["value"], "unit": line["unit"], "latent_frames_per_s": line.get("latent_frames_per_s"),
+                "projected_50_step_video_s": line.get("projected_50_step_video_s"), "workload": c.get("workload"), "tokens": c.get("tokens"),
+                "mini_batches": c.get("mini_batches"), "scan_impl": c.get("scan_impl"), "steps": c.get("timed_steps"),
+                "peak_mem_gib": line.get("peak_mem_GiB"), "valid": c.get("layers") == 42}
     r = line.get("roofline") or {}
     other = r.get("other") or {}
     dom_bwd = "bwd" in (r.get("kernel") or "")
@@ -554,6 +668,20 @@ def leg_summary(line):
             "remat_keep": line["config"].get("remat_keep"), "remat_keep_layers": line["config"].get("remat_keep_layers"), "peak_mem_gib": line.get("peak_mem_gib"), "peak_reserved_gib": line.get("peak_reserved_gib"),
             "ttt_mlp_bwd_ms": round(r["avg_launch_ms"], 3) if dom_bwd else pick("bwd"), "scan_fwd_ms": pick("fwd") if dom_bwd else round(r.get("avg_launch_ms", 0.0), 3),
             "attn_fwd_ms": pick("attn_fwd"), "attn_bwd_ms": pick("attn_bwd"), "roofline_frac": r.get("frac"), "valid": line["config"].get("valid")}
+
+
+def attach_leg(line, name, summary):
+    """A leg's result goes where the driver's record keeps it: `config.legs[name]` (the whole summary) and flat scalars
+    `config.leg_<name>_*` (round 5: the driver kept `config` / `roofline` scalars and only the NAMES of other top-level keys)."""
+    cfg = line.setdefault("config", {})
+    cfg.setdefault("legs", {})[name] = summary
+    line[name] = summary                                        # (top level too: where rounds 4 / 5 had it)
+    for k in ("value", "ms_per_step", "peak_mem_gib", "latent_frames_per_s", "projected_50_step_video_s", "ttt_mlp_bwd_ms", "valid"):
+        if isinstance(summary.get(k), (int, float, bool)):
+            cfg[f"leg_{name}_{k}"] = summary[k]
+    for k in ("skipped", "error"):
+        if k in summary:
+            cfg[f"leg_{name}_{k}"] = str(summary[k])[:200]
 
 
 def orchestrate(args, argv):
@@ -588,21 +716,29 @@ def orchestrate(args, argv):
         line["rccl"] = rccl_summary(rccl_dir)
         log(f"RCCL: {line['rccl']}")
     default_workload = args.video_length == "9sec" and args.layers is None and not args.tp and args.local_batch == 1
+    if "fsdp1" in line:                                         # (measured inside the main child)
+        line["config"]["fsdp1"] = line["fsdp1"]
+        for k in ("value", "ms_per_step"):
+            if isinstance(line["fsdp1"].get(k), (int, float)):
+                line["config"][f"fsdp1_{k}"] = line["fsdp1"][k]
     if args.gpus == 1 and not args.no_legs and default_workload:
-        for name in ("ctx3s", "ctx63s"):
+        wanted = [n for n in LEG_ORDER if args.legs == "all" or n in args.legs.split(",")]
+        for name in wanted:
             left = args.time_budget - (time.time() - t_start)
             if left < LEG_ESTIMATE_S[name]:
-                line[name] = {"skipped": f"{left:.0f} s of the {args.time_budget:.0f} s budget left, the leg needs ~{LEG_ESTIMATE_S[name]:.0f} s"}
-                log(f"{name}: skipped ({line[name]['skipped']})")
+                res = {"skipped": f"{left:.0f} s of the {args.time_budget:.0f} s budget left, the leg needs ~{LEG_ESTIMATE_S[name]:.0f} s"}
+                log(f"{name}: skipped ({res['skipped']})")
+                attach_leg(line, name, res)
                 continue
             log(f"{name} leg (child process)")
             t0 = time.time()
             rc, leg, tail = run_child(leg_command(name, args), timeout=max(300.0, left))
             if rc == 0 and leg is not None:
-                line[name] = leg_summary(leg)
-                line[name]["leg_wall_s"] = round(time.time() - t0, 1)
+                res = leg_summary(leg)
+                res["leg_wall_s"] = round(time.time() - t0, 1)
             else:
-                line[name] = {"error": f"rc {rc}: {(tail[-1] if tail else 'no output')[:300]}"}
+                res = {"error": f"rc {rc}: {(tail[-1] if tail else 'no output')[:300]}"}
+            attach_leg(line, name, res)
     if args.gpus == 1 and not args.no_cpu_baseline:
         # the CPU leg runs in a child process with a wall-clock limit: whatever happens to it (host out-of-memory kill, a slow
         # box) the GPU measurement above is still printed
@@ -778,6 +914,7 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False, tp=False, sha
 
     timer = KernelTimer(ext)
     timer.install()
+    clocks = ClockSampler(local_rank) if rank == 0 else None     # sclk / socket power during the timed region (amdsmi, best effort)
 
     def step():
         # the reference's loop (train.py:131-166): zero_grad, loss, backward, clip, optimizer.step, lr_scheduler.step
@@ -871,10 +1008,14 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False, tp=False, sha
                 log(f"timed region: {args.steps} steps, remat_free_layers={n_free}")
             timer.reset()
             timer.active = True
+            if clocks:
+                clocks.start()
 
         @staticmethod
         def after_timed():
             timer.active = False
+            if clocks:
+                clocks.stop()
 
     n_free, dt, loss = size_warm_and_time(step, Hooks, args.remat_free_layers, args.warmup, args.steps, world)
     fast0 = fast0[0]
@@ -956,6 +1097,12 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False, tp=False, sha
                     "sweep_same_xcd_frac": (fast_wgs / (ks["bwd"]["launches"] * sweep_chunks * 4 * B * NH)
                                             if args.ssm_layer == "ttt_mlp" and "bwd" in ks and CS == 64 else None),
                     "attention_share_of_step": sum(v["total_ms"] for k, v in ks.items() if k.startswith("attn")) / (1e3 * dt)}
+            # the other hand-written kernels as FLAT scalars too (the driver's record keeps roofline's scalars, not `other`)
+            for k, v in roof["other"].items():
+                name = {"fwd": "scan_fwd", "bwd": "scan_bwd"}.get(k, k)
+                roof[f"{name}_ms"] = round(v["avg_ms"], 4)
+                roof[f"{name}_tflops"] = round(v["achieved_tflops"], 2)
+                roof[f"{name}_frac"] = round(v["achieved_tflops"] / MFMA_BF16_PEAK_TFLOPS, 5)
         line = {"metric": "DiT+TTT fwd/bwd video-tokens/sec", "value": value, "unit": "video-tokens/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
                 "scaling": "strong" if (tp and dp == 1 and world > 1) else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
@@ -963,7 +1110,9 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False, tp=False, sha
                                        f"{cfg.num_layers} layers, L={L} tokens/sample, adapter={args.adapter}",
                            "global_batch": dp * LB, "seq_len": L, "parallelism": (f"tp{tp}" if no_fsdp else f"fsdp{world}(dp{dp}xtp{tp})") if tp else ("replica1" if no_fsdp else (f"flat_fsdp{world}" if (communicate or world > 1) else "flat1") if flat else f"fsdp2_{world}"), "ttt_impl": args.impl,
                            "remat_free_layers": n_free, "remat_keep": list(dit.remat_keep), "remat_keep_layers": args.remat_keep_layers, "ttt_pipeline_parts": parts_used, "fsdp_reshard_after_forward": bool(args.reshard_after_forward), "tuned_gemm_selections": bool(tuned),
-                           "sweep_error": sweep_err, "valid": args.layers is None and sweep_err == 0},
+                           "sweep_error": sweep_err, "valid": args.layers is None and sweep_err == 0,
+                           **({k: v for k, v in clocks.summary().items() if k in ("clock_mhz_avg", "clock_mhz_min", "clock_mhz_max", "power_w_avg", "power_w_max")} if clocks else {}),
+                           "clocks": clocks.summary() if clocks else None},
                 "roofline": roof, "loss": loss_val, "peak_mem_gib": peak_mem, "peak_reserved_gib": torch.cuda.max_memory_reserved() / 2 ** 30, "alloc_retries_total": Hooks.alloc_retries(), "total_tokens_per_s": dp * L / (dt / args.steps),
                 "peak_mem_gib_per_rank": [[round(float(x), 1) for x in pk] for pk in peaks],
                 "optimizer": {"groups": [c.group_name for c in sched_cfgs], "lr": oc["lr"], "lr_ssm": oc["lr_ssm"], "clip": clip,

@@ -162,33 +162,112 @@ def test_failed_multi_gpu_attempt_is_retried_once_with_safe_memory_settings(monk
 
 
 def test_one_gpu_default_run_carries_the_other_contexts_as_legs(monkeypatch, capsys):
-    """N = 1, default workload: after the 9 s measurement the parent runs BASELINE configs[1] (3 s) and the metric's second context
-    (63 s) as legs - own processes, one warm-up + two timed steps - and the CPU baseline, and merges them into the ONE line; a leg
-    that does not fit the time budget is skipped with a stated reason; a failing leg costs nothing but itself."""
+    """N = 1, default workload: after the 9 s measurement the parent runs BASELINE configs[1] (3 s), the metric's second context
+    (63 s), configs[3] (the 30 s stage) and configs[4] (one 63 s denoising step) as legs - own processes - and the CPU baseline, and
+    merges them into the ONE line where the driver's record keeps them: `config.legs` + flat `config.leg_*` scalars (round 5: the
+    driver kept only the NAMES of other top-level keys); a leg that does not fit the time budget is skipped with a stated reason; a
+    failing leg costs nothing but itself."""
     import bench
     leg3 = dict(_LINE, value=7500.0, ms_per_step=2340.0, steps=2, warmup=1, config=dict(_LINE["config"], workload="3sec"))
     leg63 = dict(_LINE, value=6400.0, ms_per_step=53000.0, steps=2, warmup=1, config=dict(_LINE["config"], workload="63sec", remat_free_layers=0, remat_keep=[]))
+    leg30 = dict(_LINE, value=6700.0, ms_per_step=24400.0, steps=2, warmup=1, config=dict(_LINE["config"], workload="30sec"))
+    samp = {"metric": "sampling_denoising_step_seconds", "value": 21.8, "unit": "s/step (cond+uncond)", "latent_frames_per_s": 11.6,
+            "projected_50_step_video_s": 1090.0, "peak_mem_GiB": 101.0,
+            "config": {"workload": "sampling 63sec", "layers": 42, "timed_steps": 1, "tokens": 351168, "mini_batches": 21948, "scan_impl": "mfma"}}
+    main_line = dict(_LINE, fsdp1={"impl": "flat", "value": 6990.0, "ms_per_step": 7100.0})
     calls, out, rc = _orchestrate(monkeypatch, capsys, ["--gpus", "1", "--steps", "7", "--warmup", "2"],
-                                  [(0, _LINE, []), (0, leg3, []), (0, leg63, []), (0, {"cpu_baseline": {"value": 1.2}}, [])])
-    assert rc == 0 and len(out) == 1 and len(calls) == 4
+                                  [(0, main_line, []), (0, leg3, []), (0, leg63, []), (0, leg30, []), (0, samp, []), (0, {"cpu_baseline": {"value": 1.2}}, [])])
+    assert rc == 0 and len(out) == 1 and len(calls) == 6
     line = out[0]
-    assert line["value"] == 7000.0 and line["ctx3s"]["value"] == 7500.0 and line["ctx63s"]["ms_per_step"] == 53000.0
-    assert line["ctx63s"]["ttt_mlp_bwd_ms"] == 10.9 and line["ctx63s"]["attn_bwd_ms"] == 13.0 and line["ctx3s"]["steps"] == 2
+    legs = line["config"]["legs"]
+    assert list(legs) == ["ctx3s", "ctx63s", "ctx30s", "sample63s"]
+    assert line["value"] == 7000.0 and legs["ctx3s"]["value"] == 7500.0 and legs["ctx63s"]["ms_per_step"] == 53000.0
+    assert legs["ctx63s"]["ttt_mlp_bwd_ms"] == 10.9 and legs["ctx63s"]["attn_bwd_ms"] == 13.0 and legs["ctx3s"]["steps"] == 2
+    assert legs["ctx30s"]["value"] == 6700.0 and legs["sample63s"]["value"] == 21.8 and legs["sample63s"]["latent_frames_per_s"] == 11.6
+    assert legs["sample63s"]["valid"] is True and legs["sample63s"]["mini_batches"] == 21948
+    c = line["config"]                                     # the flat scalars a parser that drops nested objects still keeps
+    assert c["leg_ctx3s_value"] == 7500.0 and c["leg_ctx63s_value"] == 6400.0 and c["leg_ctx30s_value"] == 6700.0 and c["leg_sample63s_value"] == 21.8
+    assert c["leg_ctx63s_ms_per_step"] == 53000.0 and c["leg_sample63s_projected_50_step_video_s"] == 1090.0
+    assert c["fsdp1"]["value"] == 6990.0 and c["fsdp1_value"] == 6990.0
+    assert line["ctx3s"] == legs["ctx3s"] and line["ctx63s"] == legs["ctx63s"]           # (top level too, as in rounds 4 / 5)
     assert line["cpu_baseline"] == {"value": 1.2}
     assert calls[0][0][:2] == [sys.executable, os.path.abspath(bench.__file__)] and calls[0][0][-2:] == ["--role", "worker"]
-    c3, c63 = calls[1][0], calls[2][0]
-    assert c3[c3.index("--video-length") + 1] == "3sec" and c63[c63.index("--video-length") + 1] == "63sec"
+    c3, c63, c30, cs = calls[1][0], calls[2][0], calls[3][0], calls[4][0]
+    assert c3[c3.index("--video-length") + 1] == "3sec" and c63[c63.index("--video-length") + 1] == "63sec" and c30[c30.index("--video-length") + 1] == "30sec"
     assert c63[c63.index("--remat-keep") + 1] == "attn" and c63[c63.index("--remat-keep-layers") + 1] == "10" and c63[c63.index("--remat-free-layers") + 1] == "0"
-    assert "--no-fsdp1-compare" in c3 and c3[-2:] == ["--role", "worker"]
-    # no time left: both legs skipped with a reason, the main line and the CPU baseline still there
+    assert "--no-fsdp1-compare" in c3 and c3[-2:] == ["--role", "worker"] and "--remat-free-layers" not in c30
+    assert cs[1].endswith(os.path.join("tools", "sample_bench.py")) and cs[cs.index("--video-length") + 1] == "63sec" and cs[cs.index("--steps") + 1] == "1"
+    # a subset of the legs
+    calls, out, rc = _orchestrate(monkeypatch, capsys, ["--gpus", "1", "--legs", "ctx3s,sample63s", "--no-cpu-baseline"], [(0, _LINE, []), (0, leg3, []), (0, samp, [])])
+    assert rc == 0 and len(calls) == 3 and list(out[0]["config"]["legs"]) == ["ctx3s", "sample63s"]
+    # no time left: every leg skipped with a reason, the main line and the CPU baseline still there
     calls, out, rc = _orchestrate(monkeypatch, capsys, ["--gpus", "1", "--time-budget", "100"], [(0, _LINE, []), (0, {"cpu_baseline": {"value": 1.2}}, [])])
-    assert rc == 0 and len(calls) == 2 and "budget" in out[0]["ctx3s"]["skipped"] and "budget" in out[0]["ctx63s"]["skipped"]
+    assert rc == 0 and len(calls) == 2 and all("budget" in out[0]["config"]["legs"][n]["skipped"] for n in bench.LEG_ORDER)
+    assert "budget" in out[0]["config"]["leg_ctx30s_skipped"]
     # a leg that dies: its entry says so
-    calls, out, rc = _orchestrate(monkeypatch, capsys, ["--gpus", "1", "--no-cpu-baseline"], [(0, _LINE, []), (1, None, ["HIP error"]), (0, leg63, [])])
-    assert rc == 0 and "error" in out[0]["ctx3s"] and out[0]["ctx63s"]["value"] == 6400.0
+    calls, out, rc = _orchestrate(monkeypatch, capsys, ["--gpus", "1", "--no-cpu-baseline", "--legs", "ctx3s,ctx63s"], [(0, _LINE, []), (1, None, ["HIP error"]), (0, leg63, [])])
+    assert rc == 0 and "error" in out[0]["config"]["legs"]["ctx3s"] and out[0]["config"]["legs"]["ctx63s"]["value"] == 6400.0
+    assert "HIP error" in out[0]["config"]["leg_ctx3s_error"]
     # another workload than the metric's: no legs
     calls, out, rc = _orchestrate(monkeypatch, capsys, ["--gpus", "1", "--video-length", "3sec", "--no-cpu-baseline"], [(0, _LINE, [])])
-    assert len(calls) == 1 and "ctx3s" not in out[0]
+    assert len(calls) == 1 and "ctx3s" not in out[0] and "legs" not in out[0]["config"]
+
+
+def test_run_child_kills_the_whole_process_group_on_timeout(tmp_path):
+    """A child that exceeds its time (for --gpus N > 1: the torch.distributed.run launcher) is killed WITH its descendants - rank
+    processes left behind would hold the GPUs under the retry and the legs."""
+    import time
+    import bench
+    pidfile = tmp_path / "grandchild.pid"
+    prog = ("import subprocess, sys, time; p = subprocess.Popen([sys.executable, '-c', 'import time; time.sleep(600)']); "
+            f"open({str(pidfile)!r}, 'w').write(str(p.pid)); time.sleep(600)")
+    rc, line, tail = bench.run_child([sys.executable, "-c", prog], timeout=3.0)
+    assert rc == -9 and line is None and "process group" in tail[-1]
+    gpid = int(pidfile.read_text())
+    for _ in range(50):
+        try:
+            os.kill(gpid, 0)
+        except ProcessLookupError:
+            break
+        # a zombie still answers kill(0): look at its state
+        try:
+            if open(f"/proc/{gpid}/stat").read().split()[2] == "Z":
+                break
+        except FileNotFoundError:
+            break
+        time.sleep(0.1)
+    else:
+        os.kill(gpid, 9)
+        raise AssertionError("the grandchild survived the time-out")
+
+
+def test_clock_sampler_without_a_gpu_reports_an_error_not_an_exception():
+    """bench.ClockSampler is best effort: on a box where amdsmi cannot initialise (no GPU here) the summary says so and start / stop
+    are no-ops; with a fake library it averages what it read."""
+    import bench
+    cs = bench.ClockSampler(0)
+    cs.start(); cs.stop()
+    s = cs.summary()
+    assert "error" in s or "clock_mhz_avg" in s
+
+    class FakeSmi:
+        class AmdSmiClkType:
+            GFX = 0
+
+        @staticmethod
+        def amdsmi_get_clock_info(h, t):
+            return {"clk": 2100}
+
+        @staticmethod
+        def amdsmi_get_power_info(h):
+            return {"current_socket_power": 0xFFFF, "socket_power": 900, "average_socket_power": "N/A"}
+    cs._h, cs._smi, cs.period_s = object(), FakeSmi, 0.01
+    cs.start()
+    import time
+    time.sleep(0.1)
+    cs.stop()
+    s = cs.summary()
+    assert s["clock_mhz_avg"] == 2100 and s["power_w_avg"] == 900 and s["samples"] >= 2
 
 
 def test_under_a_launcher_the_process_is_a_worker(monkeypatch):

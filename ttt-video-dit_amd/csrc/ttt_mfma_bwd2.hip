@@ -33,8 +33,10 @@ bool bwd_available() { return true; }
 
 static int g_forced_gpc = 0;
 void set_debug_groups_per_chunk(int g) { g_forced_gpc = g; }
-static int g_overlap = 1;             // 1: tail of chunk c on a side stream beside the sweep of chunk c-1; 0 = one stream
+static int g_overlap = 1;             // 1: tail of chunk c on a side stream beside the sweep of chunk c-1; 0 = one stream;
+                                      // 2: the recompute of chunk c-1 too beside the sweep of chunk c (THREE record buffers; round 6 A/B)
 void set_debug_overlap_tail(int v) { g_overlap = v; }
+static int record_buffers() { return g_overlap >= 2 ? 3 : 2; }
 static int g_fast_records = 1;        // cluster hand-over: plain (L2-resident) records once same-XCD placement is proven; 0 = always write-through
 void set_debug_fast_records(int v) { g_fast_records = v; }
 // Decided by A/Bs on hardware and no longer options (rounds 3 - 5): non-temporal stores of the step records (14.28 against 14.68 ms per
@@ -88,7 +90,7 @@ size_t workspace_bytes(const ttt_dims* d, bool mlp, bool backward) {
     const size_t slots = (size_t)groups_per_chunk(d) * d->G + 1;
     // two record buffers + carried state gradient + exchange records and flag lines of the cluster sweep + the state after the
     // last step + the derivers' parking areas
-    return nbh * (2 * slots * s4::SLOT4_BYTES + b2::CARRY_FLOATS2 * sizeof(float)) + align128(nbh * 64) +
+    return nbh * ((size_t)record_buffers() * slots * s4::SLOT4_BYTES + b2::CARRY_FLOATS2 * sizeof(float)) + align128(nbh * 64) +
            nbh * (b2::XCH_BH_BYTES + 4 * b2::FLAG_STRIDE * sizeof(unsigned)) + nbh * (s4::FINAL_FLOATS * sizeof(float) + 8 * s4::PARK4_BYTES);
 }
 
@@ -96,6 +98,7 @@ size_t workspace_bytes(const ttt_dims* d, bool mlp, bool backward) {
 struct OverlapRes {
     hipStream_t side = nullptr;
     hipEvent_t ready[2] = {nullptr, nullptr}, tail_done[2] = {nullptr, nullptr}, entry = nullptr;
+    hipEvent_t rc_done[3] = {nullptr, nullptr, nullptr}, sweep_done[3] = {nullptr, nullptr, nullptr};     // schedule 2
     int state = 0;                      // 0 = not tried, 1 = usable, -1 = creation failed (one stream from then on)
 };
 static OverlapRes* overlap_resources() {
@@ -111,7 +114,16 @@ static OverlapRes* overlap_resources() {
             ok = ok && hipEventCreateWithFlags(&r.ready[i], hipEventDisableTiming) == hipSuccess;
             ok = ok && hipEventCreateWithFlags(&r.tail_done[i], hipEventDisableTiming) == hipSuccess;
         }
+        for (int i = 0; ok && i < 3; ++i) {
+            ok = ok && hipEventCreateWithFlags(&r.rc_done[i], hipEventDisableTiming) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&r.sweep_done[i], hipEventDisableTiming) == hipSuccess;
+        }
         if (!ok) {                      // usable only when EVERY object exists: release what was created
+            for (int i = 0; i < 3; ++i) {
+                if (r.rc_done[i]) (void)hipEventDestroy(r.rc_done[i]);
+                if (r.sweep_done[i]) (void)hipEventDestroy(r.sweep_done[i]);
+                r.rc_done[i] = r.sweep_done[i] = nullptr;
+            }
             for (int i = 0; i < 2; ++i) {
                 if (r.ready[i]) (void)hipEventDestroy(r.ready[i]);
                 if (r.tail_done[i]) (void)hipEventDestroy(r.tail_done[i]);
@@ -137,9 +149,10 @@ static int mlp_backward4(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws,
     const int K = (NC + G - 1) / G;
     const int gpc = groups_per_chunk(d);
     const size_t slot_stride = ((size_t)gpc * G + 1) * s4::SLOT4_BYTES;
-    char* slots = (char*)ws;                                   // two buffers of nbh * slot_stride bytes
+    char* slots = (char*)ws;                                   // two (schedule 2: three) buffers of nbh * slot_stride bytes
     const size_t slot_buf = (size_t)nbh * slot_stride;
-    float* carry = (float*)(slots + 2 * slot_buf);
+    const int NBUF = record_buffers();                         // chunk c lives in buffer c % NBUF
+    float* carry = (float*)(slots + (size_t)NBUF * slot_buf);
     char* xch = (char*)(carry + (size_t)nbh * b2::CARRY_FLOATS2) + align128((size_t)nbh * 64);
     unsigned* flags = (unsigned*)(xch + (size_t)nbh * b2::XCH_BH_BYTES);
     const size_t flag_bytes = (size_t)nbh * 4 * b2::FLAG_STRIDE * sizeof(unsigned);
@@ -175,18 +188,18 @@ static int mlp_backward4(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws,
     auto recompute = [&](int ch, int max_wg, hipStream_t st) {
         const int g0 = ch * gpc, ng = (K - g0 < gpc) ? K - g0 : gpc;
         rp.chunk_group0 = g0; rp.chunk_groups = ng; rp.chunk_lo = g0 * G;
-        rp.slots = slots + (size_t)(ch & 1) * slot_buf;
+        rp.slots = slots + (size_t)(ch % NBUF) * slot_buf;
         s4::launch_recompute4(rp, nbh, max_wg, st);
     };
     auto tail = [&](int ch, hipStream_t st) {
         const int g0 = ch * gpc, ng = (K - g0 < gpc) ? K - g0 : gpc;
         const int lo = g0 * G, hi = ((g0 + ng) * G < NC) ? (g0 + ng) * G : NC;
-        s4::launch_tail4((const __bf16*)a->grad_L_XQW, (const __bf16*)a->last_eta, (const __bf16*)a->grad_L_XV, slots + (size_t)(ch & 1) * slot_buf,
+        s4::launch_tail4((const __bf16*)a->grad_L_XQW, (const __bf16*)a->last_eta, (const __bf16*)a->grad_L_XV, slots + (size_t)(ch % NBUF) * slot_buf,
                          slot_stride, (__bf16*)a->grad_L_XQ, (__bf16*)a->grad_L_XK, NC, lo, hi - lo, nbh, st);
     };
     auto sweep = [&](int ch) {
         const int g0 = ch * gpc, ng = (K - g0 < gpc) ? K - g0 : gpc;
-        bp.slots = slots + (size_t)(ch & 1) * slot_buf;
+        bp.slots = slots + (size_t)(ch % NBUF) * slot_buf;
         bp.chunk_lo = g0 * G;
         bp.chunk_hi = ((g0 + ng) * G < NC) ? (g0 + ng) * G : NC;
         bp.first = (ch == nchunks - 1);
@@ -205,7 +218,30 @@ static int mlp_backward4(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws,
         chk(hipStreamWaitEvent(ov->side, ov->entry, 0));
     }
     recompute(nchunks - 1, 0, s);
-    if (!ov) {          // one stream: A(c) B(c) C(c) per chunk (chunk c in slot buffer c & 1)
+    if (ov && NBUF == 3) {
+        // Schedule 2 (round 6 A/B): stream s carries the sweeps only, A(n-1) B(n-1) B(n-2) ... ; beside B(c) the side stream runs
+        // A(c-1) - in launches of at most the CUs the sweep leaves free, so that a recompute workgroup never holds a CU a cluster
+        // member of the NEXT sweep is waiting for - and then C(c+1).  Chunk c lives in buffer c % 3: A(c-1) writes, B(c) reads,
+        // C(c+1) reads three different buffers; A(c-1) follows C(c+2) (same buffer) in stream order.
+        chk(hipEventRecord(ov->sweep_done[nchunks % 3], s));                       // "B(n) is done" = A(n-1) is complete
+        for (int ch = nchunks - 1; ch >= 0; --ch) {
+            if (ch + 1 < nchunks) chk(hipStreamWaitEvent(s, ov->rc_done[ch % 3], 0));
+            sweep(ch);
+            chk(hipEventRecord(ov->sweep_done[ch % 3], s));
+            chk(hipStreamWaitEvent(ov->side, ov->sweep_done[(ch + 1) % 3], 0));    // beside B(ch): released when B(ch + 1) is done
+            if (ch > 0) {
+                recompute(ch - 1, free_cus, ov->side);
+                chk(hipEventRecord(ov->rc_done[(ch - 1) % 3], ov->side));
+            }
+            if (ch + 1 < nchunks) tail(ch + 1, ov->side);
+        }
+        chk(hipStreamWaitEvent(ov->side, ov->sweep_done[0], 0));
+        tail(0, ov->side);
+        chk(hipEventRecord(ov->tail_done[0], ov->side));
+        chk(hipStreamWaitEvent(s, ov->tail_done[0], 0));
+        return rc;
+    }
+    if (!ov) {          // one stream: A(c) B(c) C(c) per chunk (chunk c in slot buffer c % NBUF)
         for (int ch = nchunks - 1; ch >= 0; --ch) {
             sweep(ch);
             if (ch > 0) recompute(ch - 1, 0, s);
