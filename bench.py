@@ -124,6 +124,9 @@ def parse():
     ap.add_argument("--pipeline-parts", type=int, default=None,
                     help="TTT-MLP layer forward as a pipeline over this many parts of the sequence (the scan of one part on a side stream beside "
                          "the projections of the next, ttt_amd/models/ssm/pipeline.py); 0 = one piece; default: the library's (TTT_PIPELINE_PARTS)")
+    ap.add_argument("--debug-option", action="append", default=[], metavar="NAME=VALUE",
+                    help="A/B: a library debug option (ttt_hip_debug_option: overlap_tail, deriver_split, fast_records, groups_per_chunk) for this run; "
+                         "recorded in config.debug_options")
     ap.add_argument("--layers", type=int, default=None, help="DEBUG: fewer layers (result flagged invalid)")
     ap.add_argument("--torch-profile", default=None, metavar="FILE",
                     help="DEBUG: after the timed region run ONE more step under torch.profiler and write per-operator tables "
@@ -839,6 +842,8 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False, tp=False, sha
 
     ext.load_library()
     ext.set_impl(args.impl)
+    for kv in args.debug_option:
+        ext.debug_option(kv.split("=")[0], int(kv.split("=")[1]))
     init_distributed("nccl")
     # RCCL builds its communicator (and allocates ~0.5 GiB of device buffers) at the FIRST collective: do that now, while the
     # device is empty - at 30 s the first collective used to come when the model had filled HBM and RCCL's allocation failed
@@ -1110,6 +1115,7 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False, tp=False, sha
                                        f"{cfg.num_layers} layers, L={L} tokens/sample, adapter={args.adapter}",
                            "global_batch": dp * LB, "seq_len": L, "parallelism": (f"tp{tp}" if no_fsdp else f"fsdp{world}(dp{dp}xtp{tp})") if tp else ("replica1" if no_fsdp else (f"flat_fsdp{world}" if (communicate or world > 1) else "flat1") if flat else f"fsdp2_{world}"), "ttt_impl": args.impl,
                            "remat_free_layers": n_free, "remat_keep": list(dit.remat_keep), "remat_keep_layers": args.remat_keep_layers, "ttt_pipeline_parts": parts_used, "fsdp_reshard_after_forward": bool(args.reshard_after_forward), "tuned_gemm_selections": bool(tuned),
+                           "debug_options": ",".join(args.debug_option) or None,
                            "sweep_error": sweep_err, "valid": args.layers is None and sweep_err == 0,
                            **({k: v for k, v in clocks.summary().items() if k in ("clock_mhz_avg", "clock_mhz_min", "clock_mhz_max", "power_w_avg", "power_w_max")} if clocks else {}),
                            "clocks": clocks.summary() if clocks else None},

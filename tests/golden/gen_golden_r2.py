@@ -142,7 +142,7 @@ def dit_mlp64_case(seed):
                                                  or k.endswith("seq_modeling_block.q.weight") or k.endswith("mlp.layer2.weight"))}}
 
 
-def dit_mlp64_multiscene_lastrow_case(seed, base_lr=1.0, lr_scale=8.0, gate=0.5):
+def dit_mlp64_multiscene_lastrow_case(seed, base_lr=1.0, lr_scale=8.0, gate=0.5, latent=(8, 16), frames=7, text_len=32):
     """A 3-scene DiffusionTransformer at mini_batch_size = 64 run by the reference's own model code with every eta tile
     replaced by its last row (``kernel_contract``): the reference-pinned target of the ASSEMBLED multi-scene HIP model - the
     case the driver benchmarks (9 s, 3 interleaved scenes).  7 frames x 32 tokens + 3 x 32 text tokens = 320 = 5 mini-batches;
@@ -150,8 +150,8 @@ def dit_mlp64_multiscene_lastrow_case(seed, base_lr=1.0, lr_scale=8.0, gate=0.5)
     dual form on the full tiles (``dit_mlp_3scene.pt``) is NOT this function (hazard C2; the difference is recorded)."""
     torch.manual_seed(seed)
     from ttt.models.cogvideo.dit import DiffusionTransformer
-    cfg = ModelConfig(model_dim=128, num_heads=2, num_layers=2, mini_batch_size=64, latent_height=8, latent_width=16,
-                      compressed_num_frames=7, ssm_layer="ttt_mlp", text_dim=32, time_embed_dim=64, attn_length=2,
+    cfg = ModelConfig(model_dim=128, num_heads=2, num_layers=2, mini_batch_size=64, latent_height=latent[0], latent_width=latent[1],
+                      compressed_num_frames=frames, ssm_layer="ttt_mlp", text_dim=32, time_embed_dim=64, attn_length=2,
                       prefix_temporal_length=1, adapter_method="sft", scan_checkpoint_group_size=2,
                       remat_transformer_layer_group_size=1, ttt_base_lr=base_lr, gating_alpha_init=gate)
     m = DiffusionTransformer(cfg)
@@ -171,8 +171,8 @@ def dit_mlp64_multiscene_lastrow_case(seed, base_lr=1.0, lr_scale=8.0, gate=0.5)
             # a model in which the inner loop matters (at initialisation the TTT update barely moves the output and the eta
             # rows of a tile are nearly identical): larger base learning rate and gates, a spread learning-rate gate
             layer.seq_modeling_block.ssm.ttt.learnable_ttt_lr_weight.mul_(lr_scale)
-    video = torch.randn(1, 7, 16, 8, 16)
-    text = torch.randn(1, 3, 32, 32)
+    video = torch.randn(1, frames, 16, latent[0], latent[1])
+    text = torch.randn(1, (frames - 1) // 2, text_len, 32)
     ts = torch.tensor([417])
     with kernel_contract():
         out = m(video, text, ts)

@@ -61,3 +61,25 @@ def test_linear3_backward_over_column_blocks_of_one_buffer():
     ref = torch.autograd.grad([torch.nn.functional.linear(x, w, b) for w, b in zip(ws, bs)], ins, blocks)
     for a, b in zip(fused, ref):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-5)
+
+
+def test_fuse_mode_values_and_the_stacked_weight_cache():
+    """TTT_FUSE_QKV_BACKWARD accepts only its five spellings (a typo used to select the fusion silently); the
+    [n0 + n1 + n2, K] weight stack of the one-GEMM input gradient is formed once per (weights, version) - the two scan directions of a TTT
+    layer share it - and again after an in-place update of a weight."""
+    import pytest
+    from ttt_amd.infra import fused_linear as FL
+    assert [FL._fuse_mode(v) for v in ("", "0", "1", "dgrad", "both")] == ["", "", "dgrad", "dgrad", "both"]
+    with pytest.raises(ValueError):
+        FL._fuse_mode("off")
+    ws = [torch.randn(4, 8), torch.randn(6, 8), torch.randn(2, 8)]
+    a = FL._stacked_weights(ws)
+    assert a.shape == (12, 8) and torch.equal(a, torch.cat(ws, 0)) and FL._stacked_weights(ws) is a
+    ws[1].mul_(2.0)                                    # (what publishing new parameters does: the version moves)
+    b = FL._stacked_weights(ws)
+    assert b is not a and torch.equal(b, torch.cat(ws, 0))
+    # other tensors at the same address with the same version (a new model after the old one was freed) are NOT the cached ones
+    ws2 = [w.clone() for w in ws]
+    c = FL._stacked_weights(ws2)
+    assert c is not b
+    FL._stack_cache.update(ws=None, key=None, value=None)

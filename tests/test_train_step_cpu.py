@@ -136,3 +136,83 @@ def test_the_optimizer_hooks_of_the_flat_sharded_path_gate_and_publish():
         assert any(not torch.equal(a, u.gathered) for a, u in zip(bf16_before, fs.units))     # published by the post-hook
     finally:
         cpu_ext.uninstall()
+
+
+def test_skipped_step_does_not_advance_an_attached_scheduler_and_remove_restores_the_instances():
+    """the reference's loop calls ``lr_scheduler.step()`` unconditionally - a scheduler handed to ``attach_optimizer``
+    stands still on a skipped step; ``checked_optimizer_step`` takes the gate decision itself and the pre-hook does not take it a second
+    time; ``remove()`` gives ``optimizer.zero_grad`` / ``lr_scheduler.step`` back."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracle import cpu_ext
+    from test_flat_fsdp_gloo import _build, _loss
+    from ttt_amd.infra.flat_fsdp import FlatFSDP
+    from ttt_amd.infra.optimizers import ScheduleType, create_grouped_lr_scheduler, create_specialized_optimizer
+    cpu_ext.install()
+    try:
+        m = _build("qkvo")
+        m.remat_free_layers = 0
+        fs = FlatFSDP(m)
+        opt, cfgs = create_specialized_optimizer(m, 1e-3, 1e-3, 1e-4, 2, 8, ScheduleType.LINEAR, ScheduleType.COSINE, "qkvo")
+        sched = create_grouped_lr_scheduler(opt, cfgs)
+        zg0, st0 = opt.zero_grad, sched.step
+
+        class CountingExt(FakeExt):
+            calls = 0
+
+            def sweep_error(self):
+                CountingExt.calls += 1
+                return self.err
+        e = CountingExt(0)
+        fs.attach_optimizer(opt, extension=e, lr_scheduler=sched)
+        assert opt.zero_grad is not zg0 and sched.step is not st0
+        lr0 = [g["lr"] for g in opt.param_groups]
+        opt.zero_grad()
+        _loss(m, 0).backward()
+        fs.clip_grad_norm_(0.1)
+        fs.units[0].grad_shard[3] = float("nan")
+        opt.step()
+        sched.step()
+        assert fs.last_step_skipped and [g["lr"] for g in opt.param_groups] == lr0          # the schedule stood still
+        opt.zero_grad()
+        _loss(m, 0).backward()
+        fs.clip_grad_norm_(0.1)
+        opt.step()
+        sched.step()
+        assert not fs.last_step_skipped and [g["lr"] for g in opt.param_groups] != lr0
+        # checked_optimizer_step drives the step: ONE look at the error word, not two
+        opt.zero_grad()
+        _loss(m, 0).backward()
+        CountingExt.calls = 0
+        train = [p for g in opt.param_groups for p in g["params"]]
+        assert checked_optimizer_step(opt, train, 0.1, extension=e, clip_fn=fs.clip_grad_norm_) is not None
+        assert CountingExt.calls == 1 and not fs.last_step_skipped
+        fs.remove()
+        assert opt.zero_grad == zg0 and sched.step == st0
+    finally:
+        cpu_ext.uninstall()
+
+
+def test_named_trainable_keeps_trainable_parameters_outside_the_wrapped_module():
+    """with a master holder on ``model.dit`` the optimizer groups used to see the holder's masters ONLY; a trainable
+    parameter of the model outside ``dit`` must still reach its group (the reference's model.named_parameters() includes it)."""
+    from ttt_amd.infra.optimizers import named_trainable
+
+    class Holder:
+        def __init__(self, mod):
+            self.m = [("layers.0.<other_wd>", torch.nn.Parameter(torch.zeros(3)))]
+
+        def named_master_parameters(self):
+            return self.m
+
+    class Model(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.dit = torch.nn.Linear(2, 2)
+            self.extra = torch.nn.Parameter(torch.zeros(4))
+            self.frozen = torch.nn.Parameter(torch.zeros(4), requires_grad=False)
+    mod = Model()
+    mod.dit._master_holder = Holder(mod.dit)
+    names = [n for n, _ in named_trainable(mod)]
+    assert names == ["layers.0.<other_wd>", "extra"]

@@ -32,4 +32,4 @@ for rev in (4,):
                     steps = sorted(set(idx[:, 2].tolist())) if v.dim() == 5 else None
                     diffs.setdefault(k, []).append((rep, int(bad.sum()), heads[:12], (steps[:6], steps[-3:]) if steps else None))
         print(f"rev {rev} overlap {overlap}: sweep_error {e.sweep_error()} ->", "DETERMINISTIC" if not diffs else diffs, flush=True)
-e.debug_option("overlap_tail", 1)
+e.debug_option("overlap_tail", 2)

@@ -29,10 +29,11 @@ def main():
     ap.add_argument("--g", type=int, default=16)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--fwd-only", action="store_true")
-    ap.add_argument("--overlap", type=int, default=1, help="A/B: TTT-MLP backward schedule, 0 = one stream, 1 = tail kernel of a chunk beside the next sweep (default), 2 = the next recompute too")
+    ap.add_argument("--overlap", type=int, default=2, help="A/B: TTT-MLP backward schedule, 0 = one stream, 1 = tail kernel of a chunk beside the next sweep (default), 2 = the next recompute too")
     ap.add_argument("--gpc", type=int, default=0, help="DEBUG A/B: checkpoint groups per backward chunk (0 = automatic)")
     ap.add_argument("--write-through-records", action="store_true", help="DEBUG A/B: the backward sweep's hand-over records always write-through (sc1), never plain")
     ap.add_argument("--ab", default=None, metavar="OPTION", help="interleaved A/B inside one process: the named debug option alternates 0 / 1 from iteration to iteration; the backward's average is reported per value (same box, same clocks)")
+    ap.add_argument("--ab-values", default="0,1", help="the two values --ab alternates between (default 0,1)")
     ap.add_argument("--ab-restore", type=int, default=1, help="value the --ab option is left at for the --phases pass")
     ap.add_argument("--ab-fixed", default=None, metavar="OPTION=VALUE", help="set one more debug option for the whole run")
     ap.add_argument("--ws-skew", type=int, default=0, help="DEBUG: the kernel workspace starts this many bytes (multiple of 256) into its allocation")
@@ -99,6 +100,7 @@ def main():
             times[_k].append((s, e))
         setattr(ext, name, wrapped)
 
+    ab_vals = [int(v) for v in a.ab_values.split(",")]
     ab = {0: [], 1: []}
     abf = {0: [], 1: []}
     for it in range(a.iters + 2):
@@ -106,7 +108,7 @@ def main():
             torch.cuda.synchronize()
             times = {"fwd": [], "bwd": []}
         if a.ab:
-            ext.debug_option(a.ab, it & 1)
+            ext.debug_option(a.ab, ab_vals[it & 1])
         n0, f0 = len(times["bwd"]), len(times["fwd"])
         out = fwd()
         if a.disturb:
@@ -138,7 +140,7 @@ def main():
                   "frac_mfma_peak": fl / (avg * 1e-3) / 2.5e15, "frac_occupied_cu_peak": fl / (avg * 1e-3) / (2.5e15 * min(B * NH, 256) / 256)}
     if a.ab:
         avg = lambda ev: sum(s.elapsed_time(e) for s, e in ev) / max(1, len(ev))
-        res["ab"] = {"option": a.ab, **{str(v): {"fwd_avg_ms": avg(abf[v]), "bwd_avg_ms": avg(ab[v]), "n": len(abf[v])} for v in (0, 1)}}
+        res["ab"] = {"option": a.ab, **{str(ab_vals[v]): {"fwd_avg_ms": avg(abf[v]), "bwd_avg_ms": avg(ab[v]), "n": len(abf[v])} for v in (0, 1)}}
     if a.phases:
         buf = torch.zeros(48, dtype=torch.int64, device=dev)
         ext.debug_timing(buf)

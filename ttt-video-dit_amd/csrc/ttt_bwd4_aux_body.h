@@ -174,9 +174,19 @@ TTT_WV_FN float gelu1(BK& bk, float x) { return x * bk.rcp(1.0f + bk.exp2(x * (x
 constexpr int PARK_BYTES = 12 * FRAG;                    // per deriver wave
 TTT_WV_FN int park_off(int arr, int ti, int s) { return ((arr * 2 + ti) * 2 + s) * FRAG; }
 
-template <class BK>
+// `mid` (round 6) is called once, behind the W2 update (2) / R2 and in front of the token tiles (1b) .. (5): nothing a reverse step
+// writes is read before the NEXT iteration (R1 by S1, R2 by S2, the parked fragments by stage_r4), and the tiles it reads belong to
+// the step below, so the sweep lets its workgroup barrier Bc fall there - the token tiles then run beside the compute waves' S4a
+// instead of in front of it (stage stamps of profiles/r6a: the 11.1 k cycles of reverse_step WERE the Bb .. Bc phase, and the
+// derivers idled from Bc to Bd).  Other positions measured on one MI355X at NC = 804 (profiles/r6d_*, interleaved pairs, ms per
+// backward): behind the whole step 10.88 (rounds 3 - 5), in front of it 10.66, HERE 10.22 - 10.30, behind the first token tile's
+// gelu' / gelu'' 10.41, behind its W1 update 10.42, between the token tiles 10.39 - 10.47.
+struct NoMid {
+    TTT_WV_FN void operator()() const {}
+};
+template <class BK, class Mid = NoMid>
 TTT_WV_FN void reverse_step(BK& bk, AuxState& st, int pp, int tile_k, int tile_g, int vec_eta, const Frags4& Z1, int off_r1, int off_r2,
-                            char* g_slice, int off_gz1t, int off_w1, char* r4_park) {
+                            char* g_slice, int off_gz1t, int off_w1, char* r4_park, Mid mid = Mid()) {
     const int l = bk.lane(), h = l >> 5, c = l & 31;
     constexpr int FRK = 8 * FRAG;
 
@@ -197,11 +207,14 @@ TTT_WV_FN void reverse_step(BK& bk, AuxState& st, int pp, int tile_k, int tile_g
             for (int b = 0; b < 2; ++b) st.W2t[b] = bk.mma3216(xs, tr_pi(bk, tile_g, 32 * ti, s, 32 * b), st.W2t[b]);
         }
     }
+    bk.stamp(0);
     // R2: W2_i (rows = n, lane = f), FR_W2 order [ni][fj][s]
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int s = 0; s < 2; ++s) st_frag(bk, off_r2, fr_idx(pp, b, s), pack(st.W2t[b], s));
+    bk.stamp(1);
+    mid();                           // (behind the W2 update / R2, in front of both token tiles)
     // (1b), (3), (4), (5) per token tile
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti) {
@@ -213,6 +226,7 @@ TTT_WV_FN void reverse_step(BK& bk, AuxState& st, int pp, int tile_k, int tile_g
 #pragma unroll
             for (int s = 0; s < 2; ++s) gx = bk.mma3216(pi_row(bk, tile_g, 32 * ti + c, 32 * b, s, h), pack(t, s), gx);
         }
+        bk.stamp(2);
         bf16x8 g1p[2], g1sp[2], x2[2], d1[2];
         {
             const f32x16 etaR = rows_from_lds(bk, vec_eta, 32 * ti, h);
@@ -237,11 +251,13 @@ TTT_WV_FN void reverse_step(BK& bk, AuxState& st, int pp, int tile_k, int tile_g
                 *reinterpret_cast<bf16x8*>(r4_park + park_off(2, ti, s) + l * 16) = x2[s];
             }
         }
+        bk.stamp(3);
         // (4) W1_i = W1_{i+1} + (eta K)^T gZ1 :  A = K^T by transposed reads (m = f, k = t), B = eta gZ1 in place (k = t, j = n)
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int a = 0; a < 2; ++a) st.W1t[a] = bk.mma3216(tr_pi(bk, tile_k, 32 * ti, s, 32 * a), g1sp[s], st.W1t[a]);
+        bk.stamp(4);
         // (5) N orientation: gZ1^T | gelu'(Z1)^T | X2^T  -> R1 (FR_GZ1T | FR_D1N | FR_XT order [nj][ti][s]), one tile at a time
         {
             const f32x16 t = transpose_tile(bk, g1p[0], g1p[1], I0, I1);
@@ -262,6 +278,7 @@ TTT_WV_FN void reverse_step(BK& bk, AuxState& st, int pp, int tile_k, int tile_g
 #pragma unroll
             for (int s = 0; s < 2; ++s) st_frag(bk, off_r1 + 2 * FRK, fr_idx(pp, ti, s), pack(t, s));
         }
+        bk.stamp(5);
     }
     // (7) packed W1_i for the tail (FR_W1 order [fi][nj][s])
 #pragma unroll

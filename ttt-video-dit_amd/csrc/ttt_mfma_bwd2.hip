@@ -33,7 +33,7 @@ bool bwd_available() { return true; }
 
 static int g_forced_gpc = 0;
 void set_debug_groups_per_chunk(int g) { g_forced_gpc = g; }
-static int g_overlap = 1;             // 1: tail of chunk c on a side stream beside the sweep of chunk c-1; 0 = one stream;
+static int g_overlap = 2;             // 1: tail of chunk c on a side stream beside the sweep of chunk c-1; 0 = one stream;
                                       // 2: the recompute of chunk c-1 too beside the sweep of chunk c (THREE record buffers; round 6 A/B)
 void set_debug_overlap_tail(int v) { g_overlap = v; }
 static int record_buffers() { return g_overlap >= 2 ? 3 : 2; }
@@ -47,6 +47,8 @@ void set_debug_fast_records(int v) { g_fast_records = v; }
 // a coin toss who is dispatched first, and "tail first" is the slow outcome (1.00 - 1.12 against 0.92 ms).  With the memset out of
 // the way the sweep follows its recompute kernel-to-kernel; round 4's driver line confirmed it inside the step (the sharded
 // `fsdp1` point within 0.1 % of the replica line, where it had been 2.4 % behind).  The gate kernels tried beside it are gone.
+static int g_deriver_split = 1;       // sweep: barrier Bc inside the derivers' reverse step (round 6); 0 = behind it (rounds 3 - 5)
+void set_debug_deriver_split(int v) { g_deriver_split = v; }
 static int g_sweep_fault = 0;         // DEBUG fault injection (tests of the hand-over failure path)
 void set_debug_sweep_fault(int v) { g_sweep_fault = v; }
 
@@ -177,7 +179,7 @@ static int mlp_backward4(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws,
     bp.NH = d->NH; bp.NC = NC;
     bp.xch = xch; bp.flags = flags; bp.fast_records = g_fast_records;
     bp.err = err_word; bp.fault = g_sweep_fault;
-    bp.W1c = a->W1_checkpoints; bp.W2c = a->W2_checkpoints; bp.wfinal = wfinal; bp.park = park; bp.G = G; bp.K = K; bp.prefetch = 1; bp.own16 = 1;
+    bp.W1c = a->W1_checkpoints; bp.W2c = a->W2_checkpoints; bp.wfinal = wfinal; bp.park = park; bp.G = G; bp.K = K; bp.prefetch = 1; bp.own16 = 1; bp.split = g_deriver_split ? 1 : 0;
 
     int rc = 0;                               // a failed event / stream call leaves the two streams unordered: the call fails (-12)
     auto chk = [&](hipError_t e) { if (e != hipSuccess) rc = -12; };

@@ -143,6 +143,7 @@ __device__ __forceinline__ void bst8_nt(__amdgpu_buffer_rsrc_t r, int voff, int 
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 2);      // aux bit 1 = nt
 }
 // the wave backend of ttt_bwd4_aux_body.h on the device
+template <bool DBG>
 struct DeriverBackend {
     char* base;
     int l;                                  // lane id, re-made opaque every step: everything derived from it (fragment / tile addresses)
@@ -160,6 +161,18 @@ struct DeriverBackend {
     __device__ __forceinline__ bf16x8 opaque8(bf16x8 v) const { asm volatile("" : "+v"(v)); return v; }
     // global store of data that only a LATER kernel reads (the tail): non-temporal
     __device__ __forceinline__ void store_stream(char* p, bf16x8 v) const { __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(p)); }
+    // DEBUG: cycle stamps INSIDE reverse_step (entries 36 + k of the timing buffer; deriver wave 0 of workgroup 0 only)
+    unsigned long long* dbg = nullptr;
+    unsigned long long t_in = 0;
+    __device__ __forceinline__ void stamp(int k) {
+        if constexpr (DBG) {
+            if (dbg != nullptr) {
+                const unsigned long long t = __builtin_readcyclecounter();
+                dbg[36 + k] += t - t_in;
+                t_in = t;
+            }
+        }
+    }
 };
 
 #define TTT_PIN_RECORDS(dep)                                                                                                              \
@@ -227,6 +240,8 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
     unsigned* const my_flag = p.flags + ((size_t)bh * 4 + cq) * FLAG_STRIDE;
     if (p.fault && cq == 3) return;             // DEBUG fault injection (tests): this workgroup's partners must time out loudly
 
+    // (Round 6 tried issue priorities by role - s_setprio 3 for the owners' hand-over chain, 2 for the compute waves, 0 for the
+    // VALU-heavy derivers: 10.37 against 10.26 ms per backward at NC = 804, worse at every position of Bc; profiles/r6e_*.  Gone.)
     if (wv < 2) {
         // =========================================================================================================== COMPUTE
         const int pp = wv;
@@ -937,7 +952,8 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
         const int pp = wv - DW0;                                // the 32 hidden units of compute wave pp
         const int l = tid & 63, h = l >> 5, c = l & 31;
         const int nO = 64 * cq + 32 * pp;
-        DeriverBackend bk{smem, (int)(threadIdx.x & 63)};
+        DeriverBackend<DBG> bk{smem, (int)(threadIdx.x & 63)};
+        if (DBG && p.dbg != nullptr && blockIdx.x == 0 && tid == 64 * DW0) bk.dbg = reinterpret_cast<unsigned long long*>(p.dbg);
         bwd4::AuxState st;
         // the state entering step `step` (a multiple of the checkpoint group size, or the end of the sequence): the forward's
         // checkpoint, or the state phase A wrote after the last step
@@ -1013,17 +1029,28 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
             TTT_DSTAMP(1)
             owner_barrier();                   // Bb: K_j, gZ2_j, eta_j staged by the owners are visible
             TTT_DSTAMP(3)
+            // Round 6 (p.split): barrier Bc falls INSIDE the reverse step, behind its W2 update - the token tiles run beside the
+            // compute waves' S4a (Bc .. Bd), where the derivers used to idle, instead of holding Bc back (see reverse_step's `mid`)
+            const bool split = p.split != 0 && more;
             if (more) {
                 if (i % p.G == 0) load_anchor(i);               // group boundary: the exact state entering step i
+                if constexpr (DBG) bk.t_in = __builtin_readcyclecounter();
                 bwd4::reverse_step(bk, st, pp, L_K + nxt * TILE_B, L_G + nxt * TILE_B, L_SM + nxt * 64 * 4, Z1, L_R1, L_R2,
-                                   slots + (size_t)slot_off(i - 1) + WREG, fro4(A_GZ1T, 0), fro4(A_W1, 0), park);
+                                   slots + (size_t)slot_off(i - 1) + WREG, fro4(A_GZ1T, 0), fro4(A_W1, 0), park, [&] {
+                                       if (split) {
+                                           TTT_DSTAMP(2)
+                                           owner_barrier();       // Bc
+                                           TTT_DSTAMP(3)
+                                           if constexpr (DBG) bk.t_in = __builtin_readcyclecounter();
+                                       }
+                                   });
             }
             // L2 prefetch of this wave's share of the slice's Z1 / Z1b fragments of step i - 2 (two consecutive 8-KiB arrays)
             unsigned touch = 0u;
             if (p.prefetch && i - 2 >= p.chunk_lo)
                 touch = __builtin_amdgcn_raw_buffer_load_b32(rS, (pp * 64 + l) * 128, slot_off(i - 2) + WREG + fro4(A_Z1, 0), 0);
             TTT_DSTAMP(2)
-            owner_barrier();                   // Bc
+            if (!split) owner_barrier();       // Bc
             owner_barrier();                   // Bd
             asm volatile("" :: "v"(touch));
             TTT_DSTAMP(3)

@@ -35,12 +35,13 @@ void launch_linear_forward_cs16(const wv::Lin16Params& p, int n_bh, hipStream_t 
 void launch_linear_backward_cs16(const wv::Lin16Params& p, int n_bh, hipStream_t s);
 void set_debug_dump(float* buf);
 unsigned long long* get_debug_timing();
-void set_debug_overlap_tail(int v);   // backward schedule: 0 one stream, 1 (default) tail of chunk c beside the sweep of chunk c-1
+void set_debug_overlap_tail(int v);   // backward schedule: 0 one stream, 1 tail of chunk c beside the sweep of chunk c-1, 2 (default) the next recompute too
 void set_debug_fast_records(int v);   // cluster sweep: 1 (default) plain records on a proven common XCD, 0 write-through always
 unsigned read_sweep_error();           // 0, or 1 + (b,h) of a cluster workgroup whose partner never arrived (synchronises)
 unsigned peek_sweep_error();           // the same word without synchronising (entry check of the TTT-MLP calls)
 void clear_sweep_error();              // acknowledge (synchronises)
 unsigned* sweep_error_word();          // device pointer of the host-mapped word (allocated on first use; nullptr on failure)
+void set_debug_deriver_split(int v);  // sweep: 1 (default, round 6) barrier Bc inside the derivers' reverse step, 0 = behind it
 void set_debug_sweep_fault(int v);     // DEBUG fault injection: workgroup 3 of every sweep cluster leaves before its first hand-over
 unsigned read_sweep_fast_count();   // DEBUG statistic (synchronises)
 

@@ -176,17 +176,24 @@ class FlatFSDP:
         tag = {"ttt_no_wd": "<ttt_no_wd_bias>", "ttt_wd": "<ttt_wd>", "other_no_wd": "<other_no_wd_bias>", "other_wd": "<other_wd>"}
         return [(f"{u.prefix}.{tag.get(k, k)}", m) for u in self.units for k, m in u.masters.items()]
 
-    def attach_optimizer(self, optimizer: torch.optim.Optimizer, gate: bool = True, extension=None):
+    def attach_optimizer(self, optimizer: torch.optim.Optimizer, gate: bool = True, extension=None, lr_scheduler=None):
         """Makes the reference's unchanged loop work on this holder (train.py:131-166: zero_grad, backward, clip, ``optimizer.step()``,
         ``lr_scheduler.step()``).  Step PRE-hook: ``finish_backward()`` (idempotent) and, with ``gate``, the look at the TTT-MLP
         backward's hand-over error word that must come before AdamW (one device synchronisation; all ranks agree by a MAX
         all-reduce): after a timed-out hand-over or with non-finite gradients the gradients are dropped, so that the step changes
-        nothing (AdamW skips parameters without a gradient; ``last_step_skipped`` says so).  Step POST-hook: ``publish()``."""
+        nothing (AdamW skips parameters without a gradient; ``last_step_skipped`` says so).  Step POST-hook: ``publish()``.
+
+        A skipped step must not advance the schedule: the reference's loop calls ``lr_scheduler.step()`` unconditionally, so either
+        pass ``lr_scheduler`` here - its ``step()`` then does nothing after a skipped optimizer step - or test ``last_step_skipped``
+        before calling it.  ``checked_optimizer_step`` (train_step.py) takes the same decision itself BEFORE ``optimizer.step()``:
+        it marks the optimizer (``_ttt_gate_done``) and the pre-hook does not synchronise a second time.  ``remove()`` takes the
+        hooks off again and gives the optimizer / scheduler their own ``zero_grad`` / ``step`` back."""
         def pre(opt, args, kwargs):
             self.finish_backward()
             self.last_step_skipped = False
-            if gate:
+            if gate and not getattr(opt, "_ttt_gate_done", False):
                 self.last_step_skipped = self._gate(extension)
+            opt._ttt_gate_done = False
             return None
 
         def post(opt, args, kwargs):
@@ -200,7 +207,17 @@ class FlatFSDP:
             self.zero_grad()
 
         optimizer.zero_grad = zero_grad
-        self._optimizers.append((optimizer, optimizer.register_step_pre_hook(pre), optimizer.register_step_post_hook(post)))
+        sched_stock = None
+        if lr_scheduler is not None:
+            sched_stock = lr_scheduler.step
+
+            def sched_step(*a, **k):
+                if self.last_step_skipped:               # warm-up / decay do not advance on a step that changed nothing
+                    return None
+                return sched_stock(*a, **k)
+
+            lr_scheduler.step = sched_step
+        self._optimizers.append((optimizer, optimizer.register_step_pre_hook(pre), optimizer.register_step_post_hook(post), stock, lr_scheduler, sched_stock))
         return optimizer
 
     def _gate(self, extension) -> bool:
@@ -499,9 +516,12 @@ class FlatFSDP:
             h.remove()
         self._hooks.clear()
         self._root_hook.remove()
-        for opt, h0, h1 in self._optimizers:
+        for opt, h0, h1, stock_zero_grad, sched, sched_stock in self._optimizers:
             h0.remove()
             h1.remove()
+            opt.zero_grad = stock_zero_grad              # (attach_optimizer replaced them on the instances)
+            if sched is not None:
+                sched.step = sched_stock
         self._optimizers.clear()
         if getattr(self.dit, "_master_holder", None) is self:
             del self.dit._master_holder

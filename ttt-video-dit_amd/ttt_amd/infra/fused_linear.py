@@ -53,7 +53,7 @@ class Linear3(torch.autograd.Function):
             # (2.85 against 3 x 0.90 ms - that shape is bound by its K-major operands, not by tile quantisation); "both" keeps
             # the one-GEMM form selectable.
             ns = [w.shape[0] for w in ctx.ws]
-            dx = cat.mm(torch.cat(ctx.ws, dim=0)).view(x.shape) if ctx.needs_input_grad[0] else None
+            dx = cat.mm(_stacked_weights(ctx.ws)).view(x.shape) if ctx.needs_input_grad[0] else None
             blocks = cat.split(ns, dim=1)
             if FUSE_QKV_BACKWARD == "both":
                 gwc = cat.t().mm(x2) if any(w.requires_grad for w in ctx.ws) else None
@@ -82,9 +82,35 @@ class Linear3(torch.autograd.Function):
         return dx, gw[0], gb[0], gw[1], gb[1], gw[2], gb[2]
 
 
-# "dgrad" (default): one input-gradient GEMM over the concatenation, one weight-gradient GEMM per projection; "both": the weight
-# gradients as one GEMM too; "" / "0": three GEMMs each (A/B switch: tools/qkv_backward_bench.py, bench.py)
-FUSE_QKV_BACKWARD = {"0": "", "1": "dgrad"}.get(os.environ.get("TTT_FUSE_QKV_BACKWARD", "dgrad"), os.environ.get("TTT_FUSE_QKV_BACKWARD", "dgrad"))
+def _fuse_mode(value: str) -> str:
+    """TTT_FUSE_QKV_BACKWARD: "dgrad" (default) / "1": one input-gradient GEMM over the concatenation, one weight-gradient GEMM per
+    projection; "both": the weight gradients as one GEMM too; "" / "0": three GEMMs each (A/B switch: tools/qkv_backward_bench.py).
+    Anything else is an error (a typo such as "off" used to select the fusion silently)."""
+    modes = {"": "", "0": "", "1": "dgrad", "dgrad": "dgrad", "both": "both"}
+    if value not in modes:
+        raise ValueError(f"TTT_FUSE_QKV_BACKWARD={value!r}: expected one of {sorted(modes)}")
+    return modes[value]
+
+
+FUSE_QKV_BACKWARD = _fuse_mode(os.environ.get("TTT_FUSE_QKV_BACKWARD", "dgrad"))
+
+# The [n0 + n1 + n2, K] stack of a group's three weights for the one-GEMM input gradient.  The two scan directions of a TTT layer
+# share wq / wk / wv and their backward nodes run back to back, so the stack of the LAST group is kept (one entry: 56 MB at D = 3072;
+# keeping every group's would be 4.7 GB of the 5B model) and re-used while the same three tensors are unchanged (`_version` moves
+# with every in-place update, e.g. the publish of new parameters after the optimizer step).
+_stack_cache = {"ws": None, "key": None, "value": None}
+
+
+def _stacked_weights(ws):
+    # identity of the three tensor OBJECTS (held here, so that their ids cannot be re-used by other tensors) + storage + version
+    key = tuple((w.data_ptr(), w._version, tuple(w.shape), w.dtype) for w in ws)
+    held = _stack_cache["ws"]
+    if held is None or len(held) != len(ws) or any(a is not b for a, b in zip(held, ws)) or _stack_cache["key"] != key:
+        _stack_cache["value"] = None                       # (free the old stack before the new one is allocated)
+        _stack_cache["value"] = torch.cat([w.detach() for w in ws], dim=0)
+        _stack_cache["ws"], _stack_cache["key"] = tuple(ws), key
+    return _stack_cache["value"]
+
 
 
 def _column_blocks(dys):

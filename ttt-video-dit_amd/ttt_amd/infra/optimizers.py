@@ -49,7 +49,11 @@ def named_trainable(model) -> List[Tuple[str, nn.Parameter]]:
     for m in (model, getattr(model, "dit", None)):
         holder = getattr(m, "_master_holder", None) if m is not None else None
         if holder is not None:
-            return list(holder.named_master_parameters())
+            # the holder's masters stand for the parameters of the module it wraps; trainable parameters of `model` OUTSIDE that
+            # module are stepped as they are (the reference's model.named_parameters() would include them, optimizers.py:200-211)
+            owned = {id(p) for p in m.parameters()}
+            extras = [(n, p) for n, p in model.named_parameters() if p.requires_grad and id(p) not in owned]
+            return list(holder.named_master_parameters()) + extras
     if hasattr(model, "named_master_parameters"):
         return list(model.named_master_parameters())
     return [(n, p) for n, p in model.named_parameters() if p.requires_grad]
@@ -183,7 +187,7 @@ def get_optimizer_and_scheduler(model, config: Any):
     if config.model.ssm_layer == "none":
         opt = create_optimizer(model, o.lr)
         return opt, create_basic_lr_scheduler(opt, t.warmup_steps, t.steps, o.lr, o.lr_end), \
-            ScheduleConfig(o.lr_schedule, t.warmup_steps, t.steps, o.lr, o.lr_end, "remaining_wd")
+            ScheduleConfig(o.lr_schedule, t.warmup_steps, t.steps, o.lr, o.lr_end, "standard")
     opt, cfgs = create_specialized_optimizer(model, o.lr, o.lr_ssm, o.lr_end, t.warmup_steps, t.steps, ScheduleType(o.lr_schedule),
                                              ScheduleType(o.lr_ssm_schedule), t.adapter_method)
     return opt, create_grouped_lr_scheduler(opt, cfgs), cfgs

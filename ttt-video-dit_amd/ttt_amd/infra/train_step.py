@@ -49,5 +49,9 @@ def checked_optimizer_step(optimizer: torch.optim.Optimizer, parameters: Iterabl
         if err:
             extension.sweep_error_clear()
         return None
-    optimizer.step()
+    optimizer._ttt_gate_done = True        # (a FlatFSDP step pre-hook would take the same decision again: one synchronisation is enough)
+    try:
+        optimizer.step()
+    finally:
+        optimizer._ttt_gate_done = False
     return total
