@@ -127,6 +127,8 @@ struct EmulWave {
     bf16x8 opaque8(bf16x8 v) const { return v; }
     void store_stream(char* p, bf16x8 v) const { *reinterpret_cast<bf16x8*>(p) = v; }
     void stamp(int) const {}                    // (device: DEBUG cycle stamps inside a body)
+    static constexpr bool kPrio = true;         // (attention bodies: the priority calls are no-ops here)
+    void setprio(int) const {}
     void sync() { sh->bar.arrive_and_wait(); }
     void barrier() { grp->bar.arrive_and_wait(); ++epoch; }     // __syncthreads()
     void lds_fence() { sync(); }                       // same-wave LDS write -> read ordering point (free on the device)

@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--b", type=int, default=1)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--no-sdpa", action="store_true")
+    ap.add_argument("--variants", default=None, help="DEBUG A/B: comma list of attn_prio values (0 / 1: the s_setprio form of csrc/attn_body.h) - the backward "
+                                                     "timed for each in interleaved rounds inside this process, outputs compared with the first")
     a = ap.parse_args()
     import test_time_training as ext
     from ttt_amd.models.cogvideo.attention import SegmentAttention
@@ -43,6 +45,7 @@ def main():
     g = torch.Generator(device=dev).manual_seed(0)
     mk = lambda: torch.randn(B, S, NH, 64, device=dev, generator=g).bfloat16().transpose(1, 2)
     q, k, v, do = mk(), mk(), mk(), mk()
+    v_ = v
     flops = 4.0 * S * S * 64 * NH * B
     res = {"shape": [B, NH, S, 64], "fwd_flops": flops}
     out = torch.empty(B, S, NH, 64, device=dev, dtype=torch.bfloat16).transpose(1, 2)
@@ -53,6 +56,23 @@ def main():
     delta = torch.empty(B, NH, S, device=dev)
     t = timeit(lambda: ext.attn_backward(q, k, v, out, do, lse, delta, dq, dk, dv, 0.125), a.iters)
     res["hip_bwd"] = {"ms": t, "tflops": 2.5 * flops / t / 1e9}
+    if a.variants:
+        vs = [int(v) for v in a.variants.split(",")]
+        times = {v: [] for v in vs}
+        ref, same = None, {}
+        for rnd in range(4):
+            for v in vs:
+                ext.debug_option("attn_prio", v)
+                times[v].append(timeit(lambda: ext.attn_backward(q, k, v_, out, do, lse, delta, dq, dk, dv, 0.125), a.iters))
+                if rnd == 0:
+                    torch.cuda.synchronize()
+                    cur = [t.clone() for t in (dq, dk, dv)]
+                    if ref is None:
+                        ref = cur
+                    same[v] = [bool(torch.equal(x, y)) for x, y in zip(cur, ref)]
+        ext.debug_option("attn_prio", 1)
+        res["variants"] = {str(v): {"bwd_ms_rounds": [round(t, 3) for t in times[v]], "bwd_ms": round(sum(times[v]) / len(times[v]), 3),
+                                    "tflops": round(2.5 * flops / (sum(times[v]) / len(times[v])) / 1e9, 1), "dq_dk_dv_equal_to_first": same[v]} for v in vs}
     if not a.no_sdpa:
         qq, kk, vv = (x.detach().clone().requires_grad_(True) for x in (q, k, v))
         t = timeit(lambda: F.scaled_dot_product_attention(qq, kk, vv), a.iters)

@@ -36,6 +36,7 @@ void launch_backward(const BwdParams& p, hipStream_t s);
 // dQ and dK / dV through the workgroup bodies of attn_body.h (attn_v2.hip)
 void launch_dq_v2(const BwdParams& p, hipStream_t s);
 void launch_dkdv_v2(const BwdParams& p, hipStream_t s);
+void set_debug_attn_variant(int v);     // DEBUG A/B: 1 (default) s_setprio around one MFMA cluster per backward kernel, 0 without
 
 }  // namespace attn
 }  // namespace ttt

@@ -56,6 +56,15 @@ constexpr float LOG2E = 1.4426950408889634f;
 #define TTT_PIN_IN_BRANCH(x) ((void)0)
 #endif
 
+// BK::kPrio (round 6): s_setprio(1) .. s_setprio(0) around ONE MFMA cluster per kernel - the dS -> dQ cluster of dq_wide and the
+// S / dP cluster of dkdv_staged - so that a wave entering its MFMA cluster is issued ahead of the waves of its SIMD that are in their
+// exp / pack / LDS phases (cdna_hip_programming.md T5).  Measured on one MI355X at 48 heads x 18 048 tokens, interleaved rounds in
+// one process (profiles/r6h_*, ms per backward): none 13.25 - 13.33; dQ's second cluster 12.76; its first cluster alone 13.25;
+// both 12.68; dK/dV's SECOND cluster alone 13.46 (worse); THIS PAIR 12.55 / 13.02 (two boxes: -5.3 % / -2.3 %); all four clusters
+// 12.51 / 13.07; static priorities by wave age 13.29.  Same bits as without (priorities only re-time).  The forward kernel
+// (attn_fwd.hip) gains nothing from either cluster (4.64 - 4.66 against 4.66 ms) and has none; packed-fp32 forms of the exp chains
+// (v_pk_mul_f32 on accumulator register pairs) LOST: hipcc splits a packed multiply by a uniform value whatever the source says, and
+// forced through inline asm it costs scheduling freedom - 12.87 against 12.62 ms, removed.
 TTT_BODY_FN int row_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 TTT_BODY_FN f32x16 zero16() {
     f32x16 z;
@@ -569,6 +578,7 @@ TTT_BODY_FN void dq_wide(BK& bk, const BwdParams& p, int bh, int qb) {
                         const float pr = bk.exp2(__builtin_fmaf(Sc[qi][r], sc, -lse2[qi]));
                         dP[qi][r] = pr * (dP[qi][r] - delta[qi]);
                     }
+                if constexpr (BK::kPrio) bk.setprio(1);
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const bf16x8 k0 = tr_frag_pi_s<false>(bk, Kt, 32 * kb, s, 0, l), k1 = tr_frag_pi_s<false>(bk, Kt, 32 * kb, s, 32, l);
@@ -579,6 +589,7 @@ TTT_BODY_FN void dq_wide(BK& bk, const BwdParams& p, int bh, int qb) {
                         dQ[qi][1] = bk.mma3216(k1, df, dQ[qi][1]);
                     }
                 }
+                if constexpr (BK::kPrio) bk.setprio(0);
             }
             }
             if (more) kv_park_s<false>(bk, st, nxt + u * DQ_BUF_ELEMS, nxt + u * DQ_BUF_ELEMS + KT_ELEMS, tid);
@@ -837,11 +848,13 @@ TTT_BODY_FN void dkdv_staged(BK& bk, const BwdParams& p, int bh, int kvb) {
                 Sc = zero16();
                 dP = zero16();
             }
+            if constexpr (BK::kPrio) bk.setprio(1);
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 Sc = bk.mma3216(row_frag_s<SWZ>(bk, Qt, 32 * qb, 16 * kk, l), Kf[kk], Sc);
                 dP = bk.mma3216(row_frag_s<SWZ>(bk, Dt, 32 * qb, 16 * kk, l), Vf[kk], dP);
             }
+            if constexpr (BK::kPrio) bk.setprio(0);
             if (ACC_INIT) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -871,6 +884,7 @@ TTT_BODY_FN void dkdv_staged(BK& bk, const BwdParams& p, int bh, int kvb) {
                     dK[db] = bk.mma3216(df, tr_frag_pi_s<SWZ>(bk, Qt, 32 * qb, s, 32 * db, l), dK[db]);
                 }
             }
+
         }
         }
         if (more) qstage_park_s<SWZ>(bk, st, nxt + u * DKV_BUF_ELEMS, tid);

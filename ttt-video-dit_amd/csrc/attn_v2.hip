@@ -11,7 +11,10 @@
 namespace ttt {
 namespace attn {
 
+template <int VAR>
 struct AttnDeviceWave {
+    static constexpr bool kPrio = VAR != 0;                           // s_setprio around one MFMA cluster per kernel (attn_body.h)
+    __device__ __forceinline__ void setprio(int v) const { if (v) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
     typedef __bf16* tile_t;                                           // element pointer into the workgroup's LDS
     typedef __attribute__((address_space(3))) wv::bf16x4 lds_b4;
     tile_t base;
@@ -38,46 +41,59 @@ struct AttnDeviceWave {
 // tests/test_emul_attention_cpu.py).  Round 4, one MI355X, 48 heads x S = 18 048 (profiles/r4a_attn_backward_stages_ab.log, r4b_*): tiles
 // per stage dQ : dK/dV 1:1 14.29 ms per backward, 2:2 13.56, 1:2 13.81, 2:3 13.52, 2:4 14.23; the XOR-swizzled unpadded tiles of round 3
 // LOST (15.08 ms).  Shipped: two tiles per stage; the other device instantiations and their options were removed in round 5.
-template <int NW, bool ACC_INIT, int MINW, int NSUB>
+template <int NW, bool ACC_INIT, int MINW, int NSUB, int VAR>
 __global__ __launch_bounds__(64 * NW, MINW) void attn_dkdv2s_kernel(BwdParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int bh, kvb;
     attnb::head_of_block(blockIdx.x, (p.S + 32 * NW - 1) / (32 * NW), p.B * p.NH, bh, kvb);
-    AttnDeviceWave bk{reinterpret_cast<__bf16*>(smem)};
+    AttnDeviceWave<VAR> bk{reinterpret_cast<__bf16*>(smem)};
     attnb::dkdv_staged<NW, ACC_INIT, NSUB, false>(bk, p, bh, kvb);
 }
 // dQ with 64 query rows per wave (attn_body.h dq_wide: every K / V fragment read from LDS feeds two MFMAs; 2 waves of <= 256
 // registers per SIMD, one 8-wave workgroup of 512 rows per CU), NSUB key tiles per stage.  Round 4, one box
 // (profiles/r4c_attn_dq_wide_ab.log): 13.26 - 13.44 ms per backward against 13.79 for 32 rows per wave; bit-identical (a query row's
 // arithmetic and its order over the keys are unchanged); one tile per stage measured best here.
-template <int NSUB>
+template <int NSUB, int VAR>
 __global__ __launch_bounds__(512, 2) void attn_dq_wide_kernel(BwdParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int bh, qb;
     attnb::head_of_block(blockIdx.x, (p.S + 2 * attnb::QB - 1) / (2 * attnb::QB), p.B * p.NH, bh, qb);
-    AttnDeviceWave bk{reinterpret_cast<__bf16*>(smem)};
+    AttnDeviceWave<VAR> bk{reinterpret_cast<__bf16*>(smem)};
     attnb::dq_wide<NSUB, 2>(bk, p, bh, qb);
 }
 
-void launch_dq_v2(const BwdParams& p, hipStream_t s) {
+static int g_attn_variant = 1;          // DEBUG A/B (ttt_hip_debug_option "attn_prio"): 1 (default) the priority form of attn_body.h, 0 without
+void set_debug_attn_variant(int v) { g_attn_variant = v; }
+
+template <int VAR>
+static void launch_dq_var(const BwdParams& p, hipStream_t s) {
     constexpr int NSUB = 1;
     static ttt::OncePerDevice attr;
     attr.run([&] {
-        (void)hipFuncSetAttribute((const void*)attn_dq_wide_kernel<NSUB>, hipFuncAttributeMaxDynamicSharedMemorySize, NSUB * attnb::LDS_DQ);
+        (void)hipFuncSetAttribute((const void*)attn_dq_wide_kernel<NSUB, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, NSUB * attnb::LDS_DQ);
     });
     const int nb = (p.S + 2 * attnb::QB - 1) / (2 * attnb::QB);
-    hipLaunchKernelGGL((attn_dq_wide_kernel<NSUB>), dim3(p.B * p.NH * nb), dim3(512), NSUB * attnb::LDS_DQ, s, p);
+    hipLaunchKernelGGL((attn_dq_wide_kernel<NSUB, VAR>), dim3(p.B * p.NH * nb), dim3(512), NSUB * attnb::LDS_DQ, s, p);
+}
+void launch_dq_v2(const BwdParams& p, hipStream_t s) {
+    if (g_attn_variant) launch_dq_var<1>(p, s);
+    else launch_dq_var<0>(p, s);
 }
 
-void launch_dkdv_v2(const BwdParams& p, hipStream_t s) {
+template <int VAR>
+static void launch_dkdv_var(const BwdParams& p, hipStream_t s) {
     constexpr int NW = 12, NSUB = 2;
     static_assert(NSUB * attnb::LDS_DKV <= 160 * 1024, "LDS budget");
     static ttt::OncePerDevice attr;
     attr.run([&] {
-        (void)hipFuncSetAttribute((const void*)attn_dkdv2s_kernel<NW, true, 3, NSUB>, hipFuncAttributeMaxDynamicSharedMemorySize, NSUB * attnb::LDS_DKV);
+        (void)hipFuncSetAttribute((const void*)attn_dkdv2s_kernel<NW, true, 3, NSUB, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, NSUB * attnb::LDS_DKV);
     });
     const int nb = (p.S + 32 * NW - 1) / (32 * NW);
-    hipLaunchKernelGGL((attn_dkdv2s_kernel<NW, true, 3, NSUB>), dim3(p.B * p.NH * nb), dim3(64 * NW), NSUB * attnb::LDS_DKV, s, p);
+    hipLaunchKernelGGL((attn_dkdv2s_kernel<NW, true, 3, NSUB, VAR>), dim3(p.B * p.NH * nb), dim3(64 * NW), NSUB * attnb::LDS_DKV, s, p);
+}
+void launch_dkdv_v2(const BwdParams& p, hipStream_t s) {
+    if (g_attn_variant) launch_dkdv_var<1>(p, s);
+    else launch_dkdv_var<0>(p, s);
 }
 
 }  // namespace attn

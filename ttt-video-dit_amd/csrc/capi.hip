@@ -58,6 +58,7 @@ int ttt_hip_debug_option(const char* name, int value) {
     else if (!strcmp(name, "overlap_tail")) ttt::mfma::set_debug_overlap_tail(value);            // backward schedule: 2 (default) tail of chunk c and recompute of chunk c-2 beside the sweep of chunk c-1 / 1 tail only / 0 one stream
     else if (!strcmp(name, "groups_per_chunk")) ttt::mfma::set_debug_groups_per_chunk(value);
     else if (!strcmp(name, "deriver_split")) ttt::mfma::set_debug_deriver_split(value);         // sweep: 1 (default) / 0 = barrier Bc behind the derivers' reverse step
+    else if (!strcmp(name, "attn_prio")) ttt::attn::set_debug_attn_variant(value);               // attention backward: 1 (default) / 0 = without the s_setprio pair per kernel
     else if (!strcmp(name, "sweep_fault")) ttt::mfma::set_debug_sweep_fault(value);              // fault injection: workgroup 3 of every sweep cluster leaves early
     else return -1;
     return 0;
