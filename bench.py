@@ -442,8 +442,8 @@ def size_warm_and_time(step, hk, remat_free_layers, warmup, steps, world):
             ok = 0
         if world > 1:
             ok = hk.all_reduce_min(ok)
-        if ok and auto and refinements < 2 and 0 < n_free < hk.num_layers:
-            # up to two refinements with the footprint measured at the chosen setting (the walk at 9 s is 3 -> 8 -> 13; a third
+        if ok and auto and refinements < 3 and 0 < n_free < hk.num_layers:
+            # up to two free refinements with the footprint measured at the chosen setting (the walk at 9 s was 3 -> 8 -> 13; a third
             # refinement finds room for a 14th layer and buys nothing measurable: 8 139 / 8 114 against 8 155 / 8 104 video-tok/s on
             # one box at 243 instead of 237 GiB, profiles/r5h_*; the probe over-estimates a layer's
             # footprint - by a third when re-materialised layers keep their kernel outputs, which a layer that keeps everything
@@ -452,6 +452,10 @@ def size_warm_and_time(step, hk, remat_free_layers, warmup, steps, world):
             per_layer = max((hk.max_allocated() - peak0) / n_free, 1.0)
             better = int(max(0, min(hk.num_layers, (cap * hk.total_memory - peak0) // per_layer)))
             log(f"sizing: peak at {n_free} free layers {hk.max_allocated() / 2**30:.1f} GiB ({per_layer / 2**30:.2f} GiB per layer) -> {better} layers")
+            if refinements == 3:
+                # (round 6: the third record buffer of the TTT-MLP backward's schedule 2 moved the second refinement from 13 to 12 layers
+                # although 13 fit - 237.9 of 253 GiB, profiles/r6f_*; the third refinement may add ONE layer, not walk on to the edge)
+                better = min(better, n_free + 1)
             if fail_at is not None:
                 better = min(better, fail_at - 1)
             if world > 1:

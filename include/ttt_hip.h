@@ -41,7 +41,7 @@ extern "C" {
  * ttt_hip_sweep_error_clear), -10 (fewer than 4 compute units visible), -11 (no host-mapped error word), -12 (a HIP event /
  * stream call of the backward's two-stream schedule failed); the round-1 exports ttt_hip_debug_variant / ttt_hip_debug_helpers
  * are gone.  1: rounds 1 - 3. */
-#define TTT_HIP_ABI_VERSION 3
+#define TTT_HIP_ABI_VERSION 4
 
 enum { TTT_DTYPE_BF16 = 0, TTT_DTYPE_F32 = 1 };
 /* implementation selector: AUTO picks the MFMA kernels when the geometry is supported - bf16, F=64 and
@@ -301,6 +301,15 @@ void        ttt_hip_sweep_error_clear(void);
  * (<= 100 000) of wall-clock time - what a collective's kernels do to the CUs a cluster launch counts on.  Returns 0 / -1. */
 int         ttt_hip_debug_occupy_cus(int workgroups, int lds_bytes, int microseconds, void* stream);
 void        ttt_hip_debug_dump(float* device_buffer);
+/* A HIP stream confined to the compute units of `cu_mask` (`mask_words` x 32 bits, hipExtStreamCreateWithCUMask): kernels enqueued on
+ * it can never occupy a CU outside the mask - e.g. the weight-gradient GEMMs or the collectives of a training step beside the TTT-MLP
+ * backward's cluster sweep, which needs its four workgroups per (b,h) co-resident.  Wrap it with torch.cuda.ExternalStream
+ * (test_time_training.masked_stream).  ttt_hip_debug_placement_probe: `workgroups` single-wave workgroups holding `lds_bytes` of
+ * LDS for `microseconds` on `stream`, each storing (XCC_ID << 16 | HW_ID[15:0]) of the CU it ran on into device_out[workgroup] - how a
+ * mask bit maps to (XCD, shader engine, CU) on this part.  Return 0, or a negative code (ttt_hip_last_error()). */
+int         ttt_hip_stream_create_masked(const unsigned* cu_mask, int mask_words, void** stream);
+int         ttt_hip_stream_destroy(void* stream);
+int         ttt_hip_debug_placement_probe(unsigned* device_out, int workgroups, int lds_bytes, int microseconds, void* stream);
 
 int         ttt_hip_abi_version(void);
 const char* ttt_hip_last_error(void);

@@ -218,3 +218,40 @@ def test_sweep_with_barrier_inside_the_reverse_step_has_the_same_bits(shape):
     if B * NH <= 16:
         ro, rc, rg = oracle_on(d, G, "mlp")
         check_per_head(f"split sweep {shape}", res[1][0][0], (), res[1][0][2], ro, (), rg, 1e-2, 3e-2)
+
+
+def test_sweep_beside_a_saturating_masked_stream_gemm_has_the_same_bits():
+    """a side stream confined to a quarter of the compute units (``ttt_hip_stream_create_masked`` =
+    hipExtStreamCreateWithCUMask, wrapped as a torch ExternalStream by ``test_time_training.masked_stream``) runs a saturating bf16 GEMM
+    loop while the TTT-MLP backward of the benchmarked head count (48 heads: 192 cluster workgroups + recompute / tail beside them) runs:
+    every gradient must equal the run without the neighbour bit for bit, no hand-over may time out, and the placement probe must show
+    the masked stream's workgroups on exactly the masked CUs (8 of every XCD).  The backward runs on a NON-default stream here: a
+    CU-masked stream is a blocking stream and would otherwise serialise with torch's default stream instead of running beside it
+    (tools/cu_mask_probe.py, profiles/r6k_*: what the neighbour costs - the 64 CUs the sweep leaves are not idle, the backward's own
+    recompute / tail kernels live there)."""
+    e = ext()
+    d = round_acts(O.make_inputs("mlp", 1, 48, 96, 64, 64, seed=1800), torch.bfloat16)
+    work = torch.cuda.Stream()
+    work.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(work):
+        o0, _, g0 = run_mlp(e, d, 16, torch.bfloat16, impl="mfma")
+        torch.cuda.synchronize()
+        # mask bit i is a CU of XCD i % 8 (profiles/r6k_cu_mask_probe.json): the low byte of every word = 8 CUs of every XCD = 64 of 256.
+        # (A mask that leaves an XCD without a CU is silently ignored by the runtime: the stream then runs everywhere.)
+        side = e.masked_stream([0xFF] * 8)
+        cus = set(e.placement_probe(256, stream=side))
+        assert len(cus) == 64 and all(sum(1 for c in cus if c[0] == x) == 8 for x in range(8)), sorted(cus)[:16]
+        a = torch.randn(4096, 4096, device=DEV).bfloat16()
+        b = torch.randn(4096, 4096, device=DEV).bfloat16()
+        for rep in range(3):
+            side.wait_stream(work)
+            with torch.cuda.stream(side):
+                for _ in range(60):
+                    torch.mm(a, b)
+            o1, _, g1 = run_mlp(e, d, 16, torch.bfloat16, impl="mfma")
+            torch.cuda.synchronize()
+            assert e.sweep_error() == 0
+            assert torch.equal(o0, o1)
+            bad = [k for k in g0 if not torch.equal(g0[k], g1[k])]
+            assert not bad, (rep, bad)
+    torch.cuda.current_stream().wait_stream(work)

@@ -80,6 +80,37 @@ int ttt_hip_debug_occupy_cus(int workgroups, int lds_bytes, int microseconds, vo
 }
 void ttt_hip_sweep_error_clear(void) { ttt::mfma::clear_sweep_error(); }
 
+// Streams confined to a set of compute units (hipExtStreamCreateWithCUMask) and a probe that reports where workgroups of a stream
+// actually run: word = HW_REG_XCC_ID[3:0] << 16 | HW_REG_HW_ID[15:0] (se_id [15:13], sh_id [12], cu_id [11:8]) per workgroup.
+int ttt_hip_stream_create_masked(const unsigned* cu_mask, int mask_words, void** stream) {
+    if (!cu_mask || mask_words < 1 || mask_words > 32 || !stream) return fail("ttt_hip: stream_create_masked: bad arguments");
+    hipStream_t s = nullptr;
+    if (hipExtStreamCreateWithCUMask(&s, (uint32_t)mask_words, cu_mask) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail("ttt_hip: hipExtStreamCreateWithCUMask failed");
+    }
+    *stream = (void*)s;
+    return 0;
+}
+int ttt_hip_stream_destroy(void* stream) { return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? 0 : -1; }
+__global__ __launch_bounds__(64) void placement_probe_kernel(unsigned* out, unsigned long long ticks) {
+    extern __shared__ __attribute__((aligned(16))) char probe_lds[];
+    probe_lds[threadIdx.x] = 0;
+    if (threadIdx.x == 0) {
+        const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));      // HW_REG_XCC_ID[3:0]
+        const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (15 << 11));       // HW_REG_HW_ID[15:0]
+        out[blockIdx.x] = (xcc << 16) | (hw & 0xffffu);
+    }
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+int ttt_hip_debug_placement_probe(unsigned* device_out, int workgroups, int lds_bytes, int microseconds, void* stream) {
+    if (!device_out || workgroups < 1 || workgroups > 4096 || lds_bytes < 64 || lds_bytes > 160 * 1024 || microseconds < 0 || microseconds > 100000) return -1;
+    if (hipFuncSetAttribute((const void*)placement_probe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) return -1;
+    hipLaunchKernelGGL(placement_probe_kernel, dim3(workgroups), dim3(64), lds_bytes, (hipStream_t)stream, device_out, 100ull * (unsigned long long)microseconds);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 // A hand-over of the TTT-MLP backward that gave up has poisoned that call's gradients (NaN); it is also STICKY: every later
 // TTT-MLP call of the process fails here, on entry, until the caller acknowledges it (no synchronisation: the word is host-mapped).
 static int check_sweep_error(const char* what) {

@@ -64,8 +64,9 @@ _LinBwd = _ptr_struct("_LinBwd", LIN_BWD_FIELDS)
 
 # TTT_HIP_ABI_VERSION of include/ttt_hip.h this binding was written against (2: return codes -3 / -10 / -11 / -12 of the TTT-MLP
 # entry points, the round-1 debug exports ttt_hip_debug_variant / _helpers gone; 3: ttt_hip_pre_backward_ld / ttt_hip_attn_pre_backward_ld,
-# ttt_hip_mlp_forward_chunk, ttt_hip_pre_forward_range / ttt_hip_post_forward_range)
-ABI_VERSION = 3
+# ttt_hip_mlp_forward_chunk, ttt_hip_pre_forward_range / ttt_hip_post_forward_range; 4 (round 6): ttt_hip_stream_create_masked /
+# ttt_hip_stream_destroy / ttt_hip_debug_placement_probe added, the tensor entry points unchanged)
+ABI_VERSION = 4
 
 # every extern "C" symbol declared in include/ttt_hip.h
 EXPORTED_SYMBOLS = (
@@ -73,6 +74,7 @@ EXPORTED_SYMBOLS = (
     "ttt_hip_linear_backward_workspace", "ttt_hip_mlp_forward", "ttt_hip_mlp_forward_chunk", "ttt_hip_mlp_backward", "ttt_hip_linear_forward",
     "ttt_hip_linear_backward", "ttt_hip_resolve_impl", "ttt_hip_abi_version", "ttt_hip_last_error",
     "ttt_hip_debug_timing", "ttt_hip_debug_groups_per_chunk", "ttt_hip_debug_dump", "ttt_hip_debug_option", "ttt_hip_debug_sweep_error", "ttt_hip_sweep_error_clear", "ttt_hip_debug_occupy_cus",
+    "ttt_hip_stream_create_masked", "ttt_hip_stream_destroy", "ttt_hip_debug_placement_probe",
     "ttt_hip_pre_forward", "ttt_hip_pre_forward_range", "ttt_hip_post_forward_range", "ttt_hip_pre_backward_partials", "ttt_hip_pre_backward", "ttt_hip_pre_backward_ld", "ttt_hip_post_partials",
     "ttt_hip_post_forward", "ttt_hip_post_backward", "ttt_hip_gate_forward", "ttt_hip_gate_backward_partials",
     "ttt_hip_gate_backward", "ttt_hip_attn_forward", "ttt_hip_attn_backward",
@@ -150,6 +152,37 @@ def debug_occupy_cus(workgroups: int, lds_bytes: int, microseconds: int, stream=
     lib.ttt_hip_debug_occupy_cus.restype = ctypes.c_int
     if lib.ttt_hip_debug_occupy_cus(int(workgroups), int(lds_bytes), int(microseconds), ctypes.c_void_p(st)) != 0:
         raise RuntimeError("ttt_hip_debug_occupy_cus: bad arguments or launch failure")
+
+
+def masked_stream(cu_mask_words) -> "torch.cuda.ExternalStream":
+    """A stream whose kernels run only on the compute units of ``cu_mask_words`` (sequence of 32-bit words, bit i of word w = logical CU
+    32 w + i; ``ttt_hip_stream_create_masked``), as a ``torch.cuda.ExternalStream`` of the current device.  The HIP stream lives as long as
+    the process (a handful per process: the sweep / side streams of a backward, a communication stream)."""
+    lib = load_library()
+    words = [int(w) & 0xFFFFFFFF for w in cu_mask_words]
+    arr = (ctypes.c_uint * len(words))(*words)
+    out = ctypes.c_void_p()
+    lib.ttt_hip_stream_create_masked.restype = ctypes.c_int
+    if lib.ttt_hip_stream_create_masked(arr, len(words), ctypes.byref(out)) != 0:
+        lib.ttt_hip_last_error.restype = ctypes.c_char_p
+        raise RuntimeError(lib.ttt_hip_last_error().decode())
+    return torch.cuda.ExternalStream(out.value)
+
+
+def placement_probe(workgroups: int, stream=None, lds_bytes: int = 150 * 1024, microseconds: int = 200):
+    """DEBUG: where ``workgroups`` one-wave workgroups of ``stream`` run - a list of (xcd, shader engine, shader array, cu) per workgroup
+    (each holds ``lds_bytes`` of LDS for ``microseconds``, so that every CU takes one).  Synchronises."""
+    lib = load_library()
+    st = stream or torch.cuda.current_stream()
+    out = torch.zeros(workgroups, dtype=torch.int32, device="cuda")
+    lib.ttt_hip_debug_placement_probe.restype = ctypes.c_int
+    with torch.cuda.stream(st):
+        rc = lib.ttt_hip_debug_placement_probe(ctypes.c_void_p(out.data_ptr()), int(workgroups), int(lds_bytes), int(microseconds), ctypes.c_void_p(st.cuda_stream))
+    if rc != 0:
+        raise RuntimeError("ttt_hip_debug_placement_probe: bad arguments or launch failure")
+    st.synchronize()
+    w = out.cpu().tolist()
+    return [((v >> 16) & 0xF, (v >> 13) & 0x7, (v >> 12) & 0x1, (v >> 8) & 0xF) for v in w]
 
 
 def sweep_error_clear() -> None:
