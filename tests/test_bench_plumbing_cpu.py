@@ -31,26 +31,28 @@ def test_pmc_traffic_lookup_matches_geometry_and_prefers_the_newest_summary():
 
 
 def test_mlp_backward_workspace_holds_three_slot_buffers():
-    """Revision 4 of the TTT-MLP backward: a step record is 7 fragment arrays x 4 hidden slices x 8 KiB + 48.5 KiB of owner
-    rows + the 8-KiB gZ2 tile = 280.5 KiB (round 2: 570 KiB), of which the recompute kernel writes 120.5 KiB.  Round 6 (schedule 2:
-    the recompute of chunk c - 1, the sweep of chunk c and the tail of chunk c + 1 run at the same time): THREE record buffers,
-    two under the older schedules (debug option overlap_tail 0 / 1)."""
+    """Revision 4 of the TTT-MLP backward: a step record is 5 fragment arrays (Z1, Z1b, dZ1, dZ1b, gZ1) x 4 hidden slices x 8 KiB + 48.5 KiB
+    of owner rows + the 8-KiB gZ2 tile = 216.5 KiB (round 2: 570 KiB; rounds 3 - 5: 280.5 with the per-step dW1' / W1 images the
+    group-sequential tail of round 6 no longer needs), of which the recompute kernel writes 104.5 KiB.  Round 6 (schedule 2: the
+    recompute of chunk c - 1, the sweep of chunk c and the tail of chunk c + 1 run at the same time): THREE record buffers, two under
+    the older schedules (debug option overlap_tail 0 / 1); plus one fp32 dW1 anchor (64 KiB) per (b, h, checkpoint group)."""
     import test_time_training as ext
     lib = ext.load_library()
     import torch
     dims = ext._dims(1, 48, 804, 64, 64, 16, torch.bfloat16)
     lib.ttt_hip_mlp_backward_workspace.restype = ctypes.c_size_t
     ws = lib.ttt_hip_mlp_backward_workspace(ctypes.byref(dims))
-    slot = 4 * 7 * 8 * 1024 + 3 * 64 * 64 * 4 + 64 * 8 + 64 * 64 * 2
-    assert slot == 287232
+    slot = 4 * 5 * 8 * 1024 + 3 * 64 * 64 * 4 + 64 * 8 + 64 * 64 * 2
+    assert slot == 221696
     steps = 5 * 16 + 1                             # 5 checkpoint groups per chunk at 48 heads + the post-update slot
-    assert 3 * 48 * steps * slot < ws < 3 * 48 * steps * slot + (64 << 20), ws
+    anchors = 48 * 51 * 64 * 256 * 4               # K = ceil(804 / 16) = 51 groups
+    assert 3 * 48 * steps * slot + anchors < ws < 3 * 48 * steps * slot + anchors + (64 << 20), ws
     ext.debug_option("overlap_tail", 1)
     try:
         ws1 = lib.ttt_hip_mlp_backward_workspace(ctypes.byref(dims))
     finally:
         ext.debug_option("overlap_tail", 2)
-    assert 2 * 48 * steps * slot < ws1 < 2 * 48 * steps * slot + (64 << 20), ws1
+    assert 2 * 48 * steps * slot + anchors < ws1 < 2 * 48 * steps * slot + anchors + (64 << 20), ws1
 
 
 def test_counter_summaries_reproduce_from_the_committed_csvs():

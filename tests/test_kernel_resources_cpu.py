@@ -46,10 +46,14 @@ def test_recompute_kernel_does_not_spill():
 
 def test_cluster_sweep_spill_budget():
     res = kernel_resources("ttt_mfma_bwd4.hip")
-    k = next(k for k in res if "mlp_bwd_cluster4_kernel" in k and "Lb0ELb1ELb1ELi2ELb1E" in k)       # the production instantiation (no stamps, bf16 records, owner overlap, derivers on waves 2 - 3)
+    # the production instantiation: no stamps, bf16 records, owner overlap, derivers on waves 2 - 3 (round 6: the derivers carry no W1
+    # tiles any more - 95 spilled dwords where rounds 4 / 5 had 114 - 138)
+    k = next(k for k in res if "mlp_bwd_cluster4_kernel" in k and "Lb0ELb1ELb1ELi2ELb1E" in k)
     v = res[k]
     assert v["vgpr_count"] <= 256, v
-    assert v["vgpr_spill_count"] <= 160, f"the cluster sweep spills {v['vgpr_spill_count']} dwords (budget 160; measured good: 138)"
+    assert v["vgpr_spill_count"] <= 130, f"the cluster sweep spills {v['vgpr_spill_count']} dwords (budget 130; measured good: 95)"
+    t5 = next(v for k, v in res.items() if "mlp_bwd_tail5_kernel" in k)      # eight waves, two per SIMD: <= 256 registers, no scratch
+    assert t5["vgpr_count"] <= 256 and t5["vgpr_spill_count"] == 0 and t5["private_segment_fixed_size"] == 0, t5
 
 
 def test_forward_scan_does_not_spill():

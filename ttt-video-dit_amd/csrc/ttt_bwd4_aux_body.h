@@ -110,10 +110,9 @@ TTT_WV_FN void gelu2(BK& bk, float x, float& y, float& dy) {
     dy = (y - y * s) * (x2 * (2.0f * GELU_3AC) + 2.0f * GELU_A) + s;
 }
 
-// the deriver wave's carried state: W1[:, Hp] as two tiles (rows = f in 32 a .., lane = n), W2[Hp, :] as two tiles (rows = n,
-// lane = f in 32 b ..), fp32
+// the deriver wave's carried state: W2[Hp, :] as two tiles (rows = n, lane = f in 32 b ..), fp32 (rounds 3 - 5 also carried W1[:, Hp])
 struct AuxState {
-    f32x16 W1t[2], W2t[2];
+    f32x16 W2t[2];
 };
 // T fragments [ti][s] of one quantity of a step for this wave's 32 hidden units (rows = t in registers, lane = n)
 struct Frags4 {
@@ -156,8 +155,8 @@ TTT_WV_FN void stage_w2t(BK& bk, const AuxState& st, int pp, int off_w2t, Frags4
     }
 }
 
-// (1) .. (7): one reverse step, ordered for SHORT LIVE RANGES: the deriver role shares the kernel's 256 registers per lane with
-// 64 registers of fp32 state, and a first version that kept the step's T fragments in registers until their staging region
+// One reverse step, ordered for SHORT LIVE RANGES: the deriver role shares the kernel's 256 registers per lane with
+// 32 (rounds 3 - 5: 64) registers of fp32 state, and a first version that kept the step's T fragments in registers until their staging region
 // was free made hipcc spill ~200 dwords per step, each reload a serialised round trip (measured: 52 k cycles per step).  So:
 //   * the T fragments D1 | M | X2 (R4 material, wanted only after the NEXT barrier Bd) are parked in a small per-wave global
 //     scratch (12 KiB, rewritten every step: it lives in L2) as soon as a token tile is done, and fetched by stage_r4() later;
@@ -166,8 +165,7 @@ TTT_WV_FN void stage_w2t(BK& bk, const AuxState& st, int pp, int off_w2t, Frags4
 //   * W2^T is re-derived per token tile (two MFMAs per 32 x 32 block) instead of living through the whole step.
 // LDS inputs: K tile, gZ2 tile (row-major [t][TS] bf16), eta[64] fp32 of the step; Z1: the step's pre-activation fragments.
 // On return `st` is the state ENTERING the step, R1 / R2 are written, `r4_park` holds D1 | M | X2 ([array][ti][s] fragments of
-// this wave), and gZ1 (N) and the packed W1 have been stored to the step's slice region `g_slice` (byte offsets off_gz1t /
-// off_w1).
+// this wave), and gZ1 (T) has been stored to the step's slice region `g_slice` (byte offset off_gz1) for the tail kernel.
 template <class BK>
 TTT_WV_FN float gelu1(BK& bk, float x) { return x * bk.rcp(1.0f + bk.exp2(x * (x * x * GELU_K1 + GELU_K0))); }
 
@@ -184,9 +182,13 @@ TTT_WV_FN int park_off(int arr, int ti, int s) { return ((arr * 2 + ti) * 2 + s)
 struct NoMid {
     TTT_WV_FN void operator()() const {}
 };
+// No W1 here since round 6: the per-step W1 existed ONLY for the dK / dQ tail, and the group-sequential tail (`mlp_bwd_tail5_kernel`)
+// rebuilds it from the group's anchor itself - the deriver carries no W1 tiles (32 registers), runs no W1 update (8 MFMAs, 8 transposed
+// reads per step) and stores no packed W1; gZ1 goes to the tail in the T orientation it is born in ([ti][nj][s] fragments like dZ1),
+// the N orientation only to R1.
 template <class BK, class Mid = NoMid>
 TTT_WV_FN void reverse_step(BK& bk, AuxState& st, int pp, int tile_k, int tile_g, int vec_eta, const Frags4& Z1, int off_r1, int off_r2,
-                            char* g_slice, int off_gz1t, int off_w1, char* r4_park, Mid mid = Mid()) {
+                            char* g_slice, int off_gz1, char* r4_park, Mid mid = Mid()) {
     const int l = bk.lane(), h = l >> 5, c = l & 31;
     constexpr int FRK = 8 * FRAG;
 
@@ -227,9 +229,8 @@ TTT_WV_FN void reverse_step(BK& bk, AuxState& st, int pp, int tile_k, int tile_g
             for (int s = 0; s < 2; ++s) gx = bk.mma3216(pi_row(bk, tile_g, 32 * ti + c, 32 * b, s, h), pack(t, s), gx);
         }
         bk.stamp(2);
-        bf16x8 g1p[2], g1sp[2], x2[2], d1[2];
+        bf16x8 g1p[2], x2[2], d1[2];
         {
-            const f32x16 etaR = rows_from_lds(bk, vec_eta, 32 * ti, h);
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const bf16x8 z = bk.opaque8(Z1.f[ti][s]);
@@ -243,7 +244,6 @@ TTT_WV_FN void reverse_step(BK& bk, AuxState& st, int pp, int tile_k, int tile_g
                     d1[s][e] = db;
                     const float g1 = gx[8 * s + e] * (float)db;            // gZ1, from the rounded gelu' the compute waves multiply with too
                     g1p[s][e] = (__bf16)g1;
-                    g1sp[s][e] = (__bf16)(g1 * etaR[8 * s + e]);
                     m[e] = (__bf16)(gx[8 * s + e] * d2y);
                 }
                 *reinterpret_cast<bf16x8*>(r4_park + park_off(0, ti, s) + l * 16) = d1[s];
@@ -252,11 +252,8 @@ TTT_WV_FN void reverse_step(BK& bk, AuxState& st, int pp, int tile_k, int tile_g
             }
         }
         bk.stamp(3);
-        // (4) W1_i = W1_{i+1} + (eta K)^T gZ1 :  A = K^T by transposed reads (m = f, k = t), B = eta gZ1 in place (k = t, j = n)
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int a = 0; a < 2; ++a) st.W1t[a] = bk.mma3216(tr_pi(bk, tile_k, 32 * ti, s, 32 * a), g1sp[s], st.W1t[a]);
+        for (int s = 0; s < 2; ++s) bk.store_stream(g_slice + off_gz1 + fr_idx(ti, pp, s) * FRAG + l * 16, g1p[s]);      // gZ1 (T) for the tail
         bk.stamp(4);
         // (5) N orientation: gZ1^T | gelu'(Z1)^T | X2^T  -> R1 (FR_GZ1T | FR_D1N | FR_XT order [nj][ti][s]), one tile at a time
         {
@@ -265,7 +262,6 @@ TTT_WV_FN void reverse_step(BK& bk, AuxState& st, int pp, int tile_k, int tile_g
             for (int s = 0; s < 2; ++s) {
                 const bf16x8 v = pack(t, s);
                 st_frag(bk, off_r1, fr_idx(pp, ti, s), v);
-                bk.store_stream(g_slice + off_gz1t + fr_idx(pp, ti, s) * FRAG + l * 16, v);
             }
         }
         {
@@ -280,12 +276,12 @@ TTT_WV_FN void reverse_step(BK& bk, AuxState& st, int pp, int tile_k, int tile_g
         }
         bk.stamp(5);
     }
-    // (7) packed W1_i for the tail (FR_W1 order [fi][nj][s])
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) bk.store_stream(g_slice + off_w1 + fr_idx(a, pp, s) * FRAG + l * 16, pack(st.W1t[a], s));
 }
+
+// (Round 6 also measured a STAGE-major form of reverse_step<false> - every stage written for both token tiles so that the compiler can
+// interleave the two chains, W2^T transposed once for both: emulator-green, same spill count, and no faster, 10.98 against 10.96 ms per
+// backward - profiles/r6p_*.  With the one-sigmoid variant and the W1-free deriver that is three forms of LESS or better-overlapped deriver
+// work that moved nothing.  Removed.)
 
 // R4: the step's T fragments D1 | M | X2 (FR_D1 | FR_GX2 | FR_X2 order [ti][nj][s]) from the wave's parking area
 template <class BK>

@@ -93,7 +93,8 @@ size_t workspace_bytes(const ttt_dims* d, bool mlp, bool backward) {
     // two record buffers + carried state gradient + exchange records and flag lines of the cluster sweep + the state after the
     // last step + the derivers' parking areas
     return nbh * ((size_t)record_buffers() * slots * s4::SLOT4_BYTES + b2::CARRY_FLOATS2 * sizeof(float)) + align128(nbh * 64) +
-           nbh * (b2::XCH_BH_BYTES + 4 * b2::FLAG_STRIDE * sizeof(unsigned)) + nbh * (s4::FINAL_FLOATS * sizeof(float) + 8 * s4::PARK4_BYTES);
+           nbh * (b2::XCH_BH_BYTES + 4 * b2::FLAG_STRIDE * sizeof(unsigned)) + nbh * (s4::FINAL_FLOATS * sizeof(float) + 8 * s4::PARK4_BYTES) +
+           nbh * (size_t)((d->NC + d->G - 1) / d->G) * 64 * 256 * sizeof(float);                      // dW1 anchors of the group-sequential tail
 }
 
 // Side stream and the events of the two-buffer hand-over, one set per device, created on first use.
@@ -160,6 +161,7 @@ static int mlp_backward4(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws,
     const size_t flag_bytes = (size_t)nbh * 4 * b2::FLAG_STRIDE * sizeof(unsigned);
     float* wfinal = (float*)((char*)flags + flag_bytes);
     char* park = (char*)(wfinal + (size_t)nbh * s4::FINAL_FLOATS);
+    float* danchor = (float*)(park + (size_t)nbh * 8 * s4::PARK4_BYTES);
 
     s4::RecomputeParams rp = {};
     rp.XQ = (const __bf16*)a->XQ; rp.XK = (const __bf16*)a->XK; rp.XV = (const __bf16*)a->XV; rp.eta = (const __bf16*)a->last_eta;
@@ -179,7 +181,7 @@ static int mlp_backward4(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws,
     bp.NH = d->NH; bp.NC = NC;
     bp.xch = xch; bp.flags = flags; bp.fast_records = g_fast_records;
     bp.err = err_word; bp.fault = g_sweep_fault;
-    bp.W1c = a->W1_checkpoints; bp.W2c = a->W2_checkpoints; bp.wfinal = wfinal; bp.park = park; bp.G = G; bp.K = K; bp.prefetch = 1; bp.own16 = 1; bp.split = g_deriver_split ? 1 : 0;
+    bp.W1c = a->W1_checkpoints; bp.W2c = a->W2_checkpoints; bp.wfinal = wfinal; bp.park = park; bp.G = G; bp.K = K; bp.danchor = danchor; bp.prefetch = 1; bp.own16 = 1; bp.split = g_deriver_split ? 1 : 0;
 
     int rc = 0;                               // a failed event / stream call leaves the two streams unordered: the call fails (-12)
     auto chk = [&](hipError_t e) { if (e != hipSuccess) rc = -12; };
@@ -195,9 +197,11 @@ static int mlp_backward4(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws,
     };
     auto tail = [&](int ch, hipStream_t st) {
         const int g0 = ch * gpc, ng = (K - g0 < gpc) ? K - g0 : gpc;
-        const int lo = g0 * G, hi = ((g0 + ng) * G < NC) ? (g0 + ng) * G : NC;
-        s4::launch_tail4((const __bf16*)a->grad_L_XQW, (const __bf16*)a->last_eta, (const __bf16*)a->grad_L_XV, slots + (size_t)(ch % NBUF) * slot_buf,
-                         slot_stride, (__bf16*)a->grad_L_XQ, (__bf16*)a->grad_L_XK, NC, lo, hi - lo, nbh, st);
+        const int lo = g0 * G;
+        s4::Tail5Args ta = {(const __bf16*)a->XQ, (const __bf16*)a->XK, (const __bf16*)a->grad_L_XQW, (const __bf16*)a->last_eta,
+                            (const __bf16*)a->grad_L_XV, slots + (size_t)(ch % NBUF) * slot_buf, slot_stride, a->W1_checkpoints, wfinal, danchor,
+                            (__bf16*)a->grad_L_XQ, (__bf16*)a->grad_L_XK, NC, G, K, lo, g0, ng};
+        s4::launch_tail5(ta, nbh, st);
     };
     auto sweep = [&](int ch) {
         const int g0 = ch * gpc, ng = (K - g0 < gpc) ? K - g0 : gpc;
@@ -225,6 +229,9 @@ static int mlp_backward4(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws,
         // A(c-1) - in launches of at most the CUs the sweep leaves free, so that a recompute workgroup never holds a CU a cluster
         // member of the NEXT sweep is waiting for - and then C(c+1).  Chunk c lives in buffer c % 3: A(c-1) writes, B(c) reads,
         // C(c+1) reads three different buffers; A(c-1) follows C(c+2) (same buffer) in stream order.
+        // (Round 6 also tried the tails on a second, low-priority side stream - on one side stream the recompute of chunk c - 2 queues behind
+        // the tail of chunk c + 1, and recompute + tail, 0.66 + 0.26 ms on the 64 free CUs, are longer than a sweep - and LOST: 10.88 against
+        // 10.38 ms per backward alone, and the whole training step 10 % slower, attention kernels included; profiles/r6p_*.  Gone.)
         chk(hipEventRecord(ov->sweep_done[nchunks % 3], s));                       // "B(n) is done" = A(n-1) is complete
         for (int ch = nchunks - 1; ch >= 0; --ch) {
             if (ch + 1 < nchunks) chk(hipStreamWaitEvent(s, ov->rc_done[ch % 3], 0));

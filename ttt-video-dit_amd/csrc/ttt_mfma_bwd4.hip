@@ -195,6 +195,9 @@ struct DeriverBackend {
 constexpr int PS16 = 72;
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 // OWN16 (round 4; on in the shipped instantiation): the inner LayerNorm's owner rows of the step record (x_hat, y - target) are bf16
+// Round 6: the dK / dQ tail is the group-sequential `mlp_bwd_tail5_kernel`, which rebuilds the per-step W1 and dW1' from one anchor per
+// checkpoint group - the derivers carry and store no W1, the compute waves store dW1 (fp32) at the top step of every group instead of a
+// packed image every step, gZ1 goes out in the T orientation.
 template <bool DBG, bool OVL, bool R16, int DW0, bool OWN16>
 __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
     constexpr int OW0 = DW0 == 2 ? 4 : 2;                        // first owner wave (it polls the partner flags)
@@ -310,10 +313,15 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
         auto publish_state = [&](int j) {
             const int l = tid & 63, h = l >> 5, c = l & 31;
             const int sj = slot_off(j) + WREG;
+            if ((j + 1) % p.G == 0 || j == NC - 1) {           // top step of a checkpoint group: the tail's anchor, natural [f][256] fp32
+                float* da = p.danchor + ((size_t)bh * p.K + j / p.G) * (64 * 256);
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) bst8_nt(rS, l * 16, sj + fro4(A_DW1, fr_idx(a, pp, s)), pack(dW1t[a], s));
+                for (int r = 0; r < 16; ++r) {
+                    const int ro = row_of(r, h);
+                    __builtin_nontemporal_store(dW1t[0][r], da + (size_t)ro * 256 + nO + c);
+                    __builtin_nontemporal_store(dW1t[1][r], da + (size_t)(32 + ro) * 256 + nO + c);
+                }
+            }
 #pragma unroll
             for (int s = 0; s < 2; ++s) *reinterpret_cast<bf16x8*>(exd + ((size_t)(pp * 2 + s) * 64 + l) * 16) = pack(dW2t[1], s);
             if (h == 0) { db1L[32 * pp + c] = db1v; db2L[fO + c] = db2v; }
@@ -958,23 +966,14 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
         // the state entering step `step` (a multiple of the checkpoint group size, or the end of the sequence): the forward's
         // checkpoint, or the state phase A wrote after the last step
         auto load_anchor = [&](int step) {
-            const float *W1g, *W2g;
-            if (step >= NC) {
-                W1g = p.wfinal + (size_t)bh * FINAL_FLOATS;
-                W2g = W1g + 64 * 256;
-            } else {
-                const size_t ck = (size_t)bh * p.K + step / p.G;
-                W1g = p.W1c + ck * 64 * 256;
-                W2g = p.W2c + ck * 256 * 64;
-            }
+            const float* W2g;
+            if (step >= NC) W2g = p.wfinal + (size_t)bh * FINAL_FLOATS + 64 * 256;
+            else W2g = p.W2c + ((size_t)bh * p.K + step / p.G) * 256 * 64;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ro = row_of(r, h);
 #pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    st.W1t[a][r] = W1g[(size_t)(32 * a + ro) * 256 + nO + c];
-                    st.W2t[a][r] = W2g[(size_t)(nO + ro) * 64 + 32 * a + c];
-                }
+                for (int a = 0; a < 2; ++a) st.W2t[a][r] = W2g[(size_t)(nO + ro) * 64 + 32 * a + c];
             }
         };
         auto load_frags = [&](int step, int arr, bwd4::Frags4& F) {
@@ -984,13 +983,6 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
                 for (int s = 0; s < 2; ++s) F.f[ti][s] = bld8(rS, l * 16, slot_off(step) + WREG + fro4(arr, fr_idx(ti, pp, s)));
         };
         load_anchor(p.chunk_hi);
-        {   // W1 entering step chunk_hi = W1' of the chunk's last step, for the tail (slot index chunk_hi - chunk_lo)
-            char* sl = slots + (size_t)slot_off(p.chunk_hi) + WREG;
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) *reinterpret_cast<bf16x8*>(sl + fro4(A_W1, fr_idx(a, pp, s)) + l * 16) = pack(st.W1t[a], s);
-        }
         bwd4::Frags4 Z1, Z1B;
         char* const park = p.park + ((size_t)(bh * 4 + cq) * 2 + pp) * bwd4::PARK_BYTES;     // this wave's R4 parking area (L2-resident)
         load_frags(i0, A_Z1, Z1);
@@ -999,8 +991,7 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
         bwd4::stage_w2t(bk, st, pp, L_R3 + 2 * FRK);                  // W2' of the chunk's last step (its output path runs before P2)
         bwd4::derive_z1b(bk, Z1B, pp, L_R3, L_R3 + FRK);
         owner_barrier();                       // P1: the tiles of step i0 (K, gZ2, eta) are visible
-        bwd4::reverse_step(bk, st, pp, L_K, L_G, L_SM, Z1, L_R1, L_R2, slots + (size_t)slot_off(i0) + WREG,
-                           fro4(A_GZ1T, 0), fro4(A_W1, 0), park);
+        bwd4::reverse_step(bk, st, pp, L_K, L_G, L_SM, Z1, L_R1, L_R2, slots + (size_t)slot_off(i0) + WREG, fro4(A_GZ1, 0), park);
         owner_barrier();                       // P2
 
         // DEBUG cycle stamps of deriver wave 0 of workgroup 0 (entries 28 .. 31: staging after Bd, derive_z1b, reverse_step, barriers)
@@ -1035,15 +1026,16 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
             if (more) {
                 if (i % p.G == 0) load_anchor(i);               // group boundary: the exact state entering step i
                 if constexpr (DBG) bk.t_in = __builtin_readcyclecounter();
+                auto mid = [&] {
+                    if (split) {
+                        TTT_DSTAMP(2)
+                        owner_barrier();       // Bc
+                        TTT_DSTAMP(3)
+                        if constexpr (DBG) bk.t_in = __builtin_readcyclecounter();
+                    }
+                };
                 bwd4::reverse_step(bk, st, pp, L_K + nxt * TILE_B, L_G + nxt * TILE_B, L_SM + nxt * 64 * 4, Z1, L_R1, L_R2,
-                                   slots + (size_t)slot_off(i - 1) + WREG, fro4(A_GZ1T, 0), fro4(A_W1, 0), park, [&] {
-                                       if (split) {
-                                           TTT_DSTAMP(2)
-                                           owner_barrier();       // Bc
-                                           TTT_DSTAMP(3)
-                                           if constexpr (DBG) bk.t_in = __builtin_readcyclecounter();
-                                       }
-                                   });
+                                   slots + (size_t)slot_off(i - 1) + WREG, fro4(A_GZ1, 0), park, mid);
             }
             // L2 prefetch of this wave's share of the slice's Z1 / Z1b fragments of step i - 2 (two consecutive 8-KiB arrays)
             unsigned touch = 0u;
@@ -1060,112 +1052,178 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
 }
 
 
-// =========================================================================================================================
-// Tail kernel (phase C): one workgroup (4 waves, wave w <-> hidden slice w) per (b, h, step of the chunk):
-//   dK = -eta (gZ1 dW1'^T) + dZ1 W1^T - dV        dQ = dOut + dZ1b W1'^T      (W1' = state entering the next step)
-// Round 2's tail kernel reading the sweep-written arrays of the slim record: dZ1, dZ1b, dW1' (compute waves), gZ1 (N) and the
-// packed W1 of the step and of the next step (deriver waves).
-struct TailParams4 {
-    const __bf16 *dOut, *eta, *dXV;
-    char* slots; size_t slot_stride_bh;
-    __bf16 *dXQ, *dXK;
-    int NC, chunk_lo, chunk_n;
-};
-constexpr int LDS_TAIL4 = 4 * 64 * PS * 4;
 __device__ __forceinline__ bf16x8 ld_frag4(const char* slice, int arr, int idx, int lane) {
     return *reinterpret_cast<const bf16x8*>(slice + fro4(arr, idx) + lane * 16);
 }
 
-__global__ __launch_bounds__(NT) void mlp_bwd_tail4_kernel(TailParams4 p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* red = reinterpret_cast<float*>(smem);
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, h = l >> 5, c = l & 31;
-    const int bh = blockIdx.x / p.chunk_n, si = blockIdx.x % p.chunk_n;
-    const int i = p.chunk_lo + si;
-    const size_t tile = (size_t)bh * p.NC + i;
-    const char* slot_w = p.slots + (size_t)bh * p.slot_stride_bh + (size_t)si * SLOT4_BYTES + (size_t)w * SLICE_BYTES;
-    const char* next_w = slot_w + SLOT4_BYTES;
-    const bf16x8 I0 = ident_pi(0, h, c), I1 = ident_pi(1, h, c);
-    const int ot = 16 * w + (l & 15), of0 = 16 * (l >> 4);
-
-    for (int pass = 0; pass < 2; ++pass) {           // 0: dK, 1: dQ
-        f32x16 PA[2][2];                             // [fj][ti]  partial (rows = f, lane = t) over this wave's hidden slice
+// =========================================================================================================================
+// Tail kernel, group-sequential form (round 6): one workgroup (8 waves, wave w <-> the 32 hidden units [32 w, +32)) per (b, h, checkpoint
+// group) walks the group's steps from the top down and REBUILDS what the per-step tail was handed:
+//   W1_i   = W1_{i+1} + (eta_i K_i)^T gZ1_i           from the forward's checkpoint of the next group (or the state after the last step),
+//   dW1'_i = dW1'_{i+1} + K_{i+1}^T dZ1_{i+1} + Q_i^T dZ1b_i   from the fp32 anchor the sweep stores at the group's top step,
+// (rounds 3 - 5: a fully parallel kernel, one workgroup per step, that was HANDED packed images of both: 64 KiB more per step written by the
+// sweep, 96 KiB more read here, and the derivers' whole W1 reversal existed for nothing else; removed after the A/B of profiles/r6q_*)
+// both as fp32 accumulator tiles in the orientation the contractions over the hidden units want (rows = n, lane = f: in-place A
+// operands), with the bf16 operand roundings the sweep's waves apply.  Per step it reads dZ1, dZ1b (compute waves) and gZ1 (derivers; T
+// orientation) - 96 KiB where the per-step tail read 192 KiB of fragment arrays - plus the K, Q, dOut, dV tiles:
+//   dQ = dOut + dZ1b W1_{i+1}^T          dK = -eta (gZ1 dW1'^T) + dZ1 W1_i^T - dV
+struct TailParams5 {
+    const __bf16 *XQ, *XK, *dOut, *eta, *dXV;
+    char* slots; size_t slot_stride_bh;
+    const float *W1c, *wfinal, *danchor;
+    __bf16 *dXQ, *dXK;
+    int NC, G, K, chunk_lo, group0, ngroups;
+};
+constexpr int T5_L_K = 0, T5_L_KS = TILE_ELEMS * 2, T5_L_Q = 2 * TILE_ELEMS * 2, T5_L_RED = 3 * TILE_ELEMS * 2;
+// EIGHT waves, wave w <-> the 32 hidden units [32 w, +32) (64 registers of state per wave, <= 256 registers: two waves per SIMD - the
+// kernel is a chain of dependent loads and MFMAs over 16 sequential steps, and a second wave per SIMD is what hides them; the first cut,
+// four waves of 64 units at 380 registers, ran 0.32 ms per chunk beside the sweep and cost the backward 2 % inside the step).  The eight
+// partial tiles meet in LDS one 32-feature HALF at a time: [8 waves][64 t][PSH] fp32 = 72 KiB.
+constexpr int NT5 = 512, PSH = 36;
+constexpr int LDS_TAIL5 = T5_L_RED + 8 * 64 * PSH * 4;
+static_assert(LDS_TAIL5 <= 160 * 1024, "LDS budget");
+__device__ __forceinline__ void write_partial_half(float* redw, const f32x16 (&P)[2], int h, int c) {      // P[ti]: rows = f in the half, lane = t
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+    for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-            for (int b = 0; b < 2; ++b) PA[a][b] = zero16();
-        if (pass == 0) {
-            // -eta * (dW1'^T)^T-contraction: A = dW1'^T tile (rows = n, lane = f) in place, B = gZ1^T (k = n, j = t)
-#pragma unroll
-            for (int nj = 0; nj < 2; ++nj) {
-                bf16x8 dWt[2][2];
-#pragma unroll
-                for (int fj = 0; fj < 2; ++fj) {
-                    const f32x16 t = transpose_tile(ld_frag4(slot_w, A_DW1, fr_idx(fj, nj, 0), l), ld_frag4(slot_w, A_DW1, fr_idx(fj, nj, 1), l), I0, I1);
-                    dWt[fj][0] = pack(t, 0);
-                    dWt[fj][1] = pack(t, 1);
-                }
-#pragma unroll
-                for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        const bf16x8 gt = ld_frag4(slot_w, A_GZ1T, fr_idx(nj, ti, s), l);
-                        PA[0][ti] = mma(dWt[0][s], gt, PA[0][ti]);
-                        PA[1][ti] = mma(dWt[1][s], gt, PA[1][ti]);
-                    }
-            }
-#pragma unroll
-            for (int ti = 0; ti < 2; ++ti) {
-                const float el = -(float)p.eta[tile * 64 + 32 * ti + c];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { PA[0][ti][r] *= el; PA[1][ti][r] *= el; }
-            }
+        for (int q = 0; q < 4; ++q) {
+            f32x4 v = {P[ti][4 * q], P[ti][4 * q + 1], P[ti][4 * q + 2], P[ti][4 * q + 3]};
+            *reinterpret_cast<f32x4*>(redw + (32 * ti + c) * PSH + 8 * q + 4 * h) = v;
         }
-        // + W^T-contraction with dZ^T:  pass 0: W1 (entering state), dZ1 ; pass 1: W1' (next slot), dZ1b
-        const char* wsrc = pass == 0 ? slot_w : next_w;
-        const int zarr = pass == 0 ? A_DZ1 : A_DZ1B;
+}
+__device__ __forceinline__ f32x4 gather_partial_half(const float* red, int t, int f0) {       // token t, features f0 .. f0 + 3 of the half: sum of the 8 waves
+    f32x4 z = *reinterpret_cast<const f32x4*>(red + (size_t)t * PSH + f0);
 #pragma unroll
-        for (int nj = 0; nj < 2; ++nj) {
-            bf16x8 W1T[2][2];
-#pragma unroll
-            for (int fj = 0; fj < 2; ++fj) {
-                const f32x16 t = transpose_tile(ld_frag4(wsrc, A_W1, fr_idx(fj, nj, 0), l), ld_frag4(wsrc, A_W1, fr_idx(fj, nj, 1), l), I0, I1);
-                W1T[fj][0] = pack(t, 0);
-                W1T[fj][1] = pack(t, 1);
-            }
-#pragma unroll
-            for (int ti = 0; ti < 2; ++ti) {
-                const f32x16 zt = transpose_tile(ld_frag4(slot_w, zarr, fr_idx(ti, nj, 0), l), ld_frag4(slot_w, zarr, fr_idx(ti, nj, 1), l), I0, I1);
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const bf16x8 zb = pack(zt, s);
-                    PA[0][ti] = mma(W1T[0][s], zb, PA[0][ti]);
-                    PA[1][ti] = mma(W1T[1][s], zb, PA[1][ti]);
-                }
-            }
-        }
-        if (pass == 1) __syncthreads();              // owners of pass 0 finished reading `red`
-        write_partial(red + (size_t)w * 64 * PS, PA, h, c);
-        __syncthreads();
-        {
-            float z[16], d[16];
-            gather_partial(red, nullptr, ot, of0, z);
-            const size_t off = tile * 4096 + (size_t)ot * 64 + of0;
-            if (pass == 0) {
-                load16_bf16(p.dXV + off, d);
-#pragma unroll
-                for (int j = 0; j < 16; ++j) z[j] -= d[j];                // dK -= dt, dt = dV
-                store16_bf16(p.dXK + off, z);
-            } else {
-                load16_bf16(p.dOut + off, d);
-#pragma unroll
-                for (int j = 0; j < 16; ++j) z[j] += d[j];
-                store16_bf16(p.dXQ + off, z);
-            }
-        }
-    }
+    for (int w = 1; w < 8; ++w) z += *reinterpret_cast<const f32x4*>(red + ((size_t)w * 64 + t) * PSH + f0);
+    return z;
+}
+__device__ __forceinline__ f32x4 ld4_bf16(const __bf16* p) {
+    const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+__device__ __forceinline__ void st4_bf16(__bf16* p, f32x4 z) {
+    bf16x4 v = {(__bf16)z[0], (__bf16)z[1], (__bf16)z[2], (__bf16)z[3]};
+    *reinterpret_cast<bf16x4*>(p) = v;
 }
 
+__global__ __launch_bounds__(NT5) void mlp_bwd_tail5_kernel(TailParams5 p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __bf16* Kt = reinterpret_cast<__bf16*>(smem + T5_L_K);
+    __bf16* Ks = reinterpret_cast<__bf16*>(smem + T5_L_KS);          // eta-scaled K (the W1 update's operand)
+    __bf16* Qt = reinterpret_cast<__bf16*>(smem + T5_L_Q);
+    float* red = reinterpret_cast<float*>(smem + T5_L_RED);
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, h = l >> 5, c = l & 31;
+    const int cq = w >> 1, nj = w & 1;                              // slice region of the step record, half of it
+    const int bh = blockIdx.x / p.ngroups, g = p.group0 + (int)(blockIdx.x % p.ngroups);
+    const int lo = g * p.G, hi = (lo + p.G < p.NC) ? lo + p.G : p.NC;
+    const bf16x8 I0 = ident_pi(0, h, c), I1 = ident_pi(1, h, c);
+    const int ot = tid >> 3, of0 = 4 * (tid & 7);                   // owner mapping of the reduction: token, 4 features of the current half
+    const int srow = tid >> 3, scol = 8 * (tid & 7);                // staging: 512 threads x 8 elements per tile
+
+    // state tiles [fj]: rows = n in 32 w .., lane = f in 32 fj ..
+    f32x16 W1T[2], DT[2];
+    {
+        const float* W1g = hi >= p.NC ? p.wfinal + (size_t)bh * FINAL_FLOATS : p.W1c + ((size_t)bh * p.K + (g + 1)) * (64 * 256);
+        const float* Dg = p.danchor + ((size_t)bh * p.K + g) * (64 * 256);
+#pragma unroll
+        for (int fj = 0; fj < 2; ++fj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const size_t o = (size_t)(32 * fj + c) * 256 + 32 * w + row_of(r, h);
+                W1T[fj][r] = W1g[o];
+                DT[fj][r] = Dg[o];
+            }
+    }
+    for (int i = hi - 1; i >= lo; --i) {
+        const size_t tile = (size_t)bh * p.NC + i;
+        const char* slot_w = p.slots + (size_t)bh * p.slot_stride_bh + (size_t)(i - p.chunk_lo) * SLOT4_BYTES + (size_t)cq * SLICE_BYTES;
+        // ---- stage K, eta K, Q of the step ------------------------------------------------------------------------------------
+        {
+            float kv[8], qv[8];
+            load8_bf16(p.XK + tile * 4096 + (size_t)srow * 64 + scol, kv);
+            load8_bf16(p.XQ + tile * 4096 + (size_t)srow * 64 + scol, qv);
+            const float e = (float)p.eta[tile * 64 + srow];
+            store8_bf16(Kt + srow * TS + scol, kv);
+            store8_bf16(Qt + srow * TS + scol, qv);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) kv[k] *= e;
+            store8_bf16(Ks + srow * TS + scol, kv);
+        }
+        __syncthreads();
+        // ---- dW1' of this step: + Q_i^T dZ1b_i (the anchor of the group's top step has it already) ------------------------------------
+        if (i < hi - 1) {
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const bf16x8 zf = ld_frag4(slot_w, A_DZ1B, fr_idx(ti, nj, s), l);
+                    DT[0] = mma(zf, tr_pi(Qt, 32 * ti, s, 0, l), DT[0]);
+                    DT[1] = mma(zf, tr_pi(Qt, 32 * ti, s, 32, l), DT[1]);
+                }
+        }
+        f32x16 PA[2][2];                             // [fj][ti]  partial (rows = f, lane = t) over this wave's 32 hidden units
+        // ---- dQ partial = W1_{i+1} dZ1b^T ---------------------------------------------------------------------------------------
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+            const f32x16 zt = transpose_tile(ld_frag4(slot_w, A_DZ1B, fr_idx(ti, nj, 0), l), ld_frag4(slot_w, A_DZ1B, fr_idx(ti, nj, 1), l), I0, I1);
+            PA[0][ti] = mma(pack(W1T[0], 0), pack(zt, 0), zero16());
+            PA[1][ti] = mma(pack(W1T[1], 0), pack(zt, 0), zero16());
+            PA[0][ti] = mma(pack(W1T[0], 1), pack(zt, 1), PA[0][ti]);
+            PA[1][ti] = mma(pack(W1T[1], 1), pack(zt, 1), PA[1][ti]);
+        }
+#pragma unroll
+        for (int fj = 0; fj < 2; ++fj) {
+            if (fj) __syncthreads();                 // the owners of the first half have read `red`
+            write_partial_half(red + (size_t)w * 64 * PSH, PA[fj], h, c);
+            __syncthreads();
+            const size_t off = tile * 4096 + (size_t)ot * 64 + 32 * fj + of0;
+            st4_bf16(p.dXQ + off, gather_partial_half(red, ot, of0) + ld4_bf16(p.dOut + off));
+        }
+        // ---- dK partial: -eta (gZ1 dW1'^T), then W1_i, then + dZ1 W1_i^T ---------------------------------------------------------
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+            const bf16x8 g0 = ld_frag4(slot_w, A_GZ1, fr_idx(ti, nj, 0), l), g1 = ld_frag4(slot_w, A_GZ1, fr_idx(ti, nj, 1), l);   // gZ1, T
+            const f32x16 gt = transpose_tile(g0, g1, I0, I1);                                                                      // gZ1, N
+            PA[0][ti] = mma(pack(DT[0], 0), pack(gt, 0), zero16());
+            PA[1][ti] = mma(pack(DT[1], 0), pack(gt, 0), zero16());
+            PA[0][ti] = mma(pack(DT[0], 1), pack(gt, 1), PA[0][ti]);
+            PA[1][ti] = mma(pack(DT[1], 1), pack(gt, 1), PA[1][ti]);
+            const float el = -(float)p.eta[tile * 64 + 32 * ti + c];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { PA[0][ti][r] *= el; PA[1][ti][r] *= el; }
+            // W1_i = W1_{i+1} + (eta K)^T gZ1 : A = gZ1 (T fragment in place: m = n lane, k = t), B = eta K by transposed reads
+            W1T[0] = mma(g0, tr_pi(Ks, 32 * ti, 0, 0, l), W1T[0]);
+            W1T[1] = mma(g0, tr_pi(Ks, 32 * ti, 0, 32, l), W1T[1]);
+            W1T[0] = mma(g1, tr_pi(Ks, 32 * ti, 1, 0, l), W1T[0]);
+            W1T[1] = mma(g1, tr_pi(Ks, 32 * ti, 1, 32, l), W1T[1]);
+        }
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+            const bf16x8 z0 = ld_frag4(slot_w, A_DZ1, fr_idx(ti, nj, 0), l), z1 = ld_frag4(slot_w, A_DZ1, fr_idx(ti, nj, 1), l);     // dZ1, T
+            const f32x16 zt = transpose_tile(z0, z1, I0, I1);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 zb = pack(zt, s);
+                PA[0][ti] = mma(pack(W1T[0], s), zb, PA[0][ti]);
+                PA[1][ti] = mma(pack(W1T[1], s), zb, PA[1][ti]);
+            }
+            // dW1' of the step below: + K_i^T dZ1_i
+            DT[0] = mma(z0, tr_pi(Kt, 32 * ti, 0, 0, l), DT[0]);
+            DT[1] = mma(z0, tr_pi(Kt, 32 * ti, 0, 32, l), DT[1]);
+            DT[0] = mma(z1, tr_pi(Kt, 32 * ti, 1, 0, l), DT[0]);
+            DT[1] = mma(z1, tr_pi(Kt, 32 * ti, 1, 32, l), DT[1]);
+        }
+#pragma unroll
+        for (int fj = 0; fj < 2; ++fj) {
+            __syncthreads();                         // the owners of the pass before have read `red`
+            write_partial_half(red + (size_t)w * 64 * PSH, PA[fj], h, c);
+            __syncthreads();
+            const size_t off = tile * 4096 + (size_t)ot * 64 + 32 * fj + of0;
+            st4_bf16(p.dXK + off, gather_partial_half(red, ot, of0) - ld4_bf16(p.dXV + off));      // dK -= dt, dt = dV
+        }
+        __syncthreads();                             // `red` and the tiles are free for the next step
+    }
+}
 }  // namespace b4
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -1228,7 +1286,7 @@ void launch_sweep_cluster4(const SweepParams4& bp, int nbh, hipStream_t s) {
         if (dev >= 0 && dev < 64 && !attr[dev]) {
             auto set = [&](auto kern) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, b4::LDS_CL); };
             set(b4::mlp_bwd_cluster4_kernel<false, true, true, 2, true>);    set(b4::mlp_bwd_cluster4_kernel<true, true, true, 2, true>);
-            (void)hipFuncSetAttribute((const void*)b4::mlp_bwd_tail4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, b4::LDS_TAIL4);
+            (void)hipFuncSetAttribute((const void*)b4::mlp_bwd_tail5_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, b4::LDS_TAIL5);
             attr[dev] = true;
         }
     }
@@ -1237,10 +1295,10 @@ void launch_sweep_cluster4(const SweepParams4& bp, int nbh, hipStream_t s) {
     else go(b4::mlp_bwd_cluster4_kernel<false, true, true, 2, true>);
 }
 
-void launch_tail4(const __bf16* dOut, const __bf16* eta, const __bf16* dXV, char* slots, size_t slot_stride_bh, __bf16* dXQ, __bf16* dXK,
-                  int NC, int chunk_lo, int chunk_n, int nbh, hipStream_t s) {
-    b4::TailParams4 tp = {dOut, eta, dXV, slots, slot_stride_bh, dXQ, dXK, NC, chunk_lo, chunk_n};
-    hipLaunchKernelGGL(b4::mlp_bwd_tail4_kernel, dim3(nbh * chunk_n), dim3(NT), b4::LDS_TAIL4, s, tp);
+void launch_tail5(const Tail5Args& a, int nbh, hipStream_t s) {
+    b4::TailParams5 tp = {a.XQ, a.XK, a.dOut, a.eta, a.dXV, a.slots, a.slot_stride_bh, a.W1c, a.wfinal, a.danchor, a.dXQ, a.dXK,
+                          a.NC, a.G, a.K, a.chunk_lo, a.group0, a.ngroups};
+    hipLaunchKernelGGL(b4::mlp_bwd_tail5_kernel, dim3(nbh * a.ngroups), dim3(b4::NT5), b4::LDS_TAIL5, s, tp);
 }
 }  // namespace s4
 
