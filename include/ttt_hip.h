@@ -41,7 +41,13 @@ extern "C" {
  * ttt_hip_sweep_error_clear), -10 (fewer than 4 compute units visible), -11 (no host-mapped error word), -12 (a HIP event /
  * stream call of the backward's two-stream schedule failed); the round-1 exports ttt_hip_debug_variant / ttt_hip_debug_helpers
  * are gone.  1: rounds 1 - 3. */
-#define TTT_HIP_ABI_VERSION 4
+/* 5 (round 6): ttt_hip_mlp_forward_workspace is non-zero for the MFMA scan at mini-batches of 64 - the forward runs as a PAIR of
+ * workgroups per (b,h) (the state chain on one CU publishes the updated state per step into a ring of records in the workspace, a second
+ * CU runs the output path from them: same bits, -25 % per scan) - and ttt_hip_mlp_forward_chunk USES its workspace arguments (NULL / too
+ * small: the one-workgroup scan, as ABI 4 callers get it).  A pair whose second workgroup is never scheduled gives up after 2 s, poisons
+ * its outputs with NaN and sets the sticky error that ttt_hip_sweep_error_clear() acknowledges (return code -3 of the next call), like
+ * the backward's cluster.  Signatures unchanged.  4: ttt_hip_stream_create_masked / _destroy / ttt_hip_debug_placement_probe. */
+#define TTT_HIP_ABI_VERSION 5
 
 enum { TTT_DTYPE_BF16 = 0, TTT_DTYPE_F32 = 1 };
 /* implementation selector: AUTO picks the MFMA kernels when the geometry is supported - bf16, F=64 and

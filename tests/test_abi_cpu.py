@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/ttt_hip.h but not exported"
     assert sorted(ext.EXPORTED_SYMBOLS) == names
     lib.ttt_hip_abi_version.restype = ctypes.c_int
-    assert lib.ttt_hip_abi_version() == 4
+    assert lib.ttt_hip_abi_version() == 5
 
 
 def test_argument_validation_without_gpu():

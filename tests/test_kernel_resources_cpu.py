@@ -65,3 +65,7 @@ def test_forward_scan_does_not_spill():
     k = next(k for k in res if "mlp_scan8_kernel" in k and "Lb0ELb1E" in k)
     v = res[k]
     assert v["vgpr_spill_count"] == 0 and v["private_segment_fixed_size"] == 0 and v["vgpr_count"] <= 256, (k, v)
+    # round 6: the pair form (role A = the same chain, role B = the output path, one kernel) - the same budget
+    k = next(k for k in res if "mlp_scan_pair_kernel" in k and "Lb0E" in k)
+    v = res[k]
+    assert v["vgpr_spill_count"] == 0 and v["private_segment_fixed_size"] == 0 and v["vgpr_count"] <= 256, (k, v)

@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--parts", default="0,2,3,4")
     ap.add_argument("--video-length", default="9sec")
     ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--debug-option", action="append", default=[], metavar="NAME=VALUE", help="library debug option(s) for the whole run (e.g. scan_pair=0)")
     a = ap.parse_args()
     import test_time_training as ext
     from bench import TEXT_LEN, TOKENS_PER_FRAME
@@ -39,6 +40,8 @@ def main():
     from ttt_amd.models.configs import ModelConfig
     from ttt_amd.models.ssm.ttt_layer import TTTWrapper
     ext.load_library()
+    for kv in a.debug_option:
+        ext.debug_option(kv.split("=")[0], int(kv.split("=")[1]))
     dev = torch.device("cuda:0")
     tuned = enable_tuned_gemms()
     cfg = ModelConfig.get_preset("5B", a.video_length, ssm_layer="ttt_mlp", adapter_method="qkvo")

@@ -60,6 +60,8 @@ int ttt_hip_debug_option(const char* name, int value) {
     else if (!strcmp(name, "deriver_split")) ttt::mfma::set_debug_deriver_split(value);         // sweep: 1 (default) / 0 = barrier Bc behind the derivers' reverse step
     else if (!strcmp(name, "attn_prio")) ttt::attn::set_debug_attn_variant(value);               // attention backward: 1 (default) / 0 = without the s_setprio pair per kernel
     else if (!strcmp(name, "sweep_fault")) ttt::mfma::set_debug_sweep_fault(value);              // fault injection: workgroup 3 of every sweep cluster leaves early
+    else if (!strcmp(name, "scan_pair")) ttt::mfma::set_debug_scan_pair(value);                  // forward scan at CS = 64: 1 (default) a pair of workgroups per (b,h) / 0 = one
+    else if (!strcmp(name, "scan_fault")) ttt::mfma::set_debug_scan_fault(value);                // fault injection: role B of every scan pair leaves at once
     else return -1;
     return 0;
 }
@@ -116,8 +118,9 @@ int ttt_hip_debug_placement_probe(unsigned* device_out, int workgroups, int lds_
 static int check_sweep_error(const char* what) {
     const unsigned e = ttt::mfma::peek_sweep_error();
     if (!e) return 0;
-    snprintf(g_err, sizeof(g_err), "ttt_hip: %s refused: an earlier TTT-MLP backward hand-over timed out in this process (cluster of (b,h) %u: a "
-             "partner workgroup was never scheduled); that call's gradients were poisoned with NaN.  Acknowledge with ttt_hip_sweep_error_clear().",
+    snprintf(g_err, sizeof(g_err), "ttt_hip: %s refused: an earlier TTT-MLP hand-over timed out in this process (the backward's cluster or the "
+             "forward scan's pair of (b,h) %u: a partner workgroup was never scheduled); that call's results were poisoned with NaN.  Acknowledge "
+             "with ttt_hip_sweep_error_clear().",
              what, e - 1u);
     return -3;
 }
@@ -158,7 +161,6 @@ int ttt_hip_mlp_forward(const ttt_dims* d, const ttt_mlp_fwd_args* a, void* ws, 
 
 int ttt_hip_mlp_forward_chunk(const ttt_dims* d, const ttt_mlp_fwd_args* a, int step0, int nsteps, float* W1_final, float* b1_final,
                               float* W2_final, float* b2_final, void* ws, size_t wsb, void* stream) {
-    (void)ws; (void)wsb;
     if (check_dims(d)) return -1;
     if (!a) return fail("ttt_hip: null args");
     NEED(XQ); NEED(XK); NEED(XV); NEED(last_eta); NEED(ttt_norm_weight); NEED(ttt_norm_bias);
@@ -171,7 +173,9 @@ int ttt_hip_mlp_forward_chunk(const ttt_dims* d, const ttt_mlp_fwd_args* a, int 
     if ((W1_final || b1_final || W2_final || b2_final) && !(W1_final && b1_final && W2_final && b2_final))
         return fail("ttt_hip: mlp_forward_chunk: give all four final-state buffers or none");
     if (check_sweep_error("mlp_forward_chunk")) return -3;
-    ttt::mfma::mlp_forward_chunk(d, a, step0, nsteps, W1_final, b1_final, W2_final, b2_final, (hipStream_t)stream);
+    // the workspace of ttt_hip_mlp_forward_workspace (the pair scan's ring); null / too small: the one-workgroup scan (ABI 4 callers)
+    void* use_ws = (ws && wsb >= ws_bytes(d, true, false)) ? ws : nullptr;
+    ttt::mfma::mlp_forward_chunk(d, a, step0, nsteps, W1_final, b1_final, W2_final, b2_final, use_ws, (hipStream_t)stream);
     return post_launch("mlp_forward_chunk");
 }
 

@@ -24,7 +24,7 @@ bool supports(const ttt_dims* d, bool mlp, bool backward) {
     return d->CS == 64 && (!backward || bwd_available());
 }
 
-void mlp_forward(const ttt_dims* d, const ttt_mlp_fwd_args* a, void*, hipStream_t s) {
+void mlp_forward(const ttt_dims* d, const ttt_mlp_fwd_args* a, void* ws, hipStream_t s) {
     ScanParams p = {};
     p.XQ = (const __bf16*)a->XQ; p.XK = (const __bf16*)a->XK; p.XV = (const __bf16*)a->XV; p.eta = (const __bf16*)a->last_eta;
     p.ln_w = a->ttt_norm_weight; p.ln_b = a->ttt_norm_bias;
@@ -33,12 +33,12 @@ void mlp_forward(const ttt_dims* d, const ttt_mlp_fwd_args* a, void*, hipStream_
     p.out = (__bf16*)a->XQW;
     p.NH = d->NH; p.NC = d->NC; p.G = d->G; p.K = (d->NC + d->G - 1) / d->G; p.eps = d->eps;
     if (d->CS == 16) launch_scan_forward_cs16(p, d->B * d->NH, g_dbg, s);
-    else launch_scan_forward_v2(p, d->B * d->NH, g_dbg, s);
+    else launch_scan_forward_v2(p, d->B * d->NH, ws, g_dbg, s);
 }
 // steps [step0, step0 + nsteps) of the CS = 64 scan: the same kernel over a part of the sequence, started from the state in
 // a->*_init (what the previous part left in *_final), its checkpoints written at their places in the whole sequence's arrays
 void mlp_forward_chunk(const ttt_dims* d, const ttt_mlp_fwd_args* a, int step0, int nsteps, float* W1f, float* b1f, float* W2f, float* b2f,
-                       hipStream_t s) {
+                       void* ws, hipStream_t s) {
     ScanParams p = {};
     const size_t t0 = (size_t)step0 * 64 * 64, e0 = (size_t)step0 * 64;
     p.XQ = (const __bf16*)a->XQ + t0; p.XK = (const __bf16*)a->XK + t0; p.XV = (const __bf16*)a->XV + t0; p.eta = (const __bf16*)a->last_eta + e0;
@@ -49,7 +49,7 @@ void mlp_forward_chunk(const ttt_dims* d, const ttt_mlp_fwd_args* a, int step0, 
     p.NH = d->NH; p.NC = nsteps; p.G = d->G; p.K = (d->NC + d->G - 1) / d->G; p.eps = d->eps;
     p.NCs = d->NC; p.ck0 = step0 / d->G;
     p.W1f = W1f; p.b1f = b1f; p.W2f = W2f; p.b2f = b2f;
-    launch_scan_forward_v2(p, d->B * d->NH, g_dbg, s);
+    launch_scan_forward_v2(p, d->B * d->NH, ws, g_dbg, s);
 }
 void linear_forward(const ttt_dims* d, const ttt_linear_fwd_args* a, void*, hipStream_t s) {
     wv::Lin16Params p = {};

@@ -57,6 +57,59 @@ constexpr int LDS_V2 = L_SMALL + (64 + 256 + 64 + 64 + 64) * 4;
 static_assert(LDS_V2 <= 160 * 1024, "LDS budget");
 static_assert(8 * 4 * 1024 <= X2IMG_BYTES, "exchange buffer fits the X2 image");
 
+// ---- the scan as a PAIR of workgroups (round 6) ------------------------------------------------------------------------------
+// The chain that carries the state from step to step is  A1 -> A2 -> P3 -> C  (11.6 k of a step's 18.9 k cycles, stage stamps of
+// profiles/r4o_*); the OUTPUT path of a step - f6 (Z1b = Q W1' + b1', gelu), the X2b exchange, E (Z2b partials), P6 (LayerNorm, +Q)
+// - hangs off the UPDATED state and nothing downstream waits for it.  In pair form the state workgroup (role A) runs the chain only
+// and publishes, per step, the updated state as the bf16 operand fragments the output path consumes (pack(W1'), pack(W2'): 64 KiB,
+// plus b1' / b2' in fp32) into a ring of RING records in the caller's workspace; a second workgroup (role B, on another CU - the scan
+// leaves 208 of 256 idle) polls a flag word, runs the output path from the record with the SAME instructions in the same order
+// (bit-identical outputs) and publishes its progress for the ring's back-pressure.  The hand-over is ONE-WAY - A never waits for B
+// unless it is RING steps ahead - so no round trip sits on the chain (the backward's cluster sweep pays 3.8 k cycles per step for
+// its all-gather).  Recipe = cdna_hip_programming.md Guideline 16 form R1, as in ttt_mfma_bwd4.hip: records stored write-through
+// (sc1) - or plain once B's HW_REG_XCC_ID word proves a common XCD -, every storing wave drains, workgroup barrier, ONE lane stores
+// the flag (relaxed, agent scope); the consumer polls (bounded by the wall clock), then reads with sc1 loads.  A's drain costs
+// nothing: the stores of step i are waited for in front of barrier B0 of step i + 1, a whole A1 later.  A poll that gives up
+// stores 1 + (b,h) into the process's host-mapped error word (the sweep's: the next extension call raises) and poisons the outputs.
+constexpr int RING = 4;
+constexpr int REC_W1F = 0;                                    // 8 waves x 4 fragments x 1 KiB: pack(W1'[a], s) of wave (w, p)
+constexpr int REC_W2F = 32 * 1024;                            // the same of W2'
+constexpr int REC_B1 = 64 * 1024;                             // b1' [256] fp32
+constexpr int REC_B2 = REC_B1 + 1024;                         // b2' [64] fp32
+constexpr int REC_BYTES = REC_B2 + 256;
+static_assert(REC_BYTES % 256 == 0, "records are line aligned");
+constexpr int FLAG_WORDS = 64;                                // per (b,h): two 128-byte lines
+constexpr int FL_A = 0;                                       // [0] records published by A, [1] A gave up (poison)
+constexpr int FL_B = 32;                                      // [32] steps finished by B, [33] 1 + HW_REG_XCC_ID of B's workgroup
+struct PairParams {
+    char* ring;                                               // [B NH][RING][REC_BYTES]
+    unsigned* flags;                                          // [B NH][FLAG_WORDS], zeroed in front of every launch
+    unsigned* err;                                            // host-mapped error word of the process
+    int nbh, nbh8;                                            // workgroup b < nbh: role A of (b,h) = b; b >= nbh8: role B of b - nbh8 (nbh8 % 8 == 0: same XCD)
+    int fast;                                                 // 1: plain records once a common XCD is proven
+    int fault;                                                // DEBUG fault injection: role B leaves at once
+};
+// role A: K, V (both double-buffered by step parity), Gs, the X2 image, the partials, eta[2][64] b2[64] gamma[64] beta[64]
+constexpr int LA_K = 0;
+constexpr int LA_V = LA_K + 2 * TILE_ELEMS * 2;
+constexpr int LA_G = LA_V + 2 * TILE_ELEMS * 2;
+constexpr int LA_X2 = LA_G + TILE_ELEMS * 2;
+constexpr int LA_RED = LA_X2 + X2IMG_BYTES;
+constexpr int LA_SMALL = LA_RED + RED_BYTES;
+constexpr int LDS_PAIR = LA_SMALL + (2 * 64 + 64 + 64 + 64) * 4;
+static_assert(LDS_PAIR <= 160 * 1024, "LDS budget");
+// role B: Q, the X2b exchange, the partials, gamma[64] beta[64], one sync word
+constexpr int LB_Q = 0;
+constexpr int LB_EX = LB_Q + TILE_ELEMS * 2;
+constexpr int LB_RED = LB_EX + 8 * 4 * 1024;
+constexpr int LB_SMALL = LB_RED + RED_BYTES;
+static_assert(LB_SMALL + (64 + 64 + 4) * 4 <= LDS_PAIR, "role B fits role A's allocation");
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const void* base, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(bytes > 0x7fffffffull ? 0x7fffffffull : bytes), 0x00020000);
+}
+
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 // ---- DPP reductions over the 8 lanes of an owner group ---------------------------------------------
@@ -148,6 +201,32 @@ __device__ __forceinline__ void write_partial2(float* redw, const f32x16& P, int
     }
 }
 
+// gelu and gelu' of (z + b) over a C tile, on ALIGNED register pairs with the packed f32 instructions: the IEEE operations of
+// gelu_fwd_grad() (ttt_mfma_dev.h) in the same order, two elements per v_pk_add / v_pk_mul / v_pk_fma - identical bits.  Why: A1 is
+// VALU-bound (round 6 stamps: wave 0 leaves A1 after 3.0 k cycles and waits 1.4 k at B0 for the wave it shares its SIMD with;
+// 32 elements x (9 VALU + 2 transcendental) x 2 waves = 4.4 k cycles per SIMD).
+__device__ __forceinline__ void gelu_fwd_grad_tile_pk(f32x16& z, float b, f32x16& d) {
+    const f32x2 k0 = {GELU_K0, GELU_K0}, k1 = {GELU_K1, GELU_K1}, one = {1.0f, 1.0f}, bb = {b, b};
+    const f32x2 c0 = {2.0f * GELU_A, 2.0f * GELU_A}, c1 = {2.0f * GELU_3AC, 2.0f * GELU_3AC};
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const f32x2 x = f32x2{z[r], z[r + 1]} + bb;
+        const f32x2 x2 = x * x;
+        const f32x2 a = x * __builtin_elementwise_fma(x2, k1, k0);
+        const f32x2 e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+        const f32x2 dd = one + e;
+        const f32x2 s = {__builtin_amdgcn_rcpf(dd[0]), __builtin_amdgcn_rcpf(dd[1])};
+        const f32x2 y = x * s;
+        const f32x2 t = __builtin_elementwise_fma(-y, s, y);
+        const f32x2 u = __builtin_elementwise_fma(x2, c1, c0);
+        const f32x2 dy = __builtin_elementwise_fma(t, u, s);
+        z[r] = y[0];
+        z[r + 1] = y[1];
+        d[r] = dy[0];
+        d[r + 1] = dy[1];
+    }
+}
+
 #define TTT_STAMP2(k)                                                        \
     if (DBG && p.dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {    \
         const unsigned long long _t = __builtin_readcyclecounter();          \
@@ -155,21 +234,26 @@ __device__ __forceinline__ void write_partial2(float* redw, const f32x16& P, int
         t_last = _t;                                                         \
     }
 
-template <bool DBG, bool SW>
-__global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    __bf16* Kt = reinterpret_cast<__bf16*>(smem + L_K);
-    __bf16* Qt = reinterpret_cast<__bf16*>(smem + L_Q);
-    __bf16* Vt = reinterpret_cast<__bf16*>(smem + L_V);
-    __bf16* Gs = reinterpret_cast<__bf16*>(smem + L_G);
-    __bf16* X2img = reinterpret_cast<__bf16*>(smem + L_X2);
-    char* exch = smem + L_X2;
-    float* red = reinterpret_cast<float*>(smem + L_RED);
-    float* etaL = reinterpret_cast<float*>(smem + L_SMALL);
-    float* b1L = etaL + 64;
-    float* b2L = b1L + 256;
+// PAIR = false: the whole step in one workgroup (the round-2 .. round-5 kernel).  PAIR = true: role A of the pair form - the same
+// chain A1 .. C with the same instructions; K / V / eta are double-buffered by step parity (without the phases of the output path no
+// window is left in which the single buffers are free), the output path is replaced by the record of the updated state.
+template <bool DBG, bool SW, bool PAIR>
+__device__ __forceinline__ void scan8_body(const ScanParams& p, const PairParams& q, char* smem, const int bh) {
+    __bf16* const Kt2 = reinterpret_cast<__bf16*>(smem + (PAIR ? LA_K : L_K));
+    __bf16* const Vt2 = reinterpret_cast<__bf16*>(smem + (PAIR ? LA_V : L_V));
+    __bf16* Qt = reinterpret_cast<__bf16*>(smem + L_Q);                        // (PAIR: unused)
+    __bf16* Gs = reinterpret_cast<__bf16*>(smem + (PAIR ? LA_G : L_G));
+    __bf16* X2img = reinterpret_cast<__bf16*>(smem + (PAIR ? LA_X2 : L_X2));
+    char* exch = smem + L_X2;                                                  // (PAIR: unused)
+    float* red = reinterpret_cast<float*>(smem + (PAIR ? LA_RED : L_RED));
+    float* const etaL2 = reinterpret_cast<float*>(smem + (PAIR ? LA_SMALL : L_SMALL));
+    float* b1L = etaL2 + 64;                                                   // (PAIR: unused; the second eta buffer lives here)
+    float* b2L = PAIR ? etaL2 + 128 : b1L + 256;
     float* gamL = b2L + 64;
     float* betL = gamL + 64;
+    __bf16* Kt = Kt2;
+    __bf16* Vt = Vt2;
+    float* etaL = etaL2;
 
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform, provably (scalar branches below)
@@ -180,7 +264,12 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
     const int nO = 64 * w + 32 * pp, nX = 64 * w + 32 * (1 - pp);
     const int fO = 32 * pp, fX = 32 * (1 - pp);
     const int NC = p.NC, G = p.G;
-    const int bh = blockIdx.x, head = bh % p.NH;
+    const int head = bh % p.NH;
+    // pair form: this (b,h)'s ring of records and flag lines
+    const __amdgpu_buffer_rsrc_t rR = make_srd(PAIR ? q.ring + (size_t)bh * RING * REC_BYTES : nullptr, (size_t)RING * REC_BYTES);
+    unsigned* const fl = PAIR ? q.flags + (size_t)bh * FLAG_WORDS : nullptr;
+    const unsigned my_xcc = PAIR ? __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) : 0u;      // HW_REG_XCC_ID[3:0]
+    bool gave_up = false;                                     // this wave stopped waiting for role B (error word stored)
 
     // ---- state ------------------------------------------------------------------------------------
     f32x16 W1t[2];      // [a]  W1[f in 32a.., n in Hp]                      (rows=f, lane=n)   a absolute
@@ -259,6 +348,17 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
         const int prow = tid >> 3, pcol = (tid & 7) * 8;
         const int hs = SW ? (h ^ sw_x(c)) : h;                // the row walkers' half selector (rows = 32 k + c): see sw_x
         const int xo = SW ? sw_x(ot) : 0;                     // the 16-byte accessors' swap (row ot == prow)
+        if (PAIR) {                                           // tiles of this step: the buffers of its parity
+            Kt = Kt2 + (i & 1) * TILE_ELEMS;
+            Vt = Vt2 + (i & 1) * TILE_ELEMS;
+            etaL = etaL2 + (i & 1) * 64;
+        }
+        // pair form: role B's progress and XCC words, requested here and looked at in front of this step's record stores
+        unsigned b_done = 0u, b_xcc = 0u;
+        if (PAIR) {
+            b_done = __hip_atomic_load(fl + FL_B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            b_xcc = __hip_atomic_load(fl + FL_B + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
 
         if (i % G == 0) {   // checkpoint: state entering step i (mlp_tk.py:95-98)
             const size_t ck = (size_t)bh * p.K + p.ck0 + i / G;
@@ -280,12 +380,18 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
         // line of the NEXT step's K / V / Q tiles is touched to pull them into L2 (waves 0..2, one tile each; the
         // value is only "used" after B3); (2) the real 16-byte loads are issued after B3 - L2 hits by then - and
         // parked before B5 (K, V, eta) or after the next B0 (Q), live only across the low-pressure tail of the step.
+        // (pair form: the real loads of step i + 1 follow barrier B0 of step i and are parked behind A2, so the lines of step i + 2
+        // are touched here; role B fetches Q itself)
         unsigned touch = 0;
-        if (more && wv < 3) {
+        if (!PAIR && more && wv < 3) {
             const __bf16* src = (wv == 0 ? p.XK : wv == 1 ? p.XV : p.XQ) + (tile + 1) * 4096 + (size_t)l * 64;
             touch = *reinterpret_cast<const unsigned*>(src);
         }
-        if (i == 0) pfQ = *reinterpret_cast<const uint4*>(p.XQ + tile * 4096 + (size_t)prow * 64 + pcol);
+        if (PAIR && i + 2 < NC && wv < 2) {
+            const __bf16* src = (wv == 0 ? p.XK : p.XV) + (tile + 2) * 4096 + (size_t)l * 64;
+            touch = *reinterpret_cast<const unsigned*>(src);
+        }
+        if (!PAIR && i == 0) pfQ = *reinterpret_cast<const uint4*>(p.XQ + tile * 4096 + (size_t)prow * 64 + pcol);
 
         // ================= A1: Z1 = K W1 + b1 ; X2, D1 ; X2 image ================================
         f32x16 D1[2];                 // gelu'(Z1)
@@ -297,13 +403,7 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
                     Z = mma(pi_read(Kt + (32 * ti + c) * TS, 32 * a, s, hs), W1F[a][s], Z);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float y, dy;
-                gelu_fwd_grad(Z[r] + b1v, y, dy);
-                Z[r] = y;
-                D1[ti][r] = dy;
-            }
+            gelu_fwd_grad_tile_pk(Z, b1v, D1[ti]);
             // pin gelu' here: hipcc otherwise sinks half of its arithmetic into phase C and keeps Z1 (+ temporaries,
             // ~56 registers) alive across A2 / P3 instead of these 16
             asm volatile("" : "+v"(D1[ti]));
@@ -311,8 +411,18 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
             for (int s = 0; s < 2; ++s) st_image(X2img + (nO + c) * TS, 32 * ti, s, hs, pack(Z, s));
         }
         TTT_STAMP2(0)
+        if (PAIR) asm volatile("s_waitcnt vmcnt(0) ; drain: the record of step i - 1 is in memory before its flag is stored" ::: "memory");
         __syncthreads();              // B0: X2 image complete; every P6 read of step i-1 (red, Qt, b2L) is done
         TTT_STAMP2(8)
+        if (PAIR) {
+            if (tid == 0 && i > 0) __hip_atomic_store(fl + FL_A, (unsigned)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // records 0 .. i - 1
+            if (more) {               // next step's K, V, eta: L2 hits (touched a step ago), parked behind A2
+                const size_t off = (tile + 1) * 4096 + (size_t)prow * 64 + pcol;
+                pfK = *reinterpret_cast<const uint4*>(p.XK + off);
+                pfV = *reinterpret_cast<const uint4*>(p.XV + off);
+                pfE = reinterpret_cast<const unsigned short*>(p.eta)[(tile + 1) * 64 + (tid & 63)];
+            }
+        }
         if (DBG && p.dump && blockIdx.x == 0 && i == 0)
             for (int e = tid; e < 256 * 64; e += NT2) p.dump[e] = (float)X2img[(e >> 6) * TS + ((e & 63) ^ (SW ? 4 * sw_x(e >> 6) : 0))];
 
@@ -334,7 +444,7 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
                 write_partial2(red + (size_t)w * 64 * PS, P, ti, pp, h, c);
             }
         }
-        *reinterpret_cast<uint4*>(Qt + prow * TS + pcol) = sw16<SW>(pfQ, xo);   // Q of this step (read only after B2)
+        if (!PAIR) *reinterpret_cast<uint4*>(Qt + prow * TS + pcol) = sw16<SW>(pfQ, xo);   // Q of this step (read only after B2)
         TTT_STAMP2(1)
         __syncthreads();              // B1: partials visible
         TTT_STAMP2(9)
@@ -384,7 +494,42 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
         if (DBG && p.dump && blockIdx.x == 0 && i == 0)
             for (int e = tid; e < 64 * 64; e += NT2) p.dump[20480 + e] = (float)Gs[(e >> 6) * TS + ((e & 63) ^ (SW ? 4 * sw_x(e >> 6) : 0))];
 
+        // pair form: the next step's tiles, requested behind B0, go to the other parity's buffers (last read in phase C of step i - 1) HERE -
+        // behind A2 the wait for them cost 0.5 k cycles per step (stamps of profiles/r6t_* / r6v_*), now they have had A2 and P3 to arrive
+        if (PAIR && more) {           // the other parity's buffers: last read in phase C of step i - 1
+            const int nb = (i & 1) ^ 1;
+            *reinterpret_cast<uint4*>(Kt2 + nb * TILE_ELEMS + prow * TS + pcol) = sw16<SW>(pfK, xo);
+            *reinterpret_cast<uint4*>(Vt2 + nb * TILE_ELEMS + prow * TS + pcol) = sw16<SW>(pfV, xo);
+            unsigned pfEu = pfE;
+            asm volatile("" : "+v"(pfEu));
+            const float pfEf = __builtin_bit_cast(float, pfEu << 16);
+            if (tid < 64) etaL2[nb * 64 + tid] = pfEf;
+        }
         // ================= C: state updates, f3, f4 ===============================================
+        // pair form: record i goes to ring slot i % RING, which was record i - RING's - role B must have finished that step
+        bool pub_fast = false;
+        int pub_soff = 0;
+        if constexpr (PAIR) {
+            if (i >= RING && !gave_up) {
+                unsigned bd = (unsigned)__builtin_amdgcn_readfirstlane((int)b_done);
+                if (bd + RING <= (unsigned)i) {
+                    const unsigned long long t_poll = wall_clock64();
+                    const unsigned long long t_lim = q.fault ? 200000ull : 200000000ull;       // 2 ms under fault injection, else 2 s
+                    unsigned spins = 0u;
+                    do {
+                        __builtin_amdgcn_s_sleep(1);
+                        bd = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(fl + FL_B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                        if ((++spins & 255u) == 0u && wall_clock64() - t_poll > t_lim) gave_up = true;
+                    } while (bd + RING <= (unsigned)i && !gave_up);
+                    if (gave_up && l == 0) {       // role B is not running: loud, not silent - the error word + a poison word for B, and go on
+                        __hip_atomic_store(q.err, 1u + (unsigned)bh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        __hip_atomic_store(fl + FL_A + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+            pub_fast = q.fast != 0 && (unsigned)__builtin_amdgcn_readfirstlane((int)b_xcc) == my_xcc + 1u;
+            pub_soff = (i % RING) * REC_BYTES;
+        }
         {
             // operands of the ENTERING W2^T for f3, packed before the accumulator copy is updated
             bf16x8 W2TF[2][2];
@@ -415,6 +560,16 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
                     W2Tt[0] = mma(gO, xO, W2Tt[0]);
                     W2Tt[1] = mma(tr_frag_pi_sw<SW>(Gs, TS, 32 * ti, s, fX, l), xO, W2Tt[1]);
                 }
+            if constexpr (PAIR) {     // W2' is final: its half of the record leaves under f3 / f4
+                const int vo = (wv * 4) * 1024 + l * 16;
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        if (pub_fast) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pack(W2t[a], s)), rR, vo + (a * 2 + s) * 1024, pub_soff + REC_W2F, 0);
+                        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pack(W2t[a], s)), rR, vo + (a * 2 + s) * 1024, pub_soff + REC_W2F, 16);
+                    }
+            }
             // f3: gX2s = Gs W2^T ; gZ1s = gX2s * D1   (rows=t, lane=n) ; f4: W1[f, n in Hp] += K[:, f]^T gZ1s
             float sb = 0.f;
 #pragma unroll
@@ -456,6 +611,38 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
             }
         }
         TTT_STAMP2(3)
+        if constexpr (PAIR) {
+            // ---- the rest of record i: W1' (the operands of the next A1 anyway), b1', b2' - stored BEHIND barrier B3, so that they
+            // drain under the next step's VALU-bound A1 (all eight stores of a wave at the end of C cost 1.6 k cycles per step: 64 KiB
+            // through a CU's 64-byte store path, profiles/r6t_*); their drain wait is the one in front of the next B0 -----------------
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) W1F[a][s] = pack(W1t[a], s);
+            if (w == 0 && h == 0) b2L[fO + c] = b2v;          // (P3 of step i + 1 reads it behind B3, B0, B1)
+            asm volatile("" :: "v"(touch));
+            TTT_STAMP2(4)
+            __syncthreads();          // B3: every read of the X2 image, of Gs and of this parity's K / V / eta is done
+            TTT_STAMP2(11)
+            const int vo = (wv * 4) * 1024 + l * 16;
+            if (pub_fast) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, W1F[a][s]), rR, vo + (a * 2 + s) * 1024, pub_soff + REC_W1F, 0);
+                if (h == 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, b1v), rR, (nO + c) * 4, pub_soff + REC_B1, 0);
+                if (w == 0 && h == 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, b2v), rR, (fO + c) * 4, pub_soff + REC_B2, 0);
+            } else {
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, W1F[a][s]), rR, vo + (a * 2 + s) * 1024, pub_soff + REC_W1F, 16);
+                if (h == 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, b1v), rR, (nO + c) * 4, pub_soff + REC_B1, 16);
+                if (w == 0 && h == 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, b2v), rR, (fO + c) * 4, pub_soff + REC_B2, 16);
+            }
+        } else {
         // ---- f6: Z1b^T = W1'^T Q^T + b1' (rows=n, lane=t) ; X2b = gelu ---------------------------
         bf16x8 X2bF[2][2];            // [ti][s]  (outer=t, k=n in Hp)
         {
@@ -555,6 +742,12 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
             *reinterpret_cast<bf16x8*>(p.out + tile * 4096 + (size_t)ot * 64 + of0) = o;
         }
         TTT_STAMP2(6)
+        }   // !PAIR
+    }
+    if (PAIR) {         // the last record
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(fl + FL_A, (unsigned)NC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (p.W1f) {        // the state after the last step of this launch: what the next part of the sequence starts from (fp32, exact)
         float* W1g = p.W1f + (size_t)bh * 64 * 256;
@@ -575,11 +768,204 @@ __global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
     }
 }
 
+template <bool DBG, bool SW>
+__global__ __launch_bounds__(NT2) void mlp_scan8_kernel(ScanParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    scan8_body<DBG, SW, false>(p, PairParams{}, smem, (int)blockIdx.x);
+}
+
+// ---- role B of the pair form: the output path of every step, from the records role A publishes -----------------------------------
+// Wave (w, p) does what wave (w, p) of the one-workgroup kernel does between its phase C and the end of the step, with the same
+// operands - W1F / W2F are the fragments that wave packed, b1' / b2' travel in fp32 - in the same order: identical bits.
+#define TTT_STAMP2B(k)                                                             \
+    if (DBG && p.dbg != nullptr && bh == 0 && threadIdx.x == 0) {                  \
+        const unsigned long long _t = __builtin_readcyclecounter();                \
+        p.dbg[k] += _t - t_last;                                                   \
+        t_last = _t;                                                               \
+    }
+template <bool DBG, bool SW>
+__device__ __forceinline__ void scan8_output_role(const ScanParams& p, const PairParams& q, char* smem, const int bh) {
+    __bf16* Qt = reinterpret_cast<__bf16*>(smem + LB_Q);
+    char* exch = smem + LB_EX;
+    float* red = reinterpret_cast<float*>(smem + LB_RED);
+    float* gamL = reinterpret_cast<float*>(smem + LB_SMALL);
+    float* betL = gamL + 64;
+    unsigned* syncw = reinterpret_cast<unsigned*>(betL + 64);        // [0] poisoned (a poll of this workgroup gave up, or role A did)
+
+    const int tid = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = wv >> 1, pp = wv & 1;
+    const int nO = 64 * w + 32 * pp;
+    const int NC = p.NC;
+    const int head = bh % p.NH;
+    const __amdgpu_buffer_rsrc_t rR = make_srd(q.ring + (size_t)bh * RING * REC_BYTES, (size_t)RING * REC_BYTES);
+    unsigned* const fl = q.flags + (size_t)bh * FLAG_WORDS;
+    if (tid < 64) {
+        gamL[tid] = p.ln_w[(size_t)head * 64 + tid];
+        betL[tid] = p.ln_b[(size_t)head * 64 + tid];
+    }
+    if (tid == 0) {
+        syncw[0] = 0u;
+        const unsigned my_xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));      // HW_REG_XCC_ID[3:0]
+        __hip_atomic_store(fl + FL_B + 1, my_xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const size_t tile0 = (size_t)bh * (p.NCs ? p.NCs : NC);
+    uint4 qcur, qnext;
+    {
+        const int prow = tid >> 3, pcol = (tid & 7) * 8;
+        qcur = *reinterpret_cast<const uint4*>(p.XQ + tile0 * 4096 + (size_t)prow * 64 + pcol);
+        *reinterpret_cast<uint4*>(Qt + prow * TS + pcol) = sw16<SW>(qcur, SW ? sw_x(prow) : 0);
+    }
+    qnext = qcur;
+    bool gave_up = false;
+    __syncthreads();
+
+    unsigned long long t_last = __builtin_readcyclecounter();
+    for (int i = 0; i < NC; ++i) {
+        const size_t tile = tile0 + i;
+        const bool more = (i + 1 < NC);
+        int l_op = tid & 63, tid_op = tid;
+        asm volatile("" : "+v"(l_op), "+v"(tid_op));
+        const int l = l_op, h = l >> 5, c = l & 31;
+        const int tid = tid_op;
+        const int ot = tid >> 3, of0 = 8 * (tid & 7);
+        const int prow = tid >> 3, pcol = (tid & 7) * 8;
+        const int hs = SW ? (h ^ sw_x(c)) : h;
+        const int xo = SW ? sw_x(ot) : 0;
+        if (more) qnext = *reinterpret_cast<const uint4*>(p.XQ + (tile + 1) * 4096 + (size_t)prow * 64 + pcol);
+
+        // ---- wait for record i (every wave polls for itself: one lane, bounded by the wall clock) ---------------------------
+        if (!gave_up) {
+            unsigned af = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(fl + FL_A, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (af <= (unsigned)i) {
+                const unsigned long long t_poll = wall_clock64();
+                const unsigned long long t_lim = 200000000ull;                      // 2 s of the constant 100-MHz counter
+                unsigned spins = 0u;
+                do {
+                    __builtin_amdgcn_s_sleep(1);
+                    af = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(fl + FL_A, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    if ((++spins & 255u) == 0u && wall_clock64() - t_poll > t_lim) gave_up = true;
+                } while (af <= (unsigned)i && !gave_up);
+                if (gave_up && l == 0) {
+                    __hip_atomic_store(q.err, 1u + (unsigned)bh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(syncw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+            // role A gave up on this workgroup earlier (its ring was overwritten): everything from here on is poison
+            if (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(fl + FL_A + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) {
+                gave_up = true;
+                if (l == 0) __hip_atomic_store(syncw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        TTT_STAMP2B(12)
+        // ---- record i: this wave's operand fragments of W1' and W2', its rows of b1', the owner's b2' chunk (sc1: never from this CU's L1)
+        const int soff = (i % RING) * REC_BYTES;
+        bf16x8 W1F[2][2], W2F[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                W1F[a][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rR, (wv * 4 + a * 2 + s) * 1024 + l * 16, soff + REC_W1F, 16));
+                W2F[a][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rR, (wv * 4 + a * 2 + s) * 1024 + l * 16, soff + REC_W2F, 16));
+            }
+        f32x16 bias;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rR, (nO + 8 * q4 + 4 * h) * 4, soff + REC_B1, 16));
+            bias[4 * q4] = v[0]; bias[4 * q4 + 1] = v[1]; bias[4 * q4 + 2] = v[2]; bias[4 * q4 + 3] = v[3];
+        }
+        const f32x4 b2lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rR, of0 * 4, soff + REC_B2, 16));
+        const f32x4 b2hi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rR, of0 * 4 + 16, soff + REC_B2, 16));
+
+        // ---- f6: Z1b^T = W1'^T Q^T + b1' (rows=n, lane=t) ; X2b = gelu ---------------------------
+        bf16x8 X2bF[2][2];
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+            f32x16 zb = bias;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+                    zb = mma(W1F[a][s], pi_read(Qt + (32 * ti + c) * TS, 32 * a, s, hs), zb);
+            gelu_fwd_tile_pk(zb);
+            X2bF[ti][0] = pack(zb, 0);
+            X2bF[ti][1] = pack(zb, 1);
+        }
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                *reinterpret_cast<bf16x8*>(exch + ((size_t)(wv * 4 + ti * 2 + s) * 64 + l) * 16) = X2bF[ti][s];
+        TTT_STAMP2B(5)
+        __syncthreads();              // B4: exchange visible; every P6 read of step i - 1 (red) is done
+        TTT_STAMP2B(13)
+
+        // ================= E: partial Z2b^T[Fp, t] ================================================
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+            f32x16 P = zero16();
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 xo = *reinterpret_cast<const bf16x8*>(exch + ((size_t)((wv ^ 1) * 4 + ti * 2 + s) * 64 + l) * 16);
+                P = mma(W2F[0][s], X2bF[ti][s], P);
+                P = mma(W2F[1][s], xo, P);
+            }
+            write_partial2(red + (size_t)w * 64 * PS, P, ti, pp, h, c);
+        }
+        if (more) *reinterpret_cast<uint4*>(Qt + prow * TS + pcol) = sw16<SW>(qnext, xo);       // (its readers, f6 of this step, are behind B4)
+        asm volatile("s_waitcnt vmcnt(0) ; every load of record i has landed before its slot is released" ::: "memory");
+        TTT_STAMP2B(6)
+        __syncthreads();              // B5
+        if (tid == 0) __hip_atomic_store(fl + FL_B, (unsigned)(i + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+        // ================= P6: owners - reduce, LayerNorm, residual -> XQW ========================
+        {
+            float z[8], qf[8];
+            z[0] = b2lo[0]; z[1] = b2lo[1]; z[2] = b2lo[2]; z[3] = b2lo[3]; z[4] = b2hi[0]; z[5] = b2hi[1]; z[6] = b2hi[2]; z[7] = b2hi[3];
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) add8_f32(red + ((size_t)ww * 64 + ot) * PS + of0, z);
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += z[j];
+            const float mu = sum8(s) * (1.0f / 64.0f);
+            float v = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = z[j] - mu; v += d * d; }
+            const float rstd = __builtin_amdgcn_rsqf(sum8(v) * (1.0f / 64.0f) + p.eps);
+            {
+                const bf16x8 qa = __builtin_bit_cast(bf16x8, qcur);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) qf[j] = (float)qa[j];
+            }
+            const bool poisoned = __hip_atomic_load(syncw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u;
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float y = qf[j] + gamL[of0 + j] * ((z[j] - mu) * rstd) + betL[of0 + j];
+                o[j] = (__bf16)(poisoned ? __builtin_nanf("") : y);
+            }
+            *reinterpret_cast<bf16x8*>(p.out + tile * 4096 + (size_t)ot * 64 + of0) = o;
+        }
+        qcur = qnext;
+        TTT_STAMP2B(7)
+    }
+}
+
+template <bool DBG>
+__global__ __launch_bounds__(NT2) void mlp_scan_pair_kernel(ScanParams p, PairParams q) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = (int)blockIdx.x;
+    if (b < q.nbh) scan8_body<DBG, true, true>(p, q, smem, b);
+    else if (b >= q.nbh8 && !q.fault) scan8_output_role<DBG, true>(p, q, smem, b - q.nbh8);
+}
+
 static void set_attr_once() {
     static ttt::OncePerDevice done;
     done.run([&] {
         (void)hipFuncSetAttribute((const void*)mlp_scan8_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_V2);
         (void)hipFuncSetAttribute((const void*)mlp_scan8_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_V2);
+        (void)hipFuncSetAttribute((const void*)mlp_scan_pair_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_PAIR);
+        (void)hipFuncSetAttribute((const void*)mlp_scan_pair_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_PAIR);
     });
 }
 
@@ -589,12 +975,35 @@ static float* g_dump = nullptr;
 void set_debug_dump(float* buf) { g_dump = buf; }
 // (the half-chunk swap of the LDS tile rows - template parameter SW, sw_x above - is always on since round 5: 6.06 against 6.22 ms at
 // NC = 804, 2.14 against 2.19 at NC = 282, identical bits, profiles/r4m_*)
-void launch_scan_forward_v2(const ScanParams& p0, int n_bh, unsigned long long* dbg, hipStream_t s) {
+static int g_scan_pair = 1;           // 1 (default, round 6): the CS = 64 forward scan as a pair of workgroups per (b,h); 0 = one workgroup
+void set_debug_scan_pair(int v) { g_scan_pair = v; }
+static int g_scan_fault = 0;          // DEBUG fault injection: role B never runs - role A must give up loudly
+void set_debug_scan_fault(int v) { g_scan_fault = v; }
+size_t scan_pair_workspace_bytes(int n_bh) { return (size_t)n_bh * ((size_t)v2::RING * v2::REC_BYTES + v2::FLAG_WORDS * sizeof(unsigned)); }
+
+void launch_scan_forward_v2(const ScanParams& p0, int n_bh, void* ws, unsigned long long* dbg, hipStream_t s) {
     ScanParams p = p0;
     p.dbg = dbg;
     p.dump = g_dump;
     v2::set_attr_once();
     const bool dbg_build = p.dbg || p.dump;
+    // Pair form: two workgroups per (b,h), each a whole CU (LDS) - all of them must be co-resident (role B polls role A's flags);
+    // needs the caller's workspace (ring + flag lines) and the host-mapped error word.  Otherwise the one-workgroup kernel.
+    const int n_bh8 = (n_bh + 7) & ~7;
+    unsigned* err = (g_scan_pair && ws && !p.dump) ? sweep_error_word() : nullptr;
+    if (err && n_bh8 + n_bh <= device_cu_count()) {
+        v2::PairParams q = {};
+        q.ring = (char*)ws;
+        q.flags = (unsigned*)((char*)ws + (size_t)n_bh * v2::RING * v2::REC_BYTES);
+        q.err = err;
+        q.nbh = n_bh; q.nbh8 = n_bh8;
+        q.fast = get_debug_fast_records();
+        q.fault = g_scan_fault;
+        (void)hipMemsetAsync(q.flags, 0, (size_t)n_bh * v2::FLAG_WORDS * sizeof(unsigned), s);     // flags restart at 0 for every launch
+        if (dbg_build) hipLaunchKernelGGL((v2::mlp_scan_pair_kernel<true>), dim3(n_bh8 + n_bh), dim3(v2::NT2), v2::LDS_PAIR, s, p, q);
+        else hipLaunchKernelGGL((v2::mlp_scan_pair_kernel<false>), dim3(n_bh8 + n_bh), dim3(v2::NT2), v2::LDS_PAIR, s, p, q);
+        return;
+    }
     if (dbg_build) hipLaunchKernelGGL((v2::mlp_scan8_kernel<true, true>), dim3(n_bh), dim3(v2::NT2), v2::LDS_V2, s, p);
     else hipLaunchKernelGGL((v2::mlp_scan8_kernel<false, true>), dim3(n_bh), dim3(v2::NT2), v2::LDS_V2, s, p);
 }

@@ -39,6 +39,7 @@ void set_debug_overlap_tail(int v) { g_overlap = v; }
 static int record_buffers() { return g_overlap >= 2 ? 3 : 2; }
 static int g_fast_records = 1;        // cluster hand-over: plain (L2-resident) records once same-XCD placement is proven; 0 = always write-through
 void set_debug_fast_records(int v) { g_fast_records = v; }
+int get_debug_fast_records() { return g_fast_records; }
 // Decided by A/Bs on hardware and no longer options (rounds 3 - 5): non-temporal stores of the step records (14.28 against 14.68 ms per
 // backward), bf16 inner-LayerNorm owner rows (11.35 against 11.63), L2 prefetch touches two steps ahead (14.68 against 16.03), and
 // the hand-over flags of the NEXT sweep cleared right behind the current one instead of in front of the next: a rocprofv3 trace of
@@ -68,6 +69,7 @@ static int device_cus() {
     return cus[dev];
 }
 int sweep_clusters_per_launch() { return device_cus() / 4; }
+int device_cu_count() { return device_cus(); }
 
 int groups_per_chunk(const ttt_dims* d) {
     const int nbh = d->B * d->NH;
@@ -87,6 +89,7 @@ int groups_per_chunk(const ttt_dims* d) {
 static size_t align128(size_t v) { return (v + 127) & ~(size_t)127; }
 
 size_t workspace_bytes(const ttt_dims* d, bool mlp, bool backward) {
+    if (mlp && !backward && d->CS == 64) return scan_pair_workspace_bytes(d->B * d->NH);     // the pair scan's ring + flag lines
     if (!mlp || !backward) return 0;
     const size_t nbh = (size_t)d->B * d->NH;
     const size_t slots = (size_t)groups_per_chunk(d) * d->G + 1;

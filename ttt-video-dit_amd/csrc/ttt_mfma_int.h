@@ -28,7 +28,14 @@ struct ScanParams {
 bool bwd_available();
 int groups_per_chunk(const ttt_dims* d);
 // revision-2 forward scan (ttt_mfma2.hip): 8 waves per (b,h), VGPR-form MFMA, LDS transposed reads
-void launch_scan_forward_v2(const ScanParams& p, int n_bh, unsigned long long* dbg, hipStream_t s);
+// `ws`: the caller's forward workspace (scan_pair_workspace_bytes) or null; with it, the scan runs as a PAIR of workgroups per (b,h)
+// (round 6: role A carries the state, role B runs the output path from the records A publishes - ttt_mfma2.hip)
+void launch_scan_forward_v2(const ScanParams& p, int n_bh, void* ws, unsigned long long* dbg, hipStream_t s);
+size_t scan_pair_workspace_bytes(int n_bh);
+void set_debug_scan_pair(int v);      // 1 (default) pair form / 0 one workgroup per (b,h)
+void set_debug_scan_fault(int v);     // DEBUG fault injection: role B of every pair leaves at once
+int device_cu_count();                // compute units of the current device (cached)
+int get_debug_fast_records();
 // mini-batches of 16 tokens, forward only (ttt_mfma16.hip): the evaluation / sampling geometry
 void launch_scan_forward_cs16(const ScanParams& p, int n_bh, unsigned long long* dbg, hipStream_t s);
 void launch_linear_forward_cs16(const wv::Lin16Params& p, int n_bh, hipStream_t s);   // TTT-Linear, one wave per (b,h)

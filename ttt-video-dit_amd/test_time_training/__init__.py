@@ -65,8 +65,9 @@ _LinBwd = _ptr_struct("_LinBwd", LIN_BWD_FIELDS)
 # TTT_HIP_ABI_VERSION of include/ttt_hip.h this binding was written against (2: return codes -3 / -10 / -11 / -12 of the TTT-MLP
 # entry points, the round-1 debug exports ttt_hip_debug_variant / _helpers gone; 3: ttt_hip_pre_backward_ld / ttt_hip_attn_pre_backward_ld,
 # ttt_hip_mlp_forward_chunk, ttt_hip_pre_forward_range / ttt_hip_post_forward_range; 4 (round 6): ttt_hip_stream_create_masked /
-# ttt_hip_stream_destroy / ttt_hip_debug_placement_probe added, the tensor entry points unchanged)
-ABI_VERSION = 4
+# ttt_hip_stream_destroy / ttt_hip_debug_placement_probe added, the tensor entry points unchanged; 5 (round 6): the TTT-MLP forward has a
+# workspace - the ring of state records of the pair scan - and ttt_hip_mlp_forward_chunk uses its workspace arguments)
+ABI_VERSION = 5
 
 # every extern "C" symbol declared in include/ttt_hip.h
 EXPORTED_SYMBOLS = (
@@ -352,9 +353,12 @@ def ttt_forward_chunk(XQ, XK, XV, last_eta, ttt_norm_weight, ttt_norm_bias, W1_s
     dims = _dims(B, NH, NC, CS, F, G, act)
     lib = load_library()
     stream = torch.cuda.current_stream(XQ.device).cuda_stream
+    ws_bytes = lib.ttt_hip_mlp_forward_workspace(ctypes.byref(dims))       # the pair scan's ring of state records (round 6)
+    ws = _workspace(XQ.device, stream, ws_bytes) if ws_bytes else None
     with torch.cuda.device(XQ.device):
         rc = lib.ttt_hip_mlp_forward_chunk(ctypes.byref(dims), ctypes.byref(args), ctypes.c_int(int(step0)), ctypes.c_int(int(nsteps)),
-                                           _p(W1_state), _p(b1_state), _p(W2_state), _p(b2_state), None, ctypes.c_size_t(0), ctypes.c_void_p(stream))
+                                           _p(W1_state), _p(b1_state), _p(W2_state), _p(b2_state), ctypes.c_void_p(ws.data_ptr() if ws is not None else None),
+                                           ctypes.c_size_t(ws_bytes), ctypes.c_void_p(stream))
     if rc != 0:
         raise RuntimeError(lib.ttt_hip_last_error().decode())
 
