@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--parts", default="0,2,3,4")
     ap.add_argument("--video-length", default="9sec")
     ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--tuning-file", default=None, help="GEMM solution selections to load instead of the committed ttt_amd/infra/gemm_tuning_gfx950.csv")
     ap.add_argument("--debug-option", action="append", default=[], metavar="NAME=VALUE", help="library debug option(s) for the whole run (e.g. scan_pair=0)")
     a = ap.parse_args()
     import test_time_training as ext
@@ -43,7 +44,7 @@ def main():
     for kv in a.debug_option:
         ext.debug_option(kv.split("=")[0], int(kv.split("=")[1]))
     dev = torch.device("cuda:0")
-    tuned = enable_tuned_gemms()
+    tuned = enable_tuned_gemms(a.tuning_file)
     cfg = ModelConfig.get_preset("5B", a.video_length, ssm_layer="ttt_mlp", adapter_method="qkvo")
     frames, tl = cfg.compressed_num_frames, TEXT_LEN[a.video_length]
     scenes = max((frames - 1) // 12, 1)

@@ -45,10 +45,14 @@ def main():
     ap.add_argument("out")
     ap.add_argument("--video-length", default="9sec")
     ap.add_argument("--parts", default="4")
+    ap.add_argument("--min-rows", type=int, default=0, help="skip the row counts below this (the text runs)")
+    ap.add_argument("--occupy", type=int, default=0, metavar="CUS", help="tune BESIDE a kernel that holds this many CUs (round 6: the pair scan takes 96; "
+                    "a stream-K selection made on the free chip runs its 256 workgroups in two waves on the 160 CUs that are left)")
     a = ap.parse_args()
     from torch.cuda import tunable
     from ttt_amd.infra.parallelisms import enable_tuned_gemms
-    enable_tuned_gemms()
+    if not a.occupy:           # (a search beside a CU holder starts from nothing: shapes already in the committed file would not be searched again)
+        enable_tuned_gemms()
     tunable.enable(True)
     tunable.tuning_enable(True)
     tunable.set_max_tuning_duration(30)
@@ -61,11 +65,18 @@ def main():
     for vl in a.video_length.split(","):
         for n in (int(v) for v in a.parts.split(",")):
             for m in row_counts(vl, n):
-                if m in done:
+                if m in done or m < a.min_rows:
                     continue
                 done.add(m)
                 x = torch.randn(m, D, device=dev).bfloat16()
                 out = torch.empty(m, D, device=dev, dtype=torch.bfloat16)
+                if a.occupy:           # 35 s of CU holders on a side stream (100 ms each), the search runs beside them
+                    import test_time_training as ext
+                    ext.load_library()
+                    side = torch.cuda.Stream()
+                    torch.cuda.synchronize()
+                    for _ in range(350):
+                        ext.debug_occupy_cus(a.occupy, 150 * 1024, 100000, stream=side)
                 torch.addmm(b, x, w.t(), out=out)
                 torch.cuda.synchronize()
                 print("tuned rows", m, flush=True)

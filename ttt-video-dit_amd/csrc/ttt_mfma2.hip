@@ -96,7 +96,8 @@ constexpr int LA_G = LA_V + 2 * TILE_ELEMS * 2;
 constexpr int LA_X2 = LA_G + TILE_ELEMS * 2;
 constexpr int LA_RED = LA_X2 + X2IMG_BYTES;
 constexpr int LA_SMALL = LA_RED + RED_BYTES;
-constexpr int LDS_PAIR = LA_SMALL + (2 * 64 + 64 + 64 + 64) * 4;
+constexpr int LA_SYNC = LA_SMALL + (2 * 64 + 64 + 64 + 64) * 4;      // one word per wave: the step whose X2 rows it has written
+constexpr int LDS_PAIR = LA_SYNC + 8 * 4;
 static_assert(LDS_PAIR <= 160 * 1024, "LDS budget");
 // role B: Q, the X2b exchange, the partials, gamma[64] beta[64], one sync word
 constexpr int LB_Q = 0;
@@ -254,6 +255,8 @@ __device__ __forceinline__ void scan8_body(const ScanParams& p, const PairParams
     __bf16* Kt = Kt2;
     __bf16* Vt = Vt2;
     float* etaL = etaL2;
+    unsigned* const x2sync = reinterpret_cast<unsigned*>(smem + LA_SYNC);     // (PAIR)
+    if (PAIR && threadIdx.x < 8) x2sync[threadIdx.x] = 0u;
 
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform, provably (scalar branches below)
@@ -411,11 +414,19 @@ __device__ __forceinline__ void scan8_body(const ScanParams& p, const PairParams
             for (int s = 0; s < 2; ++s) st_image(X2img + (nO + c) * TS, 32 * ti, s, hs, pack(Z, s));
         }
         TTT_STAMP2(0)
-        if (PAIR) asm volatile("s_waitcnt vmcnt(0) ; drain: the record of step i - 1 is in memory before its flag is stored" ::: "memory");
-        __syncthreads();              // B0: X2 image complete; every P6 read of step i-1 (red, Qt, b2L) is done
+        if constexpr (PAIR) {
+            // B0 in pair form is a hand-off between the TWO waves of a hidden slice, not a workgroup barrier: A2 reads the X2 rows of its own
+            // wave and of its partner (w, 1 - p) only, and nothing else is due here (the one-workgroup kernel also orders P6's reads).  The
+            // four waves that share their SIMDs with a younger wave leave A1 ~1.4 k cycles before those (VALU-bound phase, oldest wave
+            // first): they run their A2 under the younger waves' A1 instead of waiting for them.  LDS executes a wave's operations in
+            // order: the word follows the image rows.
+            if (l == 0) __hip_atomic_store(x2sync + wv, (unsigned)(i + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            while (__hip_atomic_load(x2sync + (wv ^ 1), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)(i + 1)) __builtin_amdgcn_s_sleep(0);
+        } else {
+            __syncthreads();          // B0: X2 image complete; every P6 read of step i-1 (red, Qt, b2L) is done
+        }
         TTT_STAMP2(8)
         if (PAIR) {
-            if (tid == 0 && i > 0) __hip_atomic_store(fl + FL_A, (unsigned)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // records 0 .. i - 1
             if (more) {               // next step's K, V, eta: L2 hits (touched a step ago), parked behind A2
                 const size_t off = (tile + 1) * 4096 + (size_t)prow * 64 + pcol;
                 pfK = *reinterpret_cast<const uint4*>(p.XK + off);
@@ -446,8 +457,10 @@ __device__ __forceinline__ void scan8_body(const ScanParams& p, const PairParams
         }
         if (!PAIR) *reinterpret_cast<uint4*>(Qt + prow * TS + pcol) = sw16<SW>(pfQ, xo);   // Q of this step (read only after B2)
         TTT_STAMP2(1)
+        if (PAIR) asm volatile("s_waitcnt vmcnt(0) ; drain: the record of step i - 1 is in memory before its flag is stored" ::: "memory");
         __syncthreads();              // B1: partials visible
         TTT_STAMP2(9)
+        if (PAIR && tid == 0 && i > 0) __hip_atomic_store(fl + FL_A, (unsigned)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // records 0 .. i - 1
 
         // ================= P3: owners - reduce, fused LN / L2 backward -> Gs = -eta gZ2 ===========
         {
