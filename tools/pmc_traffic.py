@@ -27,7 +27,7 @@ def per_kernel(path, counter):
 def short(name):
     for key, tag in (("mlp_bwd_cluster4_kernel", "sweep_cluster"), ("mlp_recompute8_kernel", "recompute"), ("mlp_bwd_tail4_kernel", "tail"), ("mlp_bwd_tail5_kernel", "tail"),
                      ("mlp_bwd_cluster_kernel", "sweep_cluster"), ("mlp_scan_kernel", "recompute"), ("mlp_bwd_tail_kernel", "tail"),
-                     ("mlp_scan8_kernel", "forward_scan")):
+                     ("mlp_scan8_kernel", "forward_scan"), ("mlp_scan_pair_kernel", "forward_scan")):
         if key in name:
             return tag
     return None

@@ -33,7 +33,10 @@ def side_stream(device) -> torch.cuda.Stream:
     idx = torch.cuda.current_device() if idx is None else idx
     st = _side.get(idx)
     if st is None:
-        st = _side[idx] = torch.cuda.Stream(device=idx)
+        # TTT_SCAN_STREAM_PRIORITY (A/B knob, round 6): -1 = a high-priority queue for the scan - its workgroups take the CUs that come
+        # free before the workgroups of the GEMMs queued beside it do; default 0
+        import os
+        st = _side[idx] = torch.cuda.Stream(device=idx, priority=int(os.environ.get("TTT_SCAN_STREAM_PRIORITY", "0")))
     return st
 
 
@@ -88,16 +91,46 @@ class InjectedLinear(torch.autograd.Function):
 
 
 # ---- the plan: parts of the scan order and the token runs they cover ---------------------------------------------------------------
+# Shares of the checkpoint groups per part.  Round 6: with the pair scan (4.9 ms on 96 CUs beside the GEMMs) the compute stream is the
+# pipeline's co-bottleneck - its GEMMs run 1.7 - 1.85x slower on the 160 CUs the scan leaves (profiles/r6x_layer_fwd_timeline_parts4.txt) -
+# and the forward ends with the LAST part's scan running alone (0.6 ms at four equal parts) + its output projection.  Parts that TAPER
+# towards the end cut that tail; a two-resource model of the timeline fitted to the trace puts the optimum for four parts near these
+# shares (6.26 against 6.50 ms).  TTT_PIPELINE_WEIGHTS="w0,w1,..." overrides (A/B knob; "equal" = the round-5 plan).
+TAPER = {4: (0.31, 0.33, 0.24, 0.12), 5: (0.31, 0.31, 0.22, 0.12, 0.04), 6: (0.26, 0.27, 0.21, 0.14, 0.08, 0.04)}
+
+
+def part_group_counts(K: int, n_parts: int):
+    import os
+    env = os.environ.get("TTT_PIPELINE_WEIGHTS", "")
+    w = None
+    if env and env != "equal":
+        w = [float(v) for v in env.split(",")]
+        if len(w) != n_parts:
+            w = None
+    elif env != "equal":
+        w = TAPER.get(n_parts)
+    if w is None:
+        per, extra = divmod(K, n_parts)
+        return [per + (1 if c < extra else 0) for c in range(n_parts)]
+    tot = sum(w)
+    counts = [max(1, int(round(K * v / tot))) for v in w]
+    while sum(counts) > K:                      # (rounding: take from / give to the largest part)
+        counts[counts.index(max(counts))] -= 1
+    while sum(counts) < K:
+        counts[counts.index(max(counts))] += 1
+    return counts
+
+
 def plan_parts(src_cpu, L: int, CS: int, G: int, n_parts: int):
     """[(step0, nsteps, [(r0, r1), ...])]: parts of whole checkpoint groups, as equal as they come; ``src_cpu`` maps scan position ->
     token (None: identity).  The runs of a part are the maximal contiguous token ranges it covers, ascending."""
     NC = L // CS
     K = math.ceil(NC / G)
     n_parts = max(1, min(n_parts, K))
-    per, extra = divmod(K, n_parts)
+    counts = part_group_counts(K, n_parts)
     parts, g0 = [], 0
     for c in range(n_parts):
-        g1 = g0 + per + (1 if c < extra else 0)
+        g1 = g0 + counts[c]
         s0, s1 = g0 * G, min(g1 * G, NC)
         t0, t1 = s0 * CS, s1 * CS
         if src_cpu is None:
