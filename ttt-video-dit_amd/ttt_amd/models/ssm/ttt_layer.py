@@ -133,9 +133,12 @@ class TTTBase(nn.Module):
         self.use_fused = True          # fused HIP pre/post-processing when the activations are bf16 on a HIP device
         # TTT-MLP forward as a pipeline over this many parts of the sequence: the scan of one part on a side stream beside the
         # projections of the next and the post-norm / output projection of the previous (ttt_amd/models/ssm/pipeline.py); 0 / 1 = off.
-        # Default 4 (round 5, one MI355X, 5B / 9 s: layer forward 10.3 -> 7.8 ms, the training step +3.3 %; 6 parts measured the same,
-        # 8 slower; profiles/r5d_*, r5e_*).  Applies where a part has at least two checkpoint groups, on the MFMA scan at CS = 64.
-        self.pipeline_parts = int(os.environ.get("TTT_PIPELINE_PARTS", "4"))
+        # Round 5: 4 equal parts (one MI355X, 5B / 9 s: layer forward 10.3 -> 7.8 ms, the training step +3.3 %; profiles/r5d_*, r5e_*).
+        # Round 6, with the pair scan (the compute stream became the pipeline's co-bottleneck): 5 parts that TAPER towards the end
+        # (pipeline.TAPER: 16 / 16 / 11 / 6 / 2 of 51 checkpoint groups at 9 s) - in-step 8 554 - 8 574 against 8 484 - 8 501 video-tok/s for
+        # 4 equal parts on one box (+0.8 %), 4 tapered parts the same as 4 equal (profiles/r6ab2_*).  Fewer parts where the scan has
+        # fewer than two checkpoint groups per part; on the MFMA scan at CS = 64 only.
+        self.pipeline_parts = int(os.environ.get("TTT_PIPELINE_PARTS", "5"))
         # ... and more of them for long scans (up to 8, one per ~40 checkpoint groups): what stays exposed is the first part's projections
         # and the last part's output projection, which grow with the sequence - at 63 s (343 groups) 8 parts measured 7 122 against 7 001
         # video-tok/s for 4 on one box (profiles/r5i_*); False: exactly `pipeline_parts`
@@ -399,8 +402,9 @@ class TTTBase(nn.Module):
         G = self._group_size(NC)
         if self.pipeline_parts_auto:
             n = max(n, min(8, -(-NC // G) // 40))
-        if -(-NC // G) < 2 * n:
+        if -(-NC // G) < 8:                    # (rounds 5 / 6: a scan of fewer than eight checkpoint groups runs as one piece)
             return None
+        n = min(n, -(-NC // G) // 2)           # at least two checkpoint groups per part on average
         import test_time_training as ext
         if ext.resolved_impl(x.shape[0], self.num_heads, NC, CS, self.head_dim, G, torch.bfloat16, mlp=True, backward=False) != "mfma":
             return None
