@@ -60,7 +60,6 @@ int ttt_hip_debug_option(const char* name, int value) {
     else if (!strcmp(name, "deriver_split")) ttt::mfma::set_debug_deriver_split(value);         // sweep: 1 (default) / 0 = barrier Bc behind the derivers' reverse step
     else if (!strcmp(name, "attn_prio")) ttt::attn::set_debug_attn_variant(value);               // attention backward: 1 (default) / 0 = without the s_setprio pair per kernel
     else if (!strcmp(name, "sweep_fault")) ttt::mfma::set_debug_sweep_fault(value);              // fault injection: workgroup 3 of every sweep cluster leaves early
-    else if (!strcmp(name, "own_early")) ttt::mfma::set_debug_own_early(value);                  // sweep: 1 (default) the owners stage step j in front of barrier Ba / 0 = behind it
     else if (!strcmp(name, "scan_pair")) ttt::mfma::set_debug_scan_pair(value);                  // forward scan at CS = 64: 1 (default) a pair of workgroups per (b,h) / 0 = one
     else if (!strcmp(name, "scan_fault")) ttt::mfma::set_debug_scan_fault(value);                // fault injection: role B of every scan pair leaves at once
     else return -1;

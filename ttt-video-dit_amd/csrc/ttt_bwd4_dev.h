@@ -68,7 +68,6 @@ struct SweepParams4 : b2::SweepParams2 {
     int prefetch;                          // 1 (always, since round 5): owners / derivers touch the records of step i - 2 (L2 prefetch)
     int own16;                             // as RecomputeParams::own16 (both kernels of a backward call agree)
     int split;                             // 1 (round 6): barrier Bc INSIDE the derivers' reverse step, behind its W2 update; 0: behind the step
-    int own_early;                         // 1 (round 6): the owners stage step j's tiles / run its output-LayerNorm backward in FRONT of barrier Ba (beside S1)
 };
 constexpr size_t PARK4_BYTES = 12 * FRAG_BYTES;
 void launch_sweep_cluster4(const SweepParams4& bp, int nbh, hipStream_t s);

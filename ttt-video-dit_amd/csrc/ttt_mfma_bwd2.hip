@@ -50,8 +50,6 @@ int get_debug_fast_records() { return g_fast_records; }
 // `fsdp1` point within 0.1 % of the replica line, where it had been 2.4 % behind).  The gate kernels tried beside it are gone.
 static int g_deriver_split = 1;       // sweep: barrier Bc inside the derivers' reverse step (round 6); 0 = behind it (rounds 3 - 5)
 void set_debug_deriver_split(int v) { g_deriver_split = v; }
-static int g_own_early = 1;           // sweep: the owners' staging of step j in front of barrier Ba (round 6 A/B); 0 = between Ba and Bb (rounds 3 - 5)
-void set_debug_own_early(int v) { g_own_early = v; }
 static int g_sweep_fault = 0;         // DEBUG fault injection (tests of the hand-over failure path)
 void set_debug_sweep_fault(int v) { g_sweep_fault = v; }
 
@@ -186,7 +184,7 @@ static int mlp_backward4(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws,
     bp.NH = d->NH; bp.NC = NC;
     bp.xch = xch; bp.flags = flags; bp.fast_records = g_fast_records;
     bp.err = err_word; bp.fault = g_sweep_fault;
-    bp.W1c = a->W1_checkpoints; bp.W2c = a->W2_checkpoints; bp.wfinal = wfinal; bp.park = park; bp.G = G; bp.K = K; bp.danchor = danchor; bp.prefetch = 1; bp.own16 = 1; bp.split = g_deriver_split ? 1 : 0; bp.own_early = g_own_early ? 1 : 0;
+    bp.W1c = a->W1_checkpoints; bp.W2c = a->W2_checkpoints; bp.wfinal = wfinal; bp.park = park; bp.G = G; bp.K = K; bp.danchor = danchor; bp.prefetch = 1; bp.own16 = 1; bp.split = g_deriver_split ? 1 : 0;
 
     int rc = 0;                               // a failed event / stream call leaves the two streams unordered: the call fails (-12)
     auto chk = [&](hipError_t e) { if (e != hipSuccess) rc = -12; };

@@ -674,11 +674,6 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
         owner_barrier();                       // P2
 
         unsigned long long t_prev = 0;
-        // own_early: the tiles / output-LayerNorm inputs of step j are requested BEHIND barrier Bc of the previous iteration (the owners idle during
-        // S4a) and consumed at the top of this one - in front of barrier Ba, beside the compute waves' S1; the record lives in registers from Bc to
-        // the top of the next iteration only, not across the hand-over chain
-        StepLoads Lj;
-        if (p.own_early && i0 > p.chunk_lo) request_step(i0 - 1, Lj);
         for (int i = i0; i >= p.chunk_lo; --i) {
             // opaque owner index per step (as the compute / deriver waves do with their lane id): what derives from it - record
             // and tile offsets, LDS rows - is re-made inside the step instead of being carried through the loop in spilled registers
@@ -705,7 +700,8 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
                 ld16f(rS, ow * 64, so + (int)SLOT_OWN_ARR, go);
             }
             const float r = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rS, ot * 8, so + 3 * (int)SLOT_OWN_ARR, 0));
-            if (more && !p.own_early) request_step(i - 1, Lj);
+            StepLoads Lj;
+            if (more) request_step(i - 1, Lj);
             // DEBUG stamps 32 .. 35 (owner wave 0 of workgroup 0): Bd .. Ba arrival, wait at Ba, consume_step, wait at Bb
             unsigned long long t_o = 0;
 #define TTT_OSTAMP2(k)                                                           \
@@ -715,17 +711,10 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
                 t_prev = _t;                                                     \
             }
             TTT_OSTAMP2(0)
-            // Round 6 (p.own_early): the owners' tile staging + output-LayerNorm backward of step j runs IN FRONT of barrier Ba - beside the compute
-            // waves' S1, where the owners used to wait - instead of between Ba and Bb, where it (3.1 k cycles) outlasted S2 (1.9 k): everything it
-            // writes (the other parity's K / gZ2 / eta buffers, Q_j, dZ2b_j) was last read before barrier Bd of the previous iteration; only its
-            // column-sum partials cannot go to the dW2 exchange region then (S1 reads it) - they go to the dZ2 tile Bt, which is idle from Bd
-            // until the owners write dZ2_i at the end of this iteration's hand-over (behind add_parts: wave OW0 releases the others after it).
-            float* const part_j = reinterpret_cast<float*>(p.own_early ? reinterpret_cast<char*>(Bt) : exd);
-            if (!p.own_early) owner_barrier();  // Ba (rounds 3 - 5: nothing of the owners is due yet: they arrive at once)
+            owner_barrier();                   // Ba (nothing of the owners is due yet: they arrive at once)
             TTT_OSTAMP2(1)
-            if (more) consume_step(cur ^ 1, Lj, part_j);
+            if (more) consume_step(cur ^ 1, Lj, reinterpret_cast<float*>(exd));
             TTT_OSTAMP2(2)
-            if (p.own_early) owner_barrier();   // Ba
             owner_barrier();                   // Bb: this workgroup's record is complete and drained; At / Q_j / R3 visible
             TTT_OSTAMP2(3)
             if (DBG && p.dbg != nullptr && blockIdx.x == 0 && ow == 0) t_o = __builtin_readcyclecounter();
@@ -750,7 +739,7 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
             }
             if (wv == OW0) {
                 const int l = tid & 63;
-                if (more) add_parts(part_j, db2oL + cur * 64, db2oL + (cur ^ 1) * 64);
+                if (more) add_parts(reinterpret_cast<const float*>(exd), db2oL + cur * 64, db2oL + (cur ^ 1) * 64);
                 if (l < 3) {
                     const unsigned* f = p.flags + ((size_t)bh * 4 + ((cq + 1 + l) & 3)) * FLAG_STRIDE;
                     // A partner that is not running: give up LOUDLY instead of hanging the GPU - after a WALL-CLOCK time (the
@@ -923,17 +912,15 @@ __global__ __launch_bounds__(NTC) void mlp_bwd_cluster4_kernel(SweepParams4 p) {
             // loads of these waves are the requests at the top of the next iteration.  (Round 2 tried touches with the 570-KiB
             // records and lost - three steps of six heads did not fit an XCD's 4-MB L2; with the slim record they are 2.7 MB.)
             unsigned touch = 0u;
-            const int ta = p.own_early ? 3 : 2;            // (own_early: the requests of step i - 2 follow right here, so the touches run one step further ahead)
-            if (p.prefetch && i - ta >= p.chunk_lo) {
-                const int s2 = slot_off(i - ta) + (int)SLOT4_FR;
+            if (p.prefetch && i - 2 >= p.chunk_lo) {
+                const int s2 = slot_off(i - 2) + (int)SLOT4_FR;
                 if (!(OWN16 && (ow & 64))) touch = __builtin_amdgcn_raw_buffer_load_b32(rS, ow * 128, s2, 0);      // (own16: the second halves of the first two arrays are unused)
                 if (ow < 452 - 256) touch += __builtin_amdgcn_raw_buffer_load_b32(rS, (256 + ow) * 128, s2, 0);
                 if (ow < 192) {
                     const __amdgpu_buffer_rsrc_t rT = ow < 64 ? rK : ow < 128 ? rQ : rO;
-                    touch += __builtin_amdgcn_raw_buffer_load_b32(rT, (ow & 63) * 128, (i - ta) * 8192, 0);
+                    touch += __builtin_amdgcn_raw_buffer_load_b32(rT, (ow & 63) * 128, (i - 2) * 8192, 0);
                 }
             }
-            if (p.own_early && i - 2 >= p.chunk_lo) request_step(i - 2, Lj);
             owner_barrier();                   // Bd
             asm volatile("" :: "v"(touch));    // (keeps the prefetch loads alive; they landed long ago)
             if (DBG && p.dbg != nullptr && blockIdx.x == 0 && ow == 0) t_prev = __builtin_readcyclecounter();

@@ -49,7 +49,6 @@ unsigned peek_sweep_error();           // the same word without synchronising (e
 void clear_sweep_error();              // acknowledge (synchronises)
 unsigned* sweep_error_word();          // device pointer of the host-mapped word (allocated on first use; nullptr on failure)
 void set_debug_deriver_split(int v);  // sweep: 1 (default, round 6) barrier Bc inside the derivers' reverse step, 0 = behind it
-void set_debug_own_early(int v);      // sweep: 1 (default, round 6) the owners' staging of step j in front of barrier Ba, 0 = between Ba and Bb
 void set_debug_sweep_fault(int v);     // DEBUG fault injection: workgroup 3 of every sweep cluster leaves before its first hand-over
 unsigned read_sweep_fast_count();   // DEBUG statistic (synchronises)
 
