@@ -189,17 +189,23 @@ static int mlp_backward4(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws,
     int rc = 0;                               // a failed event / stream call leaves the two streams unordered: the call fails (-12)
     auto chk = [&](hipError_t e) { if (e != hipSuccess) rc = -12; };
     const int nchunks = (K + gpc - 1) / gpc;
+    // Chunk ch covers checkpoint groups [chunk_g0(ch), + chunk_ng(ch)).  The RAGGED chunk is chunk 0 - the one processed LAST - since round 6: with
+    // the ragged chunk at the end of the sequence (processed first: 1 group of 51 at the 9 s length) the first sweep lasted 58 us and the second
+    // chunk's recompute - on the side stream, in launches of 64 workgroups - ran 0.5 ms with nothing beside it (profiles/r6tl_bwd_timeline_nc804.txt).
+    const int r0 = K - (nchunks - 1) * gpc;
+    auto chunk_g0 = [&](int ch) { return ch == 0 ? 0 : r0 + (ch - 1) * gpc; };
+    auto chunk_ng = [&](int ch) { return ch == 0 ? r0 : gpc; };
     OverlapRes* ov = (g_overlap && nchunks > 1) ? overlap_resources() : nullptr;
     const int free_cus = device_cus() - 4 * (nbh < per_launch ? nbh : per_launch);
     if (ov && (free_cus < 32 || nbh > per_launch)) ov = nullptr;      // nothing free beside the sweep, or several sweep launches per chunk
     auto recompute = [&](int ch, int max_wg, hipStream_t st) {
-        const int g0 = ch * gpc, ng = (K - g0 < gpc) ? K - g0 : gpc;
+        const int g0 = chunk_g0(ch), ng = chunk_ng(ch);
         rp.chunk_group0 = g0; rp.chunk_groups = ng; rp.chunk_lo = g0 * G;
         rp.slots = slots + (size_t)(ch % NBUF) * slot_buf;
         s4::launch_recompute4(rp, nbh, max_wg, st);
     };
     auto tail = [&](int ch, hipStream_t st) {
-        const int g0 = ch * gpc, ng = (K - g0 < gpc) ? K - g0 : gpc;
+        const int g0 = chunk_g0(ch), ng = chunk_ng(ch);
         const int lo = g0 * G;
         s4::Tail5Args ta = {(const __bf16*)a->XQ, (const __bf16*)a->XK, (const __bf16*)a->grad_L_XQW, (const __bf16*)a->last_eta,
                             (const __bf16*)a->grad_L_XV, slots + (size_t)(ch % NBUF) * slot_buf, slot_stride, a->W1_checkpoints, wfinal, danchor,
@@ -207,7 +213,7 @@ static int mlp_backward4(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws,
         s4::launch_tail5(ta, nbh, st);
     };
     auto sweep = [&](int ch) {
-        const int g0 = ch * gpc, ng = (K - g0 < gpc) ? K - g0 : gpc;
+        const int g0 = chunk_g0(ch), ng = chunk_ng(ch);
         bp.slots = slots + (size_t)(ch % NBUF) * slot_buf;
         bp.chunk_lo = g0 * G;
         bp.chunk_hi = ((g0 + ng) * G < NC) ? (g0 + ng) * G : NC;
@@ -227,6 +233,25 @@ static int mlp_backward4(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws,
         chk(hipStreamWaitEvent(ov->side, ov->entry, 0));
     }
     recompute(nchunks - 1, 0, s);
+    if (ov && NBUF == 3 && g_overlap >= 3) {
+        // Schedule 3 (round 6): the recompute of chunk c - 1 beside the sweep of chunk c as in schedule 2, the tail of chunk c BEHIND its sweep on
+        // stream s, on the whole chip.  The group-sequential tail (round 6) takes 0.06 ms alone and 0.26 ms beside a sweep - on the few CUs
+        // the sweep and the recompute leave - and costs that sweep 0.17 ms (0.75 -> 0.93 ms in the kernel trace profiles/r6tl_*): the per-step
+        // tail of rounds 3 - 5 (0.15 ms alone) was worth hiding, this one is not.
+        chk(hipEventRecord(ov->sweep_done[nchunks % 3], s));
+        for (int ch = nchunks - 1; ch >= 0; --ch) {
+            if (ch + 1 < nchunks) chk(hipStreamWaitEvent(s, ov->rc_done[ch % 3], 0));
+            sweep(ch);
+            chk(hipEventRecord(ov->sweep_done[ch % 3], s));
+            tail(ch, s);
+            chk(hipStreamWaitEvent(ov->side, ov->sweep_done[(ch + 1) % 3], 0));    // beside C(ch + 1) and B(ch): released when B(ch + 1) is done
+            if (ch > 0) {
+                recompute(ch - 1, free_cus, ov->side);
+                chk(hipEventRecord(ov->rc_done[(ch - 1) % 3], ov->side));
+            }
+        }
+        return rc;
+    }
     if (ov && NBUF == 3) {
         // Schedule 2 (round 6 A/B): stream s carries the sweeps only, A(n-1) B(n-1) B(n-2) ... ; beside B(c) the side stream runs
         // A(c-1) - in launches of at most the CUs the sweep leaves free, so that a recompute workgroup never holds a CU a cluster
