@@ -233,25 +233,9 @@ static int mlp_backward4(const ttt_dims* d, const ttt_mlp_bwd_args* a, void* ws,
         chk(hipStreamWaitEvent(ov->side, ov->entry, 0));
     }
     recompute(nchunks - 1, 0, s);
-    if (ov && NBUF == 3 && g_overlap >= 3) {
-        // Schedule 3 (round 6): the recompute of chunk c - 1 beside the sweep of chunk c as in schedule 2, the tail of chunk c BEHIND its sweep on
-        // stream s, on the whole chip.  The group-sequential tail (round 6) takes 0.06 ms alone and 0.26 ms beside a sweep - on the few CUs
-        // the sweep and the recompute leave - and costs that sweep 0.17 ms (0.75 -> 0.93 ms in the kernel trace profiles/r6tl_*): the per-step
-        // tail of rounds 3 - 5 (0.15 ms alone) was worth hiding, this one is not.
-        chk(hipEventRecord(ov->sweep_done[nchunks % 3], s));
-        for (int ch = nchunks - 1; ch >= 0; --ch) {
-            if (ch + 1 < nchunks) chk(hipStreamWaitEvent(s, ov->rc_done[ch % 3], 0));
-            sweep(ch);
-            chk(hipEventRecord(ov->sweep_done[ch % 3], s));
-            tail(ch, s);
-            chk(hipStreamWaitEvent(ov->side, ov->sweep_done[(ch + 1) % 3], 0));    // beside C(ch + 1) and B(ch): released when B(ch + 1) is done
-            if (ch > 0) {
-                recompute(ch - 1, free_cus, ov->side);
-                chk(hipEventRecord(ov->rc_done[(ch - 1) % 3], ov->side));
-            }
-        }
-        return rc;
-    }
+    // (Round 6 also tried schedule 3 - the recompute beside the sweep as in schedule 2, the tail BEHIND its sweep on the whole chip, where it takes
+    // 0.06 ms against 0.26 ms beside a sweep - and it LOST: 9.75 - 9.80 against 9.54 - 9.57 ms per backward alone, 9.53 - 9.55 against 9.25 - 9.30
+    // inside the step; profiles/r6s3_*.  Gone.)
     if (ov && NBUF == 3) {
         // Schedule 2 (round 6 A/B): stream s carries the sweeps only, A(n-1) B(n-1) B(n-2) ... ; beside B(c) the side stream runs
         // A(c-1) - in launches of at most the CUs the sweep leaves free, so that a recompute workgroup never holds a CU a cluster
