@@ -109,6 +109,8 @@ def part_group_counts(K: int, n_parts: int):
             w = None
     elif env != "equal":
         w = TAPER.get(n_parts)
+        if w is None and n_parts >= 7:              # long scans (63 s: 8 parts): the same shape - the last three parts at 0.8 / 0.5 / 0.2 of a full one
+            w = [1.1] * (n_parts - 4) + [1.0, 0.8, 0.5, 0.2]
     if w is None:
         per, extra = divmod(K, n_parts)
         return [per + (1 if c < extra else 0) for c in range(n_parts)]
