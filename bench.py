@@ -94,6 +94,19 @@ def parse():
     ap.add_argument("--remat-free-layers", default="auto",
                     help="transformer layers that keep their activations instead of being re-materialised in backward: "
                          "'auto' (sized to the free HBM of this GPU), or an integer; 0 = the reference's 80-GB-GPU setting")
+    ap.add_argument("--offload-gib-per-layer", type=float, default=0.0,
+                    help="GiB of saved activations EVERY remat-free layer parks in pinned host memory between its forward and its backward "
+                         "(ttt_amd/infra/host_offload.py: D2H / H2D copies on side streams beside the compute, same bits); the freed HBM goes to more "
+                         "remat-free layers (--remat-free-layers auto sizes them with the offload in place); 0 = off")
+    ap.add_argument("--offload-park-kept", action="store_true",
+                    help="the kernel outputs re-materialised layers keep (--remat-keep) wait in pinned host memory too, fetched back two layers ahead of the backward")
+    ap.add_argument("--offload-layers", type=int, default=None, help="only the first N remat-free layers offload (default: all of them)")
+    ap.add_argument("--offload-soft-frac", type=float, default=2.0,
+                    help="share of the device memory above which the host thread waits for every copy out before it saves more (default: never)")
+    ap.add_argument("--offload-lookahead", type=int, default=2, help="layers ahead of the backward whose parked tensors are fetched")
+    ap.add_argument("--offload-trace", action="store_true", help="DEBUG: timed events around every copy and compute-stream wait of the LAST timed step (config.host_offload.trace)")
+    ap.add_argument("--offload-backlog-gib", type=float, default=16.0,
+                    help="GiB of copies out the host thread may have queued before it waits for the oldest")
     ap.add_argument("--no-tuned-gemms", action="store_true", help="use hipBLASLt's default heuristic instead of the committed "
                     "solution selections (ttt_amd/infra/gemm_tuning_gfx950.csv)")
     ap.add_argument("--reshard-after-forward", action="store_true",
@@ -927,6 +940,8 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False, tp=False, sha
 
     def step():
         # the reference's loop (train.py:131-166): zero_grad, loss, backward, clip, optimizer.step, lr_scheduler.step
+        if args.offload_trace and dit.host_offload is not None:
+            dit.host_offload.trace = []                # (DEBUG: the events of the most recent step)
         opt.zero_grad(set_to_none=True)
         loss = model(vid, text).mean()
         loss.backward()
@@ -954,6 +969,12 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False, tp=False, sha
     # ---- activation re-materialisation sized for this GPU (untimed), warm-up, timed region: size_warm_and_time() ------------
     dit = model.dit if hasattr(model, "dit") else model
     fast0 = [0]
+    offload = None
+    if args.offload_gib_per_layer > 0 or args.offload_park_kept:
+        from ttt_amd.infra.host_offload import HostOffload
+        offload = dit.host_offload = HostOffload(int(args.offload_gib_per_layer * 2 ** 30), layers=args.offload_layers, park_kept=args.offload_park_kept,
+                                                 max_backlog_bytes=int(args.offload_backlog_gib * 2 ** 30), lookahead=args.offload_lookahead,
+                                                 soft_limit_bytes=int(args.offload_soft_frac * torch.cuda.get_device_properties(dev).total_memory))
 
     class Hooks:
         oom = torch.cuda.OutOfMemoryError
@@ -1017,6 +1038,8 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False, tp=False, sha
                 log(f"timed region: {args.steps} steps, remat_free_layers={n_free}")
             timer.reset()
             timer.active = True
+            if offload:
+                offload.stats.clear()
             if clocks:
                 clocks.start()
 
@@ -1120,6 +1143,14 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False, tp=False, sha
                            "global_batch": dp * LB, "seq_len": L, "parallelism": (f"tp{tp}" if no_fsdp else f"fsdp{world}(dp{dp}xtp{tp})") if tp else ("replica1" if no_fsdp else (f"flat_fsdp{world}" if (communicate or world > 1) else "flat1") if flat else f"fsdp2_{world}"), "ttt_impl": args.impl,
                            "remat_free_layers": n_free, "remat_keep": list(dit.remat_keep), "remat_keep_layers": args.remat_keep_layers, "ttt_pipeline_parts": parts_used, "fsdp_reshard_after_forward": bool(args.reshard_after_forward), "tuned_gemm_selections": bool(tuned),
                            "debug_options": ",".join(args.debug_option) or None,
+                           "host_offload": ({"gib_per_layer": args.offload_gib_per_layer, "layers": args.offload_layers, "park_kept": args.offload_park_kept,
+                                             "gib_per_step": round(offload.stats["offloaded_bytes"] / args.steps / 2 ** 30, 2),
+                                             "storages_per_step": offload.stats["offloaded_storages"] // args.steps,
+                                             "kept_on_device": offload.stats["kept_on_device"], "late_fetches": offload.stats["late_fetches"],
+                                             "throttle_waits": offload.stats["throttle_waits"], "lookahead": args.offload_lookahead, "backlog_gib": args.offload_backlog_gib,
+                                             "trace": offload.trace_summary() if offload.trace is not None else None,
+                                             "host_s_per_step": {k[7:]: round(v / args.steps, 3) for k, v in offload.stats.items() if k.startswith("host_s_")},
+                                             "pinned_gib": round(sum(t.numel() for t in offload._slots) / 2 ** 30, 1)} if offload else None),
                            "sweep_error": sweep_err, "valid": args.layers is None and sweep_err == 0,
                            **({k: v for k, v in clocks.summary().items() if k in ("clock_mhz_avg", "clock_mhz_min", "clock_mhz_max", "power_w_avg", "power_w_max")} if clocks else {}),
                            "clocks": clocks.summary() if clocks else None},

@@ -1,0 +1,10 @@
+#!/bin/bash
+# round 6, call HO2: host offload - device test (all variants), are copies to slices of a pinned chunk asynchronous, the 9 s step without the memory throttle
+cd /root/repo; mkdir -p gpurun_out/r6ho2; O=gpurun_out/r6ho2
+timeout 600 python -m pytest tests/test_host_offload_gpu.py -q -s > $O/test.log 2>&1; tail -8 $O/test.log
+timeout 120 python tools/pinned_slice_probe.py > $O/pinned_slice.json 2> $O/pinned_slice.err; cat $O/pinned_slice.json
+show() { grep -h "^{" $1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; c=d['config']; print('$2', round(d['value'],1), 'ms', round(d['ms_per_step'],1), 'free', c['remat_free_layers'], 'off', c.get('host_offload'), 'bwd', round(r['avg_launch_ms'],3), 'peak', round(d['peak_mem_gib'],1), 'retries', d['alloc_retries_total'])" || tail -5 ${1%.json}.err; }
+for g in 2 3; do
+timeout 900 python bench.py --role worker --gpus 1 --steps 3 --warmup 1 --no-fsdp1-compare --offload-gib-per-layer $g --offload-soft-frac 2 > $O/bench_off$g.json 2> $O/bench_off$g.err; show $O/bench_off$g.json off$g
+done
+grep -h "sizing" $O/bench_off*.err | tail -20

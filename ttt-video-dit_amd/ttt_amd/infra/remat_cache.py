@@ -24,10 +24,10 @@ class _Region:
     """The kept kernel outputs of ONE ``checkpoint`` call, in call order.  Entries stay until the region is freed with its
     checkpoint frame (they share storage with what the recomputed graph saves anyway), so a second recomputation of the same
     region - ``retain_graph=True``, or a double backward through it - finds them again instead of an empty queue."""
-    __slots__ = ("kinds", "entries", "cursor")
+    __slots__ = ("kinds", "entries", "cursor", "park")
 
-    def __init__(self, kinds):
-        self.kinds, self.entries, self.cursor = frozenset(kinds), [], 0
+    def __init__(self, kinds, park=None):
+        self.kinds, self.entries, self.cursor, self.park = frozenset(kinds), [], 0, park
 
 
 class _Scope:
@@ -48,9 +48,11 @@ class _Scope:
         return False
 
 
-def context_fn(kinds):
-    """``context_fn`` for ``torch.utils.checkpoint.checkpoint(..., use_reentrant=False)``: one region per checkpoint call."""
-    region = _Region(kinds)
+def context_fn(kinds, park=None):
+    """``context_fn`` for ``torch.utils.checkpoint.checkpoint(..., use_reentrant=False)``: one region per checkpoint call.
+    ``park = (HostOffload, layer index)``: the kept outputs wait in pinned host memory (``ttt_amd/infra/host_offload.py``: copied out
+    behind the kernel, fetched back when the backward approaches the layer) instead of in HBM - the same bits either way."""
+    region = _Region(kinds, park)
     return lambda: (_Scope(region, "forward"), _Scope(region, "recompute"))
 
 
@@ -79,7 +81,10 @@ def kernel_result(kind: str, compute):
     if mode == "forward":
         out = compute()
         kept = tuple(t.detach() for t in out)
-        region.entries.append((kind, kept, tuple(t._version for t in kept)))
+        versions = tuple(t._version for t in kept)
+        if region.park is not None:
+            kept = region.park[0].park(region.park[1], kept)       # (handles; small tensors and views stay as they are)
+        region.entries.append((kind, kept, versions))
         return out
     if region.cursor >= len(region.entries):
         raise RuntimeError(f"remat_cache: the recomputation asks for a {kind!r} result the forward pass of this region did not produce "
@@ -88,7 +93,9 @@ def kernel_result(kind: str, compute):
     region.cursor += 1
     if got != kind:
         raise RuntimeError(f"remat_cache: recomputation asked for {kind!r} where the forward pass produced {got!r}")
-    if any(t._version != v for t, v in zip(out, versions)):
+    if region.park is not None:
+        out = region.park[0].unpark(out)
+    elif any(t._version != v for t, v in zip(out, versions)):
         raise RuntimeError(f"remat_cache: a kept {kind!r} output was modified in place after the forward pass (the kept copy aliases it); "
                            "clone before writing into a kernel output inside a region that keeps it")
     return tuple(t.detach() for t in out)

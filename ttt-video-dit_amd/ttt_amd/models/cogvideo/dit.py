@@ -468,6 +468,8 @@ class DiffusionTransformer(nn.Module):
         self.transformer_norm = nn.LayerNorm(config.model_dim, eps=config.layer_norm_eps).requires_grad_(train)
         self.final_layer = FinalLayer(config)
         self.sequence_parallel = None      # a ttt_amd.infra.sequence_parallel.SeqParallel: one sample over the ranks of its group
+        # a ttt_amd.infra.host_offload.HostOffload: what the remat-free layers save waits in pinned host memory between forward and backward
+        self.host_offload = None
 
     def _run_group(self, start, vid_emb, text_emb, seq_metadata, sp=None):
         for layer in self.layers[start:start + self.remat_transformer_layer_group_size]:
@@ -489,16 +491,27 @@ class DiffusionTransformer(nn.Module):
         if sp is not None:        # every rank got the same inputs; each keeps 1/T of the tokens: what a layer group's checkpoint
             n_vid = vid_emb.shape[1]     # saves is a token shard (reference shard_transformer_inputs, dit.py:494-498)
             vid_emb, text_emb = sp.shard_tokens(vid_emb), sp.shard_tokens(text_emb)
+        off = self.host_offload if torch.is_grad_enabled() else None
+        if off is not None:
+            off.begin_step()
         for i in range(0, len(self.layers), self.remat_transformer_layer_group_size):
-            if torch.is_grad_enabled() and i >= self.remat_free_layers:
+            if off is not None and i < self.remat_free_layers:
+                with off.layer(i):
+                    vid_emb, text_emb = self._run_group(i, vid_emb, text_emb, meta, sp)
+            elif torch.is_grad_enabled() and i >= self.remat_free_layers:
                 keeps = self.remat_keep_layers is None or (i - self.remat_free_layers) < self.remat_keep_layers
                 if self.remat_keep and keeps:
+                    park = (off, i) if off is not None and off.park_kept else None      # the kept outputs wait in host memory
                     vid_emb, text_emb = checkpoint(self._run_group, i, vid_emb, text_emb, meta, sp, use_reentrant=False,
-                                                   context_fn=remat_cache.context_fn(self.remat_keep))
+                                                   context_fn=remat_cache.context_fn(self.remat_keep, park))
                 else:
                     vid_emb, text_emb = checkpoint(self._run_group, i, vid_emb, text_emb, meta, sp, use_reentrant=False)
             else:
                 vid_emb, text_emb = self._run_group(i, vid_emb, text_emb, meta, sp)
+            if off is not None and vid_emb.requires_grad:       # the backward announces itself one layer group at a time
+                vid_emb.register_hook(lambda g, i=i: off.backward_reaches(i))
+        if off is not None:
+            off.end_forward()
         if sp is not None:
             # final norm / AdaLN / projection are token-wise too; only the unpatchify reshape needs the whole sequence.  Every
             # rank then evaluates the same loss on the gathered output, hence replicated_consumer.
