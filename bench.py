@@ -878,7 +878,9 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False, tp=False, sha
         over["num_layers"] = args.layers
     if args.ssm_layer == "ttt_linear":      # the reference trains TTT-Linear with these (configs/train/ttt-linear/3s.toml:9,32)
         over.update(mini_batch_size=16, scan_checkpoint_group_size=4)
-    over["remat_keep"] = tuple(k for k in args.remat_keep.split(",") if k and k != "none")
+    keep_items = [k for k in args.remat_keep.split(",") if k and k != "none"]          # "scan:20" = scan outputs in the first 20 re-materialised layers only
+    over["remat_keep"] = tuple(k.split(":")[0] for k in keep_items)
+    over["remat_keep_limits"] = {k.split(":")[0]: int(k.split(":")[1]) for k in keep_items if ":" in k}
     over["remat_keep_layers"] = args.remat_keep_layers
     cfg = ModelConfig.get_preset("5B", args.video_length, ssm_layer=args.ssm_layer, adapter_method=args.adapter, **over)
     frames, text_len = cfg.compressed_num_frames, TEXT_LEN[args.video_length]
@@ -1141,7 +1143,7 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False, tp=False, sha
                 "config": {"workload": f"CogVideoX-5B+{args.ssm_layer} {args.video_length} training step (fwd+bwd+AdamW), "
                                        f"{cfg.num_layers} layers, L={L} tokens/sample, adapter={args.adapter}",
                            "global_batch": dp * LB, "seq_len": L, "parallelism": (f"tp{tp}" if no_fsdp else f"fsdp{world}(dp{dp}xtp{tp})") if tp else ("replica1" if no_fsdp else (f"flat_fsdp{world}" if (communicate or world > 1) else "flat1") if flat else f"fsdp2_{world}"), "ttt_impl": args.impl,
-                           "remat_free_layers": n_free, "remat_keep": list(dit.remat_keep), "remat_keep_layers": args.remat_keep_layers, "ttt_pipeline_parts": parts_used, "fsdp_reshard_after_forward": bool(args.reshard_after_forward), "tuned_gemm_selections": bool(tuned),
+                           "remat_free_layers": n_free, "remat_keep": list(dit.remat_keep), "remat_keep_layers": args.remat_keep_layers, "remat_keep_limits": dict(dit.remat_keep_limits) or None, "ttt_pipeline_parts": parts_used, "fsdp_reshard_after_forward": bool(args.reshard_after_forward), "tuned_gemm_selections": bool(tuned),
                            "debug_options": ",".join(args.debug_option) or None,
                            "host_offload": ({"gib_per_layer": args.offload_gib_per_layer, "layers": args.offload_layers, "park_kept": args.offload_park_kept,
                                              "gib_per_step": round(offload.stats["offloaded_bytes"] / args.steps / 2 ** 30, 2),

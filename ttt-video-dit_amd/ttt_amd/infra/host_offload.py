@@ -205,8 +205,8 @@ class HostOffload:
         out = []
         for t in tensors:
             nb = t.numel() * t.element_size()
-            if nb < self.min_bytes or not t.is_contiguous() or t.storage_offset() != 0 or t.untyped_storage().nbytes() != nb:
-                out.append(t)
+            if nb < self.min_bytes or t.storage_offset() != 0 or t.untyped_storage().nbytes() != nb:
+                out.append(t)                                         # (small, or not the sole - possibly permuted - owner of its storage)
             else:
                 out.append(_View(self._send(layer, t), t))
         return tuple(out)

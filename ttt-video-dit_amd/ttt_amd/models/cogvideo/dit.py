@@ -457,6 +457,8 @@ class DiffusionTransformer(nn.Module):
         # ... and how many of the re-materialised layers do so (the FIRST ones; None = all of them): at 63 s on one GPU there is room
         # for the kept attention outputs of about ten layers, not of 42
         self.remat_keep_layers = getattr(config, "remat_keep_layers", None)
+        # ... per kind: {"scan": 20} = only the first 20 re-materialised layers keep their scan outputs (the other kinds: all that keep)
+        self.remat_keep_limits = dict(getattr(config, "remat_keep_limits", None) or {})
         assert config.num_layers % self.remat_transformer_layer_group_size == 0, "Remat group size must be divisible into num layers"
         self.model_dim = config.model_dim
         self.shard_transformer_inputs = config.shard_transformer_inputs
@@ -500,10 +502,12 @@ class DiffusionTransformer(nn.Module):
                     vid_emb, text_emb = self._run_group(i, vid_emb, text_emb, meta, sp)
             elif torch.is_grad_enabled() and i >= self.remat_free_layers:
                 keeps = self.remat_keep_layers is None or (i - self.remat_free_layers) < self.remat_keep_layers
-                if self.remat_keep and keeps:
+                kinds = tuple(k for k in self.remat_keep
+                              if self.remat_keep_limits.get(k) is None or (i - self.remat_free_layers) < self.remat_keep_limits[k]) if keeps else ()
+                if kinds:
                     park = (off, i) if off is not None and off.park_kept else None      # the kept outputs wait in host memory
                     vid_emb, text_emb = checkpoint(self._run_group, i, vid_emb, text_emb, meta, sp, use_reentrant=False,
-                                                   context_fn=remat_cache.context_fn(self.remat_keep, park))
+                                                   context_fn=remat_cache.context_fn(kinds, park))
                 else:
                     vid_emb, text_emb = checkpoint(self._run_group, i, vid_emb, text_emb, meta, sp, use_reentrant=False)
             else:

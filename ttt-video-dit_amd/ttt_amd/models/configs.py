@@ -60,6 +60,7 @@ class ModelConfig:
     # MI355X: kernel outputs a re-materialised layer keeps instead of recomputing them ("attn", "scan"; () = reference behaviour)
     remat_keep: tuple = ()
     remat_keep_layers: object = None      # int: only the first N re-materialised layers keep their kernel outputs (None: all)
+    remat_keep_limits: object = None      # dict kind -> N: that kind only in the first N re-materialised layers
     remat_forward_ssm: bool = False
     remat_reverse_ssm: bool = False
     remat_attention: bool = False
