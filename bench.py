@@ -103,9 +103,14 @@ def parse():
     ap.add_argument("--offload-layers", type=int, default=None, help="only the first N remat-free layers offload (default: all of them)")
     ap.add_argument("--offload-soft-frac", type=float, default=2.0,
                     help="share of the device memory above which the host thread waits for every copy out before it saves more (default: never)")
+    ap.add_argument("--offload-one-stream", action="store_true", help="(the default since call HO13; kept for the call scripts)")
+    ap.add_argument("--offload-nonblocking-end", action="store_true", help="(the default since call HO13; kept for the call scripts)")
+    ap.add_argument("--offload-two-streams", action="store_true", help="A/B: a side stream per copy direction (aliases with the scan / backward side streams on 4 hardware queues: -12 %%)")
+    ap.add_argument("--offload-blocking-end", action="store_true", help="A/B: the host thread waits for every copy out at the end of the forward")
+    ap.add_argument("--offload-no-batch", action="store_true", help="A/B: every copy out is issued at once behind its own event instead of together with its layer's (4 - 5 x slower copies)")
     ap.add_argument("--offload-lookahead", type=int, default=2, help="layers ahead of the backward whose parked tensors are fetched")
     ap.add_argument("--offload-trace", action="store_true", help="DEBUG: timed events around every copy and compute-stream wait of the LAST timed step (config.host_offload.trace)")
-    ap.add_argument("--offload-backlog-gib", type=float, default=16.0,
+    ap.add_argument("--offload-backlog-gib", type=float, default=64.0,
                     help="GiB of copies out the host thread may have queued before it waits for the oldest")
     ap.add_argument("--no-tuned-gemms", action="store_true", help="use hipBLASLt's default heuristic instead of the committed "
                     "solution selections (ttt_amd/infra/gemm_tuning_gfx950.csv)")
@@ -977,6 +982,9 @@ def _run(args, world, rank, local_rank, dev, no_fsdp, quiet=False, tp=False, sha
         offload = dit.host_offload = HostOffload(int(args.offload_gib_per_layer * 2 ** 30), layers=args.offload_layers, park_kept=args.offload_park_kept,
                                                  max_backlog_bytes=int(args.offload_backlog_gib * 2 ** 30), lookahead=args.offload_lookahead,
                                                  soft_limit_bytes=int(args.offload_soft_frac * torch.cuda.get_device_properties(dev).total_memory))
+
+        offload.batch = not args.offload_no_batch
+        offload.one_stream, offload.blocking_end = not args.offload_two_streams, args.offload_blocking_end
 
     class Hooks:
         oom = torch.cuda.OutOfMemoryError

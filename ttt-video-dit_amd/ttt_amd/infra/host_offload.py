@@ -32,11 +32,12 @@ import torch
 
 class _Stor:
     """One offloaded storage of one step."""
-    __slots__ = ("layer", "nbytes", "slot", "dev", "d2h_done", "restored", "h2d_done", "device")
+    __slots__ = ("layer", "nbytes", "slot", "dev", "d2h_done", "restored", "h2d_done", "device", "queued")
 
     def __init__(self, layer, nbytes, slot, dev, device):
         self.layer, self.nbytes, self.slot, self.dev, self.device = layer, nbytes, slot, dev, device
         self.d2h_done = self.restored = self.h2d_done = None
+        self.queued = False                           # batch mode: the copy out has not been issued yet
 
 
 class _View:
@@ -59,6 +60,18 @@ class HostOffload:
         self.bytes_per_layer, self.layers, self.min_bytes, self.lookahead = int(bytes_per_layer), layers, int(min_bytes), int(lookahead)
         self.soft_limit_bytes, self.max_storage_ratio, self.pin = soft_limit_bytes, max_storage_ratio, pin
         self.max_backlog_bytes = max_backlog_bytes
+        # batch: the copies out of a layer are issued together behind the layer's forward, behind ONE event of the compute stream (the runtime
+        # picks the SDMA engine of a copy when it is queued; a marker between two copies makes it choose again, and with the first engine busy it
+        # takes the next free one - copies that trickle in one by one end up spread over engines that are slower on the host link)
+        self.batch = True
+        # one_stream: copies out and in share ONE side stream (measured: with a stream each, the fourth and fifth stream of the process alias
+        # with the scan's / the backward's side streams on the 4 hardware queues and the step loses 12 %; with 8 queues the baseline loses 4.6 %)
+        self.one_stream = True
+        # end_forward() waits for every copy out (False, the default: it lets go of what is complete and the rest follows as the backward
+        # proceeds - the host thread of the training step has no slack: every wait of it is idle time of the device)
+        self.blocking_end = False
+        self._batch: list = []
+        self._scope_depth = 0
         self.park_kept = park_kept                    # the kernel outputs re-materialised layers keep (remat_cache) wait in host memory as well
         self._slots: list[torch.Tensor] = []          # pinned host buffers, slot k = the k-th storage a step offloads
         self.chunk_bytes, self._chunk, self._chunk_used = 1 << 32, None, 0
@@ -86,8 +99,12 @@ class HostOffload:
 
     # ---- streams (CUDA only) -----------------------------------------------------------------------------------------------------
     def _st(self, device):
+        """(copy-out stream, copy-in stream).  ``one_stream``: the same stream for both directions - the copies out belong to the forward, the
+        copies in to the backward, and a process has few hardware queues (4 by default: the compute stream, the scan's side stream, the
+        backward's side stream ... a stream more aliases with one of them, and its copies then sit in front of that stream's kernels)."""
         if self._streams is None:
-            self._streams = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+            a = torch.cuda.Stream(device=device)
+            self._streams = (a, a if self.one_stream else torch.cuda.Stream(device=device))
         return self._streams
 
     def _ev(self, stream, rec=None):
@@ -144,10 +161,22 @@ class HostOffload:
             return
         prev, self._cur_layer, self._spent = self._cur_layer, idx, 0
         try:
-            with torch.autograd.graph.saved_tensors_hooks(self._pack, self._unpack):
+            with self.scope(), torch.autograd.graph.saved_tensors_hooks(self._pack, self._unpack):
                 yield
         finally:
             self._cur_layer = prev
+
+    @contextlib.contextmanager
+    def scope(self):
+        """Batch mode: the copies out queued inside are issued together at the exit (a layer's forward: free layers through ``layer()``, the
+        forward of a re-materialised layer whose kept outputs are parked through this)."""
+        self._scope_depth += 1
+        try:
+            yield
+        finally:
+            self._scope_depth -= 1
+            if self._scope_depth == 0:
+                self._flush()
 
     def _pack(self, t):
         if (not isinstance(t, torch.Tensor) or isinstance(t, torch.nn.Parameter) or (t.requires_grad and t.is_leaf) or t.is_sparse
@@ -177,16 +206,12 @@ class HostOffload:
         nbytes = storage.nbytes()
         stor = _Stor(layer, nbytes, self._next_slot, _bytes_of(storage, t.device), t.device)
         host = self._slot(stor.slot, nbytes)[:nbytes]
-        if t.is_cuda:
-            main = torch.cuda.current_stream(t.device)
-            out, _ = self._st(t.device)
-            t0 = time.perf_counter()
-            out.wait_event(main.record_event())
-            with torch.cuda.stream(out):
-                e0 = self._ev(out)
-                host.copy_(stor.dev, non_blocking=True)
-                stor.d2h_done = self._ev(out, ("d2h", nbytes, e0))
-            self.stats["host_s_enqueue_out"] += time.perf_counter() - t0
+        if t.is_cuda and self.batch and self._scope_depth > 0:
+            stor.queued = True
+            self._batch.append((stor, host))
+            self._pending.append(stor)
+        elif t.is_cuda:
+            self._issue([(stor, host)])
             self._pending.append(stor)
             self._throttle()
         else:
@@ -197,6 +222,27 @@ class HostOffload:
         self.stats["offloaded_bytes"] += nbytes
         self.stats["offloaded_storages"] += 1
         return stor
+
+    def _issue(self, items):
+        """the copies out of ``items`` = [(storage record, pinned slot)], behind ONE event of the compute stream"""
+        dev = items[0][0].device
+        main = torch.cuda.current_stream(dev)
+        out, _ = self._st(dev)
+        t0 = time.perf_counter()
+        out.wait_event(main.record_event())
+        with torch.cuda.stream(out):
+            for stor, host in items:
+                e0 = self._ev(out)
+                host.copy_(stor.dev, non_blocking=True)
+                stor.d2h_done = self._ev(out, ("d2h", stor.nbytes, e0))
+                stor.queued = False
+        self.stats["host_s_enqueue_out"] += time.perf_counter() - t0
+
+    def _flush(self):
+        if self._batch:
+            items, self._batch = self._batch, []
+            self._issue(items)
+            self._throttle()
 
     # ---- kernel outputs a re-materialised layer keeps (ttt_amd/infra/remat_cache.py) ------------------------------------------------
     def park(self, layer: int, tensors):
@@ -216,7 +262,8 @@ class HostOffload:
 
     def _release_done(self):
         """lets go of the device copies whose copy out has completed (oldest first: the D2H stream is in order)"""
-        while self._pending and (self._pending[0].dev is None or self._pending[0].d2h_done is None or self._pending[0].d2h_done.query()):
+        while self._pending and not self._pending[0].queued and (self._pending[0].dev is None or self._pending[0].d2h_done is None
+                                                                 or self._pending[0].d2h_done.query()):
             self._drop_dev(self._pending.popleft())
 
     def _drop_dev(self, s):
@@ -234,6 +281,7 @@ class HostOffload:
         layers of compute: the device does not run dry) and, above ``soft_limit_bytes`` of allocated memory, no backlog at all."""
         if self.soft_limit_bytes is None and self.max_backlog_bytes is None:
             return
+        self._flush()
         t0 = time.perf_counter()
         while self._pending and ((self.max_backlog_bytes is not None and self._backlog() > self.max_backlog_bytes)
                                  or (self.soft_limit_bytes is not None and torch.cuda.memory_allocated() > self.soft_limit_bytes)):
@@ -248,6 +296,10 @@ class HostOffload:
     def end_forward(self):
         """Every copy out finished, every device copy let go (the host thread waits; the compute stream does not): call behind the last
         layer's forward, where the step's memory peak is."""
+        self._flush()
+        if not self.blocking_end:
+            self._release_done()
+            return
         t0 = time.perf_counter()
         while self._pending:
             s = self._pending.popleft()

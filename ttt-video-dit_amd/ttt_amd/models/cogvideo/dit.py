@@ -10,6 +10,8 @@ softmax / PV and their backward) goes to the MFMA kernels behind ``ttt_amd.model
 """
 from __future__ import annotations
 
+import contextlib
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -506,8 +508,9 @@ class DiffusionTransformer(nn.Module):
                               if self.remat_keep_limits.get(k) is None or (i - self.remat_free_layers) < self.remat_keep_limits[k]) if keeps else ()
                 if kinds:
                     park = (off, i) if off is not None and off.park_kept else None      # the kept outputs wait in host memory
-                    vid_emb, text_emb = checkpoint(self._run_group, i, vid_emb, text_emb, meta, sp, use_reentrant=False,
-                                                   context_fn=remat_cache.context_fn(kinds, park))
+                    with (off.scope() if park else contextlib.nullcontext()):
+                        vid_emb, text_emb = checkpoint(self._run_group, i, vid_emb, text_emb, meta, sp, use_reentrant=False,
+                                                       context_fn=remat_cache.context_fn(kinds, park))
                 else:
                     vid_emb, text_emb = checkpoint(self._run_group, i, vid_emb, text_emb, meta, sp, use_reentrant=False)
             else:
