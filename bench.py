@@ -649,14 +649,18 @@ def rccl_summary(log_dir):
 # the 63 s step on ONE GPU: every layer re-materialised; of the kernel outputs a re-materialised layer could keep only the attention
 # outputs (2.3 GB per layer at 63 s, 37 ms saved per GB) of the first ten layers fit beside 223 GiB (round 5, one box,
 # profiles/r5h_*: 6 929 against 6 804 video-tok/s, 49.3 against 50.2 s per step, 245.5 GiB allocated / 256.2 reserved)
-CTX63S_KEEP = ["--remat-keep", "attn", "--remat-keep-layers", "10"]
+# The 63 s leg: every layer re-materialised; the attention outputs of ALL 42 layers are kept - parked in pinned host memory (91 GiB per step,
+# ttt_amd/infra/host_offload.py; round 6, call HO13: 42.9 s per step against 45.9 with the attention outputs of ten layers kept on the device,
+# the setting of rounds 5 / 6 and the leg's fallback if the parked attempt fails).
+CTX63S_KEEP = ["--remat-keep", "attn", "--offload-park-kept", "--offload-lookahead", "2"]
+CTX63S_KEEP_FALLBACK = ["--remat-keep", "attn", "--remat-keep-layers", "10"]
 # generous estimates (model build + sizing probes + 1 warm-up + 2 timed steps; 24 s per step at 30 s, 49 s at 63 s; sampling: two
 # network evaluations of 22 s on the guidance pair + the build)
 LEG_ESTIMATE_S = {"ctx3s": 150.0, "ctx63s": 480.0, "ctx30s": 380.0, "sample63s": 240.0}
 LEG_ORDER = ("ctx3s", "ctx63s", "ctx30s", "sample63s")     # the metric's two contexts first, then BASELINE configs[3] and configs[4]
 
 
-def leg_command(name, args):
+def leg_command(name, args, fallback=False):
     """`ctx3s` = BASELINE configs[1] (configs/train/ttt-mlp/3s.toml: one segment, adapter sft), `ctx63s` = the metric's second context
     (63s.toml: 21 scenes, L = 351 168; every layer re-materialised, the first ten keep their attention outputs - what fits ONE 288-GB GPU,
     DESIGN.md section 6; the reference shards this stage over 4 x 4 GPUs), `ctx30s` = BASELINE configs[3] (30s.toml: 10 scenes,
@@ -669,7 +673,7 @@ def leg_command(name, args):
     argv = ["--gpus", "1", "--video-length", length, "--steps", str(max(1, args.leg_steps)), "--warmup", "1", "--no-fsdp1-compare",
             "--ssm-layer", args.ssm_layer, "--impl", args.impl]
     if name == "ctx63s":
-        argv += ["--remat-free-layers", "0"] + CTX63S_KEEP
+        argv += ["--remat-free-layers", "0"] + (CTX63S_KEEP_FALLBACK if fallback else CTX63S_KEEP)
     if args.no_tuned_gemms:
         argv.append("--no-tuned-gemms")
     if args.pipeline_parts is not None:
@@ -690,7 +694,8 @@ def leg_summary(line):
     pick = lambda k: round(other[k]["avg_ms"], 3) if k in other else None
     return {"value": line["value"], "unit": line["unit"], "ms_per_step": line["ms_per_step"], "steps": line["steps"], "warmup": line["warmup"],
             "workload": line["config"]["workload"], "remat_free_layers": line["config"]["remat_free_layers"],
-            "remat_keep": line["config"].get("remat_keep"), "remat_keep_layers": line["config"].get("remat_keep_layers"), "peak_mem_gib": line.get("peak_mem_gib"), "peak_reserved_gib": line.get("peak_reserved_gib"),
+            "remat_keep": line["config"].get("remat_keep"), "remat_keep_layers": line["config"].get("remat_keep_layers"),
+            "host_offload_gib_per_step": (line["config"].get("host_offload") or {}).get("gib_per_step"), "peak_mem_gib": line.get("peak_mem_gib"), "peak_reserved_gib": line.get("peak_reserved_gib"),
             "ttt_mlp_bwd_ms": round(r["avg_launch_ms"], 3) if dom_bwd else pick("bwd"), "scan_fwd_ms": pick("fwd") if dom_bwd else round(r.get("avg_launch_ms", 0.0), 3),
             "attn_fwd_ms": pick("attn_fwd"), "attn_bwd_ms": pick("attn_bwd"), "roofline_frac": r.get("frac"), "valid": line["config"].get("valid")}
 
@@ -758,9 +763,17 @@ def orchestrate(args, argv):
             log(f"{name} leg (child process)")
             t0 = time.time()
             rc, leg, tail = run_child(leg_command(name, args), timeout=max(300.0, left))
+            fell_back = None
+            if name == "ctx63s" and not (rc == 0 and leg is not None) and args.time_budget - (time.time() - t_start) >= LEG_ESTIMATE_S[name]:
+                # the parked attempt failed: once more with the attention outputs of ten layers kept on the device (rounds 5 / 6)
+                fell_back = f"rc {rc}: {(tail[-1] if tail else 'no output')[:200]}"
+                log(f"{name}: parked attempt failed ({fell_back}); once more with {' '.join(CTX63S_KEEP_FALLBACK)}")
+                rc, leg, tail = run_child(leg_command(name, args, fallback=True), timeout=max(300.0, args.time_budget - (time.time() - t_start)))
             if rc == 0 and leg is not None:
                 res = leg_summary(leg)
                 res["leg_wall_s"] = round(time.time() - t0, 1)
+                if fell_back:
+                    res["fallback_after"] = fell_back
             else:
                 res = {"error": f"rc {rc}: {(tail[-1] if tail else 'no output')[:300]}"}
             attach_leg(line, name, res)

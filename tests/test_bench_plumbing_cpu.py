@@ -204,7 +204,8 @@ def test_one_gpu_default_run_carries_the_other_contexts_as_legs(monkeypatch, cap
     assert calls[0][0][:2] == [sys.executable, os.path.abspath(bench.__file__)] and calls[0][0][-2:] == ["--role", "worker"]
     c3, c63, c30, cs = calls[1][0], calls[2][0], calls[3][0], calls[4][0]
     assert c3[c3.index("--video-length") + 1] == "3sec" and c63[c63.index("--video-length") + 1] == "63sec" and c30[c30.index("--video-length") + 1] == "30sec"
-    assert c63[c63.index("--remat-keep") + 1] == "attn" and c63[c63.index("--remat-keep-layers") + 1] == "10" and c63[c63.index("--remat-free-layers") + 1] == "0"
+    # the 63 s leg keeps the attention outputs of every layer, parked in host memory (round 6)
+    assert c63[c63.index("--remat-keep") + 1] == "attn" and "--offload-park-kept" in c63 and "--remat-keep-layers" not in c63 and c63[c63.index("--remat-free-layers") + 1] == "0"
     assert "--no-fsdp1-compare" in c3 and c3[-2:] == ["--role", "worker"] and "--remat-free-layers" not in c30
     assert cs[1].endswith(os.path.join("tools", "sample_bench.py")) and cs[cs.index("--video-length") + 1] == "63sec" and cs[cs.index("--steps") + 1] == "1"
     # a subset of the legs
@@ -218,6 +219,11 @@ def test_one_gpu_default_run_carries_the_other_contexts_as_legs(monkeypatch, cap
     calls, out, rc = _orchestrate(monkeypatch, capsys, ["--gpus", "1", "--no-cpu-baseline", "--legs", "ctx3s,ctx63s"], [(0, _LINE, []), (1, None, ["HIP error"]), (0, leg63, [])])
     assert rc == 0 and "error" in out[0]["config"]["legs"]["ctx3s"] and out[0]["config"]["legs"]["ctx63s"]["value"] == 6400.0
     assert "HIP error" in out[0]["config"]["leg_ctx3s_error"]
+    # the parked 63 s attempt dies: once more with the attention outputs of ten layers on the device, and the entry says why
+    calls, out, rc = _orchestrate(monkeypatch, capsys, ["--gpus", "1", "--no-cpu-baseline", "--legs", "ctx63s"], [(0, _LINE, []), (1, None, ["HIP out of memory"]), (0, leg63, [])])
+    fb = calls[2][0]
+    assert rc == 0 and len(calls) == 3 and fb[fb.index("--remat-keep-layers") + 1] == "10" and "--offload-park-kept" not in fb
+    assert out[0]["config"]["legs"]["ctx63s"]["value"] == 6400.0 and "out of memory" in out[0]["config"]["legs"]["ctx63s"]["fallback_after"]
     # another workload than the metric's: no legs
     calls, out, rc = _orchestrate(monkeypatch, capsys, ["--gpus", "1", "--video-length", "3sec", "--no-cpu-baseline"], [(0, _LINE, [])])
     assert len(calls) == 1 and "ctx3s" not in out[0] and "legs" not in out[0]["config"]

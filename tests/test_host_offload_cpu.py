@@ -157,3 +157,19 @@ def test_kept_kernel_outputs_of_rematerialised_regions_wait_in_host_memory():
         assert torch.equal(a, r)
     assert off.stats["offloaded_storages"] == 6 and off.stats["fetched_bytes"] == off.stats["offloaded_bytes"] == 6 * 64 * 8 * 4
     assert off.stats["late_fetches"] == 0
+
+
+def test_pinned_pool_cap_keeps_the_rest_on_the_device():
+    """``max_pinned_bytes``: the pool never grows beyond the cap; tensors that find no room stay where they are - same bits, fewer travel."""
+    unit = 64 * 32 * 4
+    off = HostOffload(bytes_per_layer=1 << 30, min_bytes=unit, pin=False, max_pinned_bytes=1 << 16)
+    off.chunk_bytes = 1 << 15                      # two chunks of 32 KiB fit under the cap: 8 units, then refusals
+    ref, got = run(None), run(off)
+    for a, r in zip(got, ref):
+        assert torch.equal(a, r)
+    assert off.stats["pinned_bytes"] <= 1 << 16 and off.stats["pool_full_refusals"] > 0
+    assert 0 < off.stats["offloaded_storages"] < 11
+    again = run(off)                               # the next step re-uses the slots it has, refuses the same tensors
+    for a, r in zip(again, ref):
+        assert torch.equal(a, r)
+    assert off.stats["pinned_bytes"] <= 1 << 16

@@ -21,12 +21,19 @@ def _step(m, vid, text, ts, dout):
     return out.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
 
 
-@pytest.mark.parametrize("free,keep,soft,park,batch,defaults", [
-    (2, (), None, False, False, False), (2, (), 0, False, False, False), (2, (), 0, False, True, False),
-    (1, ("attn", "scan", "fc2"), None, False, True, False), (1, ("attn", "scan", "fc2"), None, True, False, False),
-    (0, ("attn", "scan", "fc2"), 0, True, False, False),
-    (2, (), None, False, True, True), (0, ("attn", "scan", "fc2"), None, True, True, True)])
+CASES = [(2, (), None, False, False, False), (2, (), 0, False, False, False), (2, (), 0, False, True, False),
+         (1, ("attn", "scan", "fc2"), None, False, True, False), (1, ("attn", "scan", "fc2"), None, True, False, False),
+         (0, ("attn", "scan", "fc2"), 0, True, False, False)]
+# the shipped defaults (one copy stream, no host wait at the end of the forward): tests/test_zzz_host_offload_defaults_gpu.py
+DEFAULT_CASES = [(2, (), None, False, True, True), (0, ("attn", "scan", "fc2"), None, True, True, True)]
+
+
+@pytest.mark.parametrize("free,keep,soft,park,batch,defaults", CASES)
 def test_offloaded_free_layers_give_the_same_bits(free, keep, soft, park, batch, defaults):
+    check(free, keep, soft, park, batch, defaults)
+
+
+def check(free, keep, soft, park, batch, defaults):
     from ttt_amd.infra.host_offload import HostOffload
     ext()
     m = _dit()

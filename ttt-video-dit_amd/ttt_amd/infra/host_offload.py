@@ -56,10 +56,11 @@ def _bytes_of(storage, device):
 class HostOffload:
     def __init__(self, bytes_per_layer: int, layers: int | None = None, min_bytes: int = 96 << 20, lookahead: int = 2,
                  soft_limit_bytes: int | None = None, max_storage_ratio: float = 4.0, pin: bool = True, park_kept: bool = False,
-                 max_backlog_bytes: int | None = None):
+                 max_backlog_bytes: int | None = None, max_pinned_bytes: int = 160 << 30):
         self.bytes_per_layer, self.layers, self.min_bytes, self.lookahead = int(bytes_per_layer), layers, int(min_bytes), int(lookahead)
         self.soft_limit_bytes, self.max_storage_ratio, self.pin = soft_limit_bytes, max_storage_ratio, pin
         self.max_backlog_bytes = max_backlog_bytes
+        self.max_pinned_bytes = int(max_pinned_bytes)  # cap of the pinned pool; what does not fit stays on the device
         # batch: the copies out of a layer are issued together behind the layer's forward, behind ONE event of the compute stream (the runtime
         # picks the SDMA engine of a copy when it is queued; a marker between two copies makes it choose again, and with the first engine busy it
         # takes the next free one - copies that trickle in one by one end up spread over engines that are slower on the host link)
@@ -141,6 +142,11 @@ class HostOffload:
             size = self.chunk_bytes
             while size < need:
                 size *= 2
+            if self.stats["pinned_bytes"] + size > self.max_pinned_bytes:
+                # The pool is full: the caller keeps the tensor on the device.  (Pinned memory cannot be paged out: a pool beyond what the box
+                # gives the process takes the box down with it - round 6, call HO14, a setting that would have pinned 560 GiB.)
+                self.stats["pool_full_refusals"] += 1
+                return None
             self._chunk, self._chunk_used = torch.empty(size, dtype=torch.uint8, pin_memory=self.pin and torch.cuda.is_available()), 0
             self.stats["pinned_bytes"] += size
         buf = self._chunk[self._chunk_used:self._chunk_used + need]
@@ -194,18 +200,23 @@ class HostOffload:
         if nbytes > self.max_storage_ratio * nbytes_view or self._spent + nbytes > self.bytes_per_layer:
             return t                                                  # a slice of a big buffer / the layer's budget is spent
         stor = self._send(self._cur_layer, t)
+        if stor is None:
+            return t
         self._spent += nbytes
         if stor.dev is not None:                                      # (a throttled copy may be complete, and its device copy let go, already)
             self._by_ptr[ptr] = stor
         return _View(stor, t)
 
-    def _send(self, layer, t) -> _Stor:
-        """queues the copy out of ``t``'s whole storage into the step's next pinned slot"""
+    def _send(self, layer, t) -> _Stor | None:
+        """queues the copy out of ``t``'s whole storage into the step's next pinned slot (None: the pinned pool is at its cap)"""
         self._release_done()
         storage = t.untyped_storage()
         nbytes = storage.nbytes()
+        host = self._slot(self._next_slot, nbytes)
+        if host is None:
+            return None
+        host = host[:nbytes]
         stor = _Stor(layer, nbytes, self._next_slot, _bytes_of(storage, t.device), t.device)
-        host = self._slot(stor.slot, nbytes)[:nbytes]
         if t.is_cuda and self.batch and self._scope_depth > 0:
             stor.queued = True
             self._batch.append((stor, host))
@@ -254,7 +265,8 @@ class HostOffload:
             if nb < self.min_bytes or t.storage_offset() != 0 or t.untyped_storage().nbytes() != nb:
                 out.append(t)                                         # (small, or not the sole - possibly permuted - owner of its storage)
             else:
-                out.append(_View(self._send(layer, t), t))
+                stor = self._send(layer, t)
+                out.append(t if stor is None else _View(stor, t))
         return tuple(out)
 
     def unpark(self, handles):
