@@ -5,6 +5,6 @@ show() { grep -h "^{" $1 | python -c "import sys,json; d=json.loads(sys.stdin.re
 OS="--offload-one-stream --offload-nonblocking-end --offload-backlog-gib 64"
 run63() { timeout 900 python bench.py --role worker --gpus 1 --video-length 63sec --steps 2 --warmup 1 --no-fsdp1-compare --remat-free-layers 0 $OS "${@:2}" > $O/bench63_$1.json 2> $O/bench63_$1.err; show $O/bench63_$1.json 63$1; }
 run63 attnscan20 --remat-keep attn,scan:20 --offload-park-kept --offload-lookahead 1
-run63 all --remat-keep attn,scan,fc2 --offload-park-kept --offload-lookahead 1
+# (NOT to be run again: 560 GiB of pinned host memory, took the boxes down) run63 all --remat-keep attn,scan,fc2 --offload-park-kept --offload-lookahead 1
 timeout 900 python bench.py --role worker --gpus 1 --video-length 30sec --steps 2 --warmup 1 --no-fsdp1-compare $OS --offload-park-kept --offload-lookahead 1 > $O/bench30_park.json 2> $O/bench30_park.err; show $O/bench30_park.json 30park
 timeout 900 python bench.py --role worker --gpus 1 --steps 4 --warmup 1 --no-fsdp1-compare $OS --offload-gib-per-layer 3 > $O/bench_off3os.json 2> $O/bench_off3os.err; show $O/bench_off3os.json off3os

@@ -75,7 +75,7 @@ class HostOffload:
         self._scope_depth = 0
         self.park_kept = park_kept                    # the kernel outputs re-materialised layers keep (remat_cache) wait in host memory as well
         self._slots: list[torch.Tensor] = []          # pinned host buffers, slot k = the k-th storage a step offloads
-        self.chunk_bytes, self._chunk, self._chunk_used = 1 << 32, None, 0
+        self.chunk_bytes, self._chunk, self._chunk_used, self._pinned_total = 1 << 32, None, 0, 0
         self._streams = None
         self.stats = collections.Counter()
         self.trace = None                             # DEBUG: a list -> (kind, bytes, start event, end event) of every copy and compute-stream wait
@@ -142,13 +142,14 @@ class HostOffload:
             size = self.chunk_bytes
             while size < need:
                 size *= 2
-            if self.stats["pinned_bytes"] + size > self.max_pinned_bytes:
+            if self._pinned_total + size > self.max_pinned_bytes:
                 # The pool is full: the caller keeps the tensor on the device.  (Pinned memory cannot be paged out: a pool beyond what the box
                 # gives the process takes the box down with it - round 6, call HO14, a setting that would have pinned 560 GiB.)
                 self.stats["pool_full_refusals"] += 1
                 return None
             self._chunk, self._chunk_used = torch.empty(size, dtype=torch.uint8, pin_memory=self.pin and torch.cuda.is_available()), 0
             self.stats["pinned_bytes"] += size
+            self._pinned_total += size
         buf = self._chunk[self._chunk_used:self._chunk_used + need]
         self._chunk_used += need
         if k < len(self._slots):
