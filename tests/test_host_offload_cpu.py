@@ -173,3 +173,46 @@ def test_pinned_pool_cap_keeps_the_rest_on_the_device():
     for a, r in zip(again, ref):
         assert torch.equal(a, r)
     assert off.stats["pinned_bytes"] <= 1 << 16
+
+
+def test_diffusion_transformer_wiring_on_cpu():
+    """``DiffusionTransformer.host_offload`` end to end on CPU tensors (the oracle stands in for the extension, as in tests/test_remat_cache_cpu.py):
+    a remat-free layer under the saved-tensor hooks, re-materialised layers whose kept kernel outputs are parked, the per-kind layer limits
+    (``remat_keep_limits``), the backward's layer hooks - outputs and every gradient equal to the plain run, bit for bit."""
+    from oracle import cpu_ext
+    from ttt_amd.models.cogvideo.dit import DiffusionTransformer
+    from ttt_amd.models.configs import ModelConfig
+    cpu_ext.install()
+    try:
+        torch.manual_seed(0)
+        cfg = ModelConfig(model_dim=64, num_heads=2, num_layers=4, mini_batch_size=16, latent_height=4, latent_width=8, compressed_num_frames=2,
+                          ssm_layer="ttt_linear", text_dim=16, time_embed_dim=32, attn_length=2, prefix_temporal_length=1, scan_checkpoint_group_size=2)
+        m = DiffusionTransformer(cfg)
+        vid, text, ts = torch.randn(1, 2, 16, 8, 16), torch.randn(1, 1, 16, 16), torch.tensor([100])
+
+        def step():
+            m.zero_grad(set_to_none=True)
+            out = m(vid, text, ts)
+            out.square().mean().backward()
+            return out.detach().clone(), [p.grad.clone() for p in m.parameters() if p.grad is not None]
+
+        m.remat_free_layers, m.remat_keep = 1, ("attn", "scan", "fc2")
+        ref = step()
+        for limits, park, per_layer in (({}, True, 1 << 30), ({"scan": 1, "fc2": 2}, True, 0), ({"scan": 1}, False, 1 << 30)):
+            off = HostOffload(bytes_per_layer=per_layer, min_bytes=1 << 10, pin=False, park_kept=park)
+            off.chunk_bytes = 1 << 20
+            m.host_offload, m.remat_keep_limits = off, limits
+            for _ in range(2):                                           # the second step re-uses the first step's slots
+                out, grads = step()
+                assert torch.equal(out, ref[0]) and all(torch.equal(a, b) for a, b in zip(grads, ref[1]))
+            st = off.stats
+            assert st["late_fetches"] == 0 and st["fetched_bytes"] == st["offloaded_bytes"], dict(st)
+            if per_layer:
+                assert st["offloaded_storages"] >= 2 * 20, dict(st)       # the free layer's saved tensors travelled, in both steps
+            else:                                                         # (the kernels whose outputs are kept do not run on CPU tensors: the parked
+                assert st["views_shared"] == 0                            # path itself is the toy test above; here nothing may come through the hooks)
+        m.host_offload, m.remat_keep_limits = None, {}
+        out, grads = step()
+        assert torch.equal(out, ref[0])
+    finally:
+        cpu_ext.uninstall()

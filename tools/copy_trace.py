@@ -12,7 +12,7 @@ key_b = next((k for k in ("Bytes", "Size", "bytes") if rows and k in rows[0]), N
 by = collections.defaultdict(list)
 for r in rows:
     nb = float(r.get(key_b, 0) or 0) if key_b else 0.0
-    if nb >= a.min_bytes:
+    if nb >= a.min_bytes or not key_b:             # (rocprofv3 7.2 writes no size column: every copy counts, the rates below are then 0)
         by[r.get("Direction", r.get("Operation", "?"))].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), nb))
 for d, v in by.items():
     v.sort()

@@ -89,7 +89,6 @@ class HostOffload:
         self._next_slot = 0
         self._spent = 0
         self._cur_layer = None
-        self._prefetched_below = None
 
     def begin_step(self):
         """Call once in front of a forward pass (``DiffusionTransformer.forward`` does): forgets the previous step's handles."""
