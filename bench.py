@@ -660,6 +660,15 @@ LEG_ESTIMATE_S = {"ctx3s": 150.0, "ctx63s": 480.0, "ctx30s": 380.0, "sample63s":
 LEG_ORDER = ("ctx3s", "ctx63s", "ctx30s", "sample63s")     # the metric's two contexts first, then BASELINE configs[3] and configs[4]
 
 
+def host_room_gib():
+    """GiB of host memory this process may still take (ttt_amd/infra/host_offload.py: MemAvailable and the cgroup's limit; tests replace this)"""
+    from ttt_amd.infra.host_offload import host_room_gib as f
+    return f()
+
+
+CTX63S_PARKED_HOST_GIB = 160.0      # the parked 63 s leg pins 92 GiB; it is only tried with this much host memory to spare
+
+
 def leg_command(name, args, fallback=False):
     """`ctx3s` = BASELINE configs[1] (configs/train/ttt-mlp/3s.toml: one segment, adapter sft), `ctx63s` = the metric's second context
     (63s.toml: 21 scenes, L = 351 168; every layer re-materialised, the first ten keep their attention outputs - what fits ONE 288-GB GPU,
@@ -762,9 +771,13 @@ def orchestrate(args, argv):
                 continue
             log(f"{name} leg (child process)")
             t0 = time.time()
-            rc, leg, tail = run_child(leg_command(name, args), timeout=max(300.0, left))
-            fell_back = None
-            if name == "ctx63s" and not (rc == 0 and leg is not None) and args.time_budget - (time.time() - t_start) >= LEG_ESTIMATE_S[name]:
+            room = host_room_gib() if name == "ctx63s" else None
+            short = room is not None and room < CTX63S_PARKED_HOST_GIB
+            if short:
+                log(f"{name}: {room:.0f} GiB of host memory to spare (< {CTX63S_PARKED_HOST_GIB:.0f}): attention outputs of ten layers on the device instead of parked")
+            rc, leg, tail = run_child(leg_command(name, args, fallback=short), timeout=max(300.0, left))
+            fell_back = f"host memory: {room:.0f} GiB to spare" if short else None
+            if name == "ctx63s" and not short and not (rc == 0 and leg is not None) and args.time_budget - (time.time() - t_start) >= LEG_ESTIMATE_S[name]:
                 # the parked attempt failed: once more with the attention outputs of ten layers kept on the device (rounds 5 / 6)
                 fell_back = f"rc {rc}: {(tail[-1] if tail else 'no output')[:200]}"
                 log(f"{name}: parked attempt failed ({fell_back}); once more with {' '.join(CTX63S_KEEP_FALLBACK)}")

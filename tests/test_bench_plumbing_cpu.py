@@ -113,7 +113,7 @@ _LINE = {"metric": "DiT+TTT fwd/bwd video-tokens/sec", "value": 7000.0, "unit": 
          "peak_mem_gib": 236.0, "peak_reserved_gib": 245.0}
 
 
-def _orchestrate(monkeypatch, capsys, argv, replies):
+def _orchestrate(monkeypatch, capsys, argv, replies, host_gib=2000.0):
     """bench.main() as the driver starts it (no launcher environment) with run_child replaced by a script of replies;
     returns (the commands it ran, the JSON objects it printed)"""
     import copy
@@ -126,6 +126,7 @@ def _orchestrate(monkeypatch, capsys, argv, replies):
         return r[0], copy.deepcopy(r[1]), list(r[2])
 
     monkeypatch.setattr(bench, "run_child", fake_run_child)
+    monkeypatch.setattr(bench, "host_room_gib", lambda: host_gib)          # (a GPU box has 3 TB of host memory; this container 64 GB)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "NCCL_DEBUG"):
         monkeypatch.delenv(k, raising=False)
     monkeypatch.setattr(sys, "argv", ["bench.py"] + argv)
@@ -224,6 +225,11 @@ def test_one_gpu_default_run_carries_the_other_contexts_as_legs(monkeypatch, cap
     fb = calls[2][0]
     assert rc == 0 and len(calls) == 3 and fb[fb.index("--remat-keep-layers") + 1] == "10" and "--offload-park-kept" not in fb
     assert out[0]["config"]["legs"]["ctx63s"]["value"] == 6400.0 and "out of memory" in out[0]["config"]["legs"]["ctx63s"]["fallback_after"]
+    # a box without 160 GiB of host memory to spare: the parked attempt is not made at all
+    calls, out, rc = _orchestrate(monkeypatch, capsys, ["--gpus", "1", "--no-cpu-baseline", "--legs", "ctx63s"], [(0, _LINE, []), (0, leg63, [])], host_gib=62.0)
+    only = calls[1][0]
+    assert rc == 0 and len(calls) == 2 and "--offload-park-kept" not in only and only[only.index("--remat-keep-layers") + 1] == "10"
+    assert "62 GiB" in out[0]["config"]["legs"]["ctx63s"]["fallback_after"]
     # another workload than the metric's: no legs
     calls, out, rc = _orchestrate(monkeypatch, capsys, ["--gpus", "1", "--video-length", "3sec", "--no-cpu-baseline"], [(0, _LINE, [])])
     assert len(calls) == 1 and "ctx3s" not in out[0] and "legs" not in out[0]["config"]

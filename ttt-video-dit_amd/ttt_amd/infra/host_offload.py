@@ -30,6 +30,27 @@ import time
 import torch
 
 
+def host_room_gib():
+    """GiB of host memory this process may still take: MemAvailable, and the cgroup's limit minus its usage where there is one (pinned memory
+    cannot be paged out and is charged to the box; None if nothing can be read)."""
+    room = []
+    try:
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable:"):
+                room.append(int(ln.split()[1]) / 2 ** 20)
+    except OSError:
+        pass
+    for lim, cur in (("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory.current"),
+                     ("/sys/fs/cgroup/memory/memory.limit_in_bytes", "/sys/fs/cgroup/memory/memory.usage_in_bytes")):
+        try:
+            v = open(lim).read().strip()
+            if v.isdigit() and int(v) < 1 << 60:
+                room.append((int(v) - int(open(cur).read().strip())) / 2 ** 30)
+        except (OSError, ValueError):
+            pass
+    return min(room) if room else None
+
+
 class _Stor:
     """One offloaded storage of one step."""
     __slots__ = ("layer", "nbytes", "slot", "dev", "d2h_done", "restored", "h2d_done", "device", "queued")
@@ -61,6 +82,9 @@ class HostOffload:
         self.soft_limit_bytes, self.max_storage_ratio, self.pin = soft_limit_bytes, max_storage_ratio, pin
         self.max_backlog_bytes = max_backlog_bytes
         self.max_pinned_bytes = int(max_pinned_bytes)  # cap of the pinned pool; what does not fit stays on the device
+        room = host_room_gib() if pin else None
+        if room is not None:                           # ... and never more than 60 % of what the host has to spare when the pool is created
+            self.max_pinned_bytes = min(self.max_pinned_bytes, int(0.6 * room * 2 ** 30))
         # batch: the copies out of a layer are issued together behind the layer's forward, behind ONE event of the compute stream (the runtime
         # picks the SDMA engine of a copy when it is queued; a marker between two copies makes it choose again, and with the first engine busy it
         # takes the next free one - copies that trickle in one by one end up spread over engines that are slower on the host link)
